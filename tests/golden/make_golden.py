@@ -1,0 +1,464 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by running the UNMODIFIED reference.
+
+Run only where /root/reference exists (this container):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only NAME]
+
+The reference ships no tests/golden vectors of its own, so every parity
+artefact is produced here: inputs (seeds, maps, actions) and the reference's outputs.  The
+fixtures are data only; no reference source travels.  `gym` is provided by gym_shim.py.
+
+Fixture families:
+  rng.npz          numpy-legacy draw rules under gym<=0.21 hashed seeding
+  stats_*.npz      map -> get_stats() known-answer tests per problem (random + adversarial maps)
+  sokoban_solver.npz  engineered solvable/unsolvable levels -> dist-win, sol-length, agent iterations
+  range_reward.npz exhaustive small table of helper.get_range_reward
+  adjust_param.npz  the adjust_param ordering quirk (Q9) and spaces
+  traj_*.npz       full env trajectories (obs map/pos/heatmap, reward, done, info) with auto-reset
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import gym_shim  # noqa: E402
+
+gym = gym_shim.install()
+import gym_pcgrl  # noqa: E402,F401  (registers ids)
+from gym_pcgrl.envs.helper import get_range_reward, get_string_map  # noqa: E402
+from gym_pcgrl.envs.probs import PROBLEMS  # noqa: E402
+from gym_pcgrl.envs.probs.sokoban.engine import AStarAgent, BFSAgent, State  # noqa: E402
+
+INFO_KEYS = {
+    "binary": ["regions", "path-length", "path-imp"],
+    "zelda": ["player", "key", "door", "enemies", "regions", "nearest-enemy", "path-length"],
+    "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
+}
+STAT_KEYS = {
+    "binary": ["regions", "path-length"],
+    "zelda": ["player", "key", "door", "enemies", "regions", "nearest-enemy", "path-length"],
+    "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
+}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("  wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+# ----------------------------------------------------------------------------- rng
+def gen_rng():
+    from gym.utils import seeding
+    seeds = [0, 1, 42, 2 ** 32 + 7, 1000, 2 ** 64 + 5]
+    bounds = [14, 5, 11, 16, 64, 7, 1, 2, 3]
+    out = {"seeds": np.array([s % 2 ** 64 for s in seeds], dtype=np.uint64), "bounds": np.array(bounds)}
+    keys, randints, randoms, choices2, choices8, mixed, nodraw = [], [], [], [], [], [], []
+    for s in seeds:
+        rng, used = seeding.np_random(s)
+        st = rng.get_state()
+        assert st[2] == 624
+        keys.append(np.asarray(st[1], dtype=np.uint32))
+        rows = []
+        for n in bounds:
+            rng, _ = seeding.np_random(s)
+            rows.append([rng.randint(n) for _ in range(64)])
+        randints.append(rows)
+        rng, _ = seeding.np_random(s)
+        randoms.append([rng.random() for _ in range(700)])  # crosses the 624-word regeneration
+        rng, _ = seeding.np_random(s)
+        choices2.append(rng.choice([0, 1], size=(14, 14), p=[0.3, 0.7]).astype(np.uint8))
+        rng, _ = seeding.np_random(s)
+        p8 = np.array([0.58, 0.3, 0.02, 0.02, 0.02, 0.02, 0.02, 0.02])
+        choices8.append(rng.choice(list(range(8)), size=(16, 11), p=list(p8 / p8.sum())).astype(np.uint8))
+        # interleaved stream: choice map, randint(14) x2, random(), randint(5) x3
+        rng, _ = seeding.np_random(s)
+        m = rng.choice([0, 1], size=(5, 5), p=[0.5, 0.5]).astype(np.int64).ravel().tolist()
+        m += [rng.randint(14), rng.randint(14)]
+        r = rng.random()
+        m += [rng.randint(5) for _ in range(3)]
+        mixed.append((m, r))
+        rng, _ = seeding.np_random(s)      # randint(1) must consume no draw
+        nodraw.append([rng.randint(1), rng.randint(14), rng.randint(1), rng.randint(5), rng.randint(1), rng.randint(64)])
+    out["mt_key"] = np.array(keys)
+    out["randint"] = np.array(randints, dtype=np.int64)          # [seed, bound, 64]
+    out["random"] = np.array(randoms, dtype=np.float64)          # [seed, 700]
+    out["choice2_p"] = np.array([0.3, 0.7])
+    out["choice2"] = np.array(choices2)
+    out["choice8_p"] = p8 / p8.sum()
+    out["choice8"] = np.array(choices8)
+    out["mixed_ints"] = np.array([m for m, _ in mixed], dtype=np.int64)
+    out["nodraw_ints"] = np.array(nodraw, dtype=np.int64)
+    out["mixed_float"] = np.array([r for _, r in mixed], dtype=np.float64)
+    save("rng", **out)
+
+
+# ----------------------------------------------------------------------------- maps for KATs
+def adversarial_binary(h, w):
+    maps = []
+    z = np.zeros((h, w), np.uint8)
+    o = np.ones((h, w), np.uint8)
+    maps += [z.copy(), o.copy()]
+    m = o.copy(); m[h // 2, w // 2] = 0; maps.append(m)                       # single cell
+    m = o.copy(); m[0, 0] = 0; m[h - 1, w - 1] = 0; maps.append(m)              # two corners
+    m = z.copy(); m[:, 1::2] = 1; maps.append(m)                                # vertical comb, disconnected
+    m = z.copy(); m[:-1, 1::2] = 1; maps.append(m)                              # comb joined at bottom
+    m = z.copy(); m[1:, 1::2] = 1; maps.append(m)                               # comb joined at top
+    m = z.copy(); m[1::2, :] = 1; maps.append(m)                                # horizontal stripes
+    m = z.copy()                                                                # serpentine
+    for y in range(1, h, 2):
+        m[y, :] = 1
+        m[y, (w - 1) if (y // 2) % 2 == 0 else 0] = 0
+    maps.append(m)
+    m = np.indices((h, w)).sum(0) % 2; maps.append(m.astype(np.uint8))          # checkerboard
+    maps.append((1 - m).astype(np.uint8))
+    m = o.copy()                                                                # spiral
+    y0, x0, y1, x1 = 0, 0, h - 1, w - 1
+    m[:] = 1
+    yy, xx, k = 0, 0, 0
+    sp = np.ones((h, w), np.uint8)
+    top, left, bot, right = 0, 0, h - 1, w - 1
+    while top <= bot and left <= right:
+        sp[top, left:right + 1] = 0
+        sp[top:bot + 1, right] = 0
+        if top + 2 <= bot:
+            sp[bot, left + 2 if left + 2 <= right else right:right + 1] = 0
+        top += 2; left += 2; bot -= 2; right -= 2
+    maps.append(sp)
+    m = z.copy(); m[h // 2, :] = 1; maps.append(m)                              # two halves
+    m = z.copy(); m[h // 2, :] = 1; m[:, w // 2] = 1; maps.append(m)            # four quadrants
+    m = o.copy(); m[h // 2, :] = 0; maps.append(m)                              # a corridor (argmax ties at the ends)
+    m = o.copy(); m[:, w // 2] = 0; maps.append(m)
+    m = o.copy(); m[h // 2, :] = 0; m[:, w // 2] = 0; maps.append(m)            # plus sign: 4-way argmax tie
+    m = z.copy(); m[1:-1, 1:-1] = 1; maps.append(m)                             # ring
+    m = z.copy(); m[0, :] = 1; maps.append(m)
+    return [np.ascontiguousarray(x, dtype=np.uint8) for x in maps]
+
+
+def random_maps(rs, n, h, w, ntiles, probs=None):
+    maps = []
+    for k in range(n):
+        if ntiles == 2:
+            p = rs.random_sample()
+            maps.append((rs.random_sample((h, w)) < p).astype(np.uint8))
+        else:
+            pr = np.asarray(probs, dtype=np.float64)
+            solid = rs.uniform(0.0, 0.6)
+            pr = pr.copy(); pr[1] = solid; pr[0] = max(1e-3, 1 - solid - pr[2:].sum())
+            pr /= pr.sum()
+            maps.append(rs.choice(ntiles, size=(h, w), p=pr).astype(np.uint8))
+    return maps
+
+
+def stats_of(prob, m):
+    st = prob.get_stats(get_string_map(m, prob.get_tile_types()))
+    return st
+
+
+def gen_stats_binary():
+    rs = np.random.RandomState(7)
+    prob = PROBLEMS["binary"]()
+    for (h, w, nrand) in [(14, 14, 260), (5, 5, 80), (16, 11, 60), (9, 32, 40), (64, 64, 10), (3, 7, 30), (1, 1, 0), (1, 9, 6), (8, 1, 6)]:
+        prob._width, prob._height = w, h
+        maps = adversarial_binary(h, w) + random_maps(rs, nrand, h, w, 2)
+        if (h, w) == (64, 64):
+            maps = maps[:12] + maps[-nrand:]
+        res = np.array([[int(stats_of(prob, m)[k]) for k in STAT_KEYS["binary"]] for m in maps], dtype=np.int64)
+        save("stats_binary_%dx%d" % (h, w), maps=np.array(maps), stats=res, keys=np.array(STAT_KEYS["binary"]))
+
+
+def engineer_zelda(rs, h, w, n):
+    """Maps that satisfy player==1 (often regions==1, key==1, door==1) so the BFS branches run."""
+    maps = []
+    for k in range(n):
+        solid = rs.uniform(0.0, 0.45)
+        m = (rs.random_sample((h, w)) < solid).astype(np.uint8)  # 0 empty / 1 solid
+        cells = rs.permutation(h * w)
+        c = 0
+        def put(tile, cnt):
+            nonlocal c
+            for _ in range(cnt):
+                m.flat[cells[c]] = tile
+                c += 1
+        put(2, 1 if rs.random_sample() < 0.9 else rs.randint(0, 3))
+        put(3, 1 if rs.random_sample() < 0.85 else rs.randint(0, 3))
+        put(4, 1 if rs.random_sample() < 0.85 else rs.randint(0, 3))
+        for t in (5, 6, 7):
+            put(t, rs.randint(0, 3))
+        if rs.random_sample() < 0.5:
+            # connect: carve solids away with decreasing density so regions==1 is likely
+            m[m == 1] = (rs.random_sample((m == 1).sum()) < 0.3).astype(np.uint8)
+        if rs.random_sample() < 0.15:
+            # wall the door off (the d2 == -1 branch)
+            ys, xs = np.where(m == 4)
+            for y, x in zip(ys, xs):
+                for dy, dx in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                    yy, xx = y + dy, x + dx
+                    if 0 <= yy < h and 0 <= xx < w and m[yy, xx] not in (2, 3):
+                        m[yy, xx] = 1
+        maps.append(m)
+    return maps
+
+
+def gen_stats_zelda():
+    rs = np.random.RandomState(11)
+    prob = PROBLEMS["zelda"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng) in [(7, 11, 120, 300), (16, 11, 80, 300), (11, 16, 30, 80), (5, 5, 40, 100)]:
+        prob._width, prob._height = w, h
+        maps = [np.zeros((h, w), np.uint8), np.ones((h, w), np.uint8)]
+        for t in range(2, 8):
+            maps.append(np.full((h, w), t, np.uint8))
+        maps += random_maps(rs, nrand, h, w, 8, pr) + engineer_zelda(rs, h, w, neng)
+        res = np.array([[int(stats_of(prob, m)[k]) for k in STAT_KEYS["zelda"]] for m in maps], dtype=np.int64)
+        hit = int(((res[:, 0] == 1) & (res[:, 4] == 1)).sum())
+        print("  zelda %dx%d: %d maps, precondition hit %d, key/door branch %d, d2=-1-ish %d" % (
+            h, w, len(maps), hit, int(((res[:, 0] == 1) & (res[:, 4] == 1) & (res[:, 1] == 1) & (res[:, 2] == 1)).sum()),
+            int((res[:, 6] < 0).sum() + 0)))
+        save("stats_zelda_%dx%d" % (h, w), maps=np.array(maps), stats=res, keys=np.array(STAT_KEYS["zelda"]))
+
+
+def engineer_sokoban(rs, h, w, n, max_k=3, solid_max=0.35):
+    maps = []
+    for _ in range(n):
+        solid = rs.uniform(0.0, solid_max)
+        m = (rs.random_sample((h, w)) < solid).astype(np.uint8)
+        cells = rs.permutation(h * w)
+        k = rs.randint(1, max_k + 1)
+        m.flat[cells[0]] = 2
+        for i in range(k):
+            m.flat[cells[1 + i]] = 3
+        nt = k if rs.random_sample() < 0.9 else rs.randint(0, max_k + 1)
+        for i in range(nt):
+            m.flat[cells[1 + k + i]] = 4
+        maps.append(m)
+    return maps
+
+
+def run_agents(prob, m):
+    """Re-run what SokobanProblem._run_game does (sokoban_prob.py:85-122), keeping iteration counts."""
+    smap = get_string_map(m, prob.get_tile_types())
+    chars = " #@$."
+    s2c = dict((s, chars[i]) for i, s in enumerate(prob.get_tile_types()))
+    W = prob._width
+    lvl = "#" * (W + 2) + "\n"
+    for row in smap:
+        lvl += "#" + "".join(s2c[c] for c in row) + "#\n"
+    lvl += "#" * (W + 2) + "\n"
+    state = State()
+    state.stringInitialize(lvl.split("\n"))
+    iters = []
+    win = -1
+    sol, st, it = BFSAgent().getSolution(state, prob._solver_power)
+    iters.append(it)
+    if st.checkWin():
+        win = 0
+    else:
+        for k, bal in enumerate((1, 0.5, 0)):
+            sol, st, it = AStarAgent().getSolution(state, bal, prob._solver_power)
+            iters.append(it)
+            if st.checkWin():
+                win = k + 1
+                break
+    while len(iters) < 4:
+        iters.append(0)
+    return iters, win, (0 if win >= 0 else st.getHeuristic()), (len(sol) if win >= 0 else 0)
+
+
+def gen_stats_sokoban():
+    rs = np.random.RandomState(13)
+    prob = PROBLEMS["sokoban"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng, max_k, power, smax) in [(5, 5, 150, 260, 3, 5000, 0.35), (6, 6, 20, 60, 3, 5000, 0.35),
+                                                     (7, 7, 10, 40, 4, 5000, 0.35), (4, 6, 20, 60, 2, 300, 0.35),
+                                                     (5, 6, 0, 120, 3, 5000, 0.12), (7, 8, 0, 40, 4, 5000, 0.08),
+                                                     (8, 8, 0, 24, 3, 2000, 0.05)]:
+        prob._width, prob._height, prob._solver_power = w, h, power
+        maps = [np.zeros((h, w), np.uint8), np.ones((h, w), np.uint8)]
+        maps += random_maps(rs, nrand, h, w, 5, pr) + engineer_sokoban(rs, h, w, neng, max_k, smax)
+        t0 = time.time()
+        res, agents = [], []
+        for m in maps:
+            st = stats_of(prob, m)
+            row = [int(st[k]) if k != "sol-length" else len(st["solution"]) for k in STAT_KEYS["sokoban"]]
+            res.append(row)
+            if st["player"] == 1 and st["crate"] == st["target"] and st["crate"] > 0 and st["regions"] == 1:
+                iters, win, dist, sl = run_agents(prob, m)
+                assert dist == row[4] and sl == row[5], (dist, sl, row)
+                agents.append(iters + [win])
+            else:
+                agents.append([0, 0, 0, 0, -2])
+        res = np.array(res, dtype=np.int64)
+        agents = np.array(agents, dtype=np.int64)
+        print("  sokoban %dx%d: %d maps, solver ran %d, wins by agent %s, cap hits %d, %.1fs" % (
+            h, w, len(maps), int((agents[:, 4] > -2).sum()),
+            [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)],
+            int((agents[:, :4] >= power).any(1).sum()), time.time() - t0))
+        save("stats_sokoban_%dx%d" % (h, w), maps=np.array(maps), stats=res, agents=agents,
+             solver_power=np.array(power), keys=np.array(STAT_KEYS["sokoban"]))
+
+
+# ----------------------------------------------------------------------------- range reward
+def gen_range_reward():
+    bands = [(1, 1), (np.inf, np.inf), (-np.inf, -np.inf), (2, 5), (4, np.inf), (1, 3), (0, 0), (3, 3), (2, 2), (1, 5)]
+    vals = list(range(-2, 12)) + [25, 176, 196, 250]
+    rows = []
+    for lo, hi in bands:
+        for nv in vals:
+            for ov in vals:
+                r = get_range_reward(nv, ov, lo, hi)
+                assert r is not None
+                rows.append((lo, hi, nv, ov, float(r)))
+    save("range_reward", table=np.array(rows, dtype=np.float64))
+
+
+# ----------------------------------------------------------------------------- adjust_param / spaces
+def space_desc(sp):
+    from gym import spaces
+    if isinstance(sp, spaces.Discrete):
+        return [0, sp.n, 0, 0]
+    if isinstance(sp, spaces.MultiDiscrete):
+        return [1] + [int(v) for v in sp.nvec]
+    raise TypeError(sp)
+
+
+def gen_adjust_param():
+    rows = []
+    cases = [
+        ("binary", "narrow", []),
+        ("binary", "narrow", [dict(width=64, height=64)]),
+        ("binary", "turtle", [dict(width=64, height=64), dict(change_percentage=0.2)]),
+        ("binary", "turtle", [dict(width=64, height=64, change_percentage=0.2)]),
+        ("binary", "wide", [dict(change_percentage=0.5)]),
+        ("binary", "narrow", [dict(change_percentage=2.0)]),
+        ("binary", "narrow", [dict(change_percentage=-1.0)]),
+        ("binary", "narrow", [dict(change_percentage=0.001)]),
+        ("zelda", "wide", []),
+        ("zelda", "wide", [dict(width=11, height=16)]),
+        ("zelda", "wide", [dict(width=11, height=16), dict(change_percentage=0.2)]),
+        ("zelda", "narrow", [dict(width=16, height=11, change_percentage=0.1)]),
+        ("sokoban", "narrow", []),
+        ("sokoban", "narrow", [dict(width=7, height=6), dict(change_percentage=0.4)]),
+        ("sokoban", "turtle", [dict(change_percentage=1.0)]),
+    ]
+    for prob, rep, calls in cases:
+        env = gym.make("%s-%s-v0" % (prob, rep))
+        for kw in calls:
+            env.adjust_param(**kw)
+        osp = env.observation_space.spaces
+        rows.append([env._prob._width, env._prob._height, env._max_changes, env._max_iterations,
+                     env.get_num_tiles(), env.get_border_tile()] + space_desc(env.action_space)
+                    + [int(osp["map"].shape[0]), int(osp["map"].shape[1]), int(osp["map"].high.max()),
+                       int(osp["heatmap"].high.max()), int("pos" in osp)])
+    save("adjust_param", cases=np.array([repr(c) for c in cases]), rows=np.array(rows, dtype=np.int64))
+
+
+# ----------------------------------------------------------------------------- trajectories
+def sample_actions(rs, rep, T, E, W, H, ntiles):
+    if rep == "narrow":
+        return rs.randint(0, ntiles + 1, size=(T, E, 1)).astype(np.int32)
+    if rep == "turtle":
+        return rs.randint(0, ntiles + 4, size=(T, E, 1)).astype(np.int32)
+    a = np.stack([rs.randint(0, W, size=(T, E)), rs.randint(0, H, size=(T, E)), rs.randint(0, ntiles, size=(T, E))], -1)
+    return a.astype(np.int32)
+
+
+def gen_traj(name, prob, rep, E, T, calls=(), seed0=1000, action_seed=5):
+    t0 = time.time()
+    envs = []
+    for i in range(E):
+        env = gym.make("%s-%s-v0" % (prob, rep))
+        for kw in calls:
+            env.adjust_param(**kw)
+        env.seed(seed0 + i)
+        envs.append(env)
+    W, H = envs[0]._prob._width, envs[0]._prob._height
+    nt = envs[0].get_num_tiles()
+    keys = INFO_KEYS[prob]
+    acts = sample_actions(np.random.RandomState(action_seed), rep, T, E, W, H, nt)
+    has_pos = rep != "wide"
+    map0 = np.zeros((E, H, W), np.uint8); pos0 = np.zeros((E, 2), np.uint8)
+    maps = np.zeros((T, E, H, W), np.uint8); poss = np.zeros((T, E, 2), np.uint8)
+    heat = np.zeros((T, E, H, W), np.uint16)
+    rew = np.zeros((T, E), np.float64); done = np.zeros((T, E), np.bool_)
+    info = np.zeros((T, E, len(keys) + 2), np.int64)
+    for i, env in enumerate(envs):
+        o = env.reset()
+        map0[i] = o["map"]
+        if has_pos:
+            pos0[i] = o["pos"]
+        assert o["heatmap"].sum() == 0
+    for t in range(T):
+        for i, env in enumerate(envs):
+            a = acts[t, i]
+            o, r, d, inf = env.step(int(a[0]) if rep != "wide" else [int(a[0]), int(a[1]), int(a[2])])
+            rew[t, i] = r
+            done[t, i] = d
+            info[t, i] = [int(inf[k]) for k in keys] + [inf["iterations"], inf["changes"]]
+            if d:
+                o = env.reset()   # vector-env auto-reset semantics: terminal r/d/info, post-reset obs
+            maps[t, i] = o["map"]
+            if has_pos:
+                poss[t, i] = o["pos"]
+            assert o["heatmap"].max() < 65536 and (o["heatmap"] == np.floor(o["heatmap"])).all()
+            heat[t, i] = o["heatmap"].astype(np.uint16)
+    env = envs[0]
+    cfg = np.array([W, H, env._max_changes, env._max_iterations, seed0, action_seed], dtype=np.int64)
+    save("traj_" + name, prob=np.array(prob), rep=np.array(rep), calls=np.array(repr(list(calls))), cfg=cfg,
+         actions=acts, map0=map0, pos0=pos0, maps=maps, pos=poss, heatmap=heat, reward=rew, done=done,
+         info=info, info_keys=np.array(keys + ["iterations", "changes"]))
+    print("    %s: %d env-steps, %d episodes ended, %.1fs" % (name, T * E, int(done.sum()), time.time() - t0))
+
+
+TRAJS = [
+    ("binary_narrow", "binary", "narrow", 32, 400, ()),
+    ("binary_turtle", "binary", "turtle", 16, 300, ()),
+    ("binary_wide", "binary", "wide", 16, 300, ()),
+    ("binary_narrow_seq", "binary", "narrow", 8, 300, (dict(random_tile=False),)),
+    ("binary_narrow_fixedstart", "binary", "narrow", 8, 300, (dict(random_start=False, random_probs=False),)),
+    ("binary_turtle_warp", "binary", "turtle", 8, 300, (dict(warp=True, target_path=5),)),
+    ("binary_narrow_9x21", "binary", "narrow", 8, 300, (dict(width=21, height=9), dict(change_percentage=0.3))),
+    ("binary_turtle_64", "binary", "turtle", 4, 300, (dict(width=64, height=64),)),
+    ("binary_turtle_64_cp", "binary", "turtle", 3, 240, (dict(width=64, height=64), dict(change_percentage=0.2))),
+    ("binary_wide_40x33", "binary", "wide", 4, 120, (dict(width=40, height=33),)),
+    ("zelda_wide_11x16", "zelda", "wide", 32, 300, (dict(width=11, height=16),)),
+    ("zelda_wide", "zelda", "wide", 16, 300, ()),
+    ("zelda_narrow", "zelda", "narrow", 16, 300, ()),
+    ("zelda_turtle", "zelda", "turtle", 16, 300, (dict(change_percentage=0.6),)),
+    ("zelda_wide_params", "zelda", "wide", 8, 200, (dict(max_enemies=3, target_enemy_dist=2, target_path=6,
+                                                          rewards={"regions": 2.5, "path-length": 0.25}),)),
+    ("sokoban_narrow", "sokoban", "narrow", 64, 400, ()),
+    ("sokoban_wide", "sokoban", "wide", 16, 300, ()),
+    ("sokoban_turtle", "sokoban", "turtle", 16, 300, (dict(change_percentage=0.8),)),
+    ("sokoban_narrow_7x6", "sokoban", "narrow", 8, 300, (dict(width=7, height=6), dict(change_percentage=0.4, solver_power=400, max_crates=2))),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    jobs = {
+        "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
+        "stats_sokoban": gen_stats_sokoban, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
+    }
+    for k, fn in jobs.items():
+        if a.only in (None, k):
+            print(k)
+            fn()
+    if a.only in (None, "traj") or (a.only or "").startswith("traj_"):
+        print("traj")
+        for name, prob, rep, E, T, calls in TRAJS:
+            if a.only in (None, "traj", "traj_" + name):
+                gen_traj(name, prob, rep, E, T, calls)
+
+
+if __name__ == "__main__":
+    main()
