@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched PCGRL hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--envs E]
+
+A "step" is one BatchedPcgrlEnv.step() over the whole batch (E environments per GPU, weak scaling):
+Representation.update + Problem.get_stats/get_reward + in-kernel auto-reset, random actions that
+are generated on the device *before* the timed region.  The metric is
+env-steps/s over all GPUs.  One JSON line is printed by rank 0.
+
+Extra objects on the JSON line:
+  roofline      HBM roofline of the step pipeline: achieved = E * B_alg / (GPU time of the step's
+                kernels, from HIP events recorded around every launch on the launch stream, over
+                the same timed steps), B_alg = 2*H*W + 64 bytes per env-step.
+  cpu_baseline  the CPU oracle (oracle/pcgrl_oracle.c, a bit-exact port of the reference) timed on
+                this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (prob, rep, adjust_param calls, envs per GPU, description)
+    "C2": ("binary", "narrow", (), 65536, "binary-narrow-v0 14x14, 65536 envs/GPU"),
+    "C3": ("zelda", "wide", (dict(width=11, height=16),), 65536, "zelda-wide-v0 11x16, 65536 envs/GPU"),
+    "C4": ("sokoban", "narrow", (), 131072, "sokoban-narrow-v0 5x5, 131072 envs/GPU"),
+    "C5": ("binary", "turtle", (dict(width=64, height=64),), 8192, "binary-turtle-v0 64x64 (adjust_param), 8192 envs/GPU"),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def make_actions(torch, rep, steps, n, W, H, nt, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    if rep == "narrow":
+        return torch.randint(0, nt + 1, (steps, n), generator=g, device=device, dtype=torch.int32)
+    if rep == "turtle":
+        return torch.randint(0, nt + 4, (steps, n), generator=g, device=device, dtype=torch.int32)
+    return torch.stack([torch.randint(0, W, (steps, n), generator=g, device=device, dtype=torch.int32),
+                        torch.randint(0, H, (steps, n), generator=g, device=device, dtype=torch.int32),
+                        torch.randint(0, nt, (steps, n), generator=g, device=device, dtype=torch.int32)], -1).contiguous()
+
+
+def cpu_baseline(prob, rep, calls, budget_s=12.0):
+    """Oracle (kind 'port') on every host core: one environment per thread, random actions."""
+    import concurrent.futures as cf
+
+    import numpy as np
+
+    import oracle_lib as ol
+    cores = os.cpu_count() or 1
+
+    def make(i):
+        e = ol.OracleEnv(prob, rep)
+        for kw in calls:
+            e.adjust_param(**kw)
+        e.seed(i)
+        e.reset()
+        return e
+
+    def actions(e, T, seed):
+        rs = np.random.RandomState(seed)
+        nt = e.num_tiles
+        a = np.zeros((T, 3), np.int32)
+        if rep == "narrow":
+            a[:, 0] = rs.randint(0, nt + 1, T)
+        elif rep == "turtle":
+            a[:, 0] = rs.randint(0, nt + 4, T)
+        else:
+            a[:, 0], a[:, 1], a[:, 2] = rs.randint(0, e.width, T), rs.randint(0, e.height, T), rs.randint(0, nt, T)
+        return a
+
+    probe = make(0)
+    t0 = time.perf_counter()
+    probe.rollout(actions(probe, 2000, 1), want_maps=False, want_heat=False)
+    rate1 = 2000 / (time.perf_counter() - t0)
+    T = max(2000, int(rate1 * budget_s))
+    envs = [make(i) for i in range(cores)]
+    acts = [actions(e, T, 100 + i) for i, e in enumerate(envs)]
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL inside orc_rollout
+        list(ex.map(lambda ea: ea[0].rollout(ea[1], want_maps=False, want_heat=False), zip(envs, acts)))
+    dt = time.perf_counter() - t0
+    return {"value": cores * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d random-action steps of the same workload, one env per host thread" % (cores, T),
+            "single_core": rate1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    prob, rep, calls, n_default, desc = WORKLOADS[a.workload]
+    n = a.envs or n_default
+    # environment axis sharded contiguously: rank r owns global envs [r*n, (r+1)*n), seed = global index
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, device=device, seed=rank * n)
+    for kw in calls:
+        env.adjust_param(**kw)
+    env.reset()
+    W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
+    acts = make_actions(torch, rep, a.steps + a.warmup, n, W, H, nt, device, 1234 + rank)
+    for t in range(a.warmup):
+        env.step(acts[t])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    env.profile(True)           # HIP events around every launch, on the launch stream
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(a.warmup, a.warmup + a.steps):
+        env.step(acts[t])
+    barrier()
+    dt = time.perf_counter() - t0
+    phase_ms, prof_steps = env.profile_read()
+    env.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_steps = float(n) * world * a.steps
+        value = total_steps / dt
+        b_alg = 2 * H * W + 64
+        gpu_ms_per_step = sum(phase_ms.values()) / max(prof_steps, 1)
+        achieved = n * b_alg / (gpu_ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), binary-narrow 14x14 @ 65536 envs" if a.workload == "C2" else "env-steps/sec (whole node)",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": desc, "envs_per_gpu": n, "width": W, "height": H, "max_changes": env._max_changes,
+                       "max_iterations": env._max_iterations, "actions": "uniform random, device-generated before the timed region",
+                       "parallelism": "env-axis shard x%d, no collective on the step path" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "step pipeline (k_update+k_stats+k_mapgen+k_stats)",
+                         "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
+                         "phase_ms_per_step": {k: v / max(prof_steps, 1) for k, v in phase_ms.items()}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, rep, calls)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,48 @@
+"""gym_pcgrl_amd: MI355X-native batched PCGRL environment (the step()/reset() hot path of
+amidos2006/gym-pcgrl as hand-written HIP kernels for gfx950, behind the reference's env surface).
+
+    import gym_pcgrl_amd
+    env = gym_pcgrl_amd.make("binary-narrow-v0")                       # reference-style single env
+    venv = gym_pcgrl_amd.make_batched("binary-narrow-v0", num_envs=65536)  # one GPU, lockstep batch
+
+Ids follow gym_pcgrl/__init__.py:6-12: '{prob}-{rep}-v0' for the in-scope problems
+(binary, zelda, sokoban) x representations (narrow, wide, turtle).
+"""
+__version__ = "0.1.0"
+
+_ENV_IDS = {}
+
+
+def _register_all():
+    from .envs.problems import PROBLEMS
+    from .envs.representations import REPRESENTATIONS
+    for prob in PROBLEMS:
+        for rep in REPRESENTATIONS:
+            _ENV_IDS["%s-%s-v0" % (prob, rep)] = (prob, rep)
+
+
+def registered_ids():
+    if not _ENV_IDS:
+        _register_all()
+    return sorted(_ENV_IDS)
+
+
+def _lookup(env_id):
+    if not _ENV_IDS:
+        _register_all()
+    if env_id not in _ENV_IDS:
+        raise KeyError("unknown environment id %r; available: %s" % (env_id, ", ".join(sorted(_ENV_IDS))))
+    return _ENV_IDS[env_id]
+
+
+def make(env_id, **kwargs):
+    """gym.make(id) replacement: a single reference-style PcgrlEnv backed by the HIP kernels."""
+    from .envs import PcgrlEnv
+    prob, rep = _lookup(env_id)
+    return PcgrlEnv(prob=prob, rep=rep, **kwargs)
+
+
+def make_batched(env_id, num_envs, **kwargs):
+    from .envs import BatchedPcgrlEnv
+    prob, rep = _lookup(env_id)
+    return BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=num_envs, **kwargs)

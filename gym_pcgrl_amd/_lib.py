@@ -1,0 +1,111 @@
+"""ctypes binding of the C ABI in include/pcgrl_hip.h (gym_pcgrl_amd/lib/libpcgrl_hip.so).
+
+There is no CPU fallback: if the HIP library is missing the import of the product path fails
+loudly with instructions to build it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+SO = os.path.join(LIBDIR, "libpcgrl_hip.so")
+SOURCES = [os.path.join(CSRC, "pcgrl_kernels.hip")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+PCGRL_OK, PCGRL_EINVAL, PCGRL_EHIP, PCGRL_ESTATE = 0, -1, -2, -3
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "prob", "rep", "num_envs", "width", "height", "max_changes", "max_iterations",
+        "random_start", "random_tile", "warp", "random_probs", "auto_reset", "target_path",
+        "max_enemies", "target_enemy_dist", "max_crates", "target_solution", "solver_power", "reserved_")] + [
+        ("tile_probs", C.c_double * 8), ("rewards", C.c_double * 8)]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("group", "mask_bytes", "nplanes", "nstats")] + [
+        (n, C.c_size_t) for n in ("map", "old_map", "heatmap", "pos", "planes", "counters", "stats", "start_stats",
+                                  "info", "reward", "done", "tile_p", "rng_rep", "rng_prob", "rng_cursor", "scratch")]
+
+
+BUFFER_NAMES = ("map", "old_map", "heatmap", "pos", "planes", "counters", "stats", "start_stats", "info", "reward",
+                "done", "tile_p", "rng_rep", "rng_prob", "rng_cursor", "scratch")
+
+
+class Buffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
+
+
+EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
+           "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
+           "pcgrl_step", "pcgrl_set_maps", "pcgrl_profile", "pcgrl_profile_read")
+NPHASE = 6
+PHASES = ("update", "stats_step", "solver_step", "mapgen", "stats_start", "clear")
+
+
+def sources_newer_than_lib():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "pcgrl_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if not force and not sources_newer_than_lib():
+        return SO
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + SOURCES + ["-o", SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise RuntimeError(
+            "gym_pcgrl_amd: HIP library %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the batched environment." % SO)
+    L = C.CDLL(SO)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError("gym_pcgrl_amd: %s does not export %s (stale build?)" % (SO, name))
+    L.pcgrl_abi_version.restype = C.c_int
+    L.pcgrl_error_string.restype = C.c_char_p
+    L.pcgrl_error_string.argtypes = [C.c_int]
+    L.pcgrl_last_hip_error.restype = C.c_int
+    L.pcgrl_query_layout.argtypes = [C.POINTER(Config), C.POINTER(Layout)]
+    L.pcgrl_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.pcgrl_destroy.argtypes = [C.c_void_p]
+    L.pcgrl_bind.argtypes = [C.c_void_p, C.POINTER(Buffers), C.c_void_p]
+    L.pcgrl_configure.argtypes = [C.c_void_p, C.POINTER(Config)]
+    L.pcgrl_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.pcgrl_set_tile_probs.argtypes = [C.c_void_p, C.c_void_p]
+    L.pcgrl_reset.argtypes = [C.c_void_p, C.c_void_p]
+    L.pcgrl_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcgrl_set_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcgrl_profile.argtypes = [C.c_void_p, C.c_int]
+    L.pcgrl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        L = load()
+        msg = L.pcgrl_error_string(rc).decode()
+        extra = " (hipError %d)" % L.pcgrl_last_hip_error() if rc == PCGRL_EHIP else ""
+        raise RuntimeError("gym_pcgrl_amd: %s failed: %s%s" % (what, msg, extra))

@@ -1,0 +1,726 @@
+// HIP kernels (gfx950 / CDNA4) and C ABI of the batched PCGRL environment.
+//
+// One `pcgrl_step` is four launches on the caller's stream:
+//
+//   k_update   thread per environment.  Representation.update (narrow_rep.py:99-114, wide_rep.py:67-70,
+//              turtle_rep.py:101-129), counters + heatmap (pcgrl_env.py:130-137).  Unchanged
+//              environments are finished here (reward 0, done, info); changed ones are compacted into
+//              a work list with a ballot / prefix-popcount append (one atomic per 256-thread block).
+//   k_stats    one lane group (16 lanes = one DPP row, or a full wavefront for maps taller than 16) per
+//              changed environment: Problem.get_stats as row-bitboard BFS (pcgrl_algos.h), get_reward,
+//              get_episode_over, get_debug_info (pcgrl_env.py:138-148).  Done environments go to the
+//              reset list.
+//   k_mapgen   one wavefront per environment to reset: PcgrlEnv.reset (pcgrl_env.py:66-76): the MT19937
+//              ring is staged in LDS and the wave produces 128 words per round, tiles are drawn with
+//              numpy's choice() rule, written coalesced as uint8 and transposed through LDS into the
+//              row bit planes; cursor draw; BinaryProblem.reset (binary_prob.py:68-72).
+//   k_stats    again in START mode over the reset list (start stats, problem.py:45-46).
+//
+// State is structure-of-arrays over the environment axis, all in HBM, owned by the caller
+// (include/pcgrl_hip.h).  The uint8 map is the observation; the kernels compute on `planes`
+// (row bitboards of the tile-id bits, [N][nplanes][group]) which k_update keeps in sync, so the
+// statistics never re-read or transpose the byte map.  No MFMA: integer/bit work only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/pcgrl_hip.h"
+#include "lanegroup_dev.h"
+#include "mt19937.h"
+#include "pcgrl_algos.h"
+
+#define PCGRL_BLOCK 256
+enum { CNT_CHG = 0, CNT_RST = 1, CNT_SOL = 2, CNT_STRIDE = 4 };
+enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
+
+struct DevBufs {
+    uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
+    int32_t* counters; int32_t* stats; int32_t* start_stats; int32_t* info;
+    double* reward; uint8_t* done; double* tile_p;
+    uint32_t* rng_rep; uint32_t* rng_prob; int32_t* rng_cur;
+    int32_t* counts; int32_t* chg_list; int32_t* rst_list; int32_t* sol_list;
+};
+
+// ------------------------------------------------------------------------------------------
+// Block-wide stream compaction: every thread of the block must call this.
+__device__ __forceinline__ void block_append(bool flag, int value, int32_t* list, int32_t* counter,
+                                             int* s_cnt, int* s_base) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t m = __ballot(flag);
+    if (lane == 0) s_cnt[w] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        *s_base = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    if (flag) {
+        int off = *s_base;
+        for (int i = 0; i < w; i++) off += s_cnt[i];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        list[off] = value;
+    }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ------------------------------------------------------------------------------------------
+// k_update: thread per environment
+template <int REP, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
+    __shared__ int s_cnt[2][4];
+    __shared__ int s_base[2];
+    const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
+    const bool act = e < P.num_envs;
+    bool chg = false, rst = false;
+    if (act) {
+        const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
+        int2 c = reinterpret_cast<int2*>(B.counters)[e];
+        const int iter = c.x + 1;
+        int changes = c.y;
+        int x = 0, y = 0;
+        if (REP != PCGRL_REP_WIDE) {
+            uchar2 p = reinterpret_cast<uchar2*>(B.pos)[e];
+            x = p.x; y = p.y;
+        }
+        int tile = -1, wx = 0, wy = 0, hx = 0, hy = 0;
+        if (REP == PCGRL_REP_NARROW) {
+            int a = clampi(actions[e], 0, P.ntiles);
+            if (a > 0) { tile = a - 1; wx = x; wy = y; }
+        } else if (REP == PCGRL_REP_WIDE) {
+            wx = clampi(actions[3 * e + 0], 0, W - 1);
+            wy = clampi(actions[3 * e + 1], 0, H - 1);
+            tile = clampi(actions[3 * e + 2], 0, P.ntiles - 1);
+            hx = wx; hy = wy;
+        } else {
+            int a = clampi(actions[e], 0, P.ntiles + 3);
+            if (a < 4) {   // turtle_rep.py:18,103-125: L,R,U,D with clamp or warp on both axes
+                const int dx = (a == 0) ? -1 : (a == 1 ? 1 : 0), dy = (a == 2) ? -1 : (a == 3 ? 1 : 0);
+                x += dx;
+                if (x < 0) x = P.warp ? x + W : 0;
+                if (x >= W) x = P.warp ? x - W : W - 1;
+                y += dy;
+                if (y < 0) y = P.warp ? y + H : 0;
+                if (y >= H) y = P.warp ? y - H : H - 1;
+            } else {
+                tile = a - 4; wx = x; wy = y;
+            }
+            hx = x; hy = y;
+        }
+        if (tile >= 0) {
+            uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
+            const int old = *cell;
+            if (old != tile) {
+                chg = true;
+                *cell = (uint8_t)tile;
+                MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G + wy;
+                const MaskT bit = (MaskT)1 << wx;
+                for (int b = 0; b < NPL; b++) {
+                    MaskT m = pl[b * G];
+                    m = ((tile >> b) & 1) ? (m | bit) : (m & ~bit);
+                    pl[b * G] = m;
+                }
+            }
+        }
+        if (REP == PCGRL_REP_NARROW) {   // the cursor moves on every step (narrow_rep.py:104-113)
+            if (P.random_tile) {
+                uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
+                int cur = B.rng_cur[2 * e];
+                x = mt_randint(ring, cur, W);
+                y = mt_randint(ring, cur, H);
+                B.rng_cur[2 * e] = cur;
+            } else {
+                x += 1;
+                if (x >= W) { x = 0; y += 1; if (y >= H) y = 0; }
+            }
+            hx = x; hy = y;   // pcgrl_env.py:137 marks the *new* cursor cell
+        }
+        if (chg) {
+            changes += 1;
+            B.heat[((size_t)e * H + hy) * W + hx] += 1;
+        }
+        reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
+        if (REP != PCGRL_REP_WIDE) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        if (!chg) {
+            // new_stats is old_stats (pcgrl_env.py:132-142): reward 0, done/info from the current stats
+            int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
+            const int4* sp = reinterpret_cast<const int4*>(B.stats + (size_t)e * 8);
+            const int4* tp = reinterpret_cast<const int4*>(B.start_stats + (size_t)e * 8);
+            int4 a0 = sp[0], a1 = sp[1], b0 = tp[0], b1 = tp[1];
+            s[0] = a0.x; s[1] = a0.y; s[2] = a0.z; s[3] = a0.w; s[4] = a1.x; s[5] = a1.y; s[6] = a1.z; s[7] = a1.w;
+            st[0] = b0.x; st[1] = b0.y; st[2] = b0.z; st[3] = b0.w; st[4] = b1.x; st[5] = b1.y; st[6] = b1.z; st[7] = b1.w;
+            const bool d = episode_over(P, s, st) || changes >= P.max_changes || iter >= P.max_iterations;
+            B.reward[e] = 0.0;
+            B.done[e] = d ? 1 : 0;
+            int32_t* inf = B.info + (size_t)e * 10;
+            inf[0] = a0.x; inf[1] = a0.y; inf[2] = a0.z; inf[3] = a0.w;
+            inf[4] = a1.x; inf[5] = a1.y; inf[6] = a1.z; inf[7] = a1.w;
+            if (P.prob == PCGRL_PROB_BINARY) inf[2] = a0.y - b0.y;   // path-imp (binary_prob.py:137)
+            inf[8] = iter; inf[9] = changes;
+            rst = d && P.auto_reset;
+        }
+    }
+    int32_t* counts = B.counts + parity * CNT_STRIDE;
+    block_append(chg, e, B.chg_list, counts + CNT_CHG, s_cnt[0], &s_base[0]);
+    block_append(rst, e, B.rst_list, counts + CNT_RST, s_cnt[1], &s_base[1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_stats: lane group per work item
+template <class MaskT>
+__device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
+    MaskT full = (W >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << W) - 1);
+    return lane < H ? full : (MaskT)0;
+}
+
+__device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
+                                              int mode, int32_t* counts) {
+    int32_t* st = B.stats + (size_t)e * 8;
+    int32_t* start = B.start_stats + (size_t)e * 8;
+    if (mode == MODE_STEP) {
+        int32_t old[PCGRL_MAX_STATS], sv[PCGRL_MAX_STATS];
+        for (int k = 0; k < 8; k++) { old[k] = st[k]; sv[k] = start[k]; }
+        const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
+        const double r = compute_reward(P, s, old);
+        const bool d = episode_over(P, s, sv) || c.y >= P.max_changes || c.x >= P.max_iterations;
+        B.reward[e] = r;
+        B.done[e] = d ? 1 : 0;
+        int32_t* inf = B.info + (size_t)e * 10;
+        for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
+        if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
+        inf[8] = c.x; inf[9] = c.y;
+        if (d && P.auto_reset) {
+            int i = atomicAdd(counts + CNT_RST, 1);
+            B.rst_list[i] = e;
+        }
+    } else {
+        for (int k = 0; k < 8; k++) st[k] = s[k];
+        if (mode == MODE_START)
+            for (int k = 0; k < 8; k++) start[k] = s[k];
+    }
+}
+
+template <int PROB, int G, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, const int32_t* __restrict__ list,
+                                                        int count_idx, int parity, int mode) {
+    DevGroup<G, MaskT> g;
+    constexpr int GPB = PCGRL_BLOCK / G;
+    int32_t* counts = B.counts + parity * CNT_STRIDE;
+    const int n = counts[count_idx];
+    const int gi = threadIdx.x / G;
+    const int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
+    for (int item = blockIdx.x * GPB + gi; item < n; item += gridDim.x * GPB) {
+        const int e = list[item];
+        const MaskT* pl = reinterpret_cast<const MaskT*>(B.planes) + (size_t)e * NPL * G + g.lane;
+        const MaskT valid = row_valid<MaskT>(g.lane, P.width, P.height);
+        int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool need_solver = false;
+        if (PROB == PCGRL_PROB_BINARY) {
+            const MaskT b0 = pl[0];
+            int regions, path;
+            regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path);
+            s[0] = regions; s[1] = path;
+        } else {
+            const MaskT b0 = pl[0], b1 = pl[G], b2 = pl[2 * G];
+            if (PROB == PCGRL_PROB_ZELDA) zelda_stats(g, P, b0, b1, b2, valid, s);
+            else need_solver = sokoban_stats(g, P, b0, b1, b2, valid, s);
+        }
+        if (g.lane == 0) {
+            if (need_solver) {
+                // park the partial stats in the info row and hand the environment to the solver kernel
+                int32_t* inf = B.info + (size_t)e * 10;
+                for (int k = 0; k < 8; k++) inf[k] = s[k];
+                int i = atomicAdd(counts + CNT_SOL, 1);
+                B.sol_list[i] = e;
+            } else {
+                finalize_item(P, B, e, s, mode, counts);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row bit planes from a tile byte map staged in LDS; lanes [0,G) of the wave each take one row.
+template <class MaskT>
+__device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const uint8_t* tiles, MaskT* planes_e, int lane) {
+    const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
+    if (lane < G) {
+        MaskT m0 = 0, m1 = 0, m2 = 0;
+        if (lane < H) {
+            const uint8_t* row = tiles + lane * W;
+            for (int x = 0; x < W; x++) {
+                const MaskT t = row[x];
+                m0 |= (t & 1) << x;
+                m1 |= ((t >> 1) & 1) << x;
+                m2 |= ((t >> 2) & 1) << x;
+            }
+        }
+        planes_e[lane] = m0;
+        if (NPL > 1) { planes_e[G + lane] = m1; planes_e[2 * G + lane] = m2; }
+    }
+}
+
+// k_mapgen: wavefront per environment to reset
+template <class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_mapgen(PcgrlParams P, DevBufs B, int parity, int gen_map) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W = P.width, H = P.height, cells = W * H;
+    const int tiles_bytes = (cells + 15) & ~15;
+    uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)wv * (PCGRL_MT_N * 4 + tiles_bytes));
+    uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
+    int32_t* counts = B.counts + parity * CNT_STRIDE;
+    const int n = counts[CNT_RST];
+    for (int item = blockIdx.x * 4 + wv; item < n; item += gridDim.x * 4) {
+        const int e = B.rst_list[item];
+        uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
+        uint8_t* map_g = B.map + (size_t)e * cells;
+        uint8_t* old_g = B.old_map + (size_t)e * cells;
+        int cur = B.rng_cur[2 * e];
+        for (int i = lane; i < PCGRL_MT_N; i += 64) mt[i] = ring_g[i];
+        __builtin_amdgcn_wave_barrier();
+        if (gen_map) {
+            // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
+            double cdf[PCGRL_MAX_TILES];
+            if (P.prob == PCGRL_PROB_BINARY) {
+                double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};
+                pcgrl_build_cdf(p, 2, cdf);
+            } else {
+                for (int i = 0; i < P.ntiles; i++) cdf[i] = P.cdf[i];
+            }
+            for (int c0 = 0; c0 < cells; c0 += 64) {
+                // cell c draws ring words 2c, 2c+1 of this episode: 128 new words per round, every
+                // operand is an *old* word (distance 397 > 128), so all reads come before all writes
+                const int c = c0 + lane;
+                int s = cur + 2 * lane; s = s >= PCGRL_MT_N ? s - PCGRL_MT_N : s;
+                const uint32_t x0 = mt[s], x1 = mt[mt_wrap(s + 1)], x2 = mt[mt_wrap(s + 2)];
+                const uint32_t xm0 = mt[mt_wrap(s + PCGRL_MT_M)], xm1 = mt[mt_wrap(s + PCGRL_MT_M + 1)];
+                const uint32_t ya = mt_twist(x0, x1, xm0), yb = mt_twist(x1, x2, xm1);
+                __builtin_amdgcn_wave_barrier();
+                if (c < cells) {
+                    mt[s] = ya;
+                    mt[mt_wrap(s + 1)] = yb;
+                    const double u = mt_to_double(mt_temper(ya), mt_temper(yb));
+                    const uint8_t t = (uint8_t)pcgrl_pick_tile(cdf, P.ntiles, u);
+                    tiles[c] = t;
+                    map_g[c] = t;
+                    old_g[c] = t;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int adv = 2 * ((cells - c0) < 64 ? (cells - c0) : 64);
+                cur += adv; cur = cur >= PCGRL_MT_N ? cur - PCGRL_MT_N : cur;
+            }
+        } else {
+            // representation.py:44-45: restore the first map of this environment
+            for (int c = lane; c < cells; c += 64) { const uint8_t t = old_g[c]; tiles[c] = t; map_g[c] = t; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33
+            int x = 0, y = 0;
+            if (lane == 0) {
+                x = mt_randint(mt, cur, W);
+                y = mt_randint(mt, cur, H);
+                reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+            }
+            cur = __shfl(cur, 0, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < PCGRL_MT_N; i += 64) ring_g[i] = mt[i];
+        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane);
+        uint16_t* heat_g = B.heat + (size_t)e * cells;
+        for (int c = lane; c < cells; c += 64) heat_g[c] = 0;        // pcgrl_env.py:72
+        if (lane == 0) {
+            B.rng_cur[2 * e] = cur;
+            reinterpret_cast<int2*>(B.counters)[e] = make_int2(0, 0);   // pcgrl_env.py:67-68
+            if (P.prob == PCGRL_PROB_BINARY && P.random_probs) {         // binary_prob.py:68-72 (problem stream)
+                uint32_t* ring_p = B.rng_prob + (size_t)e * PCGRL_MT_N;
+                int cp = B.rng_cur[2 * e + 1];
+                const double pe = mt_random(ring_p, cp);
+                B.rng_cur[2 * e + 1] = cp;
+                B.tile_p[2 * e] = pe;
+                B.tile_p[2 * e + 1] = 1 - pe;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// set_maps support: byte maps -> planes (wavefront per environment)
+template <class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_planes_from_map(PcgrlParams P, DevBufs B, const uint8_t* __restrict__ src) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cells = P.width * P.height;
+    uint8_t* tiles = smem + (size_t)wv * ((cells + 15) & ~15);
+    for (int e = blockIdx.x * 4 + wv; e < P.num_envs; e += gridDim.x * 4) {
+        for (int c = lane; c < cells; c += 64) {
+            uint8_t t = src[(size_t)e * cells + c];
+            t = t < P.ntiles ? t : (uint8_t)(P.ntiles - 1);
+            tiles[c] = t;
+            B.map[(size_t)e * cells + c] = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void k_fill_all(DevBufs B, int n, int parity, int count_idx, int32_t* list) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) list[i] = i;
+    if (i == 0) B.counts[parity * CNT_STRIDE + count_idx] = n;
+}
+__global__ void k_clear_counts(DevBufs B, int parity) {
+    if (threadIdx.x < CNT_STRIDE) B.counts[parity * CNT_STRIDE + threadIdx.x] = 0;
+}
+__global__ void k_bcast_tile_p(double* tile_p, int n, double p0, double p1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { tile_p[2 * i] = p0; tile_p[2 * i + 1] = p1; }
+}
+__global__ void k_zero_cursors(int32_t* cur, int first, int count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { cur[2 * (first + i)] = 0; cur[2 * (first + i) + 1] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side of the ABI
+struct pcgrl_env {
+    pcgrl_config cfg;
+    PcgrlParams P;
+    pcgrl_layout L;
+    DevBufs B;
+    int bound;
+    int has_old;      // at least one random reset happened (representation.py:41)
+    int was_reset;
+    int parity;
+    int device;
+    // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
+    int profiling;
+    std::vector<hipEvent_t> events;
+    size_t ev_used;
+    int prof_steps;
+};
+#define PCGRL_NPHASE 6   /* update, stats(step), solver(step), mapgen, stats(start)+solver(start), clear */
+static int prof_mark(pcgrl_env* h, hipStream_t st) {
+    if (!h->profiling) return PCGRL_OK;
+    if (h->ev_used == h->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return PCGRL_EHIP;
+        h->events.push_back(e);
+    }
+    if (hipEventRecord(h->events[h->ev_used++], st) != hipSuccess) return PCGRL_EHIP;
+    return PCGRL_OK;
+}
+
+static thread_local int g_last_hip = 0;
+#define HIPCHK(expr) do { hipError_t err_ = (expr); if (err_ != hipSuccess) { g_last_hip = (int)err_; return PCGRL_EHIP; } } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int validate_config(const pcgrl_config* c) {
+    if (!c) return PCGRL_EINVAL;
+    if (c->prob < 0 || c->prob > 2 || c->rep < 0 || c->rep > 2) return PCGRL_EINVAL;
+    if (c->num_envs < 1) return PCGRL_EINVAL;
+    if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
+    if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
+    return PCGRL_OK;
+}
+static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_ZELDA ? 8 : 5); }
+
+static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
+    memset(P, 0, sizeof(*P));
+    P->prob = c->prob; P->rep = c->rep; P->num_envs = c->num_envs;
+    P->width = c->width; P->height = c->height;
+    P->prob_width = c->width; P->prob_height = c->height;
+    P->ntiles = ntiles_of(c->prob);
+    P->nplanes = c->prob == PCGRL_BINARY ? 1 : 3;
+    P->group = c->height <= 16 ? 16 : 64;
+    P->mask_bytes = c->width <= 32 ? 4 : 8;
+    P->max_changes = c->max_changes; P->max_iterations = c->max_iterations;
+    P->random_start = c->random_start; P->random_tile = c->random_tile; P->warp = c->warp;
+    P->random_probs = c->random_probs; P->auto_reset = c->auto_reset;
+    P->target_path = c->target_path; P->max_enemies = c->max_enemies; P->target_enemy_dist = c->target_enemy_dist;
+    P->max_crates = c->max_crates; P->target_solution = c->target_solution; P->solver_power = c->solver_power;
+    for (int i = 0; i < 8; i++) P->rewards[i] = c->rewards[i];
+    pcgrl_build_cdf(c->tile_probs, P->ntiles, P->cdf);
+}
+
+static size_t scratch_bytes(const pcgrl_config* c) {
+    size_t n = (size_t)c->num_envs;
+    return 256 + 3 * align_up(n * 4, 256);
+}
+
+extern "C" {
+
+int pcgrl_abi_version(void) { return PCGRL_ABI_VERSION; }
+int pcgrl_last_hip_error(void) { return g_last_hip; }
+const char* pcgrl_error_string(int code) {
+    switch (code) {
+        case PCGRL_OK: return "ok";
+        case PCGRL_EINVAL: return "invalid argument or unsupported configuration";
+        case PCGRL_EHIP: return "HIP runtime error";
+        case PCGRL_ESTATE: return "call order violated (bind, seed and reset before step)";
+        default: return "unknown error";
+    }
+}
+
+int pcgrl_query_layout(const pcgrl_config* c, pcgrl_layout* L) {
+    int rc = validate_config(c);
+    if (rc) return rc;
+    if (!L) return PCGRL_EINVAL;
+    PcgrlParams P;
+    fill_params(c, &P);
+    const size_t n = (size_t)c->num_envs, cells = (size_t)c->width * c->height;
+    memset(L, 0, sizeof(*L));
+    L->group = P.group; L->mask_bytes = P.mask_bytes; L->nplanes = P.nplanes; L->nstats = num_stats(c->prob);
+    L->map = n * cells; L->old_map = n * cells; L->heatmap = n * cells * 2; L->pos = n * 2;
+    L->planes = n * P.nplanes * P.group * P.mask_bytes;
+    L->counters = n * 8; L->stats = n * 32; L->start_stats = n * 32; L->info = n * 40;
+    L->reward = n * 8; L->done = n; L->tile_p = n * 16;
+    L->rng_rep = n * PCGRL_MT_N * 4; L->rng_prob = c->prob == PCGRL_BINARY ? n * PCGRL_MT_N * 4 : 0;
+    L->rng_cursor = n * 8;
+    L->scratch = scratch_bytes(c);
+    return PCGRL_OK;
+}
+
+int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
+    int rc = validate_config(c);
+    if (rc) return rc;
+    if (!out) return PCGRL_EINVAL;
+    if (c->prob == PCGRL_SOKOBAN) return PCGRL_EINVAL;   // solver kernel lands in the next milestone
+    pcgrl_env* h = new pcgrl_env();
+    h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
+    h->profiling = 0; h->ev_used = 0; h->prof_steps = 0;
+    memset(&h->B, 0, sizeof(h->B));
+    h->cfg = *c;
+    fill_params(c, &h->P);
+    pcgrl_query_layout(c, &h->L);
+    *out = h;
+    return PCGRL_OK;
+}
+
+int pcgrl_destroy(pcgrl_env* h) {
+    if (h) for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    delete h;
+    return PCGRL_OK;
+}
+
+int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
+    if (!h || !b) return PCGRL_EINVAL;
+    if (!b->map || !b->old_map || !b->heatmap || !b->pos || !b->planes || !b->counters || !b->stats ||
+        !b->start_stats || !b->info || !b->reward || !b->done || !b->tile_p || !b->rng_rep || !b->rng_cursor || !b->scratch)
+        return PCGRL_EINVAL;
+    if (h->cfg.prob == PCGRL_BINARY && !b->rng_prob) return PCGRL_EINVAL;
+    DevBufs& B = h->B;
+    B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
+    B.planes = b->planes; B.counters = (int32_t*)b->counters; B.stats = (int32_t*)b->stats;
+    B.start_stats = (int32_t*)b->start_stats; B.info = (int32_t*)b->info; B.reward = (double*)b->reward;
+    B.done = (uint8_t*)b->done; B.tile_p = (double*)b->tile_p; B.rng_rep = (uint32_t*)b->rng_rep;
+    B.rng_prob = (uint32_t*)b->rng_prob; B.rng_cur = (int32_t*)b->rng_cursor;
+    const size_t n = (size_t)h->cfg.num_envs, lst = align_up(n * 4, 256);
+    uint8_t* s = (uint8_t*)b->scratch;
+    B.counts = (int32_t*)s;
+    B.chg_list = (int32_t*)(s + 256);
+    B.rst_list = (int32_t*)(s + 256 + lst);
+    B.sol_list = (int32_t*)(s + 256 + 2 * lst);
+    HIPCHK(hipMemsetAsync(B.counts, 0, 256, (hipStream_t)stream));
+    h->bound = 1; h->has_old = 0; h->was_reset = 0; h->parity = 0;
+    return PCGRL_OK;   // tile_p is caller state: call pcgrl_set_tile_probs once after the first bind
+}
+
+int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
+    if (!h) return PCGRL_EINVAL;
+    int rc = validate_config(c);
+    if (rc) return rc;
+    if (c->prob != h->cfg.prob || c->rep != h->cfg.rep || c->num_envs != h->cfg.num_envs ||
+        c->width != h->cfg.width || c->height != h->cfg.height)
+        return PCGRL_EINVAL;
+    h->cfg = *c;
+    fill_params(c, &h->P);
+    return PCGRL_OK;
+}
+
+int pcgrl_set_tile_probs(pcgrl_env* h, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    const int n = h->cfg.num_envs;
+    hipLaunchKernelGGL(k_bcast_tile_p, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->B.tile_p, n,
+                       h->cfg.tile_probs[0], h->cfg.tile_probs[1]);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+int pcgrl_seed(pcgrl_env* h, const uint32_t* keys, int32_t first, int32_t count, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!keys || first < 0 || count < 1 || first + count > h->cfg.num_envs) return PCGRL_EINVAL;
+    const size_t bytes = (size_t)count * PCGRL_MT_N * 4, off = (size_t)first * PCGRL_MT_N;
+    HIPCHK(hipMemcpyAsync(h->B.rng_rep + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (h->B.rng_prob) HIPCHK(hipMemcpyAsync(h->B.rng_prob + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_zero_cursors, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->B.rng_cur, first, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // `keys` may be pageable host memory
+    return PCGRL_OK;
+}
+
+}  // extern "C"
+
+// ---- launch helpers ------------------------------------------------------------------------
+static int grid_for(int items, int per_block, int cap) {
+    int g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return g < cap ? g : cap;
+}
+
+template <int PROB>
+static int launch_stats_p(pcgrl_env* h, const int32_t* list, int count_idx, int parity, int mode, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const int gpb = PCGRL_BLOCK / P.group;
+    const int grid = grid_for(P.num_envs, gpb, 8192);
+    if (P.group == 16 && P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+    else if (P.group == 16)
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+    else if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+    else
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+static int launch_stats(pcgrl_env* h, const int32_t* list, int count_idx, int parity, int mode, hipStream_t st) {
+    switch (h->P.prob) {
+        case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, count_idx, parity, mode, st);
+        case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, count_idx, parity, mode, st);
+        default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, count_idx, parity, mode, st);
+    }
+}
+
+template <class MaskT>
+static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const int grid = (P.num_envs + PCGRL_BLOCK - 1) / PCGRL_BLOCK;
+    switch (P.rep) {
+        case PCGRL_REP_NARROW:
+            hipLaunchKernelGGL((k_update<PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        case PCGRL_REP_WIDE:
+            hipLaunchKernelGGL((k_update<PCGRL_REP_WIDE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        default:
+            hipLaunchKernelGGL((k_update<PCGRL_REP_TURTLE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+    }
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+static int launch_mapgen(pcgrl_env* h, int parity, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const int cells = P.width * P.height;
+    const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((cells + 15) & ~15));
+    const int grid = grid_for(P.num_envs, 4, 4096);
+    const int gen = (P.random_start || !h->has_old) ? 1 : 0;
+    if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_mapgen<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen);
+    else
+        hipLaunchKernelGGL((k_mapgen<uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+extern "C" {
+
+int pcgrl_reset(pcgrl_env* h, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = h->cfg.num_envs, par = h->parity;
+    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)CNT_RST, h->B.rst_list);
+    HIPCHK(hipGetLastError());
+    int rc = launch_mapgen(h, par, st);
+    if (rc) return rc;
+    rc = launch_stats(h, h->B.rst_list, CNT_RST, par, MODE_START, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, st, h->B, par);
+    HIPCHK(hipGetLastError());
+    h->has_old = 1;
+    h->was_reset = 1;
+    return PCGRL_OK;
+}
+
+int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!actions) return PCGRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int par = h->parity;
+    int rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    rc = (h->P.mask_bytes == 4) ? launch_update_m<uint32_t>(h, actions, par, st) : launch_update_m<uint64_t>(h, actions, par, st);
+    if (rc) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    rc = launch_stats(h, h->B.chg_list, CNT_CHG, par, MODE_STEP, st);
+    if (rc) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    if ((rc = prof_mark(h, st))) return rc;   // (solver phase placeholder)
+    if (h->P.auto_reset) {
+        rc = launch_mapgen(h, par, st);
+        if (rc) return rc;
+    }
+    if ((rc = prof_mark(h, st))) return rc;
+    if (h->P.auto_reset) {
+        rc = launch_stats(h, h->B.rst_list, CNT_RST, par, MODE_START, st);
+        if (rc) return rc;
+    }
+    if ((rc = prof_mark(h, st))) return rc;
+    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, st, h->B, par);
+    HIPCHK(hipGetLastError());
+    if ((rc = prof_mark(h, st))) return rc;
+    if (h->profiling) h->prof_steps++;
+    return PCGRL_OK;
+}
+
+int pcgrl_profile(pcgrl_env* h, int enable) {
+    if (!h) return PCGRL_EINVAL;
+    h->profiling = enable ? 1 : 0;
+    h->ev_used = 0;
+    h->prof_steps = 0;
+    return PCGRL_OK;
+}
+
+// Sums the per-phase GPU time (ms) of every step issued since pcgrl_profile(h, 1); synchronises.
+int pcgrl_profile_read(pcgrl_env* h, double* phase_ms, int32_t* steps) {
+    if (!h || !phase_ms || !steps) return PCGRL_EINVAL;
+    for (int k = 0; k < PCGRL_NPHASE; k++) phase_ms[k] = 0.0;
+    *steps = h->prof_steps;
+    if (h->ev_used == 0) return PCGRL_OK;
+    HIPCHK(hipEventSynchronize(h->events[h->ev_used - 1]));
+    const size_t per = PCGRL_NPHASE + 1;
+    for (size_t s0 = 0; s0 + per <= h->ev_used; s0 += per)
+        for (int k = 0; k < PCGRL_NPHASE; k++) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->events[s0 + k], h->events[s0 + k + 1]));
+            phase_ms[k] += ms;
+        }
+    return PCGRL_OK;
+}
+
+int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!maps) return PCGRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const PcgrlParams& P = h->P;
+    const int n = P.num_envs, par = h->parity, cells = P.width * P.height;
+    const size_t lds = 4 * (size_t)((cells + 15) & ~15);
+    const int grid = grid_for(n, 4, 4096);
+    if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_planes_from_map<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
+    else
+        hipLaunchKernelGGL((k_planes_from_map<uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)CNT_CHG, h->B.chg_list);
+    HIPCHK(hipGetLastError());
+    int rc = launch_stats(h, h->B.chg_list, CNT_CHG, par, MODE_SETMAP, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, st, h->B, par);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,306 @@
+"""BatchedPcgrlEnv: N lockstep PcgrlEnv instances on one MI355X.
+
+Mirrors the reference's PcgrlEnv (pcgrl_env.py) method for method -- seed / reset / step /
+adjust_param / get_border_tile / get_num_tiles -- with a leading environment axis, vector-env
+auto-reset (the reference leaves that to SubprocVecEnv, utils.py:60-71) and torch tensors that are
+zero-copy views of the state the HIP kernels own.  All computation happens in
+gym_pcgrl_amd/lib/libpcgrl_hip.so through the C ABI of include/pcgrl_hip.h; there is no CPU path.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib, seeding, spaces
+from .problems import PROB_IDS, PROBLEMS
+from .representations import REP_IDS, REPRESENTATIONS
+
+
+class InfoBatch:
+    """Struct-of-tensors view of the per-step info dicts (pcgrl_env.py:144-148)."""
+
+    def __init__(self, keys, table, max_iterations, max_changes):
+        self.keys = list(keys)
+        self.table = table            # int32 [N,10]: problem info (8 slots), iterations, changes
+        self.max_iterations = max_iterations
+        self.max_changes = max_changes
+
+    def __getitem__(self, key):
+        if key == "iterations":
+            return self.table[:, 8]
+        if key == "changes":
+            return self.table[:, 9]
+        if key == "max_iterations":
+            return self.max_iterations
+        if key == "max_changes":
+            return self.max_changes
+        return self.table[:, self.keys.index(key)]
+
+    def to_list(self):
+        t = self.table.cpu().numpy()
+        out = []
+        for row in t:
+            d = {k: int(row[i]) for i, k in enumerate(self.keys)}
+            d["iterations"] = int(row[8])
+            d["changes"] = int(row[9])
+            d["max_iterations"] = self.max_iterations
+            d["max_changes"] = self.max_changes
+            out.append(d)
+        return out
+
+
+class BatchedPcgrlEnv:
+    metadata = {"render.modes": []}
+
+    def __init__(self, prob="binary", rep="narrow", num_envs=1, device=None, seed=None, auto_reset=True):
+        import torch
+        self._torch = torch
+        self._lib = _lib.load()                      # fails loudly when the HIP library is absent
+        self._prob = PROBLEMS[prob]()                # KeyError on unknown names, like pcgrl_env.py:28-29
+        self._rep = REPRESENTATIONS[rep]()
+        self.num_envs = int(num_envs)
+        self.auto_reset = bool(auto_reset)
+        if device is None:
+            device = "cuda:0"
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedPcgrlEnv runs on an AMD GPU only (device=%r); there is no CPU fallback" % (device,))
+        # pcgrl_env.py:33-34
+        self._max_changes = max(int(0.2 * self._prob._width * self._prob._height), 1)
+        self._max_iterations = self._max_changes * self._prob._width * self._prob._height
+        self._handle = None
+        self._bufs = None
+        self._rng = None          # RNG tensors survive re-allocation on width/height changes
+        self._needs_reset = True
+        self._alloc_dims = None
+        self._probs_dirty = False
+        self._update_spaces()
+        self.seed(seed)
+
+    # ------------------------------------------------------------------ spaces / simple getters
+    def _update_spaces(self):
+        w, h, t = self._prob._width, self._prob._height, self.get_num_tiles()
+        self.single_action_space = self._rep.get_action_space(w, h, t)
+        self.single_observation_space = self._rep.get_observation_space(w, h, t)
+        self.single_observation_space.spaces["heatmap"] = spaces.Box(low=0, high=self._max_changes, dtype=np.uint8, shape=(h, w))
+        self.action_space = self.single_action_space
+        self.observation_space = self.single_observation_space
+
+    def get_border_tile(self):
+        return self._prob.get_tile_types().index(self._prob._border_tile)
+
+    def get_num_tiles(self):
+        return len(self._prob.get_tile_types())
+
+    # ------------------------------------------------------------------ config plumbing
+    def _config(self):
+        c = _lib.Config()
+        c.prob, c.rep, c.num_envs = PROB_IDS[self._prob.name], REP_IDS[self._rep.name], self.num_envs
+        c.width, c.height = int(self._prob._width), int(self._prob._height)
+        c.max_changes, c.max_iterations = int(self._max_changes), int(self._max_iterations)
+        c.random_start, c.random_tile, c.warp, c.random_probs = 1, 1, 0, 0
+        c.auto_reset = int(self.auto_reset)
+        for k, v in list(self._prob.device_params().items()) + list(self._rep.device_params().items()):
+            setattr(c, k, v)
+        for i, t in enumerate(self._prob.tiles):
+            c.tile_probs[i] = float(self._prob._prob[t])
+        for i, k in enumerate(self._prob.reward_keys):
+            c.rewards[i] = float(self._prob._rewards[k])
+        return c
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _free(self):
+        if self._handle is not None:
+            self._torch.cuda.synchronize(self.device)
+            self._lib.pcgrl_destroy(self._handle)
+            self._handle = None
+        self._bufs = None
+
+    def _allocate(self):
+        torch = self._torch
+        self._free()
+        cfg = self._config()
+        lay = _lib.Layout()
+        _lib.check(self._lib.pcgrl_query_layout(C.byref(cfg), C.byref(lay)), "pcgrl_query_layout")
+        n, w, h = self.num_envs, cfg.width, cfg.height
+        dev = self.device
+        mask_dtype = torch.int32 if lay.mask_bytes == 4 else torch.int64
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        b = OrderedDict()
+        b["map"] = z((n, h, w), torch.uint8)
+        b["old_map"] = z((n, h, w), torch.uint8)
+        b["heatmap"] = z((n, h, w), torch.int16)
+        b["pos"] = z((n, 2), torch.uint8)
+        b["planes"] = z((n, lay.nplanes, lay.group), mask_dtype)
+        b["counters"] = z((n, 2), torch.int32)
+        b["stats"] = z((n, 8), torch.int32)
+        b["start_stats"] = z((n, 8), torch.int32)
+        b["info"] = z((n, 10), torch.int32)
+        b["reward"] = z((n,), torch.float64)
+        b["done"] = z((n,), torch.uint8)
+        first = self._rng is None
+        if first:
+            self._rng = OrderedDict()
+            self._rng["tile_p"] = z((n, 2), torch.float64)      # BinaryProblem._prob per environment
+            self._rng["rng_rep"] = z((n, seeding.MT_N), torch.int32)
+            self._rng["rng_prob"] = z((n, seeding.MT_N), torch.int32) if self._prob.name == "binary" else None
+            self._rng["rng_cursor"] = z((n, 2), torch.int32)
+            self._rng_seeded = False
+        b.update(self._rng)
+        b["scratch"] = z((int(lay.scratch),), torch.uint8)
+        for name in _lib.BUFFER_NAMES:
+            t = b[name]
+            if t is not None:
+                assert t.is_contiguous() and t.numel() * t.element_size() >= getattr(lay, name), name
+        handle = C.c_void_p()
+        _lib.check(self._lib.pcgrl_create(C.byref(cfg), C.byref(handle)), "pcgrl_create")
+        bufs = _lib.Buffers()
+        for name in _lib.BUFFER_NAMES:
+            setattr(bufs, name, b[name].data_ptr() if b[name] is not None else None)
+        _lib.check(self._lib.pcgrl_bind(handle, C.byref(bufs), self._stream()), "pcgrl_bind")
+        self._handle, self._bufs, self._layout = handle, b, lay
+        self._alloc_dims = (w, h)
+        if first or self._probs_dirty:
+            _lib.check(self._lib.pcgrl_set_tile_probs(self._handle, self._stream()), "pcgrl_set_tile_probs")
+            self._probs_dirty = False
+        if not self._rng_seeded:
+            self._upload_seeds()
+
+    def _upload_seeds(self):
+        keys = np.ascontiguousarray(self._seed_keys, dtype=np.uint32)
+        _lib.check(self._lib.pcgrl_seed(self._handle, keys.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()), "pcgrl_seed")
+        self._rng_seeded = True
+
+    # ------------------------------------------------------------------ reference surface
+    def seed(self, seed=None):
+        """Environment i is seeded with `seed + i` (pcgrl_env.py:54-57 per environment).  `seed` may
+        also be a sequence of N seeds.  Returns the list of seeds used."""
+        if seed is None:
+            seed = seeding.create_seed(None, max_bytes=7)
+        if np.ndim(seed) == 0:
+            seeds = [int(seed) + i for i in range(self.num_envs)]
+        else:
+            seeds = [int(s) for s in seed]
+            if len(seeds) != self.num_envs:
+                raise ValueError("need %d seeds, got %d" % (self.num_envs, len(seeds)))
+        for s in seeds:
+            if s < 0:
+                raise ValueError("Seed must be a non-negative integer or omitted, not %r" % (s,))
+        self._seeds = seeds
+        self._seed_keys = seeding.mt_states_for_seeds(seeds)
+        self._rng_seeded = False
+        if self._handle is not None:
+            self._upload_seeds()
+        return seeds
+
+    def adjust_param(self, **kwargs):
+        """pcgrl_env.py:106-115, including the ordering quirk: max_changes is recomputed only when
+        change_percentage is passed, and both limits use the width/height from *before* this call."""
+        if "change_percentage" in kwargs:
+            percentage = min(1, max(0, kwargs.get("change_percentage")))
+            self._max_changes = max(int(percentage * self._prob._width * self._prob._height), 1)
+        self._max_iterations = self._max_changes * self._prob._width * self._prob._height
+        self._prob._probs_touched = False
+        self._prob.adjust_param(**kwargs)
+        self._rep.adjust_param(**kwargs)
+        self._update_spaces()
+        if self._handle is not None:
+            if (self._prob._width, self._prob._height) != self._alloc_dims:
+                self._needs_reset = True      # buffers are re-allocated by the next reset()
+            else:
+                cfg = self._config()
+                _lib.check(self._lib.pcgrl_configure(self._handle, C.byref(cfg)), "pcgrl_configure")
+                if self._prob._probs_touched:
+                    _lib.check(self._lib.pcgrl_set_tile_probs(self._handle, self._stream()), "pcgrl_set_tile_probs")
+                    self._prob._probs_touched = False
+        self._probs_dirty = self._probs_dirty or self._prob._probs_touched
+
+    def _obs(self):
+        b = self._bufs
+        o = OrderedDict()
+        if self._rep.has_pos:
+            o["pos"] = b["pos"]
+        o["map"] = b["map"]
+        o["heatmap"] = b["heatmap"]
+        return o
+
+    def reset(self):
+        """Reset every environment (pcgrl_env.py:66-76).  Returns the observation dict of tensors."""
+        if self._handle is None or (self._prob._width, self._prob._height) != self._alloc_dims:
+            self._allocate()
+        _lib.check(self._lib.pcgrl_reset(self._handle, self._stream()), "pcgrl_reset")
+        self._needs_reset = False
+        return self._obs()
+
+    def _as_actions(self, actions):
+        torch = self._torch
+        aw = self._rep.action_width()
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        if actions.device != self.device:
+            actions = actions.to(self.device)
+        if actions.dtype != torch.int32:
+            actions = actions.to(torch.int32)
+        actions = actions.reshape(self.num_envs, aw) if aw > 1 else actions.reshape(self.num_envs)
+        return actions.contiguous()
+
+    def step(self, actions):
+        """pcgrl_env.py:129-150 for every environment.  actions: int [N] (narrow/turtle) or [N,3]
+        (wide: x, y, tile).  Returns (obs, reward f64[N], done bool[N], InfoBatch); tensors are views
+        of the live state and are overwritten by the next step."""
+        if self._needs_reset:
+            raise RuntimeError("reset() must be called before step() (and again after adjust_param changed width/height)")
+        a = self._as_actions(actions)
+        self._last_actions = a   # keep the buffer alive until the launches are done
+        _lib.check(self._lib.pcgrl_step(self._handle, C.c_void_p(a.data_ptr()), self._stream()), "pcgrl_step")
+        b = self._bufs
+        info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes)
+        return self._obs(), b["reward"], b["done"].view(self._torch.bool), info
+
+    # gym.vector-style split call
+    def step_async(self, actions):
+        self._pending = self.step(actions)
+
+    def step_wait(self):
+        return self._pending
+
+    def set_maps(self, maps):
+        """Overwrite every map (uint8 [N,H,W]) and recompute the current stats on the device."""
+        torch = self._torch
+        m = torch.as_tensor(maps, device=self.device).to(torch.uint8).contiguous()
+        assert tuple(m.shape) == tuple(self._bufs["map"].shape)
+        self._last_maps = m
+        _lib.check(self._lib.pcgrl_set_maps(self._handle, C.c_void_p(m.data_ptr()), self._stream()), "pcgrl_set_maps")
+
+    def profile(self, enable=True):
+        """Record HIP events around every phase of step() on the current stream."""
+        _lib.check(self._lib.pcgrl_profile(self._handle, int(enable)), "pcgrl_profile")
+
+    def profile_read(self):
+        """-> ({phase: total ms}, steps) since profile(True); synchronises."""
+        ms = (C.c_double * _lib.NPHASE)()
+        steps = C.c_int32()
+        _lib.check(self._lib.pcgrl_profile_read(self._handle, ms, C.byref(steps)), "pcgrl_profile_read")
+        return dict(zip(_lib.PHASES, list(ms))), steps.value
+
+    @property
+    def stats(self):
+        return self._bufs["stats"][:, :len(self._prob.stat_keys)]
+
+    def state_dict(self):
+        self._torch.cuda.synchronize(self.device)
+        return {k: (v.clone() if v is not None else None) for k, v in self._bufs.items() if k != "scratch"}
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is out of scope for the batched environment (SURVEY.md 8f-4)")
+
+    def close(self):
+        self._free()
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass

@@ -1,0 +1,139 @@
+"""Host-side mirrors of the reference's Problem classes: parameters only.
+
+The statistics, rewards and episode-over tests run on the GPU (csrc/pcgrl_algos.h); these
+classes hold what the reference keeps as Python attributes (probs/problem.py:10-20,
+binary_prob.py:14-27, zelda_prob.py:17-37, sokoban_prob.py:15-36) and reproduce
+`adjust_param` (problem.py:66-72 and the subclasses) including its quirks: `probs` only
+overrides existing keys, sokoban `max_targets` overwrites `max_crates`, the sokoban kwarg is
+`min_solution`.
+"""
+from collections import OrderedDict
+
+PROB_IDS = {"binary": 0, "zelda": 1, "sokoban": 2}
+
+
+class Problem:
+    name = None
+    tiles = ()
+    stat_keys = ()     # order of the device stats row
+    info_keys = ()     # get_debug_info keys, in the reference's order
+    reward_keys = ()   # order of `_rewards` (the device weights row)
+
+    def __init__(self):
+        self._width = 9
+        self._height = 9
+        self._border_tile = self.tiles[1]
+        self._border_size = (1, 1)
+        self._tile_size = 16
+        self._prob = OrderedDict()
+        self._rewards = OrderedDict()
+        self._probs_touched = False
+
+    def get_tile_types(self):
+        return list(self.tiles)
+
+    def adjust_param(self, **kwargs):
+        self._width, self._height = kwargs.get("width", self._width), kwargs.get("height", self._height)
+        prob = kwargs.get("probs")
+        if prob is not None:
+            for t in prob:
+                if t in self._prob:
+                    self._prob[t] = prob[t]
+                    self._probs_touched = True
+        rewards = kwargs.get("rewards")
+        if rewards is not None:
+            for t in rewards:
+                if t in self._rewards:
+                    self._rewards[t] = rewards[t]
+
+    # scalars shipped to the device config
+    def device_params(self):
+        return {}
+
+
+class BinaryProblem(Problem):
+    name = "binary"
+    tiles = ("empty", "solid")
+    stat_keys = ("regions", "path-length")
+    info_keys = ("regions", "path-length", "path-imp")
+    reward_keys = ("regions", "path-length")
+
+    def __init__(self):
+        super().__init__()
+        self._width, self._height = 14, 14
+        self._prob = OrderedDict([("empty", 0.5), ("solid", 0.5)])
+        self._border_tile = "solid"
+        self._target_path = 20
+        self._random_probs = True
+        self._rewards = OrderedDict([("regions", 5), ("path-length", 1)])
+
+    def adjust_param(self, **kwargs):
+        super().adjust_param(**kwargs)
+        self._target_path = kwargs.get("target_path", self._target_path)
+        self._random_probs = kwargs.get("random_probs", self._random_probs)
+
+    def device_params(self):
+        return dict(target_path=int(self._target_path), random_probs=int(bool(self._random_probs)))
+
+
+class ZeldaProblem(Problem):
+    name = "zelda"
+    tiles = ("empty", "solid", "player", "key", "door", "bat", "scorpion", "spider")
+    stat_keys = ("player", "key", "door", "enemies", "regions", "nearest-enemy", "path-length")
+    info_keys = stat_keys
+    reward_keys = ("player", "key", "door", "regions", "enemies", "nearest-enemy", "path-length")
+
+    def __init__(self):
+        super().__init__()
+        self._width, self._height = 11, 7
+        self._prob = OrderedDict([("empty", 0.58), ("solid", 0.3), ("player", 0.02), ("key", 0.02), ("door", 0.02),
+                                  ("bat", 0.02), ("scorpion", 0.02), ("spider", 0.02)])
+        self._border_tile = "solid"
+        self._max_enemies = 5
+        self._target_enemy_dist = 4
+        self._target_path = 16
+        self._rewards = OrderedDict([("player", 3), ("key", 3), ("door", 3), ("regions", 5), ("enemies", 1),
+                                     ("nearest-enemy", 2), ("path-length", 1)])
+
+    def adjust_param(self, **kwargs):
+        super().adjust_param(**kwargs)
+        self._max_enemies = kwargs.get("max_enemies", self._max_enemies)
+        self._target_enemy_dist = kwargs.get("target_enemy_dist", self._target_enemy_dist)
+        self._target_path = kwargs.get("target_path", self._target_path)
+
+    def device_params(self):
+        return dict(target_path=int(self._target_path), max_enemies=int(self._max_enemies),
+                    target_enemy_dist=int(self._target_enemy_dist))
+
+
+class SokobanProblem(Problem):
+    name = "sokoban"
+    tiles = ("empty", "solid", "player", "crate", "target")
+    stat_keys = ("player", "crate", "target", "regions", "dist-win", "sol-length")
+    info_keys = stat_keys
+    reward_keys = ("player", "crate", "target", "regions", "ratio", "dist-win", "sol-length")
+
+    def __init__(self):
+        super().__init__()
+        self._width, self._height = 5, 5
+        self._prob = OrderedDict([("empty", 0.45), ("solid", 0.4), ("player", 0.05), ("crate", 0.05), ("target", 0.05)])
+        self._border_tile = "solid"
+        self._solver_power = 5000
+        self._max_crates = 3
+        self._target_solution = 18
+        self._rewards = OrderedDict([("player", 3), ("crate", 2), ("target", 2), ("regions", 5), ("ratio", 2),
+                                     ("dist-win", 0.0), ("sol-length", 1)])
+
+    def adjust_param(self, **kwargs):
+        super().adjust_param(**kwargs)
+        self._solver_power = kwargs.get("solver_power", self._solver_power)
+        self._max_crates = kwargs.get("max_crates", self._max_crates)
+        self._max_crates = kwargs.get("max_targets", self._max_crates)
+        self._target_solution = kwargs.get("min_solution", self._target_solution)
+
+    def device_params(self):
+        return dict(max_crates=int(self._max_crates), target_solution=int(self._target_solution),
+                    solver_power=int(self._solver_power))
+
+
+PROBLEMS = {"binary": BinaryProblem, "zelda": ZeldaProblem, "sokoban": SokobanProblem}

@@ -88,11 +88,51 @@ def mt_state_for_seed(seed):
     return np.asarray(st[1], dtype=np.uint32)
 
 
+def init_by_array_batch(keys):
+    """init_by_array for many keys of one length at once: keys [B, klen] uint -> [B, 624] uint32.
+
+    Same recurrence as `init_by_array`, with the B independent generators as the numpy vector
+    axis (the 2*624 sequential steps stay a Python loop)."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    B, klen = keys.shape
+    M32 = np.uint64(0xFFFFFFFF)
+    base = np.empty(MT_N, dtype=np.uint64)
+    base[0] = 19650218
+    for i in range(1, MT_N):
+        base[i] = (1812433253 * (int(base[i - 1]) ^ (int(base[i - 1]) >> 30)) + i) & 0xFFFFFFFF
+    mt = np.tile(base, (B, 1)).T.copy()          # [624, B], rows contiguous
+    i, j = 1, 0
+    for _ in range(max(MT_N, klen)):
+        prev = mt[i - 1]
+        mt[i] = ((mt[i] ^ (((prev ^ (prev >> np.uint64(30))) * np.uint64(1664525)) & M32)) + keys[:, j] + np.uint64(j)) & M32
+        i += 1
+        j += 1
+        if i >= MT_N:
+            mt[0] = mt[MT_N - 1]
+            i = 1
+        if j >= klen:
+            j = 0
+    for _ in range(MT_N - 1):
+        prev = mt[i - 1]
+        mt[i] = ((mt[i] ^ (((prev ^ (prev >> np.uint64(30))) * np.uint64(1566083941)) & M32)) + (np.uint64(1 << 32) - np.uint64(i))) & M32
+        i += 1
+        if i >= MT_N:
+            mt[0] = mt[MT_N - 1]
+            i = 1
+    mt[0] = 0x80000000
+    return np.ascontiguousarray(mt.T).astype(np.uint32)
+
+
 def mt_states_for_seeds(seeds):
-    """[len(seeds), 624] uint32."""
-    out = np.empty((len(seeds), MT_N), dtype=np.uint32)
-    for k, s in enumerate(seeds):
-        out[k] = mt_state_for_seed(int(s))
+    """[len(seeds), 624] uint32 MT19937 keys for `np_random(seed)` of every seed."""
+    words = [hash_seed_words(create_seed(int(s))) for s in seeds]
+    out = np.empty((len(words), MT_N), dtype=np.uint32)
+    by_len = {}
+    for k, w in enumerate(words):
+        by_len.setdefault(len(w), []).append(k)
+    for klen, idx in by_len.items():
+        keys = np.array([words[k] for k in idx], dtype=np.uint64).reshape(len(idx), klen)
+        out[idx] = init_by_array_batch(keys)
     return out
 
 

@@ -1,0 +1,122 @@
+/*
+ * pcgrl_hip.h -- C ABI of the MI355X batched PCGRL environment (libpcgrl_hip.so).
+ *
+ * The reference (amidos2006/gym-pcgrl) has no FFI of its own: its hot path sits behind a Python
+ * class.  This ABI is what a replacement for that path binds.  Each entry point names the
+ * reference interface it replaces (paths relative to gym_pcgrl/envs/):
+ *
+ *   pcgrl_create / pcgrl_configure   PcgrlEnv.__init__ pcgrl_env.py:27-42, adjust_param :106-115,
+ *                                    Problem/Representation.adjust_param (probs/problem.py:66-72,
+ *                                    binary_prob.py:49-59, zelda_prob.py:59-71, sokoban_prob.py:60-73,
+ *                                    reps/representation.py:53-54, narrow_rep.py:86-88, turtle_rep.py:42-44)
+ *   pcgrl_seed                       PcgrlEnv.seed pcgrl_env.py:54-57 (host passes MT19937 keys)
+ *   pcgrl_reset                      PcgrlEnv.reset pcgrl_env.py:66-76 for every environment
+ *   pcgrl_step                       PcgrlEnv.step pcgrl_env.py:129-150 for every environment, plus the
+ *                                    vector-env auto-reset the reference delegates to SubprocVecEnv (utils.py:60-71)
+ *   pcgrl_set_tile_probs             Problem.adjust_param(probs=...) probs/problem.py:68-72
+ *   pcgrl_set_maps                   direct assignment of Representation._map (tests, curriculum loaders)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * PCGRL_E* code (no exceptions cross the ABI); all device buffers are OWNED BY THE CALLER (hipMalloc,
+ * or a torch tensor's data_ptr()) and described by pcgrl_layout; launches are asynchronous on the
+ * given hipStream_t (passed as void*); one handle per GPU, one host thread per handle.
+ * There is no CPU fallback: without a HIP device every launch returns PCGRL_EHIP.
+ */
+#ifndef PCGRL_HIP_H
+#define PCGRL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCGRL_ABI_VERSION 1
+#define PCGRL_OK 0
+#define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
+#define PCGRL_ESTATE (-3)   /* call order violated (e.g. step before bind/reset) */
+
+enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2 };
+enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2 };
+
+/* Batch-wide parameters (everything the reference keeps as attributes of PcgrlEnv/Problem/Representation). */
+typedef struct pcgrl_config {
+    int32_t prob, rep;
+    int32_t num_envs;
+    int32_t width, height;                 /* Problem._width/_height; 1..64 each */
+    int32_t max_changes, max_iterations;   /* pcgrl_env.py:33-34 / :108-110, computed by the host */
+    int32_t random_start, random_tile, warp, random_probs;
+    int32_t auto_reset;                    /* 1: a done env is reset inside step (vector-env semantics) */
+    int32_t target_path;                   /* binary 20, zelda 16 */
+    int32_t max_enemies, target_enemy_dist;            /* zelda */
+    int32_t max_crates, target_solution, solver_power; /* sokoban */
+    int32_t reserved_;
+    double tile_probs[8];                  /* Problem._prob in tile order (un-normalised) */
+    double rewards[8];                     /* Problem._rewards in the problem's own key order */
+} pcgrl_config;
+
+/* Byte sizes of the caller-provided device buffers for a configuration (N = num_envs). */
+typedef struct pcgrl_layout {
+    int32_t group;        /* lanes per map: 16 (height <= 16) or 64 */
+    int32_t mask_bytes;   /* bytes per row mask: 4 (width <= 32) or 8 */
+    int32_t nplanes;      /* bit planes of the tile id: 1 binary, 3 zelda/sokoban */
+    int32_t nstats;       /* 2 binary, 7 zelda, 6 sokoban */
+    size_t map;           /* u8  [N,H,W]   observation "map" */
+    size_t old_map;       /* u8  [N,H,W]   Representation._old_map */
+    size_t heatmap;       /* i16 [N,H,W]   observation "heatmap" (counts) */
+    size_t pos;           /* u8  [N,2]     observation "pos" (x,y); unused for wide */
+    size_t planes;        /* mask[N,nplanes,group] row bitboards of the tile-id bits */
+    size_t counters;      /* i32 [N,2]     iteration, changes */
+    size_t stats;         /* i32 [N,8]     current _rep_stats */
+    size_t start_stats;   /* i32 [N,8]     Problem._start_stats */
+    size_t info;          /* i32 [N,10]    per-step info: stats[8], iterations, changes */
+    size_t reward;        /* f64 [N] */
+    size_t done;          /* u8  [N] */
+    size_t tile_p;        /* f64 [N,2]     binary: per-env (p_empty, p_solid) */
+    size_t rng_rep;       /* u32 [N,624]   representation MT19937 ring */
+    size_t rng_prob;      /* u32 [N,624]   problem MT19937 ring (binary only; may be NULL otherwise) */
+    size_t rng_cursor;    /* i32 [N,2]     ring cursors (rep, prob) */
+    size_t scratch;       /* work lists, counters, sokoban solver arena */
+} pcgrl_layout;
+
+typedef struct pcgrl_buffers {
+    void *map, *old_map, *heatmap, *pos, *planes, *counters, *stats, *start_stats, *info, *reward,
+         *done, *tile_p, *rng_rep, *rng_prob, *rng_cursor, *scratch;
+} pcgrl_buffers;
+
+typedef struct pcgrl_env pcgrl_env;
+
+int pcgrl_abi_version(void);
+const char* pcgrl_error_string(int code);
+int pcgrl_last_hip_error(void);
+
+int pcgrl_query_layout(const pcgrl_config* cfg, pcgrl_layout* out);
+int pcgrl_create(const pcgrl_config* cfg, pcgrl_env** out);
+int pcgrl_destroy(pcgrl_env* env);
+int pcgrl_bind(pcgrl_env* env, const pcgrl_buffers* bufs, void* stream);
+/* Change parameters that do not alter buffer sizes (anything but prob/rep/num_envs/width/height). */
+int pcgrl_configure(pcgrl_env* env, const pcgrl_config* cfg);
+/* keys: HOST pointer, [count,624] u32 = MT19937 init_by_array state of environment first..first+count-1;
+ * seeds both streams identically (pcgrl_env.py:54-57). */
+int pcgrl_seed(pcgrl_env* env, const uint32_t* keys, int32_t first, int32_t count, void* stream);
+/* Broadcast cfg.tile_probs[0..1] into tile_p (binary); call once after the first bind and whenever
+ * adjust_param(probs=...) touched them.  tile_p otherwise persists (it carries BinaryProblem._prob). */
+int pcgrl_set_tile_probs(pcgrl_env* env, void* stream);
+int pcgrl_reset(pcgrl_env* env, void* stream);
+/* actions: DEVICE pointer, i32 [N] (narrow, turtle) or i32 [N,3] = (x, y, tile) (wide). */
+int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
+/* maps: DEVICE pointer u8 [N,H,W]; replaces every map, recomputes stats (start stats unchanged). */
+int pcgrl_set_maps(pcgrl_env* env, const uint8_t* maps, void* stream);
+
+
+/* Per-phase GPU timing of pcgrl_step with HIP events recorded on the caller's stream (bench.py's
+ * roofline leg).  Phases: 0 update, 1 stats(step), 2 solver(step), 3 mapgen, 4 stats(start), 5 clear. */
+#define PCGRL_NPHASE 6
+int pcgrl_profile(pcgrl_env* env, int enable);
+int pcgrl_profile_read(pcgrl_env* env, double* phase_ms /*[PCGRL_NPHASE]*/, int32_t* steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

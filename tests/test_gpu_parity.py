@@ -1,0 +1,274 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box).  Everything goes through the C ABI
+(gym_pcgrl_amd/lib/libpcgrl_hip.so) via BatchedPcgrlEnv / PcgrlEnv and is compared bit-exactly with
+(a) the committed golden fixtures produced by the reference and (b) the CPU oracle on seeded inputs.
+Nothing here reads /root/reference."""
+import ast
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SUPPORTED = ("binary", "zelda", "sokoban")
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _make(prob, rep, n, calls=(), seed=1000, auto_reset=True):
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, seed=seed, auto_reset=auto_reset)
+    for kw in calls:
+        env.adjust_param(**kw)
+    return env
+
+
+def _supported(prob):
+    from gym_pcgrl_amd import _lib
+    import ctypes as C
+    c = _lib.Config()
+    c.prob = {"binary": 0, "zelda": 1, "sokoban": 2}[prob]
+    c.num_envs, c.width, c.height, c.max_changes, c.max_iterations = 1, 5, 5, 1, 1
+    h = C.c_void_p()
+    rc = _lib.load().pcgrl_create(C.byref(c), C.byref(h))
+    if rc == 0:
+        _lib.load().pcgrl_destroy(h)
+    return rc == 0
+
+
+# ------------------------------------------------------------------ map -> stats known answers
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_*.npz"))), ids=os.path.basename)
+def test_stats_kat(path):
+    _torch()
+    d = np.load(path)
+    prob = os.path.basename(path).split("_")[1]
+    if not _supported(prob):
+        pytest.skip("%s not built yet" % prob)
+    maps = d["maps"]
+    n, h, w = maps.shape
+    calls = [dict(width=w, height=h)]
+    if "solver_power" in d.files:
+        calls.append(dict(solver_power=int(d["solver_power"])))
+    env = _make(prob, "wide", n, calls)
+    env.reset()
+    env.set_maps(maps)
+    got = env.stats.cpu().numpy().astype(np.int64)
+    bad = np.nonzero((got != d["stats"]).any(1))[0]
+    assert bad.size == 0, (bad[:5], got[bad[:5]], d["stats"][bad[:5]])
+    assert np.array_equal(env._bufs["map"].cpu().numpy(), maps)
+
+
+# ------------------------------------------------------------------ golden trajectories
+def _compare_traj(env, d, T, check_every=1):
+    torch = _torch()
+    rep = str(d["rep"])
+    keys = [str(k) for k in d["info_keys"]]
+    acts = d["actions"]
+    for t in range(T):
+        a = acts[t] if rep == "wide" else acts[t, :, 0]
+        obs, rew, done, info = env.step(a)
+        if t % check_every:
+            continue
+        torch.cuda.synchronize()
+        assert np.array_equal(done.cpu().numpy(), d["done"][t]), ("done", t)
+        assert np.array_equal(rew.cpu().numpy(), d["reward"][t]), ("reward", t, rew.cpu().numpy(), d["reward"][t])
+        got_info = np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64)
+        assert np.array_equal(got_info, d["info"][t]), ("info", t, got_info, d["info"][t])
+        assert np.array_equal(obs["map"].cpu().numpy(), d["maps"][t]), ("map", t)
+        if rep != "wide":
+            assert np.array_equal(obs["pos"].cpu().numpy(), d["pos"][t]), ("pos", t)
+        assert np.array_equal(obs["heatmap"].cpu().numpy().astype(np.uint16), d["heatmap"][t]), ("heatmap", t)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "traj_*.npz"))), ids=os.path.basename)
+def test_golden_trajectory(path):
+    _torch()
+    d = np.load(path)
+    prob, rep = str(d["prob"]), str(d["rep"])
+    if not _supported(prob):
+        pytest.skip("%s not built yet" % prob)
+    calls = ast.literal_eval(str(d["calls"]))
+    W, H, max_changes, max_iter, seed0, _ = [int(v) for v in d["cfg"]]
+    T, E = d["actions"].shape[:2]
+    env = _make(prob, rep, E, calls, seed=seed0)
+    assert (env._max_changes, env._max_iterations) == (max_changes, max_iter)
+    obs = env.reset()
+    assert np.array_equal(obs["map"].cpu().numpy(), d["map0"])
+    if rep != "wide":
+        assert np.array_equal(obs["pos"].cpu().numpy(), d["pos0"])
+    assert int(obs["heatmap"].abs().sum().item()) == 0
+    _compare_traj(env, d, T)
+
+
+# ------------------------------------------------------------------ seeded rollouts against the oracle
+ORACLE_CASES = [
+    ("binary", "narrow", (), 192, 160),
+    ("binary", "turtle", (dict(change_percentage=0.4),), 96, 200),
+    ("binary", "wide", (dict(width=33, height=20),), 64, 80),
+    ("binary", "narrow", (dict(width=40, height=12), dict(change_percentage=0.2)), 64, 150),
+    ("zelda", "wide", (dict(width=11, height=16),), 192, 120),
+    ("zelda", "narrow", (), 128, 200),
+    ("zelda", "turtle", (dict(width=20, height=18), dict(change_percentage=0.5)), 48, 150),
+    ("sokoban", "narrow", (), 256, 120),
+    ("sokoban", "wide", (dict(width=6, height=6), dict(change_percentage=0.5)), 96, 100),
+]
+
+
+@pytest.mark.parametrize("prob,rep,calls,E,T", ORACLE_CASES, ids=lambda v: str(v) if isinstance(v, (str, int)) else "cfg")
+def test_rollout_vs_oracle(prob, rep, calls, E, T):
+    torch = _torch()
+    if not _supported(prob):
+        pytest.skip("%s not built yet" % prob)
+    seed0 = 777
+    env = _make(prob, rep, E, calls, seed=seed0)
+    obs = env.reset()
+    W, H = env._prob._width, env._prob._height
+    nt = env.get_num_tiles()
+    rs = np.random.RandomState(11)
+    if rep == "narrow":
+        acts = rs.randint(0, nt + 1, size=(T, E, 1))
+    elif rep == "turtle":
+        acts = rs.randint(0, nt + 4, size=(T, E, 1))
+    else:
+        acts = np.stack([rs.randint(0, W, size=(T, E)), rs.randint(0, H, size=(T, E)), rs.randint(0, nt, size=(T, E))], -1)
+    acts = acts.astype(np.int32)
+    # oracle side
+    exp = []
+    map0 = np.zeros((E, H, W), np.uint8)
+    for i in range(E):
+        o = ol.OracleEnv(prob, rep)
+        for kw in calls:
+            o.adjust_param(**kw)
+        o.seed(seed0 + i)
+        map0[i] = o.reset()["map"]
+        a3 = np.zeros((T, 3), np.int32)
+        a3[:, :acts.shape[2]] = acts[:, i]
+        exp.append(o.rollout(a3))
+    assert np.array_equal(obs["map"].cpu().numpy(), map0)
+    ni = len(env._prob.info_keys)
+    keys = list(env._prob.info_keys) + ["iterations", "changes"]
+    for t in range(T):
+        a = acts[t] if rep == "wide" else acts[t, :, 0]
+        obs, rew, done, info = env.step(a)
+        torch.cuda.synchronize()
+        e_done = np.array([x["done"][t] for x in exp])
+        e_rew = np.array([x["reward"][t] for x in exp])
+        e_info = np.stack([x["info"][t] for x in exp])
+        e_map = np.stack([x["maps"][t] for x in exp])
+        e_heat = np.stack([x["heatmap"][t] for x in exp])
+        assert np.array_equal(done.cpu().numpy(), e_done), ("done", t)
+        assert np.array_equal(rew.cpu().numpy(), e_rew), ("reward", t)
+        got_info = np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64)
+        assert np.array_equal(got_info, e_info), ("info", t, np.nonzero((got_info != e_info).any(1))[0][:4])
+        assert np.array_equal(obs["map"].cpu().numpy(), e_map), ("map", t)
+        assert np.array_equal(obs["heatmap"].cpu().numpy().astype(np.uint16), e_heat), ("heat", t)
+        if rep != "wide":
+            e_pos = np.stack([x["pos"][t] for x in exp]).astype(np.uint8)
+            assert np.array_equal(obs["pos"].cpu().numpy(), e_pos), ("pos", t)
+
+
+# ------------------------------------------------------------------ single-env facade (reference surface)
+def test_facade_matches_golden():
+    _torch()
+    import gym_pcgrl_amd
+    d = np.load(os.path.join(G, "traj_binary_narrow.npz"))
+    env = gym_pcgrl_amd.make("binary-narrow-v0")
+    assert "PcgrlEnv" in str(type(env))
+    assert env.seed(1000) == [1000]
+    o = env.reset()
+    assert list(o.keys()) == ["pos", "map", "heatmap"]
+    assert o["map"].dtype == np.uint8 and o["pos"].dtype == np.uint8 and o["heatmap"].dtype == np.float64
+    assert np.array_equal(o["map"], d["map0"][0]) and np.array_equal(o["pos"], d["pos0"][0])
+    keys = [str(k) for k in d["info_keys"]]
+    for t in range(150):
+        o, r, dn, info = env.step(int(d["actions"][t, 0, 0]))
+        assert r == d["reward"][t, 0] and dn == bool(d["done"][t, 0])
+        assert [info[k] for k in keys] == list(d["info"][t, 0])
+        assert info["max_changes"] == 39 and info["max_iterations"] == 7644
+        if dn:
+            o = env.reset()
+        assert np.array_equal(o["map"], d["maps"][t, 0]) and np.array_equal(o["pos"], d["pos"][t, 0])
+        assert np.array_equal(o["heatmap"], d["heatmap"][t, 0].astype(np.float64))
+
+
+# ------------------------------------------------------------------ shard invariance / determinism
+def test_shard_invariance_and_determinism():
+    torch = _torch()
+    N, T = 1024, 40
+    rs = np.random.RandomState(5)
+    acts = rs.randint(0, 3, size=(T, N)).astype(np.int32)
+
+    def run(lo, hi):
+        env = _make("binary", "narrow", hi - lo, seed=lo)
+        env.reset()
+        outs = []
+        for t in range(T):
+            obs, rew, done, info = env.step(acts[t, lo:hi])
+            outs.append((obs["map"].clone(), obs["pos"].clone(), rew.clone(), done.clone(), info.table.clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    full = run(0, N)
+    again = run(0, N)
+    a, b = run(0, N // 2), run(N // 2, N)
+    for t in range(T):
+        for k in range(5):
+            assert torch.equal(full[t][k], again[t][k]), ("determinism", t, k)
+            assert torch.equal(full[t][k], torch.cat([a[t][k], b[t][k]])), ("shard", t, k)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs)
+@pytest.mark.parametrize("prob,rep,calls,N", [
+    ("binary", "narrow", (), 65536),
+    ("zelda", "wide", (dict(width=11, height=16),), 65536),
+    ("binary", "turtle", (dict(width=64, height=64),), 8192),
+    ("sokoban", "narrow", (), 131072),
+], ids=["C2", "C3", "C5", "C4"])
+def test_full_size_properties(prob, rep, calls, N):
+    torch = _torch()
+    if not _supported(prob):
+        pytest.skip("%s not built yet" % prob)
+    env = _make(prob, rep, N, calls, seed=0)
+    env.reset()
+    W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    total_done = 0
+    for t in range(30):
+        if rep == "wide":
+            a = torch.stack([torch.randint(0, W, (N,), generator=g, device="cuda"), torch.randint(0, H, (N,), generator=g, device="cuda"),
+                             torch.randint(0, nt, (N,), generator=g, device="cuda")], 1).int()
+        else:
+            a = torch.randint(0, nt + (1 if rep == "narrow" else 4), (N,), generator=g, device="cuda").int()
+        obs, rew, done, info = env.step(a)
+        total_done += int(done.sum().item())
+        # environments that were done have been reset: counters are zero, heatmap is clear
+        cnt = env._bufs["counters"]
+        assert int(cnt[done].abs().sum().item()) == 0
+        assert int(obs["heatmap"][done].abs().sum().item()) == 0
+        # info mirrors the counters for the others
+        assert torch.equal(info["iterations"][~done], cnt[~done][:, 0])
+    # planes are the bit planes of the byte map
+    m = obs["map"].long()
+    planes = env._bufs["planes"].long()
+    xs = torch.arange(W, device="cuda")
+    for b in range(planes.shape[1]):
+        rows = (((m >> b) & 1) << xs).sum(-1)
+        got = planes[:, b, :H]
+        if env._bufs["planes"].dtype == torch.int32:
+            got = got & 0xFFFFFFFF
+        assert torch.equal(rows, got), ("plane", b)
+    # current stats of a sample equal the oracle's stats of the current maps
+    idx = np.linspace(0, N - 1, 200).astype(int)
+    maps = obs["map"][idx].cpu().numpy()
+    st = env.stats[idx].cpu().numpy().astype(np.int64)
+    power = getattr(env._prob, "_solver_power", 5000)
+    for k, i in enumerate(idx):
+        assert np.array_equal(st[k], ol.get_stats(prob, maps[k], solver_power=power)), (i, st[k])
+    assert total_done > 0 or prob == "binary"

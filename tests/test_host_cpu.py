@@ -1,0 +1,107 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol that
+include/pcgrl_hip.h declares, the layout query, seeding, spaces and the adjust_param table."""
+import ast
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    from gym_pcgrl_amd import _lib
+    _lib.build()
+    L = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "pcgrl_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pcgrl_[a-z_]+)\s*\(", hdr))
+    assert {"pcgrl_create", "pcgrl_step", "pcgrl_reset", "pcgrl_seed"} <= declared
+    for name in declared:
+        assert hasattr(L, name), name
+    assert set(_lib.EXPORTS) == declared
+    assert L.pcgrl_abi_version() == 1
+    assert L.pcgrl_error_string(-1).decode().startswith("invalid")
+
+
+def test_layout_query_and_validation():
+    from gym_pcgrl_amd import _lib
+    L = _lib.load()
+    c = _lib.Config()
+    c.prob, c.rep, c.num_envs, c.width, c.height, c.max_changes, c.max_iterations = 0, 0, 1000, 14, 14, 39, 7644
+    lay = _lib.Layout()
+    assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == 0
+    assert (lay.group, lay.mask_bytes, lay.nplanes, lay.nstats) == (16, 4, 1, 2)
+    assert lay.map == 1000 * 196 and lay.rng_rep == 1000 * 624 * 4 and lay.planes == 1000 * 16 * 4
+    c.width, c.height, c.prob = 64, 64, 1
+    assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == 0
+    assert (lay.group, lay.mask_bytes, lay.nplanes, lay.nstats) == (64, 8, 3, 7)
+    c.width = 65
+    assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == _lib.PCGRL_EINVAL
+    c.width, c.num_envs = 14, 0
+    assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == _lib.PCGRL_EINVAL
+    # calls on an unbound handle are refused, not crashed
+    c.num_envs, c.prob = 4, 0
+    h = C.c_void_p()
+    assert L.pcgrl_create(C.byref(c), C.byref(h)) == 0
+    assert L.pcgrl_reset(h, None) == _lib.PCGRL_ESTATE
+    assert L.pcgrl_step(h, None, None) == _lib.PCGRL_ESTATE
+    assert L.pcgrl_destroy(h) == 0
+
+
+def test_seeding_matches_numpy_and_fixture():
+    from gym_pcgrl_amd import seeding
+    d = np.load(os.path.join(G, "rng.npz"))
+    keys = seeding.mt_states_for_seeds([int(s) for s in d["seeds"]])
+    assert np.array_equal(keys, d["mt_key"])
+    for s in (0, 5, 2 ** 40 + 3):
+        assert np.array_equal(seeding.init_by_array(seeding.hash_seed_words(s)), seeding.mt_state_for_seed(s))
+    rng, s = seeding.np_random(42)
+    assert s == 42
+    with pytest.raises(ValueError):
+        seeding.np_random(-1)
+
+
+def test_adjust_param_table_and_spaces():
+    import gym_pcgrl_amd
+    from gym_pcgrl_amd import spaces
+    d = np.load(os.path.join(G, "adjust_param.npz"))
+    for case, row in zip(d["cases"], d["rows"]):
+        prob, rep, calls = ast.literal_eval(str(case))
+        env = gym_pcgrl_amd.make_batched("%s-%s-v0" % (prob, rep), num_envs=2, seed=0)   # no GPU touched before reset()
+        for kw in calls:
+            env.adjust_param(**kw)
+        a = env.action_space
+        adesc = [0, a.n, 0, 0] if isinstance(a, spaces.Discrete) else [1] + [int(v) for v in a.nvec]
+        osp = env.observation_space.spaces
+        got = [env._prob._width, env._prob._height, env._max_changes, env._max_iterations, env.get_num_tiles(),
+               env.get_border_tile()] + adesc + [osp["map"].shape[0], osp["map"].shape[1], int(osp["map"].high.max()),
+                                                 int(osp["heatmap"].high.max()), int("pos" in osp)]
+        assert got == list(row), (case, got, list(row))
+    assert sorted(gym_pcgrl_amd.registered_ids())[0] == "binary-narrow-v0" and len(gym_pcgrl_amd.registered_ids()) == 9
+    with pytest.raises(KeyError):
+        gym_pcgrl_amd.make_batched("nope-narrow-v0", num_envs=1)
+
+
+def test_problem_adjust_param_quirks():
+    from gym_pcgrl_amd.envs.problems import PROBLEMS
+    p = PROBLEMS["sokoban"]()
+    p.adjust_param(max_crates=4, max_targets=2, min_solution=7, target_solution=99, probs={"crate": 0.2, "bogus": 1.0},
+                   rewards={"ratio": 9, "nope": 1})
+    assert p._max_crates == 2 and p._target_solution == 7 and p._prob["crate"] == 0.2 and "bogus" not in p._prob
+    assert p._rewards["ratio"] == 9 and "nope" not in p._rewards
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import gym_pcgrl_amd
+    env = gym_pcgrl_amd.make_batched("binary-narrow-v0", num_envs=2, seed=0)
+    with pytest.raises(Exception):
+        env.reset()
+    with pytest.raises(RuntimeError):
+        gym_pcgrl_amd.make_batched("binary-narrow-v0", num_envs=2, seed=0, device="cpu")

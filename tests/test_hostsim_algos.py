@@ -1,0 +1,126 @@
+"""The bitboard templates of gym_pcgrl_amd/csrc (pcgrl_algos.h, mt19937.h) instantiated on a CPU
+lane-group simulator (tests/hostsim/sim_algos.cpp) and checked against the golden fixtures and the
+oracle.  This covers the algorithm logic on CPU; the DPP/ballot backend itself is covered by the
+-m gpu tests.  CPU only."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import _p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+SRC = os.path.join(HERE, "hostsim", "sim_algos.cpp")
+SO = os.path.join(HERE, "hostsim", "libsim_algos.so")
+CSRC = os.path.join(os.path.dirname(HERE), "gym_pcgrl_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    deps = [SRC] + glob.glob(os.path.join(CSRC, "*.h"))
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", SO, SRC])
+    L = C.CDLL(SO)
+    L.sim_stats.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.sim_range_reward.argtypes = [C.c_double] * 4
+    L.sim_range_reward.restype = C.c_double
+    L.sim_mt_randint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sim_mt_random.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.sim_mt_mapgen.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def sim_stats(L, prob, m, variant=0):
+    m = np.ascontiguousarray(m, np.uint8)
+    h, w = m.shape
+    out = np.zeros(8, np.int32)
+    need = C.c_int()
+    L.sim_stats(ol.PROBS[prob], _p(m), h, w, w, h, variant, _p(out), C.byref(need))
+    return out, need.value
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_*.npz"))), ids=os.path.basename)
+def test_bitboard_stats_vs_golden(sim, path):
+    d = np.load(path)
+    prob = os.path.basename(path).split("_")[1]
+    ns = ol.NSTATS[prob]
+    for i, m in enumerate(d["maps"]):
+        for variant in ((0,) if i % 7 else (0, 1, 2, 3)):
+            out, need = sim_stats(sim, prob, m, variant)
+            exp = d["stats"][i]
+            if prob == "sokoban":
+                ran = d["agents"][i, 4] > -2
+                assert bool(need) == bool(ran), i
+                assert np.array_equal(out[:4], exp[:4]), (i, out, exp)
+                if not ran:
+                    assert np.array_equal(out[:ns], exp), (i, out, exp)
+            else:
+                assert np.array_equal(out[:ns], exp), (i, variant, out, exp, m)
+
+
+def test_bitboard_stats_vs_oracle_random(sim):
+    rs = np.random.RandomState(99)
+    for prob, nt in (("binary", 2), ("zelda", 8)):
+        for _ in range(400):
+            h, w = rs.randint(1, 24), rs.randint(1, 40)
+            if prob == "binary":
+                m = (rs.random_sample((h, w)) < rs.random_sample()).astype(np.uint8)
+            else:
+                p = np.array([0.5, rs.uniform(0, 0.5), 0.03, 0.03, 0.03, 0.03, 0.03, 0.03])
+                m = rs.choice(8, size=(h, w), p=p / p.sum()).astype(np.uint8)
+            out, _ = sim_stats(sim, prob, m)
+            exp = ol.get_stats(prob, m)
+            assert np.array_equal(out[:len(exp)], exp), (prob, m, out, exp)
+
+
+def test_range_reward_table(sim):
+    for lo, hi, nv, ov, r in np.load(os.path.join(G, "range_reward.npz"))["table"]:
+        assert sim.sim_range_reward(nv, ov, lo, hi) == r
+
+
+def test_lazy_ring_mt_matches_numpy(sim):
+    d = np.load(os.path.join(G, "rng.npz"))
+    for si in range(len(d["seeds"])):
+        key = np.ascontiguousarray(d["mt_key"][si])
+        for bi, n in enumerate(d["bounds"]):
+            out = np.zeros(64, np.int64)
+            sim.sim_mt_randint(_p(key), int(n), 64, _p(out))
+            assert np.array_equal(out, d["randint"][si, bi])
+        f = np.zeros(700, np.float64)
+        sim.sim_mt_random(_p(key), 700, _p(f))
+        assert np.array_equal(f, d["random"][si])
+
+
+def test_parallel_mapgen_matches_numpy(sim):
+    d = np.load(os.path.join(G, "rng.npz"))
+    for si in range(len(d["seeds"])):
+        key = np.ascontiguousarray(d["mt_key"][si])
+        for (p, nt, w, h, name) in ((d["choice2_p"], 2, 14, 14, "choice2"), (d["choice8_p"], 8, 11, 16, "choice8")):
+            tiles = np.zeros((h, w), np.uint8)
+            xy = np.zeros(2, np.int32)
+            ring = np.zeros(624, np.uint32)
+            cur = C.c_int()
+            sim.sim_mt_mapgen(_p(key), _p(np.ascontiguousarray(p)), nt, w, h, _p(tiles), _p(xy), _p(ring), C.byref(cur))
+            assert np.array_equal(tiles, d[name][si])
+            rs = np.random.RandomState()
+            rs.set_state(("MT19937", key, 624))
+            rs.random_sample((h, w))
+            assert xy[0] == rs.randint(w) and xy[1] == rs.randint(h)
+    # big map: many rounds, ring wraps several times
+    key = np.ascontiguousarray(d["mt_key"][0])
+    tiles = np.zeros((64, 64), np.uint8)
+    xy = np.zeros(2, np.int32)
+    ring = np.zeros(624, np.uint32)
+    cur = C.c_int()
+    p = np.array([0.37, 0.63])
+    sim.sim_mt_mapgen(_p(key), _p(p), 2, 64, 64, _p(tiles), _p(xy), _p(ring), C.byref(cur))
+    rs = np.random.RandomState()
+    rs.set_state(("MT19937", key, 624))
+    exp = rs.choice([0, 1], size=(64, 64), p=[0.37, 0.63]).astype(np.uint8)
+    assert np.array_equal(tiles, exp)
+    assert xy[0] == rs.randint(64) and xy[1] == rs.randint(64)
