@@ -79,6 +79,10 @@ def load():
         raise RuntimeError(
             "gym_pcgrl_amd: HIP library %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the batched environment." % SO)
+    # torch must be imported first: it ships its own libamdhip64, and the kernels have to run in the same
+    # HIP runtime instance that owns the tensors whose pointers we are handed (two runtimes in one
+    # process do not share devices or allocations: hipErrorNoDevice on the first call).
+    import torch  # noqa: F401
     L = C.CDLL(SO)
     for name in EXPORTS:
         if not hasattr(L, name):

@@ -23,13 +23,14 @@ template <class T, int G> SimVec<T, G> operator~(const SimVec<T, G>& a) { SimVec
 template <class T, int G> SimVec<T, G> operator<<(const SimVec<T, G>& a, int s) { SimVec<T, G> r; for (int i = 0; i < G; i++) r.v[i] = a.v[i] << s; return r; }
 template <class T, int G> SimVec<T, G> operator>>(const SimVec<T, G>& a, int s) { SimVec<T, G> r; for (int i = 0; i < G; i++) r.v[i] = a.v[i] >> s; return r; }
 
+static long g_sim_iters = 0;
 template <int G, class T>
 struct SimGroup {
     typedef SimVec<T, G> mask_t;
     mask_t up(const mask_t& m) const { mask_t r; for (int i = 1; i < G; i++) r.v[i] = m.v[i - 1]; return r; }
     mask_t down(const mask_t& m) const { mask_t r; for (int i = 0; i + 1 < G; i++) r.v[i] = m.v[i + 1]; return r; }
     bool any(const mask_t& m) const { for (int i = 0; i < G; i++) if (m.v[i]) return true; return false; }
-    bool any_ne(const mask_t& a, const mask_t& b) const { for (int i = 0; i < G; i++) if (a.v[i] != b.v[i]) return true; return false; }
+    bool any_ne(const mask_t& a, const mask_t& b) const { g_sim_iters++; for (int i = 0; i < G; i++) if (a.v[i] != b.v[i]) return true; return false; }
     mask_t first_bit(const mask_t& m) const {
         mask_t r;
         for (int i = 0; i < G; i++) if (m.v[i]) { r.v[i] = m.v[i] & (T)(0 - m.v[i]); break; }
@@ -67,6 +68,7 @@ static void run(int prob, const uint8_t* map, int h, int w, int pw, int ph, int3
 }
 
 extern "C" {
+long sim_iters_reset() { long v = g_sim_iters; g_sim_iters = 0; return v; }
 // variant: 0 = smallest fitting (G16 if h<=16 else G64; u32 if w<=32 else u64), 1 = force G64, 2 = force u64, 3 = both
 int sim_stats(int prob, const uint8_t* map, int h, int w, int pw, int ph, int variant, int32_t* out, int* need_solver) {
     bool g64 = h > 16 || (variant & 1), m64 = w > 32 || (variant & 2);
