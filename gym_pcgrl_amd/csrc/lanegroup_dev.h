@@ -23,14 +23,37 @@ __device__ __forceinline__ uint64_t dpp_mov0(uint64_t v) {
 }
 __device__ __forceinline__ int pcg_popc(uint32_t v) { return __popc(v); }
 __device__ __forceinline__ int pcg_popc(uint64_t v) { return __popcll(v); }
+__device__ __forceinline__ uint32_t pcg_brev(uint32_t v) { return __brev(v); }
+__device__ __forceinline__ uint64_t pcg_brev(uint64_t v) { return __brevll(v); }
+
+// Lane-local pieces shared by both group sizes.
+template <class MaskT>
+struct DevLaneOps {
+    typedef MaskT mask_t;
+    typedef int ivec_t;
+    __device__ __forceinline__ ivec_t izero() const { return 0; }
+    __device__ __forceinline__ bool wave_any(mask_t m) const { return __ballot(m != 0) != 0; }
+    __device__ __forceinline__ ivec_t popc_lanes(mask_t m) const { return pcg_popc(m); }
+    __device__ __forceinline__ ivec_t isel_ne(mask_t a, mask_t b, int x, ivec_t y) const { return a != b ? x : y; }
+    __device__ __forceinline__ mask_t msel_ne(mask_t a, mask_t b, mask_t x, mask_t y) const { return a != b ? x : y; }
+    __device__ __forceinline__ mask_t keep_where_eq(ivec_t v, int x, mask_t m) const { return v == x ? m : (mask_t)0; }
+    __device__ __forceinline__ mask_t bitrev(mask_t m) const { return pcg_brev(m); }
+};
 
 template <int G, class MaskT>
 struct DevGroup;
 
 template <class MaskT>
-struct DevGroup<16, MaskT> {
+struct DevGroup<16, MaskT> : DevLaneOps<MaskT> {
     typedef MaskT mask_t;
-    enum { kGroup = 16 };
+    enum { kGroup = 16, kLog2Group = 4 };
+    // row r receives row r - 2^k (rows_down) / r + 2^k (rows_up); k is a compile-time constant after unrolling
+    __device__ __forceinline__ mask_t rows_down(mask_t m, int k) const {
+        switch (k) { case 0: return dpp_mov0<0x111>(m); case 1: return dpp_mov0<0x112>(m); case 2: return dpp_mov0<0x114>(m); default: return dpp_mov0<0x118>(m); }
+    }
+    __device__ __forceinline__ mask_t rows_up(mask_t m, int k) const {
+        switch (k) { case 0: return dpp_mov0<0x101>(m); case 1: return dpp_mov0<0x102>(m); case 2: return dpp_mov0<0x104>(m); default: return dpp_mov0<0x108>(m); }
+    }
     int lane;   // row index inside the group
     int shift;  // bit offset of this group inside the wave ballot
     __device__ __forceinline__ DevGroup() {
@@ -57,17 +80,33 @@ struct DevGroup<16, MaskT> {
         v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
         return v;
     }
+    __device__ __forceinline__ int imax(int v) const {   // values are >= 0, so the 0 fill is neutral
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+        return v;
+    }
     __device__ __forceinline__ int popcount_sum(mask_t m) const { return sum(pcg_popc(m)); }
 };
 
 template <class MaskT>
-struct DevGroup<64, MaskT> {
+struct DevGroup<64, MaskT> : DevLaneOps<MaskT> {
     typedef MaskT mask_t;
-    enum { kGroup = 64 };
+    // One wavefront per map.  Single-row moves cross the whole wave (wave_shr/wave_shl); the doubling
+    // steps of the column fill stay inside a 16-lane DPP row (kLog2Group = 4) and the fill adds one
+    // whole-wave hop per round to cross row-block boundaries (pcg_fill_cols).
+    enum { kGroup = 64, kLog2Group = 4 };
     int lane;
     __device__ __forceinline__ DevGroup() { lane = (int)(threadIdx.x & 63); }
     __device__ __forceinline__ mask_t up(mask_t m) const { return dpp_mov0<0x138>(m); }    // wave_shr:1
     __device__ __forceinline__ mask_t down(mask_t m) const { return dpp_mov0<0x130>(m); }  // wave_shl:1
+    __device__ __forceinline__ mask_t rows_down(mask_t m, int k) const {
+        switch (k) { case 0: return dpp_mov0<0x111>(m); case 1: return dpp_mov0<0x112>(m); case 2: return dpp_mov0<0x114>(m); default: return dpp_mov0<0x118>(m); }
+    }
+    __device__ __forceinline__ mask_t rows_up(mask_t m, int k) const {
+        switch (k) { case 0: return dpp_mov0<0x101>(m); case 1: return dpp_mov0<0x102>(m); case 2: return dpp_mov0<0x104>(m); default: return dpp_mov0<0x108>(m); }
+    }
     __device__ __forceinline__ bool any(mask_t m) const { return __ballot(m != 0) != 0; }
     __device__ __forceinline__ bool any_ne(mask_t a, mask_t b) const { return __ballot(a != b) != 0; }
     __device__ __forceinline__ mask_t first_bit(mask_t m) const {
@@ -75,9 +114,22 @@ struct DevGroup<64, MaskT> {
         int first = __ffsll((unsigned long long)b) - 1;
         return lane == first ? (m & (mask_t)(0 - m)) : (mask_t)0;
     }
+    // row-wise all-reduce with DPP, then the four row results are combined through SGPRs
     __device__ __forceinline__ int sum(int v) const {
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+        return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+               __builtin_amdgcn_readlane(v, 48);
+    }
+    __device__ __forceinline__ int imax(int v) const {   // values are >= 0
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));
+        v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));
+        return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                   max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
     }
     __device__ __forceinline__ int popcount_sum(mask_t m) const { return sum(pcg_popc(m)); }
 };

@@ -15,16 +15,27 @@
 //   helper.py:366-376, *_prob.get_reward/get_episode_over -> range_reward(), compute_reward(), episode_over()
 //
 // The code is a template over a backend `B` that supplies the cross-lane primitives:
-//   B::mask_t            per-lane row mask (device: uint32_t / uint64_t)
+//   B::mask_t / ivec_t   per-lane row mask (device: uint32_t / uint64_t) / per-lane int
 //   up(m), down(m)       m of the row above / below (0 outside the map)
 //   any(m)               group-uniform: is any lane's m non-zero
-//   any_ne(a, b)         group-uniform: a != b in any lane
+//   wave_any(m)          true if m != 0 in any lane of the wavefront (>= any(m); only used where an
+//                        extra loop round is harmless)
 //   first_bit(m)         m with only its first set bit in row-major order kept (whole group)
-//   popcount_sum(m)      group-uniform total popcount
+//   popcount_sum(m)      group-uniform total popcount;  popc_lanes(m) per-lane popcount
+//   imax(v)              group-uniform max of a per-lane int
+//   isel_ne / msel_ne    per lane: a != b ? x : y;   keep_where_eq(v, x, m): v == x ? m : 0
+//   bitrev(m)            reverse the bits of the mask word
+//   rows_down(m, k) / rows_up(m, k)   m of the row 2^k above / below, k < kLog2Group; may be confined
+//                        to aligned blocks of 16 rows (0 across a block edge)
 // On the GPU the backend is DevGroup (lanegroup_dev.h: DPP row shifts + ballot); tests instantiate
 // the same templates with a CPU lane-group simulator.
 #pragma once
 #include "pcgrl_common.h"
+
+// Cost-model hook for the CPU lane-group simulator (tests/hostsim); compiles to nothing in the product.
+#ifndef PCGRL_TRACE
+#define PCGRL_TRACE(g, site)
+#endif
 
 struct PcgrlParams {
     int32_t prob, rep, num_envs, width, height, ntiles, nplanes, group, mask_bytes;
@@ -88,29 +99,136 @@ PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t
 PCGRL_HD int num_stats(int prob) { return prob == PCGRL_PROB_BINARY ? 2 : (prob == PCGRL_PROB_ZELDA ? 7 : 6); }
 
 // ---------------------------------------------------------------- bitboard programs
+//
+// Work-saving structure (results are order-independent, so none of this changes an answer):
+//   * components of 1, 2 or 3 cells are recognised in closed form from per-cell neighbour counts
+//     (their region count and path length 0/1/2 need no flood at all);
+//   * a component is extracted with a *run fill*: a whole horizontal run is filled in O(1) with the
+//     carry chain of an integer add ((p + s) ^ p) & p, and its bit-reversed twin for the other
+//     direction), so extraction takes a few vertical hops instead of one step per BFS level;
+//   * the exact double BFS sweep only runs for a component that can still raise the maximum
+//     (a k-cell component cannot contain a shortest path longer than k-1);
+//   * the first component visited is the one through the fullest row, which is almost always the
+//     giant one, so the four maps that share a wavefront do their long sweeps at the same time;
+//   * BFS levels are kept per lane (iteration of the lane's last change) and reduced once per
+//     sweep, so the sweep loop needs a single wave-uniform exit test and no per-group ballot.
 template <class B>
 PCGRL_D typename B::mask_t pcg_expand(B& g, typename B::mask_t f) {
     return f | (f << 1) | (f >> 1) | g.up(f) | g.down(f);
 }
+template <class B>
+PCGRL_D typename B::mask_t pcg_neighbours(B& g, typename B::mask_t f) {
+    return (f << 1) | (f >> 1) | g.up(f) | g.down(f);
+}
+
+// Fill every horizontal run of `p` that contains a seed bit of `s` (s subset of p).  rp = bitrev(p).
+template <class B>
+PCGRL_D typename B::mask_t pcg_fill_rows(B& g, typename B::mask_t s, typename B::mask_t p, typename B::mask_t rp) {
+    typedef typename B::mask_t M;
+    M hi = (((p + s) ^ p) & p) | s;              // carry chain: seed .. top of its run
+    M rs = g.bitrev(s);
+    M lo = (((rp + rs) ^ rp) & rp) | rs;         // same in the mirrored word: seed .. bottom of its run
+    return hi | g.bitrev(lo);
+}
+
+// Per-map constants of the fills: mirrored passable mask and the Kogge-Stone "propagate" masks of
+// the vertical direction (pro_k[r] = passable in rows r, r-1, .., r-(2^k - 1), and the same upwards).
+template <class B>
+struct PcgFillCtx {
+    typename B::mask_t pass, rpass;
+    typename B::mask_t dn[B::kLog2Group], up[B::kLog2Group];
+};
+template <class B>
+PCGRL_D PcgFillCtx<B> pcg_fill_ctx(B& g, typename B::mask_t pass) {
+    PcgFillCtx<B> c;
+    c.pass = pass;
+    c.rpass = g.bitrev(pass);
+    c.dn[0] = pass; c.up[0] = pass;
+#pragma unroll
+    for (int k = 1; k < B::kLog2Group; k++) {
+        c.dn[k] = c.dn[k - 1] & g.rows_down(c.dn[k - 1], k - 1);
+        c.up[k] = c.up[k - 1] & g.rows_up(c.up[k - 1], k - 1);
+    }
+    return c;
+}
+// Fill every vertical run of passable cells that contains a bit of `f` (log2(rows) doubling steps).
+template <class B>
+PCGRL_D typename B::mask_t pcg_fill_cols(B& g, typename B::mask_t f, const PcgFillCtx<B>& c) {
+    typename B::mask_t d = f, u = f;
+#pragma unroll
+    for (int k = 0; k < B::kLog2Group; k++) {
+        d = d | (c.dn[k] & g.rows_down(d, k));    // rows_down(x, k): row r receives row r - 2^k
+        u = u | (c.up[k] & g.rows_up(u, k));
+    }
+    // The doubling steps may be confined to blocks of 16 rows (one DPP row); one plain row hop lets
+    // the next round carry the fill across a block boundary.
+    typename B::mask_t r = d | u;
+    return r | (c.pass & (g.up(r) | g.down(r)));
+}
+
+// The 4-connected component containing `seed`: alternate full-column and full-row fills until stable
+// (one round per "turn" of the most winding path instead of one step per cell).
+template <class B>
+PCGRL_D typename B::mask_t pcg_component(B& g, typename B::mask_t seed, const PcgFillCtx<B>& c) {
+    typedef typename B::mask_t M;
+    M f = pcg_fill_rows(g, seed, c.pass, c.rpass);
+    PCGRL_TRACE(g, 1);
+    for (;;) {
+        M n = pcg_fill_cols(g, f, c);
+        n = pcg_fill_rows(g, n, c.pass, c.rpass);
+        if (!g.wave_any(n ^ f)) break;           // an extra round is harmless (n == f)
+        f = n;
+    }
+    return f;
+}
+
+// Components with at most 3 cells, from neighbour counts.  Returns their union; adds their number to
+// `regions` and raises `path` to their longest path (1 for a 2-cell, 2 for a 3-cell component).
+template <class B>
+PCGRL_D typename B::mask_t pcg_tiny_components(B& g, typename B::mask_t p, int& regions, int& path) {
+    typedef typename B::mask_t M;
+    const M a = (p << 1) & p, b = (p >> 1) & p, c = g.up(p) & p, d = g.down(p) & p;   // has left/right/up/down neighbour
+    const M s0 = a ^ b, c0 = a & b, s1 = c ^ d, c1 = c & d;
+    const M n0 = s0 ^ s1, k = s0 & s1;            // count = n0 + 2*(c0 + c1 + k), at most two of c0,c1,k set
+    const M two_or_more = c0 | c1 | k;
+    const M iso = p & ~(a | b | c | d);
+    const M deg1 = n0 & ~two_or_more;
+    const M deg2 = ~n0 & (c0 ^ c1 ^ k) & ~(c0 & c1);
+    // 2-cell components: a degree-1 cell next to a degree-1 cell
+    const M dom = deg1 & pcg_neighbours(g, deg1);
+    // 3-cell components: a degree-2 centre whose two neighbours both have degree 1, plus those two
+    const M e1 = deg1 << 1, e2 = deg1 >> 1, e3 = g.up(deg1), e4 = g.down(deg1);
+    const M centre = deg2 & ((e1 & e2) | (e3 & e4) | ((e1 | e2) & (e3 | e4)));
+    const M ends = deg1 & pcg_neighbours(g, centre);
+    const int n_iso = g.popcount_sum(iso), n_dom = g.popcount_sum(dom), n_tri = g.popcount_sum(centre);
+    regions += n_iso + (n_dom >> 1) + n_tri;
+    const int tiny_path = n_tri > 0 ? 2 : (n_dom > 0 ? 1 : 0);
+    path = tiny_path > path ? tiny_path : path;
+    return iso | dom | centre | ends;
+}
 
 // BFS from `src` through `pass` until nothing new is reached.  Returns the number of levels
-// (eccentricity of src); `reached` = component, `last` = cells at maximum distance.
+// (eccentricity of src); `last` = cells at maximum distance.  Levels are tracked per lane.
 template <class B>
-PCGRL_D int bfs_levels(B& g, typename B::mask_t src, typename B::mask_t pass,
-                       typename B::mask_t& reached, typename B::mask_t& last) {
+PCGRL_D int bfs_levels(B& g, typename B::mask_t src, typename B::mask_t pass, typename B::mask_t& last) {
     typedef typename B::mask_t M;
+    typedef typename B::ivec_t I;
     M f = src, prev = src ^ src;
-    int t = 0;
+    I last_it = g.izero();
+    int it = 0;
+    PCGRL_TRACE(g, 2);
     for (;;) {
+        ++it;
         M n = pcg_expand(g, f) & pass;
-        if (!g.any_ne(n, f)) break;
-        prev = f;
+        if (!g.wave_any(n ^ f)) break;           // wave-uniform exit; a converged group just idles
+        last_it = g.isel_ne(n, f, it, last_it);
+        prev = g.msel_ne(n, f, f, prev);
         f = n;
-        ++t;
     }
-    reached = f;
-    last = f & ~prev;
-    return t;
+    const int ecc = g.imax(last_it);
+    // rows that changed at the final level hold the last frontier; with ecc == 0 it is src itself
+    last = g.keep_where_eq(last_it, ecc, f & ~prev);
+    return ecc;
 }
 
 // Distance from `src` to the nearest cell of `dst` (dst not containing src) through `pass`;
@@ -123,9 +241,9 @@ PCGRL_D int bfs_dist(B& g, typename B::mask_t src, typename B::mask_t dst, typen
     for (;;) {
         M n = pcg_expand(g, f) & pass;
         M fresh = n & ~f;
-        if (!g.any(fresh)) return -1;
         ++t;
         if (g.any(fresh & dst)) return t;
+        if (!g.any(fresh)) return -1;
         f = n;
     }
 }
@@ -134,43 +252,48 @@ PCGRL_D int bfs_dist(B& g, typename B::mask_t src, typename B::mask_t dst, typen
 template <class B>
 PCGRL_D int count_regions(B& g, typename B::mask_t pass) {
     typedef typename B::mask_t M;
-    // single-cell components need no flood
-    M nb = (pass << 1) | (pass >> 1) | g.up(pass) | g.down(pass);
-    M iso = pass & ~nb;
-    int regions = g.popcount_sum(iso);
-    M unvis = pass & ~iso;
-    while (g.any(unvis)) {
-        M f = g.first_bit(unvis);
-        for (;;) {
-            M n = pcg_expand(g, f) & unvis;
-            if (!g.any_ne(n, f)) break;
-            f = n;
-        }
-        unvis = unvis & ~f;
+    int regions = 0, dummy = 0;
+    M rest = pass & ~pcg_tiny_components(g, pass, regions, dummy);
+    if (!g.any(rest)) return regions;
+    const PcgFillCtx<B> ctx = pcg_fill_ctx(g, pass);    // components never touch, so the full mask is safe
+    while (g.any(rest)) {
+        M comp = pcg_component(g, g.first_bit(rest), ctx);
+        rest = rest & ~comp;
         ++regions;
     }
     return regions;
 }
 
-// binary_prob.py:81-86: regions + helper.py:250-264 double-sweep longest path, one pass over
-// the components in row-major order of their first cell.
+// binary_prob.py:81-86: regions + helper.py:250-264 double-sweep longest path.
 template <class B>
 PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path) {
     typedef typename B::mask_t M;
-    M nb = (pass << 1) | (pass >> 1) | g.up(pass) | g.down(pass);
-    M iso = pass & ~nb;                 // isolated cells: one region each, path 0
-    regions = g.popcount_sum(iso);
+    typedef typename B::ivec_t I;
+    regions = 0;
     path = 0;
-    M unvis = pass & ~iso;
-    while (g.any(unvis)) {
-        M src = g.first_bit(unvis);
-        M comp, last, tmp0, tmp1;
-        bfs_levels(g, src, unvis, comp, last);
-        M far = g.first_bit(last);      // np.argmax: first maximum in row-major order
-        int ecc = bfs_levels(g, far, comp, tmp0, tmp1);
-        path = ecc > path ? ecc : path;
-        unvis = unvis & ~comp;
+    M rest = pass & ~pcg_tiny_components(g, pass, regions, path);
+    if (!g.any(rest)) return;
+    const PcgFillCtx<B> ctx = pcg_fill_ctx(g, pass);    // components never touch, so the full mask is safe
+    bool first = true;
+    while (g.any(rest)) {
+        M seed;
+        if (first) {      // start in the fullest row: almost always the giant component
+            I cnt = g.popc_lanes(rest);
+            seed = g.first_bit(g.keep_where_eq(cnt, g.imax(cnt), rest));
+            first = false;
+        } else {
+            seed = g.first_bit(rest);
+        }
+        M comp = pcg_component(g, seed, ctx);
+        rest = rest & ~comp;
         ++regions;
+        const int size = g.popcount_sum(comp);
+        if (size - 1 > path) {                    // otherwise it cannot raise the maximum
+            M last, unused;
+            bfs_levels(g, g.first_bit(comp), comp, last);   // from the first cell in row-major order
+            const int ecc = bfs_levels(g, g.first_bit(last), comp, unused);   // np.argmax: first maximum
+            path = ecc > path ? ecc : path;
+        }
     }
 }
 

@@ -22,6 +22,7 @@
 // statistics never re-read or transpose the byte map.  No MFMA: integer/bit work only.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -30,37 +31,84 @@
 #include "lanegroup_dev.h"
 #include "mt19937.h"
 #include "pcgrl_algos.h"
+#include "sokoban_solver.h"
 
 #define PCGRL_BLOCK 256
-enum { CNT_CHG = 0, CNT_RST = 1, CNT_SOL = 2, CNT_STRIDE = 4 };
 enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
+
+// Work lists (changed environments, environments to reset, sokoban solver jobs).  A list is 64 shards,
+// each with its own counter on its own 64-byte line and its own segment of the item array, so appends
+// never pile up on one address (thousands of same-address atomics per step cost ~12 ns each);
+// consumers rebuild the dense index with a 64-entry prefix sum in LDS.  Counters are double-buffered
+// by step parity: the last kernel of a step zeroes the other parity's counters.
+#define WL_NSHARD 64
+#define WL_CSTRIDE 16
+enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_NLIST = 4 };   // SOL: solver jobs of the step, SOL2: of the resets
 
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     int32_t* counters; int32_t* stats; int32_t* start_stats; int32_t* info;
     double* reward; uint8_t* done; double* tile_p;
     uint32_t* rng_rep; uint32_t* rng_prob; int32_t* rng_cur;
-    int32_t* counts; int32_t* chg_list; int32_t* rst_list; int32_t* sol_list;
+    int32_t* wl_cnt;                 // [2 parities][WL_NLIST][WL_NSHARD * WL_CSTRIDE]
+    int32_t* wl_items[WL_NLIST];     // [WL_NSHARD][wl_cap]
+    int32_t wl_cap;
+    // sokoban solver arena (per resident solver block) and sticky status word
+    SokNode* sok_pool; uint32_t* sok_heap; uint32_t* sok_table; int32_t* status;
+    int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
 };
 
+__device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {
+    return B.wl_cnt + (size_t)(parity * WL_NLIST + list) * WL_NSHARD * WL_CSTRIDE;
+}
+__device__ __forceinline__ void wl_push(const DevBufs& B, int parity, int list, int shard, int value) {
+    const int i = atomicAdd(wl_counters(B, parity, list) + shard * WL_CSTRIDE, 1);
+    B.wl_items[list][(size_t)shard * B.wl_cap + i] = value;
+}
+// Every thread of the block calls this once; s_pref has WL_NSHARD + 1 entries.  Returns the list length.
+__device__ __forceinline__ int wl_load_prefix(const DevBufs& B, int parity, int list, int* s_pref) {
+    if (threadIdx.x < WL_NSHARD) {
+        int v = wl_counters(B, parity, list)[threadIdx.x * WL_CSTRIDE];
+        for (int o = 1; o < WL_NSHARD; o <<= 1) {
+            const int t = __shfl_up(v, o, 64);
+            if ((int)threadIdx.x >= o) v += t;
+        }
+        s_pref[threadIdx.x + 1] = v;
+        if (threadIdx.x == 0) s_pref[0] = 0;
+    }
+    __syncthreads();
+    return s_pref[WL_NSHARD];
+}
+__device__ __forceinline__ int wl_get(const DevBufs& B, int list, const int* s_pref, int i) {
+    int lo = 0;
+#pragma unroll
+    for (int step = WL_NSHARD / 2; step > 0; step >>= 1)
+        if (s_pref[lo + step] <= i) lo += step;
+    return B.wl_items[list][(size_t)lo * B.wl_cap + (i - s_pref[lo])];
+}
+__device__ __forceinline__ void wl_clear(const DevBufs& B, int parity) {   // one block, any size
+    for (int i = threadIdx.x; i < WL_NLIST * WL_NSHARD; i += blockDim.x) wl_counters(B, parity, 0)[i * WL_CSTRIDE] = 0;
+}
+
 // ------------------------------------------------------------------------------------------
-// Block-wide stream compaction: every thread of the block must call this.
-__device__ __forceinline__ void block_append(bool flag, int value, int32_t* list, int32_t* counter,
+// Block-wide stream compaction into a work list: every thread of the block must call this.
+__device__ __forceinline__ void block_append(bool flag, int value, const DevBufs& B, int parity, int list,
                                              int* s_cnt, int* s_base) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int shard = blockIdx.x & (WL_NSHARD - 1);
     const uint64_t m = __ballot(flag);
     if (lane == 0) s_cnt[w] = __popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        *s_base = tot ? atomicAdd(counter, tot) : 0;
+        *s_base = tot ? atomicAdd(wl_counters(B, parity, list) + shard * WL_CSTRIDE, tot) : 0;
     }
     __syncthreads();
     if (flag) {
         int off = *s_base;
         for (int i = 0; i < w; i++) off += s_cnt[i];
         off += __popcll(m & ((1ull << lane) - 1ull));
-        list[off] = value;
+        B.wl_items[list][(size_t)shard * B.wl_cap + off] = value;
     }
 }
 
@@ -162,9 +210,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             rst = d && P.auto_reset;
         }
     }
-    int32_t* counts = B.counts + parity * CNT_STRIDE;
-    block_append(chg, e, B.chg_list, counts + CNT_CHG, s_cnt[0], &s_base[0]);
-    block_append(rst, e, B.rst_list, counts + CNT_RST, s_cnt[1], &s_base[1]);
+    block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -176,25 +223,23 @@ __device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
 }
 
 __device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
-                                              int mode, int32_t* counts) {
+                                              int mode, int parity, int shard) {
     int32_t* st = B.stats + (size_t)e * 8;
     int32_t* start = B.start_stats + (size_t)e * 8;
     if (mode == MODE_STEP) {
         int32_t old[PCGRL_MAX_STATS], sv[PCGRL_MAX_STATS];
         for (int k = 0; k < 8; k++) { old[k] = st[k]; sv[k] = start[k]; }
         const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
-        const double r = compute_reward(P, s, old);
+        const double r = (P.pad_ & 8) ? 0.0 : compute_reward(P, s, old);
         const bool d = episode_over(P, s, sv) || c.y >= P.max_changes || c.x >= P.max_iterations;
         B.reward[e] = r;
         B.done[e] = d ? 1 : 0;
         int32_t* inf = B.info + (size_t)e * 10;
+        if (P.pad_ & 16) { st[0] = s[0]; st[1] = s[1]; } else {
         for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
         if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
-        inf[8] = c.x; inf[9] = c.y;
-        if (d && P.auto_reset) {
-            int i = atomicAdd(counts + CNT_RST, 1);
-            B.rst_list[i] = e;
-        }
+        inf[8] = c.x; inf[9] = c.y; }
+        if (d && P.auto_reset && !(P.pad_ & 4)) wl_push(B, parity, WL_RST, shard, e);
     } else {
         for (int k = 0; k < 8; k++) st[k] = s[k];
         if (mode == MODE_START)
@@ -203,21 +248,25 @@ __device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBuf
 }
 
 template <int PROB, int G, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, const int32_t* __restrict__ list,
-                                                        int count_idx, int parity, int mode) {
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity) {
+    __shared__ int s_pref[WL_NSHARD + 1];
+    // the last kernel of a step zeroes the *other* parity's work-list counters for the next step
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<G, MaskT> g;
     constexpr int GPB = PCGRL_BLOCK / G;
-    int32_t* counts = B.counts + parity * CNT_STRIDE;
-    const int n = counts[count_idx];
+    const int n = wl_load_prefix(B, parity, list, s_pref);
     const int gi = threadIdx.x / G;
     const int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
     for (int item = blockIdx.x * GPB + gi; item < n; item += gridDim.x * GPB) {
-        const int e = list[item];
+        const int e = wl_get(B, list, s_pref, item);
+        const int shard = (item >> 4) & (WL_NSHARD - 1);
         const MaskT* pl = reinterpret_cast<const MaskT*>(B.planes) + (size_t)e * NPL * G + g.lane;
         const MaskT valid = row_valid<MaskT>(g.lane, P.width, P.height);
         int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool need_solver = false;
-        if (PROB == PCGRL_PROB_BINARY) {
+        if (P.pad_ & 1) {
+            s[0] = (int)pl[0] & 1;
+        } else if (PROB == PCGRL_PROB_BINARY) {
             const MaskT b0 = pl[0];
             int regions, path;
             regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path);
@@ -227,16 +276,71 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
             if (PROB == PCGRL_PROB_ZELDA) zelda_stats(g, P, b0, b1, b2, valid, s);
             else need_solver = sokoban_stats(g, P, b0, b1, b2, valid, s);
         }
-        if (g.lane == 0) {
+        if (P.pad_ & 2) {
+            if (g.lane == 0) B.stats[(size_t)e * 8] = s[0] + s[1] + s[4] + s[5] + s[6];
+        } else if (g.lane == 0) {
             if (need_solver) {
-                // park the partial stats in the info row and hand the environment to the solver kernel
-                int32_t* inf = B.info + (size_t)e * 10;
-                for (int k = 0; k < 8; k++) inf[k] = s[k];
-                int i = atomicAdd(counts + CNT_SOL, 1);
-                B.sol_list[i] = e;
+                // park the partial stats and hand the environment to the solver kernel.  STEP: in the info
+                // row (the old stats are still needed for the reward); otherwise in the stats row itself
+                // (the info row keeps the terminal info of an environment that is being reset).
+                int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+                for (int k = 0; k < 8; k++) park[k] = s[k];
+                wl_push(B, parity, mode == MODE_STEP ? WL_SOL : WL_SOL2, shard, e);
             } else {
-                finalize_item(P, B, e, s, mode, counts);
+                finalize_item(P, B, e, s, mode, parity, shard);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sokoban: one wavefront per solver job (sokoban_solver.h).  Finishes what k_stats parked.
+__global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sok_lds[];
+    __shared__ int s_pref[WL_NSHARD + 1];
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    const int lane = threadIdx.x;
+    const int n = wl_load_prefix(B, parity, list, s_pref);
+    SokArena A;
+    A.pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
+    A.heap = B.sok_use_lds ? sok_lds : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
+    A.table = B.sok_use_lds ? sok_lds + SOK_LDS_HEAP : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
+    const int tsize = B.sok_use_lds ? SOK_LDS_TABLE : B.sok_table_size;
+    A.table_mask = tsize - 1;
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        const int e = wl_get(B, list, s_pref, item);
+        const int W = P.width, H = P.height;
+        SokLevel L;
+        SokNode root;
+        bool too_many = false;
+        if (lane == 0) {
+            const int ncr = sok_build_level(B.map + (size_t)e * W * H, W, H, L, root);
+            too_many = ncr > SOK_MAXC;
+            if (too_many) atomicOr(B.status, 1);
+            sok_init_deadlocks(L);
+            root.h = (uint16_t)sok_heuristic(L, root.crate);
+        }
+        int dist = 0, sol = 0;
+        bool win = false;
+        const int KS[4] = {-1, 2, 1, 0};
+        for (int a = 0; a < 4; a++) {
+            if (__shfl((int)win, 0, 64)) break;
+            for (int i = lane; i < tsize; i += 64) A.table[i] = 0;
+            __threadfence_block();
+            if (lane == 0) {
+                int hh, dd, it;
+                win = sok_search(L, A, root, KS[a], P.solver_power, hh, dd, it);
+                dist = win ? 0 : hh;
+                sol = win ? dd : 0;
+            }
+            __threadfence_block();
+        }
+        if (lane == 0) {
+            int32_t s[PCGRL_MAX_STATS];
+            const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+            for (int k = 0; k < 8; k++) s[k] = park[k];
+            s[4] = dist; s[5] = sol;
+            finalize_item(P, B, e, s, mode, parity, item & (WL_NSHARD - 1));
         }
     }
 }
@@ -271,10 +375,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_mapgen(PcgrlParams P, DevBufs B
     const int tiles_bytes = (cells + 15) & ~15;
     uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)wv * (PCGRL_MT_N * 4 + tiles_bytes));
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
-    int32_t* counts = B.counts + parity * CNT_STRIDE;
-    const int n = counts[CNT_RST];
+    __shared__ int s_pref[WL_NSHARD + 1];
+    const int n = wl_load_prefix(B, parity, WL_RST, s_pref);
     for (int item = blockIdx.x * 4 + wv; item < n; item += gridDim.x * 4) {
-        const int e = B.rst_list[item];
+        const int e = wl_get(B, WL_RST, s_pref, item);
         uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint8_t* map_g = B.map + (size_t)e * cells;
         uint8_t* old_g = B.old_map + (size_t)e * cells;
@@ -367,13 +471,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_planes_from_map(PcgrlParams P, 
     }
 }
 
-__global__ void k_fill_all(DevBufs B, int n, int parity, int count_idx, int32_t* list) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) list[i] = i;
-    if (i == 0) B.counts[parity * CNT_STRIDE + count_idx] = n;
-}
-__global__ void k_clear_counts(DevBufs B, int parity) {
-    if (threadIdx.x < CNT_STRIDE) B.counts[parity * CNT_STRIDE + threadIdx.x] = 0;
+__global__ void k_fill_all(DevBufs B, int n, int parity, int list) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) B.wl_items[list][(size_t)(i & (WL_NSHARD - 1)) * B.wl_cap + (i >> 6)] = i;
+    if (i < WL_NSHARD) wl_counters(B, parity, list)[i * WL_CSTRIDE] = (n - i + WL_NSHARD - 1) / WL_NSHARD;
 }
 __global__ void k_bcast_tile_p(double* tile_p, int n, double p0, double p1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -397,12 +498,13 @@ struct pcgrl_env {
     int parity;
     int device;
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
+    int alloc_solver_power;
     int profiling;
     std::vector<hipEvent_t> events;
     size_t ev_used;
     int prof_steps;
 };
-#define PCGRL_NPHASE 6   /* update, stats(step), solver(step), mapgen, stats(start)+solver(start), clear */
+#define PCGRL_NPHASE 6   /* update, stats(step), solver(step), mapgen, stats(start), solver(start) */
 static int prof_mark(pcgrl_env* h, hipStream_t st) {
     if (!h->profiling) return PCGRL_OK;
     if (h->ev_used == h->events.size()) {
@@ -425,6 +527,10 @@ static int validate_config(const pcgrl_config* c) {
     if (c->num_envs < 1) return PCGRL_EINVAL;
     if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
     if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
+    if (c->prob == PCGRL_SOKOBAN) {   // limits of the solver kernel (sokoban_solver.h)
+        if ((c->width + 2) * (c->height + 2) > 256) return PCGRL_EINVAL;
+        if (c->solver_power < 1 || c->solver_power > 16383) return PCGRL_EINVAL;
+    }
     return PCGRL_OK;
 }
 static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_ZELDA ? 8 : 5); }
@@ -445,11 +551,25 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     P->max_crates = c->max_crates; P->target_solution = c->target_solution; P->solver_power = c->solver_power;
     for (int i = 0; i < 8; i++) P->rewards[i] = c->rewards[i];
     pcgrl_build_cdf(c->tile_probs, P->ntiles, P->cdf);
+    const char* dbg = getenv("PCGRL_DEBUG_ABLATE");   // perf ablation only (bit0: no stats compute, bit1: no finalize)
+    P->pad_ = dbg ? atoi(dbg) : 0;
 }
 
+static const size_t WL_CNT_BYTES = 2 * WL_NLIST * WL_NSHARD * WL_CSTRIDE * sizeof(int32_t);
+static int wl_capacity(int num_envs) { return 2 * ((num_envs + WL_NSHARD - 1) / WL_NSHARD + 256); }
+#define SOK_BLOCKS 256   /* resident solver blocks (one per CU: heap + table fill most of its LDS) */
+static size_t wl_bytes(const pcgrl_config* c) {
+    return WL_CNT_BYTES + 256 + WL_NLIST * align_up((size_t)WL_NSHARD * wl_capacity(c->num_envs) * 4, 256);
+}
+static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<= 1; return t; }
 static size_t scratch_bytes(const pcgrl_config* c) {
-    size_t n = (size_t)c->num_envs;
-    return 256 + 3 * align_up(n * 4, 256);
+    size_t b = wl_bytes(c);
+    if (c->prob == PCGRL_SOKOBAN) {
+        const size_t nodes = 4 * (size_t)c->solver_power + 4;
+        b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
+        if (c->solver_power > SOK_LDS_POWER) b += SOK_BLOCKS * (align_up(nodes * 4, 256) + (size_t)sok_table_size(c->solver_power) * 4);
+    }
+    return b;
 }
 
 extern "C" {
@@ -489,7 +609,6 @@ int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
     int rc = validate_config(c);
     if (rc) return rc;
     if (!out) return PCGRL_EINVAL;
-    if (c->prob == PCGRL_SOKOBAN) return PCGRL_EINVAL;   // solver kernel lands in the next milestone
     pcgrl_env* h = new pcgrl_env();
     h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
     h->profiling = 0; h->ev_used = 0; h->prof_steps = 0;
@@ -519,13 +638,31 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     B.start_stats = (int32_t*)b->start_stats; B.info = (int32_t*)b->info; B.reward = (double*)b->reward;
     B.done = (uint8_t*)b->done; B.tile_p = (double*)b->tile_p; B.rng_rep = (uint32_t*)b->rng_rep;
     B.rng_prob = (uint32_t*)b->rng_prob; B.rng_cur = (int32_t*)b->rng_cursor;
-    const size_t n = (size_t)h->cfg.num_envs, lst = align_up(n * 4, 256);
+    B.wl_cap = wl_capacity(h->cfg.num_envs);
+    const size_t lst = align_up((size_t)WL_NSHARD * B.wl_cap * 4, 256);
     uint8_t* s = (uint8_t*)b->scratch;
-    B.counts = (int32_t*)s;
-    B.chg_list = (int32_t*)(s + 256);
-    B.rst_list = (int32_t*)(s + 256 + lst);
-    B.sol_list = (int32_t*)(s + 256 + 2 * lst);
-    HIPCHK(hipMemsetAsync(B.counts, 0, 256, (hipStream_t)stream));
+    B.wl_cnt = (int32_t*)s;
+    B.status = (int32_t*)(s + WL_CNT_BYTES);
+    for (int k = 0; k < WL_NLIST; k++) B.wl_items[k] = (int32_t*)(s + WL_CNT_BYTES + 256 + k * lst);
+    HIPCHK(hipMemsetAsync(B.wl_cnt, 0, WL_CNT_BYTES + 256, (hipStream_t)stream));
+    B.sok_pool = nullptr; B.sok_heap = nullptr; B.sok_table = nullptr;
+    if (h->cfg.prob == PCGRL_SOKOBAN) {
+        // the arena is sized for the solver_power the buffers were allocated with
+        const int power = h->alloc_solver_power = h->cfg.solver_power;
+        const size_t nodes = 4 * (size_t)power + 4;
+        uint8_t* a = s + wl_bytes(&h->cfg);
+        B.sok_pool = (SokNode*)a;
+        B.sok_pool_stride = (int32_t)(align_up(nodes * sizeof(SokNode), 256) / sizeof(SokNode));
+        a += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
+        B.sok_use_lds = power <= SOK_LDS_POWER;
+        B.sok_table_size = sok_table_size(power);
+        B.sok_heap_stride = (int32_t)(align_up(nodes * 4, 256) / 4);
+        if (!B.sok_use_lds) {
+            B.sok_heap = (uint32_t*)a;
+            a += SOK_BLOCKS * align_up(nodes * 4, 256);
+            B.sok_table = (uint32_t*)a;
+        }
+    }
     h->bound = 1; h->has_old = 0; h->was_reset = 0; h->parity = 0;
     return PCGRL_OK;   // tile_p is caller state: call pcgrl_set_tile_probs once after the first bind
 }
@@ -537,6 +674,7 @@ int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
     if (c->prob != h->cfg.prob || c->rep != h->cfg.rep || c->num_envs != h->cfg.num_envs ||
         c->width != h->cfg.width || c->height != h->cfg.height)
         return PCGRL_EINVAL;
+    if (h->bound && c->prob == PCGRL_SOKOBAN && c->solver_power > h->alloc_solver_power) return PCGRL_EINVAL;   // arena too small: re-create
     h->cfg = *c;
     fill_params(c, &h->P);
     return PCGRL_OK;
@@ -573,26 +711,27 @@ static int grid_for(int items, int per_block, int cap) {
 }
 
 template <int PROB>
-static int launch_stats_p(pcgrl_env* h, const int32_t* list, int count_idx, int parity, int mode, hipStream_t st) {
+static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const int gpb = PCGRL_BLOCK / P.group;
-    const int grid = grid_for(P.num_envs, gpb, 8192);
+    // per-step reset lists are short: a small grid-stride grid avoids dispatching thousands of empty blocks
+    const int grid = grid_for(P.num_envs, gpb, (mode == MODE_START && h->was_reset) ? 512 : 8192);
     if (P.group == 16 && P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
     else if (P.group == 16)
-        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
     else if (P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
     else
-        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, count_idx, parity, mode);
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
-static int launch_stats(pcgrl_env* h, const int32_t* list, int count_idx, int parity, int mode, hipStream_t st) {
+static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
     switch (h->P.prob) {
-        case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, count_idx, parity, mode, st);
-        case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, count_idx, parity, mode, st);
-        default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, count_idx, parity, mode, st);
+        case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, st);
+        case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, st);
+        default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, parity, mode, clr, st);
     }
 }
 
@@ -612,11 +751,24 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
     return PCGRL_OK;
 }
 
+static int launch_solver(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
+    const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sokoban), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sokoban, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list, parity, mode, clr);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
 static int launch_mapgen(pcgrl_env* h, int parity, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const int cells = P.width * P.height;
     const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((cells + 15) & ~15));
-    const int grid = grid_for(P.num_envs, 4, 4096);
+    const int grid = grid_for(P.num_envs, 4, h->was_reset ? 512 : 4096);
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
     if (P.mask_bytes == 4)
         hipLaunchKernelGGL((k_mapgen<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen);
@@ -632,14 +784,15 @@ int pcgrl_reset(pcgrl_env* h, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
     hipStream_t st = (hipStream_t)stream;
     const int n = h->cfg.num_envs, par = h->parity;
-    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)CNT_RST, h->B.rst_list);
+    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_RST);
     HIPCHK(hipGetLastError());
     int rc = launch_mapgen(h, par, st);
     if (rc) return rc;
-    rc = launch_stats(h, h->B.rst_list, CNT_RST, par, MODE_START, st);
+    const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN;
+    rc = launch_stats(h, WL_RST, par, MODE_START, sok ? -1 : (par ^ 1), st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, st, h->B, par);
-    HIPCHK(hipGetLastError());
+    if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
+    h->parity ^= 1;
     h->has_old = 1;
     h->was_reset = 1;
     return PCGRL_OK;
@@ -655,23 +808,26 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     rc = (h->P.mask_bytes == 4) ? launch_update_m<uint32_t>(h, actions, par, st) : launch_update_m<uint64_t>(h, actions, par, st);
     if (rc) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    rc = launch_stats(h, h->B.chg_list, CNT_CHG, par, MODE_STEP, st);
+    // the last kernel of the step clears the other parity's work-list counters
+    const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN, ar = h->P.auto_reset != 0;
+    rc = launch_stats(h, WL_CHG, par, MODE_STEP, (ar || sok) ? -1 : (par ^ 1), st);
     if (rc) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    if ((rc = prof_mark(h, st))) return rc;   // (solver phase placeholder)
-    if (h->P.auto_reset) {
+    if (sok && (rc = launch_solver(h, WL_SOL, par, MODE_STEP, ar ? -1 : (par ^ 1), st))) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    if (ar) {
         rc = launch_mapgen(h, par, st);
         if (rc) return rc;
     }
     if ((rc = prof_mark(h, st))) return rc;
-    if (h->P.auto_reset) {
-        rc = launch_stats(h, h->B.rst_list, CNT_RST, par, MODE_START, st);
+    if (ar) {
+        rc = launch_stats(h, WL_RST, par, MODE_START, sok ? -1 : (par ^ 1), st);
         if (rc) return rc;
     }
     if ((rc = prof_mark(h, st))) return rc;
-    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, st, h->B, par);
-    HIPCHK(hipGetLastError());
+    if (ar && sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
+    h->parity ^= 1;
     if (h->profiling) h->prof_steps++;
     return PCGRL_OK;
 }
@@ -701,6 +857,13 @@ int pcgrl_profile_read(pcgrl_env* h, double* phase_ms, int32_t* steps) {
     return PCGRL_OK;
 }
 
+int pcgrl_status(pcgrl_env* h, void* stream, int32_t* status) {
+    if (!h || !h->bound || !status) return PCGRL_ESTATE;
+    HIPCHK(hipMemcpyAsync(status, h->B.status, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return PCGRL_OK;
+}
+
 int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!maps) return PCGRL_EINVAL;
@@ -714,12 +877,13 @@ int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
     else
         hipLaunchKernelGGL((k_planes_from_map<uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)CNT_CHG, h->B.chg_list);
+    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_CHG);
     HIPCHK(hipGetLastError());
-    int rc = launch_stats(h, h->B.chg_list, CNT_CHG, par, MODE_SETMAP, st);
+    const bool sok = P.prob == PCGRL_PROB_SOKOBAN;
+    int rc = launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, st, h->B, par);
-    HIPCHK(hipGetLastError());
+    if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_SETMAP, par ^ 1, st))) return rc;
+    h->parity ^= 1;
     return PCGRL_OK;
 }
 

@@ -1,0 +1,270 @@
+// Sokoban solvability search for the reward path (device side).
+//
+// Restates probs/sokoban/engine.py as used by SokobanProblem._run_game (sokoban_prob.py:85-122):
+// BFSAgent(power), then AStarAgent with balance 1, 0.5, 0 (power pops each); the first agent whose
+// returned state wins gives (dist-win 0, sol-length = depth); otherwise dist-win is the heuristic of
+// the last agent's best node.  Exactness needs the engine's precise order of exploration:
+//   * level = map with a solid border, crates/targets collected row-major (engine.py:135-184)
+//   * children in the order L,R,U,D; dropped if the player did not move or a crate moved and any
+//     crate stands on a deadlock cell (engine.py:14-24, 203-252)
+//   * visited key = player + *ordered* crate list, tested on pop; duplicates stay queued (engine.py:62-73)
+//   * A* uses queue.PriorityQueue == CPython heapq: heappush/_siftdown, heappop/_siftup, comparing
+//     only with Node.__lt__ (h + balance*depth; here 2h + {2,1,0}*depth as integers)
+//   * bestNode = min h, then min depth, first seen.
+//
+// Mapping: one wavefront per solver job.  The search itself is a chain of data-dependent pops, so it
+// is driven by lane 0; the binary heap and the visited hash table live in LDS (flat pointers: they
+// fall back to a global arena when solver_power is too large for LDS), the node pool in a global
+// arena.  All lanes cooperate on clearing the tables.
+//
+// Limits (checked by the host): (W+2)*(H+2) <= 256, solver_power <= 16383; more than SOK_MAXC
+// crates raises the sticky status flag instead of returning a wrong answer.
+#pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#else
+#include <stdlib.h>
+#endif
+#include "pcgrl_common.h"
+
+#define SOK_MAXC 32
+#define SOK_LDS_POWER 5000                         /* solver_power up to this keeps heap+table in LDS */
+#define SOK_LDS_HEAP (4 * SOK_LDS_POWER + 4)       /* entries (u32) */
+#define SOK_LDS_TABLE 8192                         /* slots (u32), power of two */
+
+struct SokNode {            // 40 bytes
+    uint8_t crate[SOK_MAXC];
+    uint8_t player, pad;
+    uint16_t h;
+    uint16_t depth, pad2;
+};
+
+struct SokLevel {
+    uint64_t solid[4], dead[4], targetmask[4];
+    uint8_t target[SOK_MAXC];
+    int w, h, cells, nc;    // bordered dims, number of crates == targets
+    int dirs[4];
+};
+
+struct SokArena {           // per wave-slot global scratch
+    SokNode* pool;          // [4*power + 4]
+    uint32_t* heap;         // LDS or global
+    uint32_t* table;        // LDS or global
+    int table_mask;
+};
+
+PCGRL_D bool sok_bit(const uint64_t* m, int p) { return (m[p >> 6] >> (p & 63)) & 1ull; }
+PCGRL_D void sok_set(uint64_t* m, int p) { m[p >> 6] |= 1ull << (p & 63); }
+
+PCGRL_D int sok_crate_at(const SokLevel& L, const uint8_t* crate, int p) {
+    for (int i = 0; i < L.nc; i++) if (crate[i] == p) return i;
+    return -1;
+}
+PCGRL_D bool sok_win(const SokLevel& L, const uint8_t* crate) {   // engine.py:272-280
+    for (int i = 0; i < L.nc; i++) if (sok_crate_at(L, crate, L.target[i]) < 0) return false;
+    return true;
+}
+PCGRL_D int sok_heuristic(const SokLevel& L, const uint8_t* crate) {   // engine.py:282-296
+    uint32_t used = 0;   // targets removed from the shrinking list ("del targets[bestMatch]")
+    int distance = 0;
+    for (int c = 0; c < L.nc; c++) {
+        const int cx = crate[c] % L.w, cy = crate[c] / L.w;
+        int best = L.w + L.h, match = -1, firstfree = -1;
+        for (int i = 0; i < L.nc; i++) {
+            if ((used >> i) & 1u) continue;
+            if (firstfree < 0) firstfree = i;
+            const int tx = L.target[i] % L.w, ty = L.target[i] / L.w;
+            const int d = abs(cx - tx) + abs(cy - ty);
+            if (best > d) { match = i; best = d; }
+        }
+        if (match < 0) match = firstfree;   // bestMatch stays 0 = first remaining target
+        const int tx = L.target[match] % L.w, ty = L.target[match] / L.w;
+        distance += abs(tx - cx) + abs(ty - cy);
+        used |= 1u << match;
+    }
+    return distance;
+}
+
+// sokoban_prob.py:85-102 + engine.py:135-184: bordered level, crates/targets collected row-major.
+// Returns the number of crates found (may exceed SOK_MAXC; the lists are then truncated).
+PCGRL_D int sok_build_level(const uint8_t* m, int W, int H, SokLevel& L, SokNode& root) {
+    L.w = W + 2; L.h = H + 2; L.cells = L.w * L.h; L.nc = 0;
+    L.dirs[0] = -1; L.dirs[1] = 1; L.dirs[2] = -L.w; L.dirs[3] = L.w;
+    for (int k = 0; k < 4; k++) { L.solid[k] = 0; L.targetmask[k] = 0; L.dead[k] = 0; }
+    int nt = 0, ncr = 0;
+    root.player = 0; root.pad = 0; root.pad2 = 0; root.depth = 0; root.h = 0;
+    for (int i = 0; i < SOK_MAXC; i++) { root.crate[i] = 0; L.target[i] = 0; }
+    for (int y = 0; y < L.h; y++)
+        for (int x = 0; x < L.w; x++) {
+            const int p = y * L.w + x;
+            const bool border = x == 0 || y == 0 || x == L.w - 1 || y == L.h - 1;
+            const int t = border ? 1 : m[(y - 1) * W + (x - 1)];
+            if (t == 1) sok_set(L.solid, p);
+            if (t == 2) root.player = (uint8_t)p;
+            if (t == 3) { if (ncr < SOK_MAXC) root.crate[ncr] = (uint8_t)p; ncr++; }
+            if (t == 4) { if (nt < SOK_MAXC) L.target[nt] = (uint8_t)p; nt++; sok_set(L.targetmask, p); }
+        }
+    L.nc = ncr < SOK_MAXC ? ncr : SOK_MAXC;
+    return ncr;
+}
+
+// engine.py:203-246 intializeDeadlocks
+PCGRL_D void sok_init_deadlocks(SokLevel& L) {
+    for (int k = 0; k < 4; k++) L.dead[k] = 0;
+    const int w = L.w, h = L.h;
+    uint8_t corners[64];
+    int nc = 0;
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++) {
+            const int p = y * w + x;
+            if (sok_bit(L.solid, p)) continue;
+            const bool up = sok_bit(L.solid, p - w), dn = sok_bit(L.solid, p + w), lf = sok_bit(L.solid, p - 1), rt = sok_bit(L.solid, p + 1);
+            if ((up && lf) || (up && rt) || (dn && lf) || (dn && rt)) {
+                if (!sok_bit(L.targetmask, p)) {
+                    if (nc < 64) corners[nc++] = (uint8_t)p;
+                    sok_set(L.dead, p);
+                }
+            }
+        }
+    for (int a = 0; a < nc; a++)
+        for (int b = 0; b < nc; b++) {
+            const int ax = corners[a] % w, ay = corners[a] / w, bx = corners[b] % w, by = corners[b] / w;
+            const int dx = (ax > bx) - (ax < bx), dy = (ay > by) - (ay < by);
+            if ((dx == 0 && dy == 0) || (dx != 0 && dy != 0)) continue;
+            bool ok = true;
+            if (dx != 0) {
+                for (int x = bx + dx; x != ax; x += dx) {
+                    const int p = by * w + x;
+                    if (sok_bit(L.targetmask, p) || sok_bit(L.solid, p) || (!sok_bit(L.solid, p - w) && !sok_bit(L.solid, p + w))) { ok = false; break; }
+                }
+                if (ok) for (int x = bx + dx; x != ax; x += dx) sok_set(L.dead, by * w + x);
+            } else {
+                for (int y = by + dy; y != ay; y += dy) {
+                    const int p = y * w + bx;
+                    if (sok_bit(L.targetmask, p) || sok_bit(L.solid, p) || (!sok_bit(L.solid, p - 1) && !sok_bit(L.solid, p + 1))) { ok = false; break; }
+                }
+                if (ok) for (int y = by + dy; y != ay; y += dy) sok_set(L.dead, y * w + bx);
+            }
+        }
+}
+
+// --- CPython heapq on packed entries (priority << 16 | node index); only `<` on priorities ---------
+PCGRL_D bool sok_lt(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
+PCGRL_D void sok_siftdown(uint32_t* heap, int startpos, int pos) {
+    const uint32_t newitem = heap[pos];
+    while (pos > startpos) {
+        const int parentpos = (pos - 1) >> 1;
+        const uint32_t parent = heap[parentpos];
+        if (sok_lt(newitem, parent)) { heap[pos] = parent; pos = parentpos; continue; }
+        break;
+    }
+    heap[pos] = newitem;
+}
+PCGRL_D void sok_siftup(uint32_t* heap, int pos, int endpos) {
+    const int startpos = pos;
+    const uint32_t newitem = heap[pos];
+    int childpos = 2 * pos + 1;
+    while (childpos < endpos) {
+        const int rightpos = childpos + 1;
+        uint32_t c = heap[childpos];
+        if (rightpos < endpos) {
+            const uint32_t r = heap[rightpos];
+            if (!sok_lt(c, r)) { childpos = rightpos; c = r; }
+        }
+        heap[pos] = c;
+        pos = childpos;
+        childpos = 2 * pos + 1;
+    }
+    heap[pos] = newitem;
+    sok_siftdown(heap, startpos, pos);
+}
+
+PCGRL_D uint32_t sok_hash(const SokLevel& L, const SokNode& n) {
+    uint32_t hsh = 2166136261u;
+    hsh = (hsh ^ n.player) * 16777619u;
+    for (int i = 0; i < L.nc; i++) hsh = (hsh ^ n.crate[i]) * 16777619u;
+    return hsh ^ (hsh >> 15);
+}
+PCGRL_D bool sok_same(const SokLevel& L, const SokNode& a, const SokNode& b) {
+    if (a.player != b.player) return false;
+    for (int i = 0; i < L.nc; i++) if (a.crate[i] != b.crate[i]) return false;
+    return true;
+}
+
+// One search (lane 0 only).  k < 0: BFSAgent, else AStarAgent with integer weight k in {2,1,0}.
+// Returns win; out_h/out_depth describe the returned node (winner, or best node).
+PCGRL_D bool sok_search(const SokLevel& L, const SokArena& A, const SokNode& root, int k, int power,
+                                  int& out_h, int& out_depth, int& out_iters) {
+    SokNode* pool = A.pool;
+    uint32_t* heap = A.heap;
+    uint32_t* table = A.table;
+    int npool = 0, head = 0, heapn = 0, iterations = 0, best = -1, best_h = 0, best_depth = 0;
+    pool[0] = root;
+    npool = 1;
+    if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth) << 16) | 0u; heapn = 1; }
+    bool win = false;
+    int result_h = root.h, result_depth = 0;
+    while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
+        iterations++;
+        int cur;
+        if (k >= 0) {
+            const uint32_t last = heap[--heapn];
+            if (heapn > 0) { cur = (int)(heap[0] & 0xFFFFu); heap[0] = last; sok_siftup(heap, 0, heapn); }
+            else cur = (int)(last & 0xFFFFu);
+        } else {
+            cur = head++;
+        }
+        const SokNode node = pool[cur];
+        if (sok_win(L, node.crate)) { win = true; result_h = node.h; result_depth = node.depth; break; }
+        // visited test-and-add (open addressing; slot = node index + 1, low 16 bits; hash tag in the high bits)
+        const uint32_t hs = sok_hash(L, node);
+        uint32_t slot = hs & (uint32_t)A.table_mask;
+        const uint32_t tag = (hs >> 16) << 16;
+        bool seen = false;
+        for (;;) {
+            const uint32_t v = table[slot];
+            if (v == 0) break;
+            if ((v & 0xFFFF0000u) == tag && sok_same(L, pool[(v & 0xFFFFu) - 1], node)) { seen = true; break; }
+            slot = (slot + 1) & (uint32_t)A.table_mask;
+        }
+        if (seen) continue;
+        table[slot] = tag | (uint32_t)(cur + 1);
+        if (best < 0 || node.h < best_h || (node.h == best_h && node.depth < best_depth)) { best = cur; best_h = node.h; best_depth = node.depth; }
+        for (int d = 0; d < 4; d++) {          // Node.getChildren: L, R, U, D
+            SokNode child = node;
+            const int np = node.player + L.dirs[d];
+            bool crate_move = false;
+            if (!sok_bit(L.solid, np)) {       // State.update engine.py:298-327 (the popped node is never a win)
+                const int c = sok_crate_at(L, node.crate, np);
+                if (c < 0) {
+                    child.player = (uint8_t)np;
+                } else {
+                    const int cp = np + L.dirs[d];
+                    if (!sok_bit(L.solid, cp) && sok_crate_at(L, node.crate, cp) < 0) {
+                        child.player = (uint8_t)np;
+                        child.crate[c] = (uint8_t)cp;
+                        crate_move = true;
+                    }
+                }
+            }
+            if (child.player == node.player) continue;
+            if (crate_move) {
+                bool deadlock = false;
+                for (int i = 0; i < L.nc; i++) deadlock = deadlock || sok_bit(L.dead, child.crate[i]);
+                if (deadlock) continue;
+            }
+            child.depth = (uint16_t)(node.depth + 1);
+            child.h = crate_move ? (uint16_t)sok_heuristic(L, child.crate) : node.h;
+            pool[npool] = child;
+            if (k >= 0) {
+                heap[heapn] = ((uint32_t)(2 * child.h + k * child.depth) << 16) | (uint32_t)npool;
+                heapn++;
+                sok_siftdown(heap, 0, heapn - 1);
+            }
+            npool++;
+        }
+    }
+    if (!win) { result_h = best_h; result_depth = best_depth; }
+    out_h = result_h; out_depth = result_depth; out_iters = iterations;
+    return win;
+}

@@ -274,6 +274,14 @@ class BatchedPcgrlEnv:
         self._last_maps = m
         _lib.check(self._lib.pcgrl_set_maps(self._handle, C.c_void_p(m.data_ptr()), self._stream()), "pcgrl_set_maps")
 
+    def check_status(self):
+        """Raise if a kernel flagged an unsupported case (synchronises)."""
+        st = C.c_int32()
+        _lib.check(self._lib.pcgrl_status(self._handle, self._stream(), C.byref(st)), "pcgrl_status")
+        if st.value & 1:
+            raise RuntimeError("sokoban level with more than 32 crates: outside the solver kernel's limits")
+        return st.value
+
     def profile(self, enable=True):
         """Record HIP events around every phase of step() on the current stream."""
         _lib.check(self._lib.pcgrl_profile(self._handle, int(enable)), "pcgrl_profile")

@@ -108,10 +108,13 @@ int pcgrl_reset(pcgrl_env* env, void* stream);
 int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
 /* maps: DEVICE pointer u8 [N,H,W]; replaces every map, recomputes stats (start stats unchanged). */
 int pcgrl_set_maps(pcgrl_env* env, const uint8_t* maps, void* stream);
+/* Sticky device status word (0 = fine; bit 0: a sokoban level had more crates than the solver supports).
+ * Synchronises the stream. */
+int pcgrl_status(pcgrl_env* env, void* stream, int32_t* status);
 
 
 /* Per-phase GPU timing of pcgrl_step with HIP events recorded on the caller's stream (bench.py's
- * roofline leg).  Phases: 0 update, 1 stats(step), 2 solver(step), 3 mapgen, 4 stats(start), 5 clear. */
+ * roofline leg).  Phases: 0 update, 1 stats(step), 2 solver(step), 3 mapgen, 4 stats(start), 5 solver(start). */
 #define PCGRL_NPHASE 6
 int pcgrl_profile(pcgrl_env* env, int enable);
 int pcgrl_profile_read(pcgrl_env* env, double* phase_ms /*[PCGRL_NPHASE]*/, int32_t* steps);

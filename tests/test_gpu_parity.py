@@ -31,16 +31,7 @@ def _make(prob, rep, n, calls=(), seed=1000, auto_reset=True):
 
 
 def _supported(prob):
-    from gym_pcgrl_amd import _lib
-    import ctypes as C
-    c = _lib.Config()
-    c.prob = {"binary": 0, "zelda": 1, "sokoban": 2}[prob]
-    c.num_envs, c.width, c.height, c.max_changes, c.max_iterations = 1, 5, 5, 1, 1
-    h = C.c_void_p()
-    rc = _lib.load().pcgrl_create(C.byref(c), C.byref(h))
-    if rc == 0:
-        _lib.load().pcgrl_destroy(h)
-    return rc == 0
+    return prob in SUPPORTED
 
 
 # ------------------------------------------------------------------ map -> stats known answers
@@ -60,6 +51,7 @@ def test_stats_kat(path):
     env.reset()
     env.set_maps(maps)
     got = env.stats.cpu().numpy().astype(np.int64)
+    assert env.check_status() == 0
     bad = np.nonzero((got != d["stats"]).any(1))[0]
     assert bad.size == 0, (bad[:5], got[bad[:5]], d["stats"][bad[:5]])
     assert np.array_equal(env._bufs["map"].cpu().numpy(), maps)

@@ -63,6 +63,27 @@ def test_bitboard_stats_vs_golden(sim, path):
                 assert np.array_equal(out[:ns], exp), (i, variant, out, exp, m)
 
 
+def test_device_sokoban_solver_vs_golden(sim):
+    """gym_pcgrl_amd/csrc/sokoban_solver.h (the code k_sokoban runs on lane 0) compiled for the host:
+    dist-win, sol-length and the per-agent iteration counts must equal the reference's."""
+    sim.sim_sokoban_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = 0
+    for path in sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz"))):
+        d = np.load(path)
+        power = int(d["solver_power"])
+        for i, m in enumerate(d["maps"]):
+            if d["agents"][i, 4] == -2:
+                continue
+            m = np.ascontiguousarray(m)
+            dist, sol = C.c_int(), C.c_int()
+            it = np.zeros(4, np.int32)
+            assert sim.sim_sokoban_solve(_p(m), m.shape[0], m.shape[1], power, C.byref(dist), C.byref(sol), _p(it)) == 0
+            assert (dist.value, sol.value) == (d["stats"][i, 4], d["stats"][i, 5]), (path, i)
+            assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
+            n += 1
+    assert n > 300
+
+
 def test_bitboard_stats_vs_oracle_random(sim):
     rs = np.random.RandomState(99)
     for prob, nt in (("binary", 2), ("zelda", 8)):
@@ -76,6 +97,30 @@ def test_bitboard_stats_vs_oracle_random(sim):
             out, _ = sim_stats(sim, prob, m)
             exp = ol.get_stats(prob, m)
             assert np.array_equal(out[:len(exp)], exp), (prob, m, out, exp)
+
+
+def test_extra_wave_rounds_are_harmless(sim):
+    """On the GPU four maps share a wavefront and loops exit on a wave-wide test, so a group may run
+    extra rounds after it converged.  The simulator injects such spurious rounds."""
+    sim.sim_set_spurious.argtypes = [C.c_int]
+    rs = np.random.RandomState(5)
+    try:
+        for prob in ("binary", "zelda", "sokoban"):
+            for _ in range(300):
+                h, w = rs.randint(2, 20), rs.randint(2, 36)
+                if prob == "binary":
+                    m = (rs.random_sample((h, w)) < rs.random_sample()).astype(np.uint8)
+                else:
+                    nt = 8 if prob == "zelda" else 5
+                    p = np.array([0.5, rs.uniform(0, 0.5)] + [0.04] * (nt - 2))
+                    m = rs.choice(nt, size=(h, w), p=p / p.sum()).astype(np.uint8)
+                sim.sim_set_spurious(int(rs.randint(1, 40)))
+                out, _ = sim_stats(sim, prob, m)
+                exp = ol.get_stats(prob, m, solver_power=1)
+                k = 4 if prob == "sokoban" else len(exp)
+                assert np.array_equal(out[:k], exp[:k]), (prob, m, out, exp)
+    finally:
+        sim.sim_set_spurious(0)
 
 
 def test_range_reward_table(sim):
