@@ -1,0 +1,89 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the environment-axis sharding helpers that the
+N>1 path uses: partition, global seeding, and the host-side gather / scatter of per-rank tensors."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gym_pcgrl_amd import seeding, sharding
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 64, 65536, 65537, 131072 + 3):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = sharding.shard_range(total, world, r)
+                assert lo == prev and hi >= lo
+                prev = hi
+            assert prev == total
+            sizes = sharding.shard_sizes(total, world)
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 2, 2)
+
+
+def test_global_seeding_is_shard_invariant():
+    total, world = 37, 4
+    full = seeding.mt_states_for_seeds([100 + i for i in range(total)])
+    parts = []
+    for r in range(world):
+        lo, hi = sharding.shard_range(total, world, r)
+        parts.append(seeding.mt_states_for_seeds([100 + lo + i for i in range(hi - lo)]))
+    assert np.array_equal(np.concatenate(parts), full)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(total, world, rank)
+        # per-rank "step outputs": reward [n], map [n,3,2] whose content encodes the global env index
+        idx = torch.arange(lo, hi)
+        reward = idx.double() * 0.5
+        maps = (idx[:, None, None] + torch.zeros(1, 3, 2, dtype=torch.long)).to(torch.uint8)
+        g_r = sharding.gather_env_axis(reward, total)
+        g_m = sharding.gather_env_axis(maps, total)
+        ok = torch.equal(g_r, torch.arange(total).double() * 0.5) and torch.equal(g_m[:, 0, 0].long(), torch.arange(total) % 256)
+        # central policy on rank 0 -> per-rank action slices
+        full = torch.arange(total * 3, dtype=torch.int32).reshape(total, 3) if rank == 0 else None
+        like = torch.zeros(1, 3, dtype=torch.int32)
+        mine = sharding.scatter_env_axis(full, total, src=0, like=like)
+        exp = torch.arange(total * 3, dtype=torch.int32).reshape(total, 3)[lo:hi]
+        ok = ok and torch.equal(mine, exp)
+        # timing reduction used by bench.py: MAX over ranks
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and float(t.item()) == float(world)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [10, 7])
+def test_gather_scatter_world2_gloo(total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
