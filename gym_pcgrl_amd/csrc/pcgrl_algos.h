@@ -264,35 +264,65 @@ PCGRL_D int count_regions(B& g, typename B::mask_t pass) {
     return regions;
 }
 
+// helper.py:250-264 for one component: sweep from its first cell in row-major order, np.argmax == first
+// bit of the last frontier, second sweep; returns the second eccentricity.
+template <class B>
+PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp) {
+    typename B::mask_t last, unused;
+    bfs_levels(g, g.first_bit(comp), comp, last);
+    return bfs_levels(g, g.first_bit(last), comp, unused);
+}
+
 // binary_prob.py:81-86: regions + helper.py:250-264 double-sweep longest path.
+//
+// 16-lane groups (four maps per wavefront): phase 1 extracts every component (run/column fills only) and
+// remembers the two largest; phase 2 sweeps the largest -- at the same time in all four maps, which
+// keeps the lockstep cost near max-over-maps instead of sum-over-maps; the second largest and, rarely,
+// the rest are swept only if their size says they could still raise the maximum (a k-cell component
+// cannot hold a shortest path longer than k-1).  Whole-wave groups sweep as they go.
 template <class B>
 PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path) {
     typedef typename B::mask_t M;
-    typedef typename B::ivec_t I;
     regions = 0;
     path = 0;
-    M rest = pass & ~pcg_tiny_components(g, pass, regions, path);
-    if (!g.any(rest)) return;
+    const M nontiny = pass & ~pcg_tiny_components(g, pass, regions, path);
+    if (!g.any(nontiny)) return;
     const PcgFillCtx<B> ctx = pcg_fill_ctx(g, pass);    // components never touch, so the full mask is safe
-    bool first = true;
-    while (g.any(rest)) {
-        M seed;
-        if (first) {      // start in the fullest row: almost always the giant component
-            I cnt = g.popc_lanes(rest);
-            seed = g.first_bit(g.keep_where_eq(cnt, g.imax(cnt), rest));
-            first = false;
-        } else {
+    if (B::kGroup != 16) {
+        // One map per wavefront: no lockstep partner to align with, so sweep as we go.  Start in the
+        // fullest row (almost always the giant component) so that the size test prunes the most.
+        typedef typename B::ivec_t I;
+        M rest = nontiny;
+        const I cnt = g.popc_lanes(rest);
+        M seed = g.first_bit(g.keep_where_eq(cnt, g.imax(cnt), rest));
+        while (g.any(rest)) {
+            const M comp = pcg_component(g, seed, ctx);
+            rest = rest & ~comp;
+            ++regions;
+            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp); path = e > path ? e : path; }
             seed = g.first_bit(rest);
         }
-        M comp = pcg_component(g, seed, ctx);
+        return;
+    }
+    M rest = nontiny, big1 = nontiny ^ nontiny, big2 = big1;
+    int size1 = 0, size2 = 0, size3 = 0;
+    while (g.any(rest)) {
+        const M comp = pcg_component(g, g.first_bit(rest), ctx);
         rest = rest & ~comp;
         ++regions;
         const int size = g.popcount_sum(comp);
-        if (size - 1 > path) {                    // otherwise it cannot raise the maximum
-            M last, unused;
-            bfs_levels(g, g.first_bit(comp), comp, last);   // from the first cell in row-major order
-            const int ecc = bfs_levels(g, g.first_bit(last), comp, unused);   // np.argmax: first maximum
-            path = ecc > path ? ecc : path;
+        if (size > size1) { size3 = size2; size2 = size1; big2 = big1; size1 = size; big1 = comp; }
+        else if (size > size2) { size3 = size2; size2 = size; big2 = comp; }
+        else if (size > size3) size3 = size;
+    }
+    if (size1 - 1 > path) { const int e = pcg_double_sweep(g, big1); path = e > path ? e : path; }
+    if (size2 - 1 > path) { const int e = pcg_double_sweep(g, big2); path = e > path ? e : path; }
+    if (size3 - 1 > path) {   // rare: a third component is still large enough to matter
+        rest = nontiny & ~big1 & ~big2;
+        while (g.any(rest)) {
+            const M comp = pcg_component(g, g.first_bit(rest), ctx);
+            rest = rest & ~comp;
+            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp); path = e > path ? e : path; }
         }
     }
 }

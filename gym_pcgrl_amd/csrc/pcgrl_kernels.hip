@@ -1,20 +1,22 @@
 // HIP kernels (gfx950 / CDNA4) and C ABI of the batched PCGRL environment.
 //
-// One `pcgrl_step` is four launches on the caller's stream:
+// One `pcgrl_step` is three launches on the caller's stream (five for Sokoban):
 //
 //   k_update   thread per environment.  Representation.update (narrow_rep.py:99-114, wide_rep.py:67-70,
 //              turtle_rep.py:101-129), counters + heatmap (pcgrl_env.py:130-137).  Unchanged
 //              environments are finished here (reward 0, done, info); changed ones are compacted into
-//              a work list with a ballot / prefix-popcount append (one atomic per 256-thread block).
+//              a sharded work list, bucketed by expected difficulty (LDS histogram, one atomic per bucket
+//              per 256-thread block).
 //   k_stats    one lane group (16 lanes = one DPP row, or a full wavefront for maps taller than 16) per
-//              changed environment: Problem.get_stats as row-bitboard BFS (pcgrl_algos.h), get_reward,
+//              changed environment: Problem.get_stats as row-bitboard programs (pcgrl_algos.h), get_reward,
 //              get_episode_over, get_debug_info (pcgrl_env.py:138-148).  Done environments go to the
 //              reset list.
-//   k_mapgen   one wavefront per environment to reset: PcgrlEnv.reset (pcgrl_env.py:66-76): the MT19937
+//   k_sokoban  (Sokoban only) one wavefront per solver job parked by k_stats / k_reset.
+//   k_reset    one wavefront per environment to reset: PcgrlEnv.reset (pcgrl_env.py:66-76): the MT19937
 //              ring is staged in LDS and the wave produces 128 words per round, tiles are drawn with
 //              numpy's choice() rule, written coalesced as uint8 and transposed through LDS into the
-//              row bit planes; cursor draw; BinaryProblem.reset (binary_prob.py:68-72).
-//   k_stats    again in START mode over the reset list (start stats, problem.py:45-46).
+//              row bit planes; cursor draw; BinaryProblem.reset (binary_prob.py:68-72); start stats
+//              (problem.py:45-46) on the rows that are already in registers.
 //
 // State is structure-of-arrays over the environment axis, all in HBM, owned by the caller
 // (include/pcgrl_hip.h).  The uint8 map is the observation; the kernels compute on `planes`
@@ -51,8 +53,8 @@ struct DevBufs {
     double* reward; uint8_t* done; double* tile_p;
     uint32_t* rng_rep; uint32_t* rng_prob; int32_t* rng_cur;
     int32_t* wl_cnt;                 // [2 parities][WL_NLIST][WL_NSHARD * WL_CSTRIDE]
-    int32_t* wl_items[WL_NLIST];     // [WL_NSHARD][wl_cap]
-    int32_t wl_cap;
+    int32_t* wl_items[WL_NLIST];     // [WL_NSHARD][wl_cap[list]]
+    int32_t wl_cap[WL_NLIST];
     // sokoban solver arena (per resident solver block) and sticky status word
     SokNode* sok_pool; uint32_t* sok_heap; uint32_t* sok_table; int32_t* status;
     int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
@@ -63,7 +65,7 @@ __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, in
 }
 __device__ __forceinline__ void wl_push(const DevBufs& B, int parity, int list, int shard, int value) {
     const int i = atomicAdd(wl_counters(B, parity, list) + shard * WL_CSTRIDE, 1);
-    B.wl_items[list][(size_t)shard * B.wl_cap + i] = value;
+    B.wl_items[list][(size_t)shard * B.wl_cap[list] + i] = value;
 }
 // Every thread of the block calls this once; s_pref has WL_NSHARD + 1 entries.  Returns the list length.
 __device__ __forceinline__ int wl_load_prefix(const DevBufs& B, int parity, int list, int* s_pref) {
@@ -84,7 +86,7 @@ __device__ __forceinline__ int wl_get(const DevBufs& B, int list, const int* s_p
 #pragma unroll
     for (int step = WL_NSHARD / 2; step > 0; step >>= 1)
         if (s_pref[lo + step] <= i) lo += step;
-    return B.wl_items[list][(size_t)lo * B.wl_cap + (i - s_pref[lo])];
+    return B.wl_items[list][(size_t)lo * B.wl_cap[list] + (i - s_pref[lo])];
 }
 __device__ __forceinline__ void wl_clear(const DevBufs& B, int parity) {   // one block, any size
     for (int i = threadIdx.x; i < WL_NLIST * WL_NSHARD; i += blockDim.x) wl_counters(B, parity, 0)[i * WL_CSTRIDE] = 0;
@@ -108,42 +110,86 @@ __device__ __forceinline__ void block_append(bool flag, int value, const DevBufs
         int off = *s_base;
         for (int i = 0; i < w; i++) off += s_cnt[i];
         off += __popcll(m & ((1ull << lane) - 1ull));
-        B.wl_items[list][(size_t)shard * B.wl_cap + off] = value;
+        B.wl_items[list][(size_t)shard * B.wl_cap[list] + off] = value;
     }
+}
+
+// Changed environments are bucketed by how hard their statistics are expected to be (the previous
+// stats are a good predictor: one tile changed), one bucket per shard, so that the four maps sharing a
+// wavefront in k_stats have similar trip counts.  Every thread of the block must call this.
+__device__ __forceinline__ void block_append_bucketed(bool flag, int bucket, int value, const DevBufs& B, int parity, int list,
+                                                      int* s_hist, int* s_gbase) {
+    if (threadIdx.x < WL_NSHARD) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    int rank = 0;
+    if (flag) rank = atomicAdd(&s_hist[bucket], 1);
+    __syncthreads();
+    if (threadIdx.x < WL_NSHARD) {
+        const int c = s_hist[threadIdx.x];
+        if (c > 0) s_gbase[threadIdx.x] = atomicAdd(wl_counters(B, parity, list) + threadIdx.x * WL_CSTRIDE, c);
+    }
+    __syncthreads();
+    if (flag) B.wl_items[list][(size_t)bucket * B.wl_cap[list] + s_gbase[bucket] + rank] = value;
+}
+__device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int4& s0, const int4& s1) {
+    if (P.prob == PCGRL_PROB_BINARY) {   // (path-length / 6, regions / 3), 8 x 8
+        const int a = min(max(s0.y, 0) / 6, 7), b = min(max(s0.x, 0) / 3, 7);
+        return a * 8 + b;
+    }
+    const int regions = P.prob == PCGRL_PROB_ZELDA ? s1.x : s0.w;
+    return min(max(regions, 0), WL_NSHARD - 1);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------------------------------------------
 // k_update: thread per environment
+// The kernel is a chain of dependent scattered loads per thread at one wavefront per SIMD, so it is
+// written to keep that chain at three round trips: (1) action, counters, cursor, old stats; (2) the map
+// cell, its plane words and the MT19937 ring words of up to PCGRL_SPEC_DRAWS speculative draws (every
+// operand of draw i is an *old* word: distance 397); (3) the heatmap cell of the new cursor.
+#define PCGRL_SPEC_DRAWS 6
 template <int REP, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
     __shared__ int s_cnt[2][4];
     __shared__ int s_base[2];
+    __shared__ int s_hist[WL_NSHARD], s_gbase[WL_NSHARD];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
     const bool act = e < P.num_envs;
     bool chg = false, rst = false;
+    int bucket = 0;
     if (act) {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
-        int2 c = reinterpret_cast<int2*>(B.counters)[e];
+        // ---- round trip 1
+        const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
+        int a0_ = 0, a1_ = 0, a2_ = 0;
+        if (REP == PCGRL_REP_WIDE) { a0_ = actions[3 * e + 0]; a1_ = actions[3 * e + 1]; a2_ = actions[3 * e + 2]; }
+        else a0_ = actions[e];
+        uchar2 p0 = make_uchar2(0, 0);
+        if (REP != PCGRL_REP_WIDE) p0 = reinterpret_cast<const uchar2*>(B.pos)[e];
+        const bool draws = REP == PCGRL_REP_NARROW && P.random_tile;
+        int cur = 0;
+        if (draws) cur = B.rng_cur[2 * e];
+        const int4* sp = reinterpret_cast<const int4*>(B.stats + (size_t)e * 8);
+        const int4* tp = reinterpret_cast<const int4*>(B.start_stats + (size_t)e * 8);
+        const int4 s0 = sp[0], s1 = sp[1], t0 = tp[0], t1 = tp[1];
+
+        bucket = difficulty_bucket(P, s0, s1);
         const int iter = c.x + 1;
         int changes = c.y;
-        int x = 0, y = 0;
-        if (REP != PCGRL_REP_WIDE) {
-            uchar2 p = reinterpret_cast<uchar2*>(B.pos)[e];
-            x = p.x; y = p.y;
-        }
+        int x = p0.x, y = p0.y;
         int tile = -1, wx = 0, wy = 0, hx = 0, hy = 0;
         if (REP == PCGRL_REP_NARROW) {
-            int a = clampi(actions[e], 0, P.ntiles);
-            if (a > 0) { tile = a - 1; wx = x; wy = y; }
+            const int a = clampi(a0_, 0, P.ntiles);
+            if (a > 0) tile = a - 1;
+            wx = x; wy = y;
         } else if (REP == PCGRL_REP_WIDE) {
-            wx = clampi(actions[3 * e + 0], 0, W - 1);
-            wy = clampi(actions[3 * e + 1], 0, H - 1);
-            tile = clampi(actions[3 * e + 2], 0, P.ntiles - 1);
+            wx = clampi(a0_, 0, W - 1);
+            wy = clampi(a1_, 0, H - 1);
+            tile = clampi(a2_, 0, P.ntiles - 1);
             hx = wx; hy = wy;
         } else {
-            int a = clampi(actions[e], 0, P.ntiles + 3);
+            const int a = clampi(a0_, 0, P.ntiles + 3);
             if (a < 4) {   // turtle_rep.py:18,103-125: L,R,U,D with clamp or warp on both axes
                 const int dx = (a == 0) ? -1 : (a == 1 ? 1 : 0), dy = (a == 2) ? -1 : (a == 3 ? 1 : 0);
                 x += dx;
@@ -153,31 +199,63 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
                 if (y < 0) y = P.warp ? y + H : 0;
                 if (y >= H) y = P.warp ? y - H : H - 1;
             } else {
-                tile = a - 4; wx = x; wy = y;
+                tile = a - 4;
             }
-            hx = x; hy = y;
+            wx = x; wy = y; hx = x; hy = y;
         }
-        if (tile >= 0) {
-            uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
-            const int old = *cell;
-            if (old != tile) {
-                chg = true;
-                *cell = (uint8_t)tile;
-                MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G + wy;
-                const MaskT bit = (MaskT)1 << wx;
-                for (int b = 0; b < NPL; b++) {
-                    MaskT m = pl[b * G];
-                    m = ((tile >> b) & 1) ? (m | bit) : (m & ~bit);
-                    pl[b * G] = m;
-                }
+        // ---- round trip 2: everything addressed by the cursor cell and by the ring cursor
+        uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
+        MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G + wy;
+        const int old = *cell;
+        MaskT m0 = pl[0], m1 = 0, m2 = 0;
+        if (NPL > 1) { m1 = pl[G]; m2 = pl[2 * G]; }
+        uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
+        uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
+        if (draws) {
+#pragma unroll
+            for (int i = 0; i <= PCGRL_SPEC_DRAWS; i++) xa[i] = ring[mt_wrap(cur + i)];
+#pragma unroll
+            for (int i = 0; i < PCGRL_SPEC_DRAWS; i++) xb[i] = ring[mt_wrap(mt_wrap(cur + PCGRL_MT_M) + i)];
+        }
+        if (tile >= 0 && old != tile) {
+            chg = true;
+            *cell = (uint8_t)tile;
+            const MaskT bit = (MaskT)1 << wx;
+            pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
+            if (NPL > 1) {
+                pl[G] = (tile & 2) ? (m1 | bit) : (m1 & ~bit);
+                pl[2 * G] = (tile & 4) ? (m2 | bit) : (m2 & ~bit);
             }
         }
         if (REP == PCGRL_REP_NARROW) {   // the cursor moves on every step (narrow_rep.py:104-113)
-            if (P.random_tile) {
-                uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
-                int cur = B.rng_cur[2 * e];
-                x = mt_randint(ring, cur, W);
-                y = mt_randint(ring, cur, H);
+            if (draws) {
+                // numpy randint(W) then randint(H): masked rejection, consumed in order from the speculative words
+                const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
+                uint32_t mx = rx, my = ry;
+                mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
+                my |= my >> 1; my |= my >> 2; my |= my >> 4; my |= my >> 8; my |= my >> 16;
+                int stage = 0, used = 0;             // stage 0: drawing x, 1: drawing y, 2: done
+                if (rx == 0) { x = 0; stage = 1; }   // randint(1) draws nothing
+                if (stage == 1 && ry == 0) { y = 0; stage = 2; }
+#pragma unroll
+                for (int i = 0; i < PCGRL_SPEC_DRAWS; i++) {
+                    if (stage < 2) {
+                        const uint32_t yv = mt_twist(xa[i], xa[i + 1], xb[i]);
+                        ring[mt_wrap(cur + i)] = yv;
+                        used = i + 1;
+                        const uint32_t v = mt_temper(yv);
+                        if (stage == 0) {
+                            if ((v & mx) <= rx) { x = (int)(v & mx); stage = 1; if (ry == 0) { y = 0; stage = 2; } }
+                        } else {
+                            if ((v & my) <= ry) { y = (int)(v & my); stage = 2; }
+                        }
+                    }
+                }
+                cur = mt_wrap(cur + used);
+                if (stage < 2) {                      // (1/8)^k tail: finish with ordinary draws
+                    if (stage == 0) { x = mt_randint(ring, cur, W); y = mt_randint(ring, cur, H); }
+                    else y = mt_randint(ring, cur, H);
+                }
                 B.rng_cur[2 * e] = cur;
             } else {
                 x += 1;
@@ -185,6 +263,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             }
             hx = x; hy = y;   // pcgrl_env.py:137 marks the *new* cursor cell
         }
+        // ---- round trip 3
         if (chg) {
             changes += 1;
             B.heat[((size_t)e * H + hy) * W + hx] += 1;
@@ -194,23 +273,20 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         if (!chg) {
             // new_stats is old_stats (pcgrl_env.py:132-142): reward 0, done/info from the current stats
             int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
-            const int4* sp = reinterpret_cast<const int4*>(B.stats + (size_t)e * 8);
-            const int4* tp = reinterpret_cast<const int4*>(B.start_stats + (size_t)e * 8);
-            int4 a0 = sp[0], a1 = sp[1], b0 = tp[0], b1 = tp[1];
-            s[0] = a0.x; s[1] = a0.y; s[2] = a0.z; s[3] = a0.w; s[4] = a1.x; s[5] = a1.y; s[6] = a1.z; s[7] = a1.w;
-            st[0] = b0.x; st[1] = b0.y; st[2] = b0.z; st[3] = b0.w; st[4] = b1.x; st[5] = b1.y; st[6] = b1.z; st[7] = b1.w;
+            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+            st[0] = t0.x; st[1] = t0.y; st[2] = t0.z; st[3] = t0.w; st[4] = t1.x; st[5] = t1.y; st[6] = t1.z; st[7] = t1.w;
             const bool d = episode_over(P, s, st) || changes >= P.max_changes || iter >= P.max_iterations;
             B.reward[e] = 0.0;
             B.done[e] = d ? 1 : 0;
             int32_t* inf = B.info + (size_t)e * 10;
-            inf[0] = a0.x; inf[1] = a0.y; inf[2] = a0.z; inf[3] = a0.w;
-            inf[4] = a1.x; inf[5] = a1.y; inf[6] = a1.z; inf[7] = a1.w;
-            if (P.prob == PCGRL_PROB_BINARY) inf[2] = a0.y - b0.y;   // path-imp (binary_prob.py:137)
+            inf[0] = s0.x; inf[1] = s0.y; inf[2] = s0.z; inf[3] = s0.w;
+            inf[4] = s1.x; inf[5] = s1.y; inf[6] = s1.z; inf[7] = s1.w;
+            if (P.prob == PCGRL_PROB_BINARY) inf[2] = s0.y - t0.y;   // path-imp (binary_prob.py:137)
             inf[8] = iter; inf[9] = changes;
             rst = d && P.auto_reset;
         }
     }
-    block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    block_append_bucketed(chg, bucket, e, B, parity, WL_CHG, s_hist, s_gbase);
     block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
 }
 
@@ -247,6 +323,35 @@ __device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBuf
     }
 }
 
+// Problem.get_stats on the row masks of one map (b0..b2 = bit planes of the tile id).  Returns true
+// when the Sokoban solver has to finish the job.
+template <int PROB, class G, class MaskT>
+__device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, MaskT b0, MaskT b1, MaskT b2, MaskT valid, int32_t* s) {
+    if (PROB == PCGRL_PROB_BINARY) {
+        int regions, path;
+        regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path);
+        s[0] = regions; s[1] = path;
+        return false;
+    }
+    if (PROB == PCGRL_PROB_ZELDA) { zelda_stats(g, P, b0, b1, b2, valid, s); return false; }
+    return sokoban_stats(g, P, b0, b1, b2, valid, s);
+}
+
+// Lane 0 of the group: hand the item to the solver or finish it.
+__device__ __forceinline__ void finish_or_park(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s, bool need_solver,
+                                               int mode, int parity, int shard) {
+    if (need_solver) {
+        // park the partial stats and hand the environment to the solver kernel.  STEP: in the info
+        // row (the old stats are still needed for the reward); otherwise in the stats row itself
+        // (the info row keeps the terminal info of an environment that is being reset).
+        int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+        for (int k = 0; k < 8; k++) park[k] = s[k];
+        wl_push(B, parity, mode == MODE_STEP ? WL_SOL : WL_SOL2, shard, e);
+    } else {
+        finalize_item(P, B, e, s, mode, parity, shard);
+    }
+}
+
 template <int PROB, int G, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity) {
     __shared__ int s_pref[WL_NSHARD + 1];
@@ -263,33 +368,9 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
         const MaskT* pl = reinterpret_cast<const MaskT*>(B.planes) + (size_t)e * NPL * G + g.lane;
         const MaskT valid = row_valid<MaskT>(g.lane, P.width, P.height);
         int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-        bool need_solver = false;
-        if (P.pad_ & 1) {
-            s[0] = (int)pl[0] & 1;
-        } else if (PROB == PCGRL_PROB_BINARY) {
-            const MaskT b0 = pl[0];
-            int regions, path;
-            regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path);
-            s[0] = regions; s[1] = path;
-        } else {
-            const MaskT b0 = pl[0], b1 = pl[G], b2 = pl[2 * G];
-            if (PROB == PCGRL_PROB_ZELDA) zelda_stats(g, P, b0, b1, b2, valid, s);
-            else need_solver = sokoban_stats(g, P, b0, b1, b2, valid, s);
-        }
-        if (P.pad_ & 2) {
-            if (g.lane == 0) B.stats[(size_t)e * 8] = s[0] + s[1] + s[4] + s[5] + s[6];
-        } else if (g.lane == 0) {
-            if (need_solver) {
-                // park the partial stats and hand the environment to the solver kernel.  STEP: in the info
-                // row (the old stats are still needed for the reward); otherwise in the stats row itself
-                // (the info row keeps the terminal info of an environment that is being reset).
-                int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
-                for (int k = 0; k < 8; k++) park[k] = s[k];
-                wl_push(B, parity, mode == MODE_STEP ? WL_SOL : WL_SOL2, shard, e);
-            } else {
-                finalize_item(P, B, e, s, mode, parity, shard);
-            }
-        }
+        const MaskT b0 = pl[0], b1 = NPL > 1 ? pl[G] : (MaskT)0, b2 = NPL > 1 ? pl[2 * G] : (MaskT)0;
+        const bool need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, valid, s);
+        if (g.lane == 0) finish_or_park(P, B, e, s, need_solver, mode, parity, shard);
     }
 }
 
@@ -348,10 +429,11 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
 // ------------------------------------------------------------------------------------------
 // Row bit planes from a tile byte map staged in LDS; lanes [0,G) of the wave each take one row.
 template <class MaskT>
-__device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const uint8_t* tiles, MaskT* planes_e, int lane) {
+__device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const uint8_t* tiles, MaskT* planes_e, int lane,
+                                                  MaskT& m0, MaskT& m1, MaskT& m2) {
     const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
+    m0 = 0; m1 = 0; m2 = 0;
     if (lane < G) {
-        MaskT m0 = 0, m1 = 0, m2 = 0;
         if (lane < H) {
             const uint8_t* row = tiles + lane * W;
             for (int x = 0; x < W; x++) {
@@ -366,10 +448,11 @@ __device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const ui
     }
 }
 
-// k_mapgen: wavefront per environment to reset
-template <class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_mapgen(PcgrlParams P, DevBufs B, int parity, int gen_map) {
+// k_reset: wavefront per environment to reset -- PcgrlEnv.reset (pcgrl_env.py:66-76) including the start stats
+template <int PROB, int G, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_reset(PcgrlParams P, DevBufs B, int parity, int gen_map, int clear_parity) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int W = P.width, H = P.height, cells = W * H;
     const int tiles_bytes = (cells + 15) & ~15;
@@ -382,8 +465,18 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_mapgen(PcgrlParams P, DevBufs B
         uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint8_t* map_g = B.map + (size_t)e * cells;
         uint8_t* old_g = B.old_map + (size_t)e * cells;
-        int cur = B.rng_cur[2 * e];
+        const int2 curs = reinterpret_cast<const int2*>(B.rng_cur)[e];
+        int cur = curs.x;
         for (int i = lane; i < PCGRL_MT_N; i += 64) mt[i] = ring_g[i];
+        // BinaryProblem.reset (binary_prob.py:68-72) draws one double = two words from the *problem* stream
+        // after the map is made.  Its five operand words are fetched now, by five lanes, off the critical path.
+        const bool prob_draw = PROB == PCGRL_PROB_BINARY && P.random_probs;
+        uint32_t pw = 0;
+        if (prob_draw && lane < 5) {
+            const int off = lane < 3 ? lane : PCGRL_MT_M + (lane - 3);
+            int sl = curs.y + off; sl = sl >= PCGRL_MT_N ? sl - PCGRL_MT_N : sl;
+            pw = B.rng_prob[(size_t)e * PCGRL_MT_N + sl];
+        }
         __builtin_amdgcn_wave_barrier();
         if (gen_map) {
             // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
@@ -432,17 +525,33 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_mapgen(PcgrlParams P, DevBufs B
         }
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < PCGRL_MT_N; i += 64) ring_g[i] = mt[i];
-        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane);
+        MaskT b0, b1, b2;
+        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane, b0, b1, b2);
         uint16_t* heat_g = B.heat + (size_t)e * cells;
         for (int c = lane; c < cells; c += 64) heat_g[c] = 0;        // pcgrl_env.py:72
+        // start stats (pcgrl_env.py:70-71, problem.py:45-46): the rows are already in registers.  With
+        // 16-lane groups only the first DPP row holds the map; the other rows see an empty map and idle.
+        DevGroup<G, MaskT> g;
+        const MaskT valid = (lane < G) ? row_valid<MaskT>(g.lane, W, H) : (MaskT)0;
+        int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, valid, st);
         if (lane == 0) {
             B.rng_cur[2 * e] = cur;
             reinterpret_cast<int2*>(B.counters)[e] = make_int2(0, 0);   // pcgrl_env.py:67-68
-            if (P.prob == PCGRL_PROB_BINARY && P.random_probs) {         // binary_prob.py:68-72 (problem stream)
+            finish_or_park(P, B, e, st, need_solver, MODE_START, parity, item & (WL_NSHARD - 1));
+        }
+        if (prob_draw) {
+            // two consecutive lazy-ring draws at cursor c: word c uses (c, c+1, c+397), word c+1 uses
+            // (c+1, c+2, c+398); none of those operands is the slot the first draw rewrites
+            const uint32_t x0 = __shfl(pw, 0, 64), x1 = __shfl(pw, 1, 64), x2 = __shfl(pw, 2, 64);
+            const uint32_t xm0 = __shfl(pw, 3, 64), xm1 = __shfl(pw, 4, 64);
+            if (lane == 0) {
+                const uint32_t ya = mt_twist(x0, x1, xm0), yb = mt_twist(x1, x2, xm1);
                 uint32_t* ring_p = B.rng_prob + (size_t)e * PCGRL_MT_N;
-                int cp = B.rng_cur[2 * e + 1];
-                const double pe = mt_random(ring_p, cp);
-                B.rng_cur[2 * e + 1] = cp;
+                ring_p[curs.y] = ya;
+                ring_p[mt_wrap(curs.y + 1)] = yb;
+                B.rng_cur[2 * e + 1] = mt_wrap(mt_wrap(curs.y + 1) + 1);
+                const double pe = mt_to_double(mt_temper(ya), mt_temper(yb));
                 B.tile_p[2 * e] = pe;
                 B.tile_p[2 * e + 1] = 1 - pe;
             }
@@ -466,14 +575,15 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_planes_from_map(PcgrlParams P, 
             B.map[(size_t)e * cells + c] = t;
         }
         __builtin_amdgcn_wave_barrier();
-        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane);
+        MaskT b0, b1, b2;
+        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane, b0, b1, b2);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 __global__ void k_fill_all(DevBufs B, int n, int parity, int list) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) B.wl_items[list][(size_t)(i & (WL_NSHARD - 1)) * B.wl_cap + (i >> 6)] = i;
+    if (i < n) B.wl_items[list][(size_t)(i & (WL_NSHARD - 1)) * B.wl_cap[list] + (i >> 6)] = i;
     if (i < WL_NSHARD) wl_counters(B, parity, list)[i * WL_CSTRIDE] = (n - i + WL_NSHARD - 1) / WL_NSHARD;
 }
 __global__ void k_bcast_tile_p(double* tile_p, int n, double p0, double p1) {
@@ -556,10 +666,16 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
 }
 
 static const size_t WL_CNT_BYTES = 2 * WL_NLIST * WL_NSHARD * WL_CSTRIDE * sizeof(int32_t);
-static int wl_capacity(int num_envs) { return 2 * ((num_envs + WL_NSHARD - 1) / WL_NSHARD + 256); }
+// shard capacity: the changed list is bucketed by difficulty, so one bucket may receive every environment
+static int wl_capacity(int num_envs, int list) {
+    return list == WL_CHG ? num_envs : 2 * ((num_envs + WL_NSHARD - 1) / WL_NSHARD + 256);
+}
+static size_t wl_list_bytes(int num_envs, int list) { return align_up((size_t)WL_NSHARD * wl_capacity(num_envs, list) * 4, 256); }
 #define SOK_BLOCKS 256   /* resident solver blocks (one per CU: heap + table fill most of its LDS) */
 static size_t wl_bytes(const pcgrl_config* c) {
-    return WL_CNT_BYTES + 256 + WL_NLIST * align_up((size_t)WL_NSHARD * wl_capacity(c->num_envs) * 4, 256);
+    size_t b = WL_CNT_BYTES + 256;
+    for (int k = 0; k < WL_NLIST; k++) b += wl_list_bytes(c->num_envs, k);
+    return b;
 }
 static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<= 1; return t; }
 static size_t scratch_bytes(const pcgrl_config* c) {
@@ -638,12 +754,17 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     B.start_stats = (int32_t*)b->start_stats; B.info = (int32_t*)b->info; B.reward = (double*)b->reward;
     B.done = (uint8_t*)b->done; B.tile_p = (double*)b->tile_p; B.rng_rep = (uint32_t*)b->rng_rep;
     B.rng_prob = (uint32_t*)b->rng_prob; B.rng_cur = (int32_t*)b->rng_cursor;
-    B.wl_cap = wl_capacity(h->cfg.num_envs);
-    const size_t lst = align_up((size_t)WL_NSHARD * B.wl_cap * 4, 256);
     uint8_t* s = (uint8_t*)b->scratch;
     B.wl_cnt = (int32_t*)s;
     B.status = (int32_t*)(s + WL_CNT_BYTES);
-    for (int k = 0; k < WL_NLIST; k++) B.wl_items[k] = (int32_t*)(s + WL_CNT_BYTES + 256 + k * lst);
+    {
+        uint8_t* q = s + WL_CNT_BYTES + 256;
+        for (int k = 0; k < WL_NLIST; k++) {
+            B.wl_cap[k] = wl_capacity(h->cfg.num_envs, k);
+            B.wl_items[k] = (int32_t*)q;
+            q += wl_list_bytes(h->cfg.num_envs, k);
+        }
+    }
     HIPCHK(hipMemsetAsync(B.wl_cnt, 0, WL_CNT_BYTES + 256, (hipStream_t)stream));
     B.sok_pool = nullptr; B.sok_heap = nullptr; B.sok_table = nullptr;
     if (h->cfg.prob == PCGRL_SOKOBAN) {
@@ -764,18 +885,31 @@ static int launch_solver(pcgrl_env* h, int list, int parity, int mode, int clr, 
     return PCGRL_OK;
 }
 
-static int launch_mapgen(pcgrl_env* h, int parity, hipStream_t st) {
+template <int PROB>
+static int launch_reset_p(pcgrl_env* h, int parity, int clr, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const int cells = P.width * P.height;
     const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((cells + 15) & ~15));
     const int grid = grid_for(P.num_envs, 4, h->was_reset ? 512 : 4096);
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
-    if (P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_mapgen<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen);
+    if (P.group == 16 && P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_reset<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+    else if (P.group == 16)
+        hipLaunchKernelGGL((k_reset<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+    else if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_reset<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
     else
-        hipLaunchKernelGGL((k_mapgen<uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen);
+        hipLaunchKernelGGL((k_reset<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
+}
+// map generation + start stats of every environment on the reset list
+static int launch_reset(pcgrl_env* h, int parity, int clr, hipStream_t st) {
+    switch (h->P.prob) {
+        case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, parity, clr, st);
+        case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, parity, clr, st);
+        default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, parity, clr, st);
+    }
 }
 
 extern "C" {
@@ -786,10 +920,8 @@ int pcgrl_reset(pcgrl_env* h, void* stream) {
     const int n = h->cfg.num_envs, par = h->parity;
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_RST);
     HIPCHK(hipGetLastError());
-    int rc = launch_mapgen(h, par, st);
-    if (rc) return rc;
     const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN;
-    rc = launch_stats(h, WL_RST, par, MODE_START, sok ? -1 : (par ^ 1), st);
+    int rc = launch_reset(h, par, sok ? -1 : (par ^ 1), st);
     if (rc) return rc;
     if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
     h->parity ^= 1;
@@ -816,15 +948,11 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (sok && (rc = launch_solver(h, WL_SOL, par, MODE_STEP, ar ? -1 : (par ^ 1), st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     if (ar) {
-        rc = launch_mapgen(h, par, st);
+        rc = launch_reset(h, par, sok ? -1 : (par ^ 1), st);
         if (rc) return rc;
     }
     if ((rc = prof_mark(h, st))) return rc;
-    if (ar) {
-        rc = launch_stats(h, WL_RST, par, MODE_START, sok ? -1 : (par ^ 1), st);
-        if (rc) return rc;
-    }
-    if ((rc = prof_mark(h, st))) return rc;
+    if ((rc = prof_mark(h, st))) return rc;   // (the start stats are part of k_reset)
     if (ar && sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     h->parity ^= 1;
