@@ -286,7 +286,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             rst = d && P.auto_reset;
         }
     }
-    block_append_bucketed(chg, bucket, e, B, parity, WL_CHG, s_hist, s_gbase);
+    // bucketing pays where four maps share a wavefront and their cost varies a lot (binary); elsewhere the
+    // plain per-block append is cheaper (kernel-uniform branch)
+    if (P.prob == PCGRL_PROB_BINARY && P.group == 16) block_append_bucketed(chg, bucket, e, B, parity, WL_CHG, s_hist, s_gbase);
+    else block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
     block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
 }
 
