@@ -53,7 +53,7 @@ def cpu_baseline(prob, rep, calls, budget_s=12.0):
     import numpy as np
 
     import oracle_lib as ol
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
     def make(i):
         e = ol.OracleEnv(prob, rep)
@@ -112,13 +112,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
+    assert world == a.gpus or not use_dist, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)   # RCCL; only used for the barrier and the max-over-ranks time
 
     from gym_pcgrl_amd.envs import BatchedPcgrlEnv
     prob, rep, calls, n_default, desc = WORKLOADS[a.workload]
@@ -134,7 +135,7 @@ def main():
         env.step(acts[t])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -148,10 +149,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gpu_ms_per_step = ev0.elapsed_time(ev1) / a.steps
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    if use_dist:
+        tt = torch.tensor([dt, gpu_ms_per_step], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, gpu_ms_per_step = float(tt[0].item()), float(tt[1].item())
     # informational per-kernel breakdown: a second pass with HIP events around every launch
     # (each event record costs a few us on the stream, so it is kept out of the timed region)
     phase_ms, prof_steps = {}, 0
@@ -177,14 +178,15 @@ def main():
                        "parallelism": "env-axis shard x%d, no collective on the step path" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "step pipeline (k_update, k_stats, k_mapgen, k_stats; dominant: k_stats)",
+                         "kernel": "step pipeline (k_update, k_stats, k_reset [+ k_sokoban]; dominant: k_stats)",
                          "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
                          "phase_us_per_step_with_event_overhead": {k: 1e3 * v / max(prof_steps, 1) for k, v in phase_ms.items()}},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, rep, calls)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 
