@@ -385,35 +385,35 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x;
     const int n = wl_load_prefix(B, parity, list, s_pref);
-    SokArena A;
-    A.pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
-    A.heap = B.sok_use_lds ? sok_lds : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
-    A.table = B.sok_use_lds ? sok_lds + SOK_LDS_HEAP : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
+    __shared__ SokLevel s_L;             // level + node workspace in LDS: they are indexed dynamically
+    __shared__ SokNode s_root, s_work;
+    SokNode* pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
+    uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
+    uint32_t* g_table = B.sok_use_lds ? nullptr : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
     const int tsize = B.sok_use_lds ? SOK_LDS_TABLE : B.sok_table_size;
-    A.table_mask = tsize - 1;
     for (int item = blockIdx.x; item < n; item += gridDim.x) {
         const int e = wl_get(B, list, s_pref, item);
         const int W = P.width, H = P.height;
-        SokLevel L;
-        SokNode root;
-        bool too_many = false;
         if (lane == 0) {
-            const int ncr = sok_build_level(B.map + (size_t)e * W * H, W, H, L, root);
-            too_many = ncr > SOK_MAXC;
-            if (too_many) atomicOr(B.status, 1);
-            sok_init_deadlocks(L);
-            root.h = (uint16_t)sok_heuristic(L, root.crate);
+            const int ncr = sok_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+            if (ncr > SOK_MAXC) atomicOr(B.status, 1);
+            sok_init_deadlocks(s_L);
+            s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
         }
         int dist = 0, sol = 0;
         bool win = false;
         const int KS[4] = {-1, 2, 1, 0};
         for (int a = 0; a < 4; a++) {
             if (__shfl((int)win, 0, 64)) break;
-            for (int i = lane; i < tsize; i += 64) A.table[i] = 0;
+            if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
+            else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
             __threadfence_block();
             if (lane == 0) {
                 int hh, dd, it;
-                win = sok_search(L, A, root, KS[a], P.solver_power, hh, dd, it);
+                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
+                    win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it);
+                else
+                    win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it);
                 dist = win ? 0 : hh;
                 sol = win ? dd : 0;
             }

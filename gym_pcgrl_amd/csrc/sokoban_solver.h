@@ -149,8 +149,11 @@ PCGRL_D void sok_init_deadlocks(SokLevel& L) {
 }
 
 // --- CPython heapq on packed entries (priority << 16 | node index); only `<` on priorities ---------
+// The heap/table pointer types are template parameters so that, once inlined, the compiler knows the
+// address space (LDS vs global) and emits ds_* / global_* instead of flat accesses.
 PCGRL_D bool sok_lt(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
-PCGRL_D void sok_siftdown(uint32_t* heap, int startpos, int pos) {
+template <class HP>
+PCGRL_D void sok_siftdown(HP heap, int startpos, int pos) {
     const uint32_t newitem = heap[pos];
     while (pos > startpos) {
         const int parentpos = (pos - 1) >> 1;
@@ -160,7 +163,8 @@ PCGRL_D void sok_siftdown(uint32_t* heap, int startpos, int pos) {
     }
     heap[pos] = newitem;
 }
-PCGRL_D void sok_siftup(uint32_t* heap, int pos, int endpos) {
+template <class HP>
+PCGRL_D void sok_siftup(HP heap, int pos, int endpos) {
     const int startpos = pos;
     const uint32_t newitem = heap[pos];
     int childpos = 2 * pos + 1;
@@ -191,13 +195,14 @@ PCGRL_D bool sok_same(const SokLevel& L, const SokNode& a, const SokNode& b) {
     return true;
 }
 
-// One search (lane 0 only).  k < 0: BFSAgent, else AStarAgent with integer weight k in {2,1,0}.
+// One search (one lane).  k < 0: BFSAgent, else AStarAgent with integer weight k in {2,1,0}.
+// `L` and the node workspace `w` should live in LDS on the device (dynamic indexing of per-lane structs
+// would otherwise go to scratch memory).  Children are built in place in `w` (a child differs from its
+// parent in the player cell and at most one crate) and undone after being written to the pool.
 // Returns win; out_h/out_depth describe the returned node (winner, or best node).
-PCGRL_D bool sok_search(const SokLevel& L, const SokArena& A, const SokNode& root, int k, int power,
-                                  int& out_h, int& out_depth, int& out_iters) {
-    SokNode* pool = A.pool;
-    uint32_t* heap = A.heap;
-    uint32_t* table = A.table;
+template <class HP, class TP>
+PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int table_mask, SokNode& w,
+                        const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters) {
     int npool = 0, head = 0, heapn = 0, iterations = 0, best = -1, best_h = 0, best_depth = 0;
     pool[0] = root;
     npool = 1;
@@ -214,54 +219,54 @@ PCGRL_D bool sok_search(const SokLevel& L, const SokArena& A, const SokNode& roo
         } else {
             cur = head++;
         }
-        const SokNode node = pool[cur];
-        if (sok_win(L, node.crate)) { win = true; result_h = node.h; result_depth = node.depth; break; }
+        w = pool[cur];
+        const int node_h = w.h, node_depth = w.depth, node_player = w.player;
+        if (sok_win(L, w.crate)) { win = true; result_h = node_h; result_depth = node_depth; break; }
         // visited test-and-add (open addressing; slot = node index + 1, low 16 bits; hash tag in the high bits)
-        const uint32_t hs = sok_hash(L, node);
-        uint32_t slot = hs & (uint32_t)A.table_mask;
+        const uint32_t hs = sok_hash(L, w);
+        uint32_t slot = hs & (uint32_t)table_mask;
         const uint32_t tag = (hs >> 16) << 16;
         bool seen = false;
         for (;;) {
             const uint32_t v = table[slot];
             if (v == 0) break;
-            if ((v & 0xFFFF0000u) == tag && sok_same(L, pool[(v & 0xFFFFu) - 1], node)) { seen = true; break; }
-            slot = (slot + 1) & (uint32_t)A.table_mask;
+            if ((v & 0xFFFF0000u) == tag && sok_same(L, pool[(v & 0xFFFFu) - 1], w)) { seen = true; break; }
+            slot = (slot + 1) & (uint32_t)table_mask;
         }
         if (seen) continue;
         table[slot] = tag | (uint32_t)(cur + 1);
-        if (best < 0 || node.h < best_h || (node.h == best_h && node.depth < best_depth)) { best = cur; best_h = node.h; best_depth = node.depth; }
+        if (best < 0 || node_h < best_h || (node_h == best_h && node_depth < best_depth)) { best = cur; best_h = node_h; best_depth = node_depth; }
+        w.depth = (uint16_t)(node_depth + 1);
         for (int d = 0; d < 4; d++) {          // Node.getChildren: L, R, U, D
-            SokNode child = node;
-            const int np = node.player + L.dirs[d];
-            bool crate_move = false;
-            if (!sok_bit(L.solid, np)) {       // State.update engine.py:298-327 (the popped node is never a win)
-                const int c = sok_crate_at(L, node.crate, np);
-                if (c < 0) {
-                    child.player = (uint8_t)np;
-                } else {
-                    const int cp = np + L.dirs[d];
-                    if (!sok_bit(L.solid, cp) && sok_crate_at(L, node.crate, cp) < 0) {
-                        child.player = (uint8_t)np;
-                        child.crate[c] = (uint8_t)cp;
-                        crate_move = true;
-                    }
+            // State.update engine.py:298-327 (the popped node is never a win)
+            const int np = node_player + L.dirs[d];
+            if (sok_bit(L.solid, np)) continue;                 // player did not move
+            const int c = sok_crate_at(L, w.crate, np);
+            int cp = 0;
+            if (c >= 0) {
+                cp = np + L.dirs[d];
+                if (sok_bit(L.solid, cp) || sok_crate_at(L, w.crate, cp) >= 0) continue;   // blocked crate: no move
+            }
+            w.player = (uint8_t)np;
+            bool keep = true;
+            if (c >= 0) {
+                w.crate[c] = (uint8_t)cp;
+                bool deadlock = false;         // checkDeadlock looks at every crate
+                for (int i = 0; i < L.nc; i++) deadlock = deadlock || sok_bit(L.dead, w.crate[i]);
+                keep = !deadlock;
+                if (keep) w.h = (uint16_t)sok_heuristic(L, w.crate);
+            }
+            if (keep) {
+                pool[npool] = w;
+                if (k >= 0) {
+                    heap[heapn] = ((uint32_t)(2 * w.h + k * w.depth) << 16) | (uint32_t)npool;
+                    heapn++;
+                    sok_siftdown(heap, 0, heapn - 1);
                 }
+                npool++;
             }
-            if (child.player == node.player) continue;
-            if (crate_move) {
-                bool deadlock = false;
-                for (int i = 0; i < L.nc; i++) deadlock = deadlock || sok_bit(L.dead, child.crate[i]);
-                if (deadlock) continue;
-            }
-            child.depth = (uint16_t)(node.depth + 1);
-            child.h = crate_move ? (uint16_t)sok_heuristic(L, child.crate) : node.h;
-            pool[npool] = child;
-            if (k >= 0) {
-                heap[heapn] = ((uint32_t)(2 * child.h + k * child.depth) << 16) | (uint32_t)npool;
-                heapn++;
-                sok_siftdown(heap, 0, heapn - 1);
-            }
-            npool++;
+            w.player = (uint8_t)node_player;   // undo
+            if (c >= 0) { w.crate[c] = (uint8_t)np; w.h = (uint16_t)node_h; }
         }
     }
     if (!win) { result_h = best_h; result_depth = best_depth; }

@@ -115,7 +115,8 @@ int sim_sokoban_solve(const uint8_t* map, int h, int w, int power, int* dist, in
     for (int a = 0; a < 4; a++) iters[a] = 0;
     for (int a = 0; a < 4 && !win; a++) {
         for (int i = 0; i < tsize; i++) table[i] = 0;
-        win = sok_search(L, A, root, KS[a], power, hh, dd, iters[a]);
+        SokNode work;
+        win = sok_search(L, A.pool, A.heap, A.table, A.table_mask, work, root, KS[a], power, hh, dd, iters[a]);
     }
     *dist = win ? 0 : hh; *sol = win ? dd : 0;
     return 0;
