@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries of the last gpurun into profiles/<name>/ and write SUMMARY.md.
+    python tools_make_profile_summary.py <name> C2 [C3 ...]"""
+import collections, csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(ROOT, "gpurun_out")
+name, workloads = sys.argv[1], sys.argv[2:]
+dst = os.path.join(ROOT, "profiles", name)
+os.makedirs(dst, exist_ok=True)
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    if os.path.exists(path):
+        for r in csv.DictReader(open(path)):
+            d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+out = ["# %s (MI355X, rocprofv3)\n" % name,
+       "Commands: `tools_profile.sh <workload> trace sq mem` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 100 --no-cpu-baseline`,",
+       "then separate `--pmc` passes (SQ_* counters; FETCH_SIZE; WRITE_SIZE).  Bench lines: `bench_<W>.json`.\n"]
+for W in workloads:
+    out.append("## %s\n" % W)
+    ks = os.path.join(G, "prof_" + W, W + "_kernel_stats.csv")
+    if os.path.exists(ks):
+        shutil.copy(ks, os.path.join(dst, W + "_kernel_stats.csv"))
+        out.append("kernel-trace --stats (`%s_kernel_stats.csv`):\n\n| kernel | calls | avg us | min us | max us | %% |\n|---|---|---|---|---|---|" % W)
+        for r in csv.DictReader(open(ks)):
+            if r["Name"].startswith(("void k_", "k_")):
+                out.append("| %s | %s | %.2f | %.2f | %.2f | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                                    float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+        out.append("")
+    sq = agg(os.path.join(G, "pmc_sq_" + W, W + "_counter_collection.csv"))
+    sq2 = agg(os.path.join(G, "pmc_sq2_" + W, W + "_counter_collection.csv"))
+    f = agg(os.path.join(G, "pmc_fetch_" + W, W + "_counter_collection.csv"))
+    w = agg(os.path.join(G, "pmc_write_" + W, W + "_counter_collection.csv"))
+    if sq:
+        cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]
+        out.append("PMC, average per dispatch:\n\n| kernel | " + " | ".join(cols) + " | SQ_WAIT_ANY | FETCH_SIZE KB | WRITE_SIZE KB |\n|" + "---|" * (len(cols) + 4))
+        for k, v in sq.items():
+            if not k.startswith(("void k_", "k_")) or len(v[cols[0]]) < 4:
+                continue
+            m = lambda d, c: (sum(d[k][c]) / len(d[k][c])) if k in d and c in d[k] else float("nan")
+            out.append("| %s | " % k + " | ".join("%d" % m(sq, c) for c in cols) + " | %d | %.0f | %.0f |" % (m(sq2, "SQ_WAIT_ANY"), m(f, "FETCH_SIZE"), m(w, "WRITE_SIZE")))
+        out.append("")
+        tot_f = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) for k, v in f.items() if k.startswith("void k_") and len(v["FETCH_SIZE"]) > 4)
+        tot_w = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in w.items() if k.startswith("void k_") and len(v["WRITE_SIZE"]) > 4)
+        out.append("HBM traffic per step (sum over the step's kernels, as reported: rocprofv3 KB; FETCH_SIZE may under-report wide coalesced reads by 2x on gfx950, "
+                   "these kernels issue mostly narrow scattered accesses, so the figure is uncalibrated): fetch %.1f MB + write %.1f MB.\n" % (tot_f / 1024, tot_w / 1024))
+        json.dump({"workload": W, "fetch_bytes_per_step": tot_f * 1024, "write_bytes_per_step": tot_w * 1024}, open(os.path.join(dst, W + "_traffic.json"), "w"))
+    for cand in ("bench_%s.json" % W, "bench_%s.log" % W):
+        b = os.path.join(G, cand)
+        if os.path.exists(b) and os.path.getsize(b) > 10:
+            line = open(b).read().strip().splitlines()[-1]
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            open(os.path.join(dst, "bench_%s.json" % W), "w").write(line + "\n")
+            out.append("bench: **%.1f M env-steps/s**, %.1f us/step, roofline achieved %.0f GB/s (frac %.4f)%s\n" % (
+                d["value"] / 1e6, d["ms_per_step"] * 1e3, d["roofline"]["achieved"], d["roofline"]["frac"],
+                (", cpu_baseline %.2f M/s on %d threads (%.0f k/s single)" % (d["cpu_baseline"]["value"] / 1e6, d["cpu_baseline"]["cores"], d["cpu_baseline"]["single_core"] / 1e3)) if "cpu_baseline" in d else ""))
+            break
+open(os.path.join(dst, "SUMMARY.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out)[:3000])
