@@ -46,6 +46,18 @@ def make_actions(torch, rep, steps, n, W, H, nt, device, seed):
                         torch.randint(0, nt, (steps, n), generator=g, device=device, dtype=torch.int32)], -1).contiguous()
 
 
+def measured_traffic(workload):
+    """HBM bytes per step from the last committed rocprofv3 PMC passes (profiles/*/<W>_traffic.json:
+    FETCH_SIZE + WRITE_SIZE summed over the step's kernels, in bytes, as reported -- see the SUMMARY.md
+    next to it for the calibration caveat).  None when no profile is committed for the workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", workload + "_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d["fetch_bytes_per_step"] + d["write_bytes_per_step"], os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(prob, rep, calls, budget_s=12.0):
     """Oracle (kind 'port') on every host core: one environment per thread, random actions."""
     import concurrent.futures as cf
@@ -168,6 +180,7 @@ def main():
         value = total_steps / dt
         b_alg = 2 * H * W + 64
         achieved = n * b_alg / (gpu_ms_per_step * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(a.workload) if n == n_default else (None, None)
         out = {
             "metric": "env-steps/sec (whole node), binary-narrow 14x14 @ 65536 envs" if a.workload == "C2" else "env-steps/sec (whole node)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -177,7 +190,8 @@ def main():
                        "max_iterations": env._max_iterations, "actions": "uniform random, device-generated before the timed region",
                        "parallelism": "env-axis shard x%d, no collective on the step path" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": n * b_alg,
                          "kernel": "step pipeline (k_update, k_stats, k_reset [+ k_sokoban]; dominant: k_stats)",
                          "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
                          "phase_us_per_step_with_event_overhead": {k: 1e3 * v / max(prof_steps, 1) for k, v in phase_ms.items()}},
