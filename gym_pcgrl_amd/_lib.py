@@ -42,7 +42,8 @@ class Buffers(C.Structure):
 
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
-           "pcgrl_step", "pcgrl_set_maps", "pcgrl_status", "pcgrl_profile", "pcgrl_profile_read")
+           "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
+           "pcgrl_profile_read")
 NPHASE = 6
 PHASES = ("update", "stats_step", "solver_step", "mapgen", "stats_start", "solver_start")
 
@@ -101,6 +102,8 @@ def load():
     L.pcgrl_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.pcgrl_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_set_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcgrl_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.pcgrl_action_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     L.pcgrl_profile.argtypes = [C.c_void_p, C.c_int]
     L.pcgrl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]

@@ -63,30 +63,45 @@ PCGRL_HD double range_reward(double nv, double ov, double lo, double hi) {
 #define PCGRL_INF (__builtin_huge_val())
 #endif
 
-// binary_prob.py:98-106 | zelda_prob.py:124-142 | sokoban_prob.py:157-175 (same summation order)
+// The stats are small integers and every band bound is an integer or +-inf, so get_range_reward is
+// evaluated in integer arithmetic (INT_MAX / INT_MIN stand for +-inf: the comparisons and min/max then
+// behave exactly like the float version, and the two "crossing" cases cannot be reached with an infinite
+// bound).  Checked against the reference's table in tests (range_reward.npz).
+#define PCGRL_IPOS 2147483647
+#define PCGRL_INEG (-2147483647 - 1)
+PCGRL_HD int range_reward_i(int nv, int ov, int lo, int hi) {
+    if (nv >= lo && nv <= hi && ov >= lo && ov <= hi) return 0;
+    if (ov <= hi && nv <= hi) return (nv < lo ? nv : lo) - (ov < lo ? ov : lo);
+    if (ov >= lo && nv >= lo) return (ov > hi ? ov : hi) - (nv > hi ? nv : hi);
+    if (nv > hi && ov < lo) return hi - nv + ov - lo;
+    return hi - ov + nv - lo;
+}
+
+// binary_prob.py:98-106 | zelda_prob.py:124-142 | sokoban_prob.py:157-175 (same summation order; the
+// products and sums are done in fp64 exactly as Python does them with int * weight)
 PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int32_t* o) {
     const double* w = P.rewards;
     if (P.prob == PCGRL_PROB_BINARY) {
-        return range_reward(n[0], o[0], 1, 1) * w[0] + range_reward(n[1], o[1], PCGRL_INF, PCGRL_INF) * w[1];
+        return (double)range_reward_i(n[0], o[0], 1, 1) * w[0] + (double)range_reward_i(n[1], o[1], PCGRL_IPOS, PCGRL_IPOS) * w[1];
     } else if (P.prob == PCGRL_PROB_ZELDA) {
-        double r = range_reward(n[0], o[0], 1, 1) * w[0];
-        r = r + range_reward(n[1], o[1], 1, 1) * w[1];
-        r = r + range_reward(n[2], o[2], 1, 1) * w[2];
-        r = r + range_reward(n[3], o[3], 2, P.max_enemies) * w[4];
-        r = r + range_reward(n[4], o[4], 1, 1) * w[3];
-        r = r + range_reward(n[5], o[5], P.target_enemy_dist, PCGRL_INF) * w[5];
-        r = r + range_reward(n[6], o[6], PCGRL_INF, PCGRL_INF) * w[6];
+        double r = (double)range_reward_i(n[0], o[0], 1, 1) * w[0];
+        r = r + (double)range_reward_i(n[1], o[1], 1, 1) * w[1];
+        r = r + (double)range_reward_i(n[2], o[2], 1, 1) * w[2];
+        r = r + (double)range_reward_i(n[3], o[3], 2, P.max_enemies) * w[4];
+        r = r + (double)range_reward_i(n[4], o[4], 1, 1) * w[3];
+        r = r + (double)range_reward_i(n[5], o[5], P.target_enemy_dist, PCGRL_IPOS) * w[5];
+        r = r + (double)range_reward_i(n[6], o[6], PCGRL_IPOS, PCGRL_IPOS) * w[6];
         return r;
     } else {
         int nr = n[1] - n[2], orr = o[1] - o[2];
         nr = nr < 0 ? -nr : nr; orr = orr < 0 ? -orr : orr;
-        double r = range_reward(n[0], o[0], 1, 1) * w[0];
-        r = r + range_reward(n[1], o[1], 1, P.max_crates) * w[1];
-        r = r + range_reward(n[2], o[2], 1, P.max_crates) * w[2];
-        r = r + range_reward(n[3], o[3], 1, 1) * w[3];
-        r = r + range_reward(nr, orr, -PCGRL_INF, -PCGRL_INF) * w[4];
-        r = r + range_reward(n[4], o[4], -PCGRL_INF, -PCGRL_INF) * w[5];
-        r = r + range_reward(n[5], o[5], PCGRL_INF, PCGRL_INF) * w[6];
+        double r = (double)range_reward_i(n[0], o[0], 1, 1) * w[0];
+        r = r + (double)range_reward_i(n[1], o[1], 1, P.max_crates) * w[1];
+        r = r + (double)range_reward_i(n[2], o[2], 1, P.max_crates) * w[2];
+        r = r + (double)range_reward_i(n[3], o[3], 1, 1) * w[3];
+        r = r + (double)range_reward_i(nr, orr, PCGRL_INEG, PCGRL_INEG) * w[4];
+        r = r + (double)range_reward_i(n[4], o[4], PCGRL_INEG, PCGRL_INEG) * w[5];
+        r = r + (double)range_reward_i(n[5], o[5], PCGRL_IPOS, PCGRL_IPOS) * w[6];
         return r;
     }
 }

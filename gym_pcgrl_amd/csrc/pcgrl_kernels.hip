@@ -585,6 +585,47 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_planes_from_map(PcgrlParams P, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Observation formatting of the reference's composite wrappers (wrappers.py): Cropped.transform :197-206
+// (pad with the border tile, window of `size` centred on the cursor), OneHotEncoding.transform :101-104,
+// ToImage.transform :53-60 ([h, w, depth] image).  One thread per output cell; depth 1 = raw tile ids,
+// depth T = one-hot.  Writes are coalesced along (cell, depth).
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_obs_window(PcgrlParams P, DevBufs B, uint8_t* __restrict__ out, int oh, int ow,
+                                                             int centered, int pad_value, int depth) {
+    const size_t per_env = (size_t)oh * ow;
+    const size_t total = (size_t)P.num_envs * per_env;
+    for (size_t i = (size_t)blockIdx.x * PCGRL_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * PCGRL_BLOCK) {
+        const int e = (int)(i / per_env);
+        const int rc = (int)(i - (size_t)e * per_env);
+        const int r = rc / ow, c = rc - r * ow;
+        int y = r, x = c;
+        if (centered) {
+            const uchar2 p = reinterpret_cast<const uchar2*>(B.pos)[e];
+            y = (int)p.y + r - oh / 2;     // np.pad(map, size // 2) then padded[y : y + size, x : x + size]
+            x = (int)p.x + c - ow / 2;
+        }
+        int t = pad_value;
+        if (x >= 0 && y >= 0 && x < P.width && y < P.height) t = B.map[((size_t)e * P.height + y) * P.width + x];
+        uint8_t* o = out + i * depth;
+        if (depth == 1) o[0] = (uint8_t)t;
+        else if (depth == 8) {
+            *reinterpret_cast<uint64_t*>(o) = 1ull << (8 * t);
+        } else {
+            for (int d = 0; d < depth; d++) o[d] = (uint8_t)(d == t);
+        }
+    }
+}
+// ActionMap.step for the wide representation (wrappers.py:139-154): flat index into (h, w, tiles) -> (x, y, tile)
+__global__ void k_action_map(const int32_t* __restrict__ flat, int32_t* __restrict__ xyv, int n, int w, int h, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int a = flat[i];
+        a = a < 0 ? 0 : (a >= w * h * dim ? w * h * dim - 1 : a);
+        const int v = a % dim, x = (a / dim) % w, y = a / (dim * w);
+        xyv[3 * i] = x; xyv[3 * i + 1] = y; xyv[3 * i + 2] = v;
+    }
+}
+
 __global__ void k_fill_all(DevBufs B, int n, int parity, int list) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) B.wl_items[list][(size_t)(i & (WL_NSHARD - 1)) * B.wl_cap[list] + (i >> 6)] = i;
@@ -1096,6 +1137,27 @@ int pcgrl_profile_read(pcgrl_env* h, double* phase_ms, int32_t* steps) {
             HIPCHK(hipEventElapsedTime(&ms, h->events[s0 + k], h->events[s0 + k + 1]));
             phase_ms[k] += ms;
         }
+    return PCGRL_OK;
+}
+
+int pcgrl_observe(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!out || out_h < 1 || out_w < 1) return PCGRL_EINVAL;
+    if (centered && h->P.rep == PCGRL_REP_WIDE) return PCGRL_EINVAL;   // Cropped needs a cursor (wrappers.py:170)
+    const int depth = onehot ? h->P.ntiles : 1;
+    const size_t total = (size_t)h->P.num_envs * out_h * out_w;
+    const int grid = (int)((total + PCGRL_BLOCK - 1) / PCGRL_BLOCK < 16384 ? (total + PCGRL_BLOCK - 1) / PCGRL_BLOCK : 16384);
+    hipLaunchKernelGGL(k_obs_window, dim3(grid), dim3(PCGRL_BLOCK), 0, (hipStream_t)stream, h->P, h->B, out, out_h, out_w, centered, pad_value, depth);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+int pcgrl_action_map(pcgrl_env* h, const int32_t* flat, int32_t* xyv, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!flat || !xyv) return PCGRL_EINVAL;
+    const int n = h->P.num_envs;
+    hipLaunchKernelGGL(k_action_map, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, xyv, n, h->P.width, h->P.height, h->P.ntiles);
+    HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
 

@@ -108,6 +108,16 @@ int pcgrl_reset(pcgrl_env* env, void* stream);
 int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
 /* maps: DEVICE pointer u8 [N,H,W]; replaces every map, recomputes stats (start stats unchanged). */
 int pcgrl_set_maps(pcgrl_env* env, const uint8_t* maps, void* stream);
+/* Observation formatting of the reference's composite wrappers (gym_pcgrl/wrappers.py): Cropped.transform
+ * :197-206 + OneHotEncoding.transform :101-104 + ToImage.transform :53-60.  out: DEVICE u8 [N,out_h,out_w,D],
+ * D = 1 (tile ids) or number of tiles (one-hot).  centered = 1: window centred on the cursor, cells outside
+ * the map = pad_value (CroppedImagePCGRLWrapper :215-231, out_h = out_w = crop_size); centered = 0: the
+ * map itself from its origin (ActionMapImagePCGRLWrapper :234-248, out_h = H, out_w = W). */
+int pcgrl_observe(pcgrl_env* env, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value,
+                  int32_t onehot, void* stream);
+/* ActionMap.step for the wide representation (wrappers.py:139-154): flat DEVICE i32 [N] index into
+ * (H, W, tiles) -> xyv DEVICE i32 [N,3] = (x, y, tile), the action pcgrl_step takes. */
+int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* stream);
 /* Sticky device status word (0 = fine; bit 0: a sokoban level had more crates than the solver supports).
  * Synchronises the stream. */
 int pcgrl_status(pcgrl_env* env, void* stream, int32_t* status);

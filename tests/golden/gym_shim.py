@@ -27,6 +27,10 @@ class Env:
     def close(self):
         pass
 
+    @property
+    def unwrapped(self):
+        return self
+
 
 class Wrapper(Env):
     def __init__(self, env):
@@ -38,6 +42,10 @@ class Wrapper(Env):
         if name.startswith("_"):
             raise AttributeError(name)
         return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
 
     def step(self, action):
         return self.env.step(action)

@@ -441,6 +441,54 @@ TRAJS = [
 ]
 
 
+# ----------------------------------------------------------------------------- wrappers
+def gen_wrappers():
+    """Observations of the two composite wrappers train.py uses (wrappers.py:215-248), per step, with the
+    vector-env auto-reset; the flat ActionMap action index is recorded as the action."""
+    from gym_pcgrl import wrappers
+    cases = [
+        ("cropped_binary_narrow", "binary-narrow-v0", "cropped", 28, 8, 200),
+        ("cropped_zelda_narrow", "zelda-narrow-v0", "cropped", 22, 8, 200),
+        ("cropped_sokoban_turtle", "sokoban-turtle-v0", "cropped", 10, 8, 200),
+        ("cropped_binary_turtle_odd", "binary-turtle-v0", "cropped", 9, 4, 120),
+        ("actionmap_zelda_wide", "zelda-wide-v0", "actionmap", 0, 8, 150),
+        ("actionmap_binary_wide", "binary-wide-v0", "actionmap", 0, 8, 150),
+        ("actionmap_sokoban_wide", "sokoban-wide-v0", "actionmap", 0, 8, 150),
+    ]
+    for name, game, kind, size, E, T in cases:
+        envs = []
+        for i in range(E):
+            w = wrappers.CroppedImagePCGRLWrapper(game, size) if kind == "cropped" else wrappers.ActionMapImagePCGRLWrapper(game)
+            wrappers.get_pcgrl_env(w).seed(2000 + i)
+            envs.append(w)
+        base = wrappers.get_pcgrl_env(envs[0])
+        nt = base.get_num_tiles()
+        H, W = base._prob._height, base._prob._width
+        rs = np.random.RandomState(9)
+        rep = game.split("-")[1]
+        if kind == "actionmap":
+            acts = rs.randint(0, H * W * nt, size=(T, E)).astype(np.int64)
+        elif rep == "narrow":
+            acts = rs.randint(0, nt + 1, size=(T, E)).astype(np.int64)
+        else:
+            acts = rs.randint(0, nt + 4, size=(T, E)).astype(np.int64)
+        obs0 = np.stack([np.asarray(e.reset()) for e in envs])
+        obs = np.zeros((T,) + obs0.shape, dtype=np.uint8)
+        rew = np.zeros((T, E)); done = np.zeros((T, E), np.bool_)
+        for t in range(T):
+            for i, e in enumerate(envs):
+                o, r, d, _ = e.step(int(acts[t, i]))
+                rew[t, i] = r; done[t, i] = d
+                if d:
+                    o = e.reset()
+                o = np.asarray(o)
+                assert (o == o.astype(np.uint8)).all()
+                obs[t, i] = o
+        save("wrap_" + name, game=np.array(game), kind=np.array(kind), size=np.array(size), actions=acts,
+             obs0=obs0.astype(np.uint8), obs=obs, reward=rew, done=done, seed0=np.array(2000))
+        print("    %s obs %s" % (name, obs.shape))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -448,6 +496,7 @@ def main():
     jobs = {
         "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
         "stats_sokoban": gen_stats_sokoban, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
+        "wrappers": gen_wrappers,
     }
     for k, fn in jobs.items():
         if a.only in (None, k):

@@ -134,6 +134,7 @@ int sim_stats(int prob, const uint8_t* map, int h, int w, int pw, int ph, int va
     return 0;
 }
 double sim_range_reward(double n, double o, double lo, double hi) { return range_reward(n, o, lo, hi); }
+int sim_range_reward_i(int n, int o, int lo, int hi) { return range_reward_i(n, o, lo, hi); }
 double sim_reward(const PcgrlParams* P, const int32_t* n, const int32_t* o) { return compute_reward(*P, n, o); }
 int sim_params_size() { return (int)sizeof(PcgrlParams); }
 

@@ -264,3 +264,25 @@ def test_full_size_properties(prob, rep, calls, N):
     for k, i in enumerate(idx):
         assert np.array_equal(st[k], ol.get_stats(prob, maps[k], solver_power=power)), (i, st[k])
     assert total_done > 0 or prob == "binary"
+
+
+# ------------------------------------------------------------------ batched wrappers
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "wrap_*.npz"))), ids=os.path.basename)
+def test_wrapper_observations_match_reference(path):
+    torch = _torch()
+    from gym_pcgrl_amd import wrappers
+    d = np.load(path)
+    game, kind, size = str(d["game"]), str(d["kind"]), int(d["size"])
+    T, E = d["actions"].shape
+    if kind == "cropped":
+        w = wrappers.CroppedImagePCGRLWrapper(game, size, num_envs=E, seed=int(d["seed0"]))
+    else:
+        w = wrappers.ActionMapImagePCGRLWrapper(game, num_envs=E, seed=int(d["seed0"]))
+    obs = w.reset()
+    assert obs.dtype == torch.uint8 and tuple(obs.shape) == tuple(d["obs0"].shape)
+    assert np.array_equal(obs.cpu().numpy(), d["obs0"])
+    for t in range(T):
+        obs, rew, done, info = w.step(d["actions"][t])
+        assert np.array_equal(done.cpu().numpy(), d["done"][t]), t
+        assert np.array_equal(rew.cpu().numpy(), d["reward"][t]), t
+        assert np.array_equal(obs.cpu().numpy(), d["obs"][t]), t

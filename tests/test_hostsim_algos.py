@@ -124,8 +124,11 @@ def test_extra_wave_rounds_are_harmless(sim):
 
 
 def test_range_reward_table(sim):
+    sim.sim_range_reward_i.argtypes = [C.c_int] * 4
+    enc = lambda b: 2147483647 if b == np.inf else (-2147483648 if b == -np.inf else int(b))
     for lo, hi, nv, ov, r in np.load(os.path.join(G, "range_reward.npz"))["table"]:
         assert sim.sim_range_reward(nv, ov, lo, hi) == r
+        assert sim.sim_range_reward_i(int(nv), int(ov), enc(lo), enc(hi)) == r   # the integer form the kernels use
 
 
 def test_lazy_ring_mt_matches_numpy(sim):
