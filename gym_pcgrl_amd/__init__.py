@@ -6,7 +6,7 @@ amidos2006/gym-pcgrl as hand-written HIP kernels for gfx950, behind the referenc
     venv = gym_pcgrl_amd.make_batched("binary-narrow-v0", num_envs=65536)  # one GPU, lockstep batch
 
 Ids follow gym_pcgrl/__init__.py:6-12: '{prob}-{rep}-v0' for the in-scope problems
-(binary, zelda, sokoban) x representations (narrow, wide, turtle).
+(binary, zelda, sokoban) x all six representations (narrow, narrowcast, narrowmulti, wide, turtle, turtlecast).
 """
 __version__ = "0.1.0"
 

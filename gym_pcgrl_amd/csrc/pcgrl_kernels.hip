@@ -295,6 +295,112 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
 }
 
 // ------------------------------------------------------------------------------------------
+// k_update_block: the 3x3 "cast" / "multi" representations (narrow_cast_rep.py:36-59, narrow_multi_rep.py:39-59,
+// turtle_cast_rep.py:38-76).  Same contract as k_update; up to nine tiles change per step and `change`
+// counts them (pcgrl_env.py:136 adds it to _changes; the heatmap still gets +1).
+template <int REP, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
+    __shared__ int s_cnt[2][4];
+    __shared__ int s_base[2];
+    const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
+    const bool act = e < P.num_envs;
+    bool chg = false, rst = false;
+    if (act) {
+        const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes, NT = P.ntiles;
+        const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
+        const uchar2 p0 = reinterpret_cast<const uchar2*>(B.pos)[e];
+        const int iter = c.x + 1;
+        int changes = c.y, x = p0.x, y = p0.y;
+        int vals[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) vals[i] = -1;
+        if (REP == PCGRL_REP_NARROW_MULTI) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) { const int a = clampi(actions[9 * e + i], 0, NT); vals[i] = a - 1; }
+        } else {
+            const int type = actions[2 * e], value = clampi(actions[2 * e + 1], 0, NT - 1);
+            if (REP == PCGRL_REP_NARROW_CAST) {
+                const int t = clampi(type, 0, 2);
+                if (t == 1) vals[4] = value;
+                if (t == 2) { for (int i = 0; i < 9; i++) vals[i] = value; }
+            } else {
+                const int t = clampi(type, 0, 5);
+                if (t < 4) {   // turtle move (turtle_rep.py:103-125 semantics)
+                    const int dx = (t == 0) ? -1 : (t == 1 ? 1 : 0), dy = (t == 2) ? -1 : (t == 3 ? 1 : 0);
+                    x += dx;
+                    if (x < 0) x = P.warp ? x + W : 0;
+                    if (x >= W) x = P.warp ? x - W : W - 1;
+                    y += dy;
+                    if (y < 0) y = P.warp ? y + H : 0;
+                    if (y >= H) y = P.warp ? y - H : H - 1;
+                }
+                if (t == 4) vals[4] = value;
+                if (t == 5) { for (int i = 0; i < 9; i++) vals[i] = value; }
+            }
+        }
+        int change = 0;
+        uint8_t* map_e = B.map + (size_t)e * H * W;
+        MaskT* pl_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            if (vals[(dy + 1) * 3] < 0 && vals[(dy + 1) * 3 + 1] < 0 && vals[(dy + 1) * 3 + 2] < 0) continue;
+            MaskT m0 = pl_e[yy], m1 = NPL > 1 ? pl_e[G + yy] : (MaskT)0, m2 = NPL > 1 ? pl_e[2 * G + yy] : (MaskT)0;
+            bool touched = false;
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const int xx = x + dx, v = vals[(dy + 1) * 3 + dx + 1];
+                if (xx < 0 || xx >= W || v < 0) continue;
+                uint8_t* cell = map_e + yy * W + xx;
+                if (*cell != v) {
+                    change++;
+                    touched = true;
+                    *cell = (uint8_t)v;
+                    const MaskT bit = (MaskT)1 << xx;
+                    m0 = (v & 1) ? (m0 | bit) : (m0 & ~bit);
+                    m1 = (v & 2) ? (m1 | bit) : (m1 & ~bit);
+                    m2 = (v & 4) ? (m2 | bit) : (m2 & ~bit);
+                }
+            }
+            if (touched) { pl_e[yy] = m0; if (NPL > 1) { pl_e[G + yy] = m1; pl_e[2 * G + yy] = m2; } }
+        }
+        if (REP != PCGRL_REP_TURTLE_CAST) {   // narrow cursor move (narrow_rep.py:104-113), after the write
+            if (P.random_tile) {
+                uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
+                int cur = B.rng_cur[2 * e];
+                x = mt_randint(ring, cur, W);
+                y = mt_randint(ring, cur, H);
+                B.rng_cur[2 * e] = cur;
+            } else {
+                x += 1;
+                if (x >= W) { x = 0; y += 1; if (y >= H) y = 0; }
+            }
+        }
+        if (change > 0) {
+            chg = true;
+            changes += change;
+            B.heat[((size_t)e * H + y) * W + x] += 1;
+        }
+        reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
+        reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        if (!chg) {
+            int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
+            int32_t* inf = B.info + (size_t)e * 10;
+            for (int k = 0; k < 8; k++) { s[k] = B.stats[(size_t)e * 8 + k]; st[k] = B.start_stats[(size_t)e * 8 + k]; inf[k] = s[k]; }
+            const bool d = episode_over(P, s, st) || changes >= P.max_changes || iter >= P.max_iterations;
+            B.reward[e] = 0.0;
+            B.done[e] = d ? 1 : 0;
+            if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - st[1];
+            inf[8] = iter; inf[9] = changes;
+            rst = d && P.auto_reset;
+        }
+    }
+    block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_stats: lane group per work item
 template <class MaskT>
 __device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
@@ -687,7 +793,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static int validate_config(const pcgrl_config* c) {
     if (!c) return PCGRL_EINVAL;
-    if (c->prob < 0 || c->prob > 2 || c->rep < 0 || c->rep > 2) return PCGRL_EINVAL;
+    if (c->prob < 0 || c->prob > 2 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
     if (c->num_envs < 1) return PCGRL_EINVAL;
     if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
     if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
@@ -980,8 +1086,14 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
             hipLaunchKernelGGL((k_update<PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
         case PCGRL_REP_WIDE:
             hipLaunchKernelGGL((k_update<PCGRL_REP_WIDE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
-        default:
+        case PCGRL_REP_TURTLE:
             hipLaunchKernelGGL((k_update<PCGRL_REP_TURTLE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        case PCGRL_REP_NARROW_CAST:
+            hipLaunchKernelGGL((k_update_block<PCGRL_REP_NARROW_CAST, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        case PCGRL_REP_NARROW_MULTI:
+            hipLaunchKernelGGL((k_update_block<PCGRL_REP_NARROW_MULTI, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        default:
+            hipLaunchKernelGGL((k_update_block<PCGRL_REP_TURTLE_CAST, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
     }
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
@@ -1103,7 +1215,8 @@ int pcgrl_reset(pcgrl_env* h, void* stream) {
 int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!actions) return PCGRL_EINVAL;
-    const int aw = h->P.rep == PCGRL_REP_WIDE ? 3 : 1;
+    static const int kActionWidth[6] = {1, 3, 1, 2, 9, 2};
+    const int aw = kActionWidth[h->P.rep];
     int rc = for_each_sub(h, (hipStream_t)stream, [&](int k, hipStream_t st) {
         int lo = 0, hi = 0;
         sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);

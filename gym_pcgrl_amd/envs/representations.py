@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import spaces
 
-REP_IDS = {"narrow": 0, "wide": 1, "turtle": 2}
+REP_IDS = {"narrow": 0, "wide": 1, "turtle": 2, "narrowcast": 3, "narrowmulti": 4, "turtlecast": 5}
 
 
 class Representation:
@@ -102,4 +102,39 @@ class TurtleRepresentation(Representation):
         return d
 
 
-REPRESENTATIONS = {"narrow": NarrowRepresentation, "wide": WideRepresentation, "turtle": TurtleRepresentation}
+class NarrowCastRepresentation(NarrowRepresentation):
+    """narrow_cast_rep.py: action (type, tile): 0 nothing, 1 this cell, 2 the 3x3 block around the cursor."""
+    name = "narrowcast"
+
+    def get_action_space(self, width, height, num_tiles):
+        return spaces.MultiDiscrete([3, num_tiles])
+
+    def action_width(self):
+        return 2
+
+
+class NarrowMultiRepresentation(NarrowRepresentation):
+    """narrow_multi_rep.py: nine values, one per cell of the 3x3 block (0 keeps the cell, v writes tile v-1)."""
+    name = "narrowmulti"
+
+    def get_action_space(self, width, height, num_tiles):
+        return spaces.MultiDiscrete([num_tiles + 1] * 9)
+
+    def action_width(self):
+        return 9
+
+
+class TurtleCastRepresentation(TurtleRepresentation):
+    """turtle_cast_rep.py: action (type, tile): 0-3 move, 4 write this cell, 5 write the 3x3 block."""
+    name = "turtlecast"
+
+    def get_action_space(self, width, height, num_tiles):
+        return spaces.MultiDiscrete([len(self._dirs) + 2, num_tiles])
+
+    def action_width(self):
+        return 2
+
+
+REPRESENTATIONS = {"narrow": NarrowRepresentation, "wide": WideRepresentation, "turtle": TurtleRepresentation,
+                   "narrowcast": NarrowCastRepresentation, "narrowmulti": NarrowMultiRepresentation,
+                   "turtlecast": TurtleCastRepresentation}

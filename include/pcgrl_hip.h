@@ -38,7 +38,7 @@ extern "C" {
 #define PCGRL_ESTATE (-3)   /* call order violated (e.g. step before bind/reset) */
 
 enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2 };
-enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2 };
+enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2, PCGRL_NARROW_CAST = 3, PCGRL_NARROW_MULTI = 4, PCGRL_TURTLE_CAST = 5 };
 
 /* Batch-wide parameters (everything the reference keeps as attributes of PcgrlEnv/Problem/Representation). */
 typedef struct pcgrl_config {
@@ -104,7 +104,8 @@ int pcgrl_seed(pcgrl_env* env, const uint32_t* keys, int32_t first, int32_t coun
  * adjust_param(probs=...) touched them.  tile_p otherwise persists (it carries BinaryProblem._prob). */
 int pcgrl_set_tile_probs(pcgrl_env* env, void* stream);
 int pcgrl_reset(pcgrl_env* env, void* stream);
-/* actions: DEVICE pointer, i32 [N] (narrow, turtle) or i32 [N,3] = (x, y, tile) (wide). */
+/* actions: DEVICE pointer, i32 [N] (narrow, turtle), [N,3] = (x, y, tile) (wide), [N,2] = (type, tile)
+ * (narrowcast, turtlecast) or [N,9] (narrowmulti: tile+1 per cell of the 3x3 block, 0 = keep). */
 int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
 /* maps: DEVICE pointer u8 [N,H,W]; replaces every map, recomputes stats (start stats unchanged). */
 int pcgrl_set_maps(pcgrl_env* env, const uint8_t* maps, void* stream);

@@ -366,6 +366,12 @@ def sample_actions(rs, rep, T, E, W, H, ntiles):
         return rs.randint(0, ntiles + 1, size=(T, E, 1)).astype(np.int32)
     if rep == "turtle":
         return rs.randint(0, ntiles + 4, size=(T, E, 1)).astype(np.int32)
+    if rep == "narrowcast":
+        return np.stack([rs.randint(0, 3, size=(T, E)), rs.randint(0, ntiles, size=(T, E))], -1).astype(np.int32)
+    if rep == "turtlecast":
+        return np.stack([rs.randint(0, 6, size=(T, E)), rs.randint(0, ntiles, size=(T, E))], -1).astype(np.int32)
+    if rep == "narrowmulti":
+        return rs.randint(0, ntiles + 1, size=(T, E, 9)).astype(np.int32)
     a = np.stack([rs.randint(0, W, size=(T, E)), rs.randint(0, H, size=(T, E)), rs.randint(0, ntiles, size=(T, E))], -1)
     return a.astype(np.int32)
 
@@ -398,7 +404,7 @@ def gen_traj(name, prob, rep, E, T, calls=(), seed0=1000, action_seed=5):
     for t in range(T):
         for i, env in enumerate(envs):
             a = acts[t, i]
-            o, r, d, inf = env.step(int(a[0]) if rep != "wide" else [int(a[0]), int(a[1]), int(a[2])])
+            o, r, d, inf = env.step(int(a[0]) if len(a) == 1 else [int(v) for v in a])
             rew[t, i] = r
             done[t, i] = d
             info[t, i] = [int(inf[k]) for k in keys] + [inf["iterations"], inf["changes"]]
@@ -438,6 +444,14 @@ TRAJS = [
     ("sokoban_wide", "sokoban", "wide", 16, 300, ()),
     ("sokoban_turtle", "sokoban", "turtle", 16, 300, (dict(change_percentage=0.8),)),
     ("sokoban_narrow_7x6", "sokoban", "narrow", 8, 300, (dict(width=7, height=6), dict(change_percentage=0.4, solver_power=400, max_crates=2))),
+    # the 3x3 "cast" / "multi" representations
+    ("binary_narrowcast", "binary", "narrowcast", 16, 300, ()),
+    ("zelda_narrowcast_seq", "zelda", "narrowcast", 8, 300, (dict(random_tile=False, change_percentage=0.5),)),
+    ("binary_narrowmulti", "binary", "narrowmulti", 16, 300, ()),
+    ("sokoban_narrowmulti", "sokoban", "narrowmulti", 16, 300, (dict(change_percentage=0.8),)),
+    ("binary_turtlecast", "binary", "turtlecast", 16, 300, ()),
+    ("zelda_turtlecast_warp", "zelda", "turtlecast", 8, 300, (dict(warp=True, width=13, height=9), dict(change_percentage=0.5))),
+    ("binary_turtlecast_64", "binary", "turtlecast", 3, 200, (dict(width=64, height=64),)),
 ]
 
 

@@ -12,7 +12,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 SO = os.path.join(ORACLE_DIR, "libpcgrl_oracle.so")
 
 PROBS = {"binary": 0, "zelda": 1, "sokoban": 2}
-REPS = {"narrow": 0, "wide": 1, "turtle": 2}
+REPS = {"narrow": 0, "wide": 1, "turtle": 2, "narrowcast": 3, "narrowmulti": 4, "turtlecast": 5}
+MAX_ACTION = 9
 ADJ_KEYS = {k: i for i, k in enumerate([
     "change_percentage", "width", "height", "target_path", "random_probs", "max_enemies",
     "target_enemy_dist", "solver_power", "max_crates", "max_targets", "min_solution",
@@ -158,7 +159,7 @@ class OracleEnv:
         return self.obs()
 
     def step(self, action):
-        a = np.zeros(3, np.int32)
+        a = np.zeros(MAX_ACTION, np.int32)
         a[:np.size(action)] = np.asarray(action).ravel()
         r = C.c_double()
         d = C.c_int()
@@ -171,10 +172,15 @@ class OracleEnv:
         return self.obs(), r.value, bool(d.value), inf
 
     def rollout(self, actions, want_maps=True, want_heat=True):
-        """actions [T,3] int32 -> dict of per-step arrays (auto-reset semantics)."""
+        """actions [T,k<=9] int32 -> dict of per-step arrays (auto-reset semantics)."""
         L = lib()
-        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        actions = np.asarray(actions, dtype=np.int32)
+        if actions.ndim == 1:
+            actions = actions[:, None]
         T = actions.shape[0]
+        full = np.zeros((T, MAX_ACTION), np.int32)
+        full[:, :actions.shape[1]] = actions
+        actions = np.ascontiguousarray(full)
         w, h = L.orc_map_width(self._h), L.orc_map_height(self._h)
         ni = L.orc_num_info(self._h)
         maps = np.zeros((T, h, w), np.uint8) if want_maps else None

@@ -64,7 +64,7 @@ def _compare_traj(env, d, T, check_every=1):
     keys = [str(k) for k in d["info_keys"]]
     acts = d["actions"]
     for t in range(T):
-        a = acts[t] if rep == "wide" else acts[t, :, 0]
+        a = acts[t] if acts.shape[2] > 1 else acts[t, :, 0]
         obs, rew, done, info = env.step(a)
         if t % check_every:
             continue

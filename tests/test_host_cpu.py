@@ -81,7 +81,7 @@ def test_adjust_param_table_and_spaces():
                env.get_border_tile()] + adesc + [osp["map"].shape[0], osp["map"].shape[1], int(osp["map"].high.max()),
                                                  int(osp["heatmap"].high.max()), int("pos" in osp)]
         assert got == list(row), (case, got, list(row))
-    assert sorted(gym_pcgrl_amd.registered_ids())[0] == "binary-narrow-v0" and len(gym_pcgrl_amd.registered_ids()) == 9
+    assert sorted(gym_pcgrl_amd.registered_ids())[0] == "binary-narrow-v0" and len(gym_pcgrl_amd.registered_ids()) == 18
     with pytest.raises(KeyError):
         gym_pcgrl_amd.make_batched("nope-narrow-v0", num_envs=1)
 

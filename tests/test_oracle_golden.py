@@ -138,9 +138,7 @@ def test_trajectory(path):
         assert np.array_equal(o["map"], d["map0"][i])
         if rep != "wide":
             assert np.array_equal(o["pos"], d["pos0"][i])
-        a3 = np.zeros((T, 3), np.int32)
-        a3[:, :acts.shape[2]] = acts[:, i]
-        out = e.rollout(a3)
+        out = e.rollout(acts[:, i])
         bad = np.nonzero((out["maps"] != d["maps"][:, i]).reshape(T, -1).any(1))[0]
         assert bad.size == 0, ("map mismatch first at step", bad[:3])
         if rep != "wide":
