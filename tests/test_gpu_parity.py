@@ -286,3 +286,74 @@ def test_wrapper_observations_match_reference(path):
         assert np.array_equal(done.cpu().numpy(), d["done"][t]), t
         assert np.array_equal(rew.cpu().numpy(), d["reward"][t]), t
         assert np.array_equal(obs.cpu().numpy(), d["obs"][t]), t
+
+
+# ------------------------------------------------------------------ edge shapes (layout corners of the kernels)
+@pytest.mark.parametrize("prob,rep,w,h", [
+    ("binary", "narrow", 1, 1), ("binary", "turtle", 1, 9), ("binary", "wide", 9, 1), ("binary", "narrow", 32, 16),
+    ("binary", "narrow", 33, 16), ("binary", "turtle", 64, 17), ("binary", "narrowmulti", 16, 17), ("binary", "wide", 64, 64),
+    ("zelda", "narrow", 2, 2), ("zelda", "turtlecast", 33, 3), ("zelda", "wide", 64, 5), ("zelda", "narrowcast", 5, 40),
+    ("sokoban", "narrow", 1, 3), ("sokoban", "turtle", 14, 14), ("sokoban", "wide", 3, 8),
+], ids=lambda v: str(v))
+def test_edge_shapes_vs_oracle(prob, rep, w, h):
+    torch = _torch()
+    E, T, seed0 = 5, 60, 31
+    calls = (dict(width=w, height=h), dict(change_percentage=0.5, solver_power=300))
+    env = _make(prob, rep, E, calls, seed=seed0)
+    obs = env.reset()
+    nt = env.get_num_tiles()
+    rs = np.random.RandomState(3)
+    aw = env._rep.action_width()
+    if rep == "narrow":
+        acts = rs.randint(0, nt + 1, size=(T, E, 1))
+    elif rep == "turtle":
+        acts = rs.randint(0, nt + 4, size=(T, E, 1))
+    elif rep == "wide":
+        acts = np.stack([rs.randint(0, w, size=(T, E)), rs.randint(0, h, size=(T, E)), rs.randint(0, nt, size=(T, E))], -1)
+    elif rep == "narrowcast":
+        acts = np.stack([rs.randint(0, 3, size=(T, E)), rs.randint(0, nt, size=(T, E))], -1)
+    elif rep == "turtlecast":
+        acts = np.stack([rs.randint(0, 6, size=(T, E)), rs.randint(0, nt, size=(T, E))], -1)
+    else:
+        acts = rs.randint(0, nt + 1, size=(T, E, 9))
+    acts = acts.astype(np.int32)
+    exp = []
+    for i in range(E):
+        o = ol.OracleEnv(prob, rep)
+        for kw in calls:
+            o.adjust_param(**kw)
+        o.seed(seed0 + i)
+        m0 = o.reset()["map"]
+        assert np.array_equal(obs["map"][i].cpu().numpy(), m0)
+        exp.append(o.rollout(acts[:, i]))
+    keys = list(env._prob.info_keys) + ["iterations", "changes"]
+    for t in range(T):
+        obs, rew, done, info = env.step(acts[t] if aw > 1 else acts[t, :, 0])
+        assert np.array_equal(obs["map"].cpu().numpy(), np.stack([x["maps"][t] for x in exp])), ("map", t)
+        assert np.array_equal(rew.cpu().numpy(), np.array([x["reward"][t] for x in exp])), ("reward", t)
+        assert np.array_equal(done.cpu().numpy(), np.array([x["done"][t] for x in exp])), ("done", t)
+        got_info = np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64)
+        assert np.array_equal(got_info, np.stack([x["info"][t] for x in exp])), ("info", t)
+        assert np.array_equal(obs["heatmap"].cpu().numpy().astype(np.uint16), np.stack([x["heatmap"][t] for x in exp])), ("heat", t)
+        if rep != "wide":
+            assert np.array_equal(obs["pos"].cpu().numpy(), np.stack([x["pos"][t] for x in exp]).astype(np.uint8)), ("pos", t)
+    assert env.check_status() == 0
+
+
+def test_make_vec_envs_surface():
+    torch = _torch()
+    from gym_pcgrl_amd.utils import make_vec_envs
+    v = make_vec_envs("zelda-narrow-v0", "narrow", None, 64, seed=5, cropped_size=22)
+    assert v.num_envs == 64 and v.observation_space.shape == (22, 22, 8) and v.action_space.n == 9
+    obs = v.reset()
+    assert tuple(obs.shape) == (64, 22, 22, 8) and int(obs.sum().item()) == 64 * 22 * 22
+    obs, r, d, info = v.step(torch.randint(0, 9, (64,), device="cuda"))
+    assert tuple(r.shape) == (64,) and d.dtype == torch.bool
+    v.close()
+    v = make_vec_envs("binary-wide-v0", "wide", None, 32, seed=5)
+    assert v.observation_space.shape == (14, 14, 1) and v.action_space.n == 14 * 14 * 2
+    v.reset()
+    v.step_async(torch.randint(0, 392, (32,), device="cuda"))
+    obs, r, d, info = v.step_wait()
+    assert tuple(obs.shape) == (32, 14, 14, 1)
+    v.close()
