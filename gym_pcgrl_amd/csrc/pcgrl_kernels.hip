@@ -508,22 +508,26 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
             s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
         }
         int dist = 0, sol = 0;
-        bool win = false;
+        // The four agents of _run_game, with the exact exhausted-BFS shortcut (sokoban_solver.h).  The search is
+        // driven by lane 0; every lane helps to clear the visited table between agents.
         const int KS[4] = {-1, 2, 1, 0};
-        for (int a = 0; a < 4; a++) {
-            if (__shfl((int)win, 0, 64)) break;
+        int go = 1;
+        for (int a = 0; a < 4 && go; a++) {
             if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
             else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
             __threadfence_block();
             if (lane == 0) {
                 int hh, dd, it;
+                bool exhausted = false, win;
                 if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
-                    win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it);
+                    win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
                 else
-                    win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it);
+                    win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
                 dist = win ? 0 : hh;
                 sol = win ? dd : 0;
+                go = !(win || (a == 0 && exhausted));
             }
+            go = __shfl(go, 0, 64);
             __threadfence_block();
         }
         if (lane == 0) {

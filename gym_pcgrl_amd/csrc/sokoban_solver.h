@@ -32,16 +32,28 @@
 #define SOK_LDS_HEAP (4 * SOK_LDS_POWER + 4)       /* entries (u32) */
 #define SOK_LDS_TABLE 8192                         /* slots (u32), power of two */
 
-struct SokNode {            // 40 bytes
+struct alignas(8) SokNode {  // 40 bytes, moved around as five 64-bit words
     uint8_t crate[SOK_MAXC];
     uint8_t player, pad;
     uint16_t h;
     uint16_t depth, pad2;
 };
+struct SokRaw { uint64_t q[5]; };
+PCGRL_D SokRaw sok_load(const SokNode* p) {
+    const uint64_t* s = reinterpret_cast<const uint64_t*>(p);
+    SokRaw r;
+    r.q[0] = s[0]; r.q[1] = s[1]; r.q[2] = s[2]; r.q[3] = s[3]; r.q[4] = s[4];
+    return r;
+}
+PCGRL_D void sok_store(SokNode* p, const SokRaw& r) {
+    uint64_t* d = reinterpret_cast<uint64_t*>(p);
+    d[0] = r.q[0]; d[1] = r.q[1]; d[2] = r.q[2]; d[3] = r.q[3]; d[4] = r.q[4];
+}
 
 struct SokLevel {
     uint64_t solid[4], dead[4], targetmask[4];
     uint8_t target[SOK_MAXC];
+    uint8_t cx[256], cy[256];   // cell -> (x, y): the heuristic runs per child, integer division is slow on the GPU
     int w, h, cells, nc;    // bordered dims, number of crates == targets
     int dirs[4];
 };
@@ -68,18 +80,16 @@ PCGRL_D int sok_heuristic(const SokLevel& L, const uint8_t* crate) {   // engine
     uint32_t used = 0;   // targets removed from the shrinking list ("del targets[bestMatch]")
     int distance = 0;
     for (int c = 0; c < L.nc; c++) {
-        const int cx = crate[c] % L.w, cy = crate[c] / L.w;
-        int best = L.w + L.h, match = -1, firstfree = -1;
+        const int cx = L.cx[crate[c]], cy = L.cy[crate[c]];
+        int best = L.w + L.h, match = -1, firstfree = -1, matchd = 0, firstd = 0;
         for (int i = 0; i < L.nc; i++) {
             if ((used >> i) & 1u) continue;
-            if (firstfree < 0) firstfree = i;
-            const int tx = L.target[i] % L.w, ty = L.target[i] / L.w;
-            const int d = abs(cx - tx) + abs(cy - ty);
-            if (best > d) { match = i; best = d; }
+            const int d = abs(cx - (int)L.cx[L.target[i]]) + abs(cy - (int)L.cy[L.target[i]]);
+            if (firstfree < 0) { firstfree = i; firstd = d; }
+            if (best > d) { match = i; best = d; matchd = d; }
         }
-        if (match < 0) match = firstfree;   // bestMatch stays 0 = first remaining target
-        const int tx = L.target[match] % L.w, ty = L.target[match] / L.w;
-        distance += abs(tx - cx) + abs(ty - cy);
+        if (match < 0) { match = firstfree; matchd = firstd; }   // bestMatch stays 0 = first remaining target
+        distance += matchd;
         used |= 1u << match;
     }
     return distance;
@@ -97,6 +107,7 @@ PCGRL_D int sok_build_level(const uint8_t* m, int W, int H, SokLevel& L, SokNode
     for (int y = 0; y < L.h; y++)
         for (int x = 0; x < L.w; x++) {
             const int p = y * L.w + x;
+            L.cx[p] = (uint8_t)x; L.cy[p] = (uint8_t)y;
             const bool border = x == 0 || y == 0 || x == L.w - 1 || y == L.h - 1;
             const int t = border ? 1 : m[(y - 1) * W + (x - 1)];
             if (t == 1) sok_set(L.solid, p);
@@ -128,7 +139,7 @@ PCGRL_D void sok_init_deadlocks(SokLevel& L) {
         }
     for (int a = 0; a < nc; a++)
         for (int b = 0; b < nc; b++) {
-            const int ax = corners[a] % w, ay = corners[a] / w, bx = corners[b] % w, by = corners[b] / w;
+            const int ax = L.cx[corners[a]], ay = L.cy[corners[a]], bx = L.cx[corners[b]], by = L.cy[corners[b]];
             const int dx = (ax > bx) - (ax < bx), dy = (ay > by) - (ay < by);
             if ((dx == 0 && dy == 0) || (dx != 0 && dy != 0)) continue;
             bool ok = true;
@@ -200,11 +211,14 @@ PCGRL_D bool sok_same(const SokLevel& L, const SokNode& a, const SokNode& b) {
 // would otherwise go to scratch memory).  Children are built in place in `w` (a child differs from its
 // parent in the player cell and at most one crate) and undone after being written to the pool.
 // Returns win; out_h/out_depth describe the returned node (winner, or best node).
+// `out_exhausted` reports that the search ended because the queue ran empty (every reachable state was
+// expanded), not because of the iteration cap.
 template <class HP, class TP>
 PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int table_mask, SokNode& w,
-                        const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters) {
+                        const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
+                        bool& out_exhausted) {
     int npool = 0, head = 0, heapn = 0, iterations = 0, best = -1, best_h = 0, best_depth = 0;
-    pool[0] = root;
+    sok_store(pool, sok_load(&root));
     npool = 1;
     if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth) << 16) | 0u; heapn = 1; }
     bool win = false;
@@ -214,12 +228,14 @@ PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int
         int cur;
         if (k >= 0) {
             const uint32_t last = heap[--heapn];
-            if (heapn > 0) { cur = (int)(heap[0] & 0xFFFFu); heap[0] = last; sok_siftup(heap, 0, heapn); }
-            else cur = (int)(last & 0xFFFFu);
+            cur = (int)((heapn > 0 ? heap[0] : last) & 0xFFFFu);
+            const SokRaw fetched = sok_load(pool + cur);   // global load in flight while the heap is repaired
+            if (heapn > 0) { heap[0] = last; sok_siftup(heap, 0, heapn); }
+            sok_store(&w, fetched);
         } else {
             cur = head++;
+            sok_store(&w, sok_load(pool + cur));
         }
-        w = pool[cur];
         const int node_h = w.h, node_depth = w.depth, node_player = w.player;
         if (sok_win(L, w.crate)) { win = true; result_h = node_h; result_depth = node_depth; break; }
         // visited test-and-add (open addressing; slot = node index + 1, low 16 bits; hash tag in the high bits)
@@ -257,7 +273,7 @@ PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int
                 if (keep) w.h = (uint16_t)sok_heuristic(L, w.crate);
             }
             if (keep) {
-                pool[npool] = w;
+                sok_store(pool + npool, sok_load(&w));
                 if (k >= 0) {
                     heap[heapn] = ((uint32_t)(2 * w.h + k * w.depth) << 16) | (uint32_t)npool;
                     heapn++;
@@ -271,5 +287,33 @@ PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int
     }
     if (!win) { result_h = best_h; result_depth = best_depth; }
     out_h = result_h; out_depth = result_depth; out_iters = iterations;
+    out_exhausted = !win && !(k >= 0 ? heapn > 0 : head < npool);
     return win;
+}
+
+// SokobanProblem._run_game (sokoban_prob.py:104-122): BFS, then A* with balance 1, 0.5, 0; first winner gives
+// (0, depth), otherwise (heuristic of the last agent's best node, 0).
+//
+// Exact shortcut: if BFS ends because its queue ran empty without a win, every reachable state was
+// expanded and none of them wins.  Each A* run would expand exactly the same states (same children, same
+// deadlock pruning), pop exactly as many entries as BFS did (so it cannot hit the cap either), find no win,
+// and end with bestNode = a state of minimum heuristic -- the value _run_game returns is that minimum,
+// which BFS has already computed.  The three A* runs are skipped in that case.  `clear_table(size)` zeroes
+// the visited table before each agent.
+template <class HP, class TP, class ClearFn>
+PCGRL_D void sok_run_game(const SokLevel& L, SokNode* pool, HP heap, TP table, int table_size, SokNode& w,
+                          const SokNode& root, int power, bool allow_shortcut, ClearFn clear_table,
+                          int& dist_win, int& sol_len, int* iters) {
+    const int KS[4] = {-1, 2, 1, 0};
+    bool win = false;
+    int hh = 0, dd = 0;
+    for (int a = 0; a < 4; a++) iters[a] = 0;
+    for (int a = 0; a < 4 && !win; a++) {
+        clear_table(table_size);
+        bool exhausted = false;
+        win = sok_search(L, pool, heap, table, table_size - 1, w, root, KS[a], power, hh, dd, iters[a], exhausted);
+        if (a == 0 && !win && exhausted && allow_shortcut) break;
+    }
+    dist_win = win ? 0 : hh;
+    sol_len = win ? dd : 0;
 }

@@ -98,7 +98,7 @@ static void run(int prob, const uint8_t* map, int h, int w, int pw, int ph, int3
 
 extern "C" {
 // the device solver (sokoban_solver.h) run on the host: same pool/heap/table layout as k_sokoban
-int sim_sokoban_solve(const uint8_t* map, int h, int w, int power, int* dist, int* sol, int* iters) {
+int sim_sokoban_solve(const uint8_t* map, int h, int w, int power, int shortcut, int* dist, int* sol, int* iters) {
     SokLevel L; SokNode root;
     int ncr = sok_build_level(map, w, h, L, root);
     if (ncr > SOK_MAXC) return -1;
@@ -109,16 +109,10 @@ int sim_sokoban_solve(const uint8_t* map, int h, int w, int power, int* dist, in
     int tsize = 1024; while (tsize < 2 * power) tsize <<= 1;
     if (power <= SOK_LDS_POWER) tsize = SOK_LDS_TABLE;
     std::vector<uint32_t> table(tsize);
-    SokArena A; A.pool = pool.data(); A.heap = heap.data(); A.table = table.data(); A.table_mask = tsize - 1;
-    const int KS[4] = {-1, 2, 1, 0};
-    bool win = false; int hh = 0, dd = 0;
-    for (int a = 0; a < 4; a++) iters[a] = 0;
-    for (int a = 0; a < 4 && !win; a++) {
-        for (int i = 0; i < tsize; i++) table[i] = 0;
-        SokNode work;
-        win = sok_search(L, A.pool, A.heap, A.table, A.table_mask, work, root, KS[a], power, hh, dd, iters[a]);
-    }
-    *dist = win ? 0 : hh; *sol = win ? dd : 0;
+    SokNode work;
+    uint32_t* tp = table.data();
+    sok_run_game(L, pool.data(), heap.data(), tp, tsize, work, root, power, shortcut != 0,
+                 [tp](int n) { for (int i = 0; i < n; i++) tp[i] = 0; }, *dist, *sol, iters);
     return 0;
 }
 long sim_iters_reset() { long v = g_sim_iters; g_sim_iters = 0; return v; }

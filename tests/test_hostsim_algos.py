@@ -64,10 +64,12 @@ def test_bitboard_stats_vs_golden(sim, path):
 
 
 def test_device_sokoban_solver_vs_golden(sim):
-    """gym_pcgrl_amd/csrc/sokoban_solver.h (the code k_sokoban runs on lane 0) compiled for the host:
-    dist-win, sol-length and the per-agent iteration counts must equal the reference's."""
-    sim.sim_sokoban_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    n = 0
+    """gym_pcgrl_amd/csrc/sokoban_solver.h (the code k_sokoban runs) compiled for the host.  Without the
+    exhausted-BFS shortcut the per-agent iteration counts must equal the reference's; with it (what the GPU
+    runs) dist-win and sol-length must still be equal, and the A* agents are skipped exactly when BFS
+    exhausted the state space without a win."""
+    sim.sim_sokoban_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = skipped = 0
     for path in sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz"))):
         d = np.load(path)
         power = int(d["solver_power"])
@@ -77,11 +79,19 @@ def test_device_sokoban_solver_vs_golden(sim):
             m = np.ascontiguousarray(m)
             dist, sol = C.c_int(), C.c_int()
             it = np.zeros(4, np.int32)
-            assert sim.sim_sokoban_solve(_p(m), m.shape[0], m.shape[1], power, C.byref(dist), C.byref(sol), _p(it)) == 0
+            assert sim.sim_sokoban_solve(_p(m), m.shape[0], m.shape[1], power, 0, C.byref(dist), C.byref(sol), _p(it)) == 0
             assert (dist.value, sol.value) == (d["stats"][i, 4], d["stats"][i, 5]), (path, i)
             assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
+            it2 = np.zeros(4, np.int32)
+            assert sim.sim_sokoban_solve(_p(m), m.shape[0], m.shape[1], power, 1, C.byref(dist), C.byref(sol), _p(it2)) == 0
+            assert (dist.value, sol.value) == (d["stats"][i, 4], d["stats"][i, 5]), ("shortcut", path, i)
+            if it2[1] == 0 and it[1] > 0:
+                skipped += 1
+                # the argument behind the shortcut, checked on the reference's own counts: every agent popped
+                # exactly as many entries as BFS and none of them won
+                assert d["agents"][i, 4] == -1 and (d["agents"][i, :4] == d["agents"][i, 0]).all(), (path, i, d["agents"][i])
             n += 1
-    assert n > 300
+    assert n > 300 and skipped > 100
 
 
 def test_bitboard_stats_vs_oracle_random(sim):
