@@ -416,16 +416,15 @@ __device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBuf
         int32_t old[PCGRL_MAX_STATS], sv[PCGRL_MAX_STATS];
         for (int k = 0; k < 8; k++) { old[k] = st[k]; sv[k] = start[k]; }
         const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
-        const double r = (P.pad_ & 8) ? 0.0 : compute_reward(P, s, old);
+        const double r = compute_reward(P, s, old);
         const bool d = episode_over(P, s, sv) || c.y >= P.max_changes || c.x >= P.max_iterations;
         B.reward[e] = r;
         B.done[e] = d ? 1 : 0;
         int32_t* inf = B.info + (size_t)e * 10;
-        if (P.pad_ & 16) { st[0] = s[0]; st[1] = s[1]; } else {
         for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
         if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
-        inf[8] = c.x; inf[9] = c.y; }
-        if (d && P.auto_reset && !(P.pad_ & 4)) wl_push(B, parity, WL_RST, shard, e);
+        inf[8] = c.x; inf[9] = c.y;
+        if (d && P.auto_reset) wl_push(B, parity, WL_RST, shard, e);
     } else {
         for (int k = 0; k < 8; k++) st[k] = s[k];
         if (mode == MODE_START)
@@ -825,8 +824,6 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     P->max_crates = c->max_crates; P->target_solution = c->target_solution; P->solver_power = c->solver_power;
     for (int i = 0; i < 8; i++) P->rewards[i] = c->rewards[i];
     pcgrl_build_cdf(c->tile_probs, P->ntiles, P->cdf);
-    const char* dbg = getenv("PCGRL_DEBUG_ABLATE");   // perf ablation only (bit0: no stats compute, bit1: no finalize)
-    P->pad_ = dbg ? atoi(dbg) : 0;
 }
 
 static const size_t WL_CNT_BYTES = 2 * WL_NLIST * WL_NSHARD * WL_CSTRIDE * sizeof(int32_t);

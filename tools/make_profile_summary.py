@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Copy the rocprofv3 summaries of the last gpurun into profiles/<name>/ and write SUMMARY.md.
-    python tools_make_profile_summary.py <name> C2 [C3 ...]"""
+    python tools/make_profile_summary.py <name> C2 [C3 ...]"""
 import collections, csv, json, os, shutil, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 name, workloads = sys.argv[1], sys.argv[2:]
 dst = os.path.join(ROOT, "profiles", name)
@@ -14,7 +14,7 @@ def agg(path):
             d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
 out = ["# %s (MI355X, rocprofv3)\n" % name,
-       "Commands: `tools_profile.sh <workload> trace sq mem` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 100 --no-cpu-baseline`,",
+       "Commands: `tools/profile_gpu.sh <workload> trace sq mem` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 100 --no-cpu-baseline`,",
        "then separate `--pmc` passes (SQ_* counters; FETCH_SIZE; WRITE_SIZE).  Bench lines: `bench_<W>.json`.\n"]
 for W in workloads:
     out.append("## %s\n" % W)

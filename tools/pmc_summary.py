@@ -2,7 +2,7 @@
 """Summarise rocprofv3 CSVs under gpurun_out/ for one workload: per-kernel averages."""
 import collections, csv, os, sys
 W = sys.argv[1] if len(sys.argv) > 1 else "C2"
-root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 def agg(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     if not os.path.exists(path): return d

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Profiling recipe run on the GPU box (via gpurun); summaries are copied into profiles/ afterwards.
-#   tools_profile.sh <workload> [trace] [sq] [mem]
+#   tools/profile_gpu.sh <workload> [trace] [sq] [mem]
 export TMPDIR=/tmp
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 W=${1:-C2}; shift
 WHAT="${*:-trace sq mem}"
