@@ -175,10 +175,11 @@ PCGRL_D typename B::mask_t pcg_fill_cols(B& g, typename B::mask_t f, const PcgFi
         d = d | (c.dn[k] & g.rows_down(d, k));    // rows_down(x, k): row r receives row r - 2^k
         u = u | (c.up[k] & g.rows_up(u, k));
     }
-    // The doubling steps may be confined to blocks of 16 rows (one DPP row); one plain row hop lets
-    // the next round carry the fill across a block boundary.
+    // With more than 16 rows the doubling steps are confined to blocks of 16 rows (one DPP row); one plain
+    // row hop then lets the next round carry the fill across a block boundary.
     typename B::mask_t r = d | u;
-    return r | (c.pass & (g.up(r) | g.down(r)));
+    if (B::kGroup > 16) r = r | (c.pass & (g.up(r) | g.down(r)));
+    return r;
 }
 
 // The 4-connected component containing `seed`: alternate full-column and full-row fills until stable
@@ -235,10 +236,13 @@ PCGRL_D int bfs_levels(B& g, typename B::mask_t src, typename B::mask_t pass, ty
     for (;;) {
         ++it;
         M n = pcg_expand(g, f) & pass;
-        if (!g.wave_any(n ^ f)) break;           // wave-uniform exit; a converged group just idles
+        // bookkeeping before the exit test: in the final round nothing changed, so these are no-ops there,
+        // and the select mask is the very compare the exit test uses
         last_it = g.isel_ne(n, f, it, last_it);
         prev = g.msel_ne(n, f, f, prev);
+        const bool more = g.wave_any(n ^ f);     // wave-uniform exit; a converged group just idles
         f = n;
+        if (!more) break;
     }
     const int ecc = g.imax(last_it);
     // rows that changed at the final level hold the last frontier; with ecc == 0 it is src itself
