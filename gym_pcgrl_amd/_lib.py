@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 SO = os.path.join(LIBDIR, "libpcgrl_hip.so")
-SOURCES = [os.path.join(CSRC, "pcgrl_kernels.hip")]
+SOURCES = [os.path.join(CSRC, "pcgrl_abi.hip")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 PCGRL_OK, PCGRL_EINVAL, PCGRL_EHIP, PCGRL_ESTATE = 0, -1, -2, -3

@@ -1,0 +1,141 @@
+// k_stats / k_sokoban: Problem.get_stats + reward/done/info for the changed environments.
+// Part of the single translation unit pcgrl_abi.hip (see its header comment for the overall picture).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// k_stats: lane group per work item
+template <class MaskT>
+__device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
+    MaskT full = (W >= (int)(8 * sizeof(MaskT))) ? ~(MaskT)0 : (((MaskT)1 << W) - 1);
+    return lane < H ? full : (MaskT)0;
+}
+
+__device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
+                                              int mode, int parity, int shard) {
+    int32_t* st = B.stats + (size_t)e * 8;
+    int32_t* start = B.start_stats + (size_t)e * 8;
+    if (mode == MODE_STEP) {
+        int32_t old[PCGRL_MAX_STATS], sv[PCGRL_MAX_STATS];
+        for (int k = 0; k < 8; k++) { old[k] = st[k]; sv[k] = start[k]; }
+        const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
+        const double r = compute_reward(P, s, old);
+        const bool d = episode_over(P, s, sv) || c.y >= P.max_changes || c.x >= P.max_iterations;
+        B.reward[e] = r;
+        B.done[e] = d ? 1 : 0;
+        int32_t* inf = B.info + (size_t)e * 10;
+        for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
+        if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
+        inf[8] = c.x; inf[9] = c.y;
+        if (d && P.auto_reset) wl_push(B, parity, WL_RST, shard, e);
+    } else {
+        for (int k = 0; k < 8; k++) st[k] = s[k];
+        if (mode == MODE_START)
+            for (int k = 0; k < 8; k++) start[k] = s[k];
+    }
+}
+
+// Problem.get_stats on the row masks of one map (b0..b2 = bit planes of the tile id).  Returns true
+// when the Sokoban solver has to finish the job.
+template <int PROB, class G, class MaskT>
+__device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, MaskT b0, MaskT b1, MaskT b2, MaskT valid, int32_t* s) {
+    if (PROB == PCGRL_PROB_BINARY) {
+        int regions, path;
+        regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path);
+        s[0] = regions; s[1] = path;
+        return false;
+    }
+    if (PROB == PCGRL_PROB_ZELDA) { zelda_stats(g, P, b0, b1, b2, valid, s); return false; }
+    return sokoban_stats(g, P, b0, b1, b2, valid, s);
+}
+
+// Lane 0 of the group: hand the item to the solver or finish it.
+__device__ __forceinline__ void finish_or_park(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s, bool need_solver,
+                                               int mode, int parity, int shard) {
+    if (need_solver) {
+        // park the partial stats and hand the environment to the solver kernel.  STEP: in the info
+        // row (the old stats are still needed for the reward); otherwise in the stats row itself
+        // (the info row keeps the terminal info of an environment that is being reset).
+        int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+        for (int k = 0; k < 8; k++) park[k] = s[k];
+        wl_push(B, parity, mode == MODE_STEP ? WL_SOL : WL_SOL2, shard, e);
+    } else {
+        finalize_item(P, B, e, s, mode, parity, shard);
+    }
+}
+
+template <int PROB, int G, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity) {
+    __shared__ int s_pref[WL_NSHARD + 1];
+    // the last kernel of a step zeroes the *other* parity's work-list counters for the next step
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    DevGroup<G, MaskT> g;
+    constexpr int GPB = PCGRL_BLOCK / G;
+    const int n = wl_load_prefix(B, parity, list, s_pref);
+    const int gi = threadIdx.x / G;
+    const int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
+    for (int item = blockIdx.x * GPB + gi; item < n; item += gridDim.x * GPB) {
+        const int e = wl_get(B, list, s_pref, item);
+        const int shard = (item >> 4) & (WL_NSHARD - 1);
+        const MaskT* pl = reinterpret_cast<const MaskT*>(B.planes) + (size_t)e * NPL * G + g.lane;
+        const MaskT valid = row_valid<MaskT>(g.lane, P.width, P.height);
+        int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const MaskT b0 = pl[0], b1 = NPL > 1 ? pl[G] : (MaskT)0, b2 = NPL > 1 ? pl[2 * G] : (MaskT)0;
+        const bool need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, valid, s);
+        if (g.lane == 0) finish_or_park(P, B, e, s, need_solver, mode, parity, shard);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sokoban: one wavefront per solver job (sokoban_solver.h).  Finishes what k_stats parked.
+__global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sok_lds[];
+    __shared__ int s_pref[WL_NSHARD + 1];
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    const int lane = threadIdx.x;
+    const int n = wl_load_prefix(B, parity, list, s_pref);
+    __shared__ SokLevel s_L;             // level + node workspace in LDS: they are indexed dynamically
+    __shared__ SokNode s_root, s_work;
+    SokNode* pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
+    uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
+    uint32_t* g_table = B.sok_use_lds ? nullptr : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
+    const int tsize = B.sok_use_lds ? SOK_LDS_TABLE : B.sok_table_size;
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        const int e = wl_get(B, list, s_pref, item);
+        const int W = P.width, H = P.height;
+        if (lane == 0) {
+            const int ncr = sok_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+            if (ncr > SOK_MAXC) atomicOr(B.status, 1);
+            sok_init_deadlocks(s_L);
+            s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
+        }
+        int dist = 0, sol = 0;
+        // The four agents of _run_game, with the exact exhausted-BFS shortcut (sokoban_solver.h).  The search is
+        // driven by lane 0; every lane helps to clear the visited table between agents.
+        const int KS[4] = {-1, 2, 1, 0};
+        int go = 1;
+        for (int a = 0; a < 4 && go; a++) {
+            if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
+            else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
+            __threadfence_block();
+            if (lane == 0) {
+                int hh, dd, it;
+                bool exhausted = false, win;
+                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
+                    win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
+                else
+                    win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
+                dist = win ? 0 : hh;
+                sol = win ? dd : 0;
+                go = !(win || (a == 0 && exhausted));
+            }
+            go = __shfl(go, 0, 64);
+            __threadfence_block();
+        }
+        if (lane == 0) {
+            int32_t s[PCGRL_MAX_STATS];
+            const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+            for (int k = 0; k < 8; k++) s[k] = park[k];
+            s[4] = dist; s[5] = sol;
+            finalize_item(P, B, e, s, mode, parity, item & (WL_NSHARD - 1));
+        }
+    }
+}

@@ -1,0 +1,259 @@
+// k_update / k_update_block: Representation.update for every environment (thread per environment).
+// Part of the single translation unit pcgrl_abi.hip (see its header comment for the overall picture).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// k_update: thread per environment
+// The kernel is a chain of dependent scattered loads per thread at one wavefront per SIMD, so it is
+// written to keep that chain at three round trips: (1) action, counters, cursor, old stats; (2) the map
+// cell, its plane words and the MT19937 ring words of up to PCGRL_SPEC_DRAWS speculative draws (every
+// operand of draw i is an *old* word: distance 397); (3) the heatmap cell of the new cursor.
+#define PCGRL_SPEC_DRAWS 6
+template <int REP, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
+    __shared__ int s_cnt[2][4];
+    __shared__ int s_base[2];
+    __shared__ int s_hist[WL_NSHARD], s_gbase[WL_NSHARD];
+    const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
+    const bool act = e < P.num_envs;
+    bool chg = false, rst = false;
+    int bucket = 0;
+    if (act) {
+        const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
+        // ---- round trip 1
+        const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
+        int a0_ = 0, a1_ = 0, a2_ = 0;
+        if (REP == PCGRL_REP_WIDE) { a0_ = actions[3 * e + 0]; a1_ = actions[3 * e + 1]; a2_ = actions[3 * e + 2]; }
+        else a0_ = actions[e];
+        uchar2 p0 = make_uchar2(0, 0);
+        if (REP != PCGRL_REP_WIDE) p0 = reinterpret_cast<const uchar2*>(B.pos)[e];
+        const bool draws = REP == PCGRL_REP_NARROW && P.random_tile;
+        int cur = 0;
+        if (draws) cur = B.rng_cur[2 * e];
+        const int4* sp = reinterpret_cast<const int4*>(B.stats + (size_t)e * 8);
+        const int4* tp = reinterpret_cast<const int4*>(B.start_stats + (size_t)e * 8);
+        const int4 s0 = sp[0], s1 = sp[1], t0 = tp[0], t1 = tp[1];
+
+        bucket = difficulty_bucket(P, s0, s1);
+        const int iter = c.x + 1;
+        int changes = c.y;
+        int x = p0.x, y = p0.y;
+        int tile = -1, wx = 0, wy = 0, hx = 0, hy = 0;
+        if (REP == PCGRL_REP_NARROW) {
+            const int a = clampi(a0_, 0, P.ntiles);
+            if (a > 0) tile = a - 1;
+            wx = x; wy = y;
+        } else if (REP == PCGRL_REP_WIDE) {
+            wx = clampi(a0_, 0, W - 1);
+            wy = clampi(a1_, 0, H - 1);
+            tile = clampi(a2_, 0, P.ntiles - 1);
+            hx = wx; hy = wy;
+        } else {
+            const int a = clampi(a0_, 0, P.ntiles + 3);
+            if (a < 4) {   // turtle_rep.py:18,103-125: L,R,U,D with clamp or warp on both axes
+                const int dx = (a == 0) ? -1 : (a == 1 ? 1 : 0), dy = (a == 2) ? -1 : (a == 3 ? 1 : 0);
+                x += dx;
+                if (x < 0) x = P.warp ? x + W : 0;
+                if (x >= W) x = P.warp ? x - W : W - 1;
+                y += dy;
+                if (y < 0) y = P.warp ? y + H : 0;
+                if (y >= H) y = P.warp ? y - H : H - 1;
+            } else {
+                tile = a - 4;
+            }
+            wx = x; wy = y; hx = x; hy = y;
+        }
+        // ---- round trip 2: everything addressed by the cursor cell and by the ring cursor
+        uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
+        MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G + wy;
+        const int old = *cell;
+        MaskT m0 = pl[0], m1 = 0, m2 = 0;
+        if (NPL > 1) { m1 = pl[G]; m2 = pl[2 * G]; }
+        uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
+        uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
+        if (draws) {
+#pragma unroll
+            for (int i = 0; i <= PCGRL_SPEC_DRAWS; i++) xa[i] = ring[mt_wrap(cur + i)];
+#pragma unroll
+            for (int i = 0; i < PCGRL_SPEC_DRAWS; i++) xb[i] = ring[mt_wrap(mt_wrap(cur + PCGRL_MT_M) + i)];
+        }
+        if (tile >= 0 && old != tile) {
+            chg = true;
+            *cell = (uint8_t)tile;
+            const MaskT bit = (MaskT)1 << wx;
+            pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
+            if (NPL > 1) {
+                pl[G] = (tile & 2) ? (m1 | bit) : (m1 & ~bit);
+                pl[2 * G] = (tile & 4) ? (m2 | bit) : (m2 & ~bit);
+            }
+        }
+        if (REP == PCGRL_REP_NARROW) {   // the cursor moves on every step (narrow_rep.py:104-113)
+            if (draws) {
+                // numpy randint(W) then randint(H): masked rejection, consumed in order from the speculative words
+                const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
+                uint32_t mx = rx, my = ry;
+                mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
+                my |= my >> 1; my |= my >> 2; my |= my >> 4; my |= my >> 8; my |= my >> 16;
+                int stage = 0, used = 0;             // stage 0: drawing x, 1: drawing y, 2: done
+                if (rx == 0) { x = 0; stage = 1; }   // randint(1) draws nothing
+                if (stage == 1 && ry == 0) { y = 0; stage = 2; }
+#pragma unroll
+                for (int i = 0; i < PCGRL_SPEC_DRAWS; i++) {
+                    if (stage < 2) {
+                        const uint32_t yv = mt_twist(xa[i], xa[i + 1], xb[i]);
+                        ring[mt_wrap(cur + i)] = yv;
+                        used = i + 1;
+                        const uint32_t v = mt_temper(yv);
+                        if (stage == 0) {
+                            if ((v & mx) <= rx) { x = (int)(v & mx); stage = 1; if (ry == 0) { y = 0; stage = 2; } }
+                        } else {
+                            if ((v & my) <= ry) { y = (int)(v & my); stage = 2; }
+                        }
+                    }
+                }
+                cur = mt_wrap(cur + used);
+                if (stage < 2) {                      // (1/8)^k tail: finish with ordinary draws
+                    if (stage == 0) { x = mt_randint(ring, cur, W); y = mt_randint(ring, cur, H); }
+                    else y = mt_randint(ring, cur, H);
+                }
+                B.rng_cur[2 * e] = cur;
+            } else {
+                x += 1;
+                if (x >= W) { x = 0; y += 1; if (y >= H) y = 0; }
+            }
+            hx = x; hy = y;   // pcgrl_env.py:137 marks the *new* cursor cell
+        }
+        // ---- round trip 3
+        if (chg) {
+            changes += 1;
+            B.heat[((size_t)e * H + hy) * W + hx] += 1;
+        }
+        reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
+        if (REP != PCGRL_REP_WIDE) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        if (!chg) {
+            // new_stats is old_stats (pcgrl_env.py:132-142): reward 0, done/info from the current stats
+            int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
+            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+            st[0] = t0.x; st[1] = t0.y; st[2] = t0.z; st[3] = t0.w; st[4] = t1.x; st[5] = t1.y; st[6] = t1.z; st[7] = t1.w;
+            const bool d = episode_over(P, s, st) || changes >= P.max_changes || iter >= P.max_iterations;
+            B.reward[e] = 0.0;
+            B.done[e] = d ? 1 : 0;
+            int32_t* inf = B.info + (size_t)e * 10;
+            inf[0] = s0.x; inf[1] = s0.y; inf[2] = s0.z; inf[3] = s0.w;
+            inf[4] = s1.x; inf[5] = s1.y; inf[6] = s1.z; inf[7] = s1.w;
+            if (P.prob == PCGRL_PROB_BINARY) inf[2] = s0.y - t0.y;   // path-imp (binary_prob.py:137)
+            inf[8] = iter; inf[9] = changes;
+            rst = d && P.auto_reset;
+        }
+    }
+    // bucketing pays where four maps share a wavefront and their cost varies a lot (binary); elsewhere the
+    // plain per-block append is cheaper (kernel-uniform branch)
+    if (P.prob == PCGRL_PROB_BINARY && P.group == 16) block_append_bucketed(chg, bucket, e, B, parity, WL_CHG, s_hist, s_gbase);
+    else block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_update_block: the 3x3 "cast" / "multi" representations (narrow_cast_rep.py:36-59, narrow_multi_rep.py:39-59,
+// turtle_cast_rep.py:38-76).  Same contract as k_update; up to nine tiles change per step and `change`
+// counts them (pcgrl_env.py:136 adds it to _changes; the heatmap still gets +1).
+template <int REP, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
+    __shared__ int s_cnt[2][4];
+    __shared__ int s_base[2];
+    const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
+    const bool act = e < P.num_envs;
+    bool chg = false, rst = false;
+    if (act) {
+        const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes, NT = P.ntiles;
+        const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
+        const uchar2 p0 = reinterpret_cast<const uchar2*>(B.pos)[e];
+        const int iter = c.x + 1;
+        int changes = c.y, x = p0.x, y = p0.y;
+        int vals[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) vals[i] = -1;
+        if (REP == PCGRL_REP_NARROW_MULTI) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) { const int a = clampi(actions[9 * e + i], 0, NT); vals[i] = a - 1; }
+        } else {
+            const int type = actions[2 * e], value = clampi(actions[2 * e + 1], 0, NT - 1);
+            if (REP == PCGRL_REP_NARROW_CAST) {
+                const int t = clampi(type, 0, 2);
+                if (t == 1) vals[4] = value;
+                if (t == 2) { for (int i = 0; i < 9; i++) vals[i] = value; }
+            } else {
+                const int t = clampi(type, 0, 5);
+                if (t < 4) {   // turtle move (turtle_rep.py:103-125 semantics)
+                    const int dx = (t == 0) ? -1 : (t == 1 ? 1 : 0), dy = (t == 2) ? -1 : (t == 3 ? 1 : 0);
+                    x += dx;
+                    if (x < 0) x = P.warp ? x + W : 0;
+                    if (x >= W) x = P.warp ? x - W : W - 1;
+                    y += dy;
+                    if (y < 0) y = P.warp ? y + H : 0;
+                    if (y >= H) y = P.warp ? y - H : H - 1;
+                }
+                if (t == 4) vals[4] = value;
+                if (t == 5) { for (int i = 0; i < 9; i++) vals[i] = value; }
+            }
+        }
+        int change = 0;
+        uint8_t* map_e = B.map + (size_t)e * H * W;
+        MaskT* pl_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            if (vals[(dy + 1) * 3] < 0 && vals[(dy + 1) * 3 + 1] < 0 && vals[(dy + 1) * 3 + 2] < 0) continue;
+            MaskT m0 = pl_e[yy], m1 = NPL > 1 ? pl_e[G + yy] : (MaskT)0, m2 = NPL > 1 ? pl_e[2 * G + yy] : (MaskT)0;
+            bool touched = false;
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const int xx = x + dx, v = vals[(dy + 1) * 3 + dx + 1];
+                if (xx < 0 || xx >= W || v < 0) continue;
+                uint8_t* cell = map_e + yy * W + xx;
+                if (*cell != v) {
+                    change++;
+                    touched = true;
+                    *cell = (uint8_t)v;
+                    const MaskT bit = (MaskT)1 << xx;
+                    m0 = (v & 1) ? (m0 | bit) : (m0 & ~bit);
+                    m1 = (v & 2) ? (m1 | bit) : (m1 & ~bit);
+                    m2 = (v & 4) ? (m2 | bit) : (m2 & ~bit);
+                }
+            }
+            if (touched) { pl_e[yy] = m0; if (NPL > 1) { pl_e[G + yy] = m1; pl_e[2 * G + yy] = m2; } }
+        }
+        if (REP != PCGRL_REP_TURTLE_CAST) {   // narrow cursor move (narrow_rep.py:104-113), after the write
+            if (P.random_tile) {
+                uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
+                int cur = B.rng_cur[2 * e];
+                x = mt_randint(ring, cur, W);
+                y = mt_randint(ring, cur, H);
+                B.rng_cur[2 * e] = cur;
+            } else {
+                x += 1;
+                if (x >= W) { x = 0; y += 1; if (y >= H) y = 0; }
+            }
+        }
+        if (change > 0) {
+            chg = true;
+            changes += change;
+            B.heat[((size_t)e * H + y) * W + x] += 1;
+        }
+        reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
+        reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        if (!chg) {
+            int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
+            int32_t* inf = B.info + (size_t)e * 10;
+            for (int k = 0; k < 8; k++) { s[k] = B.stats[(size_t)e * 8 + k]; st[k] = B.start_stats[(size_t)e * 8 + k]; inf[k] = s[k]; }
+            const bool d = episode_over(P, s, st) || changes >= P.max_changes || iter >= P.max_iterations;
+            B.reward[e] = 0.0;
+            B.done[e] = d ? 1 : 0;
+            if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - st[1];
+            inf[8] = iter; inf[9] = changes;
+            rst = d && P.auto_reset;
+        }
+    }
+    block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+}

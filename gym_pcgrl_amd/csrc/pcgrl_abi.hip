@@ -1,0 +1,613 @@
+// C ABI of the batched PCGRL environment and, through the kernels_*.h headers it includes, its HIP
+// kernels (gfx950 / CDNA4): one translation unit.
+//
+// One `pcgrl_step` is three launches on the caller's stream (five for Sokoban):
+//
+//   k_update   thread per environment.  Representation.update (narrow_rep.py:99-114, wide_rep.py:67-70,
+//              turtle_rep.py:101-129), counters + heatmap (pcgrl_env.py:130-137).  Unchanged
+//              environments are finished here (reward 0, done, info); changed ones are compacted into
+//              a sharded work list, bucketed by expected difficulty (LDS histogram, one atomic per bucket
+//              per 256-thread block).
+//   k_stats    one lane group (16 lanes = one DPP row, or a full wavefront for maps taller than 16) per
+//              changed environment: Problem.get_stats as row-bitboard programs (pcgrl_algos.h), get_reward,
+//              get_episode_over, get_debug_info (pcgrl_env.py:138-148).  Done environments go to the
+//              reset list.
+//   k_sokoban  (Sokoban only) one wavefront per solver job parked by k_stats / k_reset.
+//   k_reset    one wavefront per environment to reset: PcgrlEnv.reset (pcgrl_env.py:66-76): the MT19937
+//              ring is staged in LDS and the wave produces 128 words per round, tiles are drawn with
+//              numpy's choice() rule, written coalesced as uint8 and transposed through LDS into the
+//              row bit planes; cursor draw; BinaryProblem.reset (binary_prob.py:68-72); start stats
+//              (problem.py:45-46) on the rows that are already in registers.
+//
+// State is structure-of-arrays over the environment axis, all in HBM, owned by the caller
+// (include/pcgrl_hip.h).  The uint8 map is the observation; the kernels compute on `planes`
+// (row bitboards of the tile-id bits, [N][nplanes][group]) which k_update keeps in sync, so the
+// statistics never re-read or transpose the byte map.  No MFMA: integer/bit work only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#include "../../include/pcgrl_hip.h"
+#include "lanegroup_dev.h"
+#include "mt19937.h"
+#include "pcgrl_algos.h"
+#include "sokoban_solver.h"
+
+#include "worklist.h"
+#include "kernels_update.h"
+#include "kernels_stats.h"
+#include "kernels_reset.h"
+#include "kernels_misc.h"
+
+// ------------------------------------------------------------------------------------------
+// Host side of the ABI
+#define PCGRL_MAX_SUB 4
+struct pcgrl_env {
+    pcgrl_config cfg;
+    PcgrlParams P;
+    pcgrl_layout L;
+    DevBufs B;
+    int bound;
+    int has_old;      // at least one random reset happened (representation.py:41)
+    int was_reset;
+    int parity;
+    int device;
+    // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
+    int alloc_solver_power;
+    // Sub-batches: the environment axis is cut into nsub contiguous slices whose kernel chains run on
+    // separate HIP streams (slice 0 on the caller's stream), so that one slice's latency-bound kernels
+    // (k_update, k_reset) overlap another slice's throughput-bound k_stats.  Fork/join with events.
+    int nsub;
+    PcgrlParams subP[PCGRL_MAX_SUB];
+    DevBufs subB[PCGRL_MAX_SUB];
+    hipStream_t sub_stream[PCGRL_MAX_SUB];
+    hipEvent_t ev_fork, ev_join[PCGRL_MAX_SUB];
+    int profiling;
+    std::vector<hipEvent_t> events;
+    size_t ev_used;
+    int prof_steps;
+};
+#define PCGRL_NPHASE 6   /* update, stats(step), solver(step), mapgen, stats(start), solver(start) */
+static int prof_mark(pcgrl_env* h, hipStream_t st) {
+    if (!h->profiling) return PCGRL_OK;
+    if (h->ev_used == h->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return PCGRL_EHIP;
+        h->events.push_back(e);
+    }
+    if (hipEventRecord(h->events[h->ev_used++], st) != hipSuccess) return PCGRL_EHIP;
+    return PCGRL_OK;
+}
+
+static thread_local int g_last_hip = 0;
+#define HIPCHK(expr) do { hipError_t err_ = (expr); if (err_ != hipSuccess) { g_last_hip = (int)err_; return PCGRL_EHIP; } } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int validate_config(const pcgrl_config* c) {
+    if (!c) return PCGRL_EINVAL;
+    if (c->prob < 0 || c->prob > 2 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
+    if (c->num_envs < 1) return PCGRL_EINVAL;
+    if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
+    if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
+    if (c->prob == PCGRL_SOKOBAN) {   // limits of the solver kernel (sokoban_solver.h)
+        if ((c->width + 2) * (c->height + 2) > 256) return PCGRL_EINVAL;
+        if (c->solver_power < 1 || c->solver_power > 16383) return PCGRL_EINVAL;
+    }
+    return PCGRL_OK;
+}
+static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_ZELDA ? 8 : 5); }
+
+static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
+    memset(P, 0, sizeof(*P));
+    P->prob = c->prob; P->rep = c->rep; P->num_envs = c->num_envs;
+    P->width = c->width; P->height = c->height;
+    P->prob_width = c->width; P->prob_height = c->height;
+    P->ntiles = ntiles_of(c->prob);
+    P->nplanes = c->prob == PCGRL_BINARY ? 1 : 3;
+    P->group = c->height <= 16 ? 16 : 64;
+    P->mask_bytes = c->width <= 32 ? 4 : 8;
+    P->max_changes = c->max_changes; P->max_iterations = c->max_iterations;
+    P->random_start = c->random_start; P->random_tile = c->random_tile; P->warp = c->warp;
+    P->random_probs = c->random_probs; P->auto_reset = c->auto_reset;
+    P->target_path = c->target_path; P->max_enemies = c->max_enemies; P->target_enemy_dist = c->target_enemy_dist;
+    P->max_crates = c->max_crates; P->target_solution = c->target_solution; P->solver_power = c->solver_power;
+    for (int i = 0; i < 8; i++) P->rewards[i] = c->rewards[i];
+    pcgrl_build_cdf(c->tile_probs, P->ntiles, P->cdf);
+}
+
+static const size_t WL_CNT_BYTES = 2 * WL_NLIST * WL_NSHARD * WL_CSTRIDE * sizeof(int32_t);
+// shard capacity: the changed list is bucketed by difficulty, so one bucket may receive every environment
+static int wl_capacity(int num_envs, int list) {
+    return list == WL_CHG ? num_envs : 2 * ((num_envs + WL_NSHARD - 1) / WL_NSHARD + 256);
+}
+static size_t wl_list_bytes(int num_envs, int list) { return align_up((size_t)WL_NSHARD * wl_capacity(num_envs, list) * 4, 256); }
+#define SOK_BLOCKS 256   /* resident solver blocks (one per CU: heap + table fill most of its LDS) */
+static size_t wl_bytes(const pcgrl_config* c) {
+    size_t b = WL_CNT_BYTES + 256;
+    for (int k = 0; k < WL_NLIST; k++) b += wl_list_bytes(c->num_envs, k);
+    return b;
+}
+static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<= 1; return t; }
+static int num_subbatches(const pcgrl_config* c) {
+    const char* e = getenv("PCGRL_SUBBATCHES");
+    // Measured on MI355X (C2/C3, 65 536 envs): 1 slice 61 us/step, 2 slices 74, 4 slices 113 -- the
+    // cross-stream event fork/join costs more than the overlap wins, so slicing is opt-in only.
+    int n = e ? atoi(e) : 1;
+    if (c->prob == PCGRL_SOKOBAN) n = 1;          // the solver arena is per handle
+    if (n < 1) n = 1;
+    if (n > PCGRL_MAX_SUB) n = PCGRL_MAX_SUB;
+    while (n > 1 && c->num_envs / n < 1024) n--;
+    return n;
+}
+static void sub_range(int num_envs, int nsub, int k, int* lo, int* hi) {
+    const int base = num_envs / nsub, extra = num_envs % nsub;
+    *lo = k * base + (k < extra ? k : extra);
+    *hi = *lo + base + (k < extra ? 1 : 0);
+}
+static size_t scratch_bytes(const pcgrl_config* c) {
+    const int nsub = num_subbatches(c);
+    pcgrl_config cc = *c;
+    cc.num_envs = (c->num_envs + nsub - 1) / nsub;
+    size_t b = nsub * wl_bytes(&cc);
+    if (c->prob == PCGRL_SOKOBAN) {
+        const size_t nodes = 4 * (size_t)c->solver_power + 4;
+        b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
+        if (c->solver_power > SOK_LDS_POWER) b += SOK_BLOCKS * (align_up(nodes * 4, 256) + (size_t)sok_table_size(c->solver_power) * 4);
+    }
+    return b;
+}
+
+extern "C" {
+
+int pcgrl_abi_version(void) { return PCGRL_ABI_VERSION; }
+int pcgrl_last_hip_error(void) { return g_last_hip; }
+const char* pcgrl_error_string(int code) {
+    switch (code) {
+        case PCGRL_OK: return "ok";
+        case PCGRL_EINVAL: return "invalid argument or unsupported configuration";
+        case PCGRL_EHIP: return "HIP runtime error";
+        case PCGRL_ESTATE: return "call order violated (bind, seed and reset before step)";
+        default: return "unknown error";
+    }
+}
+
+int pcgrl_query_layout(const pcgrl_config* c, pcgrl_layout* L) {
+    int rc = validate_config(c);
+    if (rc) return rc;
+    if (!L) return PCGRL_EINVAL;
+    PcgrlParams P;
+    fill_params(c, &P);
+    const size_t n = (size_t)c->num_envs, cells = (size_t)c->width * c->height;
+    memset(L, 0, sizeof(*L));
+    L->group = P.group; L->mask_bytes = P.mask_bytes; L->nplanes = P.nplanes; L->nstats = num_stats(c->prob);
+    L->map = n * cells; L->old_map = n * cells; L->heatmap = n * cells * 2; L->pos = n * 2;
+    L->planes = n * P.nplanes * P.group * P.mask_bytes;
+    L->counters = n * 8; L->stats = n * 32; L->start_stats = n * 32; L->info = n * 40;
+    L->reward = n * 8; L->done = n; L->tile_p = n * 16;
+    L->rng_rep = n * PCGRL_MT_N * 4; L->rng_prob = c->prob == PCGRL_BINARY ? n * PCGRL_MT_N * 4 : 0;
+    L->rng_cursor = n * 8;
+    L->scratch = scratch_bytes(c);
+    return PCGRL_OK;
+}
+
+int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
+    int rc = validate_config(c);
+    if (rc) return rc;
+    if (!out) return PCGRL_EINVAL;
+    pcgrl_env* h = new pcgrl_env();
+    h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
+    h->profiling = 0; h->ev_used = 0; h->prof_steps = 0;
+    h->nsub = 1; h->ev_fork = nullptr;
+    for (int k = 0; k < PCGRL_MAX_SUB; k++) { h->sub_stream[k] = nullptr; h->ev_join[k] = nullptr; }
+    memset(&h->B, 0, sizeof(h->B));
+    h->cfg = *c;
+    fill_params(c, &h->P);
+    pcgrl_query_layout(c, &h->L);
+    *out = h;
+    return PCGRL_OK;
+}
+
+int pcgrl_destroy(pcgrl_env* h) {
+    if (h) {
+        for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+        for (int k = 0; k < PCGRL_MAX_SUB; k++) {
+            if (h->sub_stream[k]) { (void)hipStreamSynchronize(h->sub_stream[k]); (void)hipStreamDestroy(h->sub_stream[k]); }
+            if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
+        }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    }
+    delete h;
+    return PCGRL_OK;
+}
+
+int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
+    if (!h || !b) return PCGRL_EINVAL;
+    if (!b->map || !b->old_map || !b->heatmap || !b->pos || !b->planes || !b->counters || !b->stats ||
+        !b->start_stats || !b->info || !b->reward || !b->done || !b->tile_p || !b->rng_rep || !b->rng_cursor || !b->scratch)
+        return PCGRL_EINVAL;
+    if (h->cfg.prob == PCGRL_BINARY && !b->rng_prob) return PCGRL_EINVAL;
+    DevBufs& B = h->B;
+    B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
+    B.planes = b->planes; B.counters = (int32_t*)b->counters; B.stats = (int32_t*)b->stats;
+    B.start_stats = (int32_t*)b->start_stats; B.info = (int32_t*)b->info; B.reward = (double*)b->reward;
+    B.done = (uint8_t*)b->done; B.tile_p = (double*)b->tile_p; B.rng_rep = (uint32_t*)b->rng_rep;
+    B.rng_prob = (uint32_t*)b->rng_prob; B.rng_cur = (int32_t*)b->rng_cursor;
+    uint8_t* s = (uint8_t*)b->scratch;
+    B.wl_cnt = (int32_t*)s;
+    B.status = (int32_t*)(s + WL_CNT_BYTES);
+    {
+        uint8_t* q = s + WL_CNT_BYTES + 256;
+        for (int k = 0; k < WL_NLIST; k++) {
+            B.wl_cap[k] = wl_capacity(h->cfg.num_envs, k);
+            B.wl_items[k] = (int32_t*)q;
+            q += wl_list_bytes(h->cfg.num_envs, k);
+        }
+    }
+    HIPCHK(hipMemsetAsync(B.wl_cnt, 0, WL_CNT_BYTES + 256, (hipStream_t)stream));
+    B.sok_pool = nullptr; B.sok_heap = nullptr; B.sok_table = nullptr;
+    if (h->cfg.prob == PCGRL_SOKOBAN) {
+        // the arena is sized for the solver_power the buffers were allocated with
+        const int power = h->alloc_solver_power = h->cfg.solver_power;
+        const size_t nodes = 4 * (size_t)power + 4;
+        uint8_t* a = s + wl_bytes(&h->cfg);   // (nsub == 1 for sokoban)
+        B.sok_pool = (SokNode*)a;
+        B.sok_pool_stride = (int32_t)(align_up(nodes * sizeof(SokNode), 256) / sizeof(SokNode));
+        a += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
+        B.sok_use_lds = power <= SOK_LDS_POWER;
+        B.sok_table_size = sok_table_size(power);
+        B.sok_heap_stride = (int32_t)(align_up(nodes * 4, 256) / 4);
+        if (!B.sok_use_lds) {
+            B.sok_heap = (uint32_t*)a;
+            a += SOK_BLOCKS * align_up(nodes * 4, 256);
+            B.sok_table = (uint32_t*)a;
+        }
+    }
+    // sub-batch views: every per-environment pointer offset to the slice, private work lists
+    h->nsub = num_subbatches(&h->cfg);
+    if (h->nsub > 1) {
+        const PcgrlParams& P0 = h->P;
+        const size_t cells = (size_t)P0.width * P0.height;
+        pcgrl_config cc = h->cfg;
+        cc.num_envs = (h->cfg.num_envs + h->nsub - 1) / h->nsub;
+        const size_t wlb = wl_bytes(&cc);
+        for (int k = 0; k < h->nsub; k++) {
+            int lo, hi;
+            sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
+            PcgrlParams& P = h->subP[k]; DevBufs& S = h->subB[k];
+            P = P0; P.num_envs = hi - lo;
+            S = B;
+            S.map = B.map + lo * cells; S.old_map = B.old_map + lo * cells; S.heat = B.heat + lo * cells; S.pos = B.pos + 2 * (size_t)lo;
+            S.planes = (uint8_t*)B.planes + (size_t)lo * P0.nplanes * P0.group * P0.mask_bytes;
+            S.counters = B.counters + 2 * (size_t)lo; S.stats = B.stats + 8 * (size_t)lo; S.start_stats = B.start_stats + 8 * (size_t)lo;
+            S.info = B.info + 10 * (size_t)lo; S.reward = B.reward + lo; S.done = B.done + lo; S.tile_p = B.tile_p + 2 * (size_t)lo;
+            S.rng_rep = B.rng_rep + (size_t)lo * PCGRL_MT_N; S.rng_prob = B.rng_prob ? B.rng_prob + (size_t)lo * PCGRL_MT_N : nullptr;
+            S.rng_cur = B.rng_cur + 2 * (size_t)lo;
+            uint8_t* q = s + (size_t)k * wlb;
+            S.wl_cnt = (int32_t*)q;
+            q += WL_CNT_BYTES + 256;
+            for (int l = 0; l < WL_NLIST; l++) { S.wl_cap[l] = wl_capacity(cc.num_envs, l); S.wl_items[l] = (int32_t*)q; q += wl_list_bytes(cc.num_envs, l); }
+            if (k > 0 && !h->sub_stream[k]) {
+                HIPCHK(hipStreamCreateWithFlags(&h->sub_stream[k], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+            }
+        }
+        if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipMemsetAsync(s, 0, h->nsub * wlb, (hipStream_t)stream));
+    }
+    h->bound = 1; h->has_old = 0; h->was_reset = 0; h->parity = 0;
+    return PCGRL_OK;   // tile_p is caller state: call pcgrl_set_tile_probs once after the first bind
+}
+
+int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
+    if (!h) return PCGRL_EINVAL;
+    int rc = validate_config(c);
+    if (rc) return rc;
+    if (c->prob != h->cfg.prob || c->rep != h->cfg.rep || c->num_envs != h->cfg.num_envs ||
+        c->width != h->cfg.width || c->height != h->cfg.height)
+        return PCGRL_EINVAL;
+    if (h->bound && c->prob == PCGRL_SOKOBAN && c->solver_power > h->alloc_solver_power) return PCGRL_EINVAL;   // arena too small: re-create
+    h->cfg = *c;
+    fill_params(c, &h->P);
+    for (int k = 0; k < h->nsub && h->nsub > 1; k++) { const int n = h->subP[k].num_envs; h->subP[k] = h->P; h->subP[k].num_envs = n; }
+    return PCGRL_OK;
+}
+
+int pcgrl_set_tile_probs(pcgrl_env* h, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    const int n = h->cfg.num_envs;
+    hipLaunchKernelGGL(k_bcast_tile_p, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->B.tile_p, n,
+                       h->cfg.tile_probs[0], h->cfg.tile_probs[1]);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+int pcgrl_seed(pcgrl_env* h, const uint32_t* keys, int32_t first, int32_t count, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!keys || first < 0 || count < 1 || first + count > h->cfg.num_envs) return PCGRL_EINVAL;
+    const size_t bytes = (size_t)count * PCGRL_MT_N * 4, off = (size_t)first * PCGRL_MT_N;
+    HIPCHK(hipMemcpyAsync(h->B.rng_rep + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (h->B.rng_prob) HIPCHK(hipMemcpyAsync(h->B.rng_prob + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_zero_cursors, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->B.rng_cur, first, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));   // `keys` may be pageable host memory
+    return PCGRL_OK;
+}
+
+}  // extern "C"
+
+// ---- launch helpers ------------------------------------------------------------------------
+static int grid_for(int items, int per_block, int cap) {
+    int g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return g < cap ? g : cap;
+}
+
+template <int PROB>
+static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const int gpb = PCGRL_BLOCK / P.group;
+    // per-step reset lists are short: a small grid-stride grid avoids dispatching thousands of empty blocks
+    const int grid = grid_for(P.num_envs, gpb, (mode == MODE_START && h->was_reset) ? 512 : 8192);
+    if (P.group == 16 && P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+    else if (P.group == 16)
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+    else if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+    else
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
+    switch (h->P.prob) {
+        case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, st);
+        case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, st);
+        default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, parity, mode, clr, st);
+    }
+}
+
+template <class MaskT>
+static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const int grid = (P.num_envs + PCGRL_BLOCK - 1) / PCGRL_BLOCK;
+    switch (P.rep) {
+        case PCGRL_REP_NARROW:
+            hipLaunchKernelGGL((k_update<PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        case PCGRL_REP_WIDE:
+            hipLaunchKernelGGL((k_update<PCGRL_REP_WIDE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        case PCGRL_REP_TURTLE:
+            hipLaunchKernelGGL((k_update<PCGRL_REP_TURTLE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        case PCGRL_REP_NARROW_CAST:
+            hipLaunchKernelGGL((k_update_block<PCGRL_REP_NARROW_CAST, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        case PCGRL_REP_NARROW_MULTI:
+            hipLaunchKernelGGL((k_update_block<PCGRL_REP_NARROW_MULTI, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+        default:
+            hipLaunchKernelGGL((k_update_block<PCGRL_REP_TURTLE_CAST, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
+    }
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+static int launch_solver(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
+    const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sokoban), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sokoban, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list, parity, mode, clr);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+template <int PROB>
+static int launch_reset_p(pcgrl_env* h, int parity, int clr, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const int cells = P.width * P.height;
+    const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((cells + 15) & ~15));
+    const int grid = grid_for(P.num_envs, 4, h->was_reset ? 512 : 4096);
+    const int gen = (P.random_start || !h->has_old) ? 1 : 0;
+    if (P.group == 16 && P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_reset<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+    else if (P.group == 16)
+        hipLaunchKernelGGL((k_reset<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+    else if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_reset<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+    else
+        hipLaunchKernelGGL((k_reset<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+// map generation + start stats of every environment on the reset list
+static int launch_reset(pcgrl_env* h, int parity, int clr, hipStream_t st) {
+    switch (h->P.prob) {
+        case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, parity, clr, st);
+        case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, parity, clr, st);
+        default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, parity, clr, st);
+    }
+}
+
+extern "C" {
+
+static int reset_one(pcgrl_env* h, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int n = h->P.num_envs, par = h->parity;   // (h->P is the sub-batch view here)
+    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_RST);
+    HIPCHK(hipGetLastError());
+    const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN;
+    int rc = launch_reset(h, par, sok ? -1 : (par ^ 1), st);
+    if (rc) return rc;
+    if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
+    return PCGRL_OK;
+}
+
+static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int par = h->parity;
+    int rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    rc = (h->P.mask_bytes == 4) ? launch_update_m<uint32_t>(h, actions, par, st) : launch_update_m<uint64_t>(h, actions, par, st);
+    if (rc) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    // the last kernel of the step clears the other parity's work-list counters
+    const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN, ar = h->P.auto_reset != 0;
+    rc = launch_stats(h, WL_CHG, par, MODE_STEP, (ar || sok) ? -1 : (par ^ 1), st);
+    if (rc) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    if (sok && (rc = launch_solver(h, WL_SOL, par, MODE_STEP, ar ? -1 : (par ^ 1), st))) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    if (ar) {
+        rc = launch_reset(h, par, sok ? -1 : (par ^ 1), st);
+        if (rc) return rc;
+    }
+    if ((rc = prof_mark(h, st))) return rc;
+    if ((rc = prof_mark(h, st))) return rc;   // (the start stats are part of k_reset)
+    if (ar && sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    return PCGRL_OK;
+}
+
+// Run `fn` once per sub-batch: slice 0 on the caller's stream, the others on their own streams between a
+// fork event and join events; h->P / h->B are swapped to the slice's view for the duration of the call.
+static int for_each_sub(pcgrl_env* h, hipStream_t caller, const std::function<int(int, hipStream_t)>& fn) {
+    if (h->nsub <= 1) return fn(0, caller);
+    const PcgrlParams P0 = h->P;
+    const DevBufs B0 = h->B;
+    const int prof = h->profiling;
+    int rc = PCGRL_OK;
+    if (hipEventRecord(h->ev_fork, caller) != hipSuccess) return PCGRL_EHIP;
+    for (int k = h->nsub - 1; k >= 0 && rc == PCGRL_OK; k--) {   // side streams first, the caller's slice last
+        hipStream_t st = k == 0 ? caller : h->sub_stream[k];
+        if (k > 0 && hipStreamWaitEvent(st, h->ev_fork, 0) != hipSuccess) { rc = PCGRL_EHIP; break; }
+        h->P = h->subP[k]; h->B = h->subB[k];
+        h->profiling = (k == 0) ? prof : 0;          // phase timing follows slice 0
+        rc = fn(k, st);
+        if (rc == PCGRL_OK && k > 0 && hipEventRecord(h->ev_join[k], st) != hipSuccess) rc = PCGRL_EHIP;
+    }
+    h->P = P0; h->B = B0; h->profiling = prof;
+    for (int k = 1; k < h->nsub && rc == PCGRL_OK; k++)
+        if (hipStreamWaitEvent(caller, h->ev_join[k], 0) != hipSuccess) rc = PCGRL_EHIP;
+    return rc;
+}
+
+int pcgrl_reset(pcgrl_env* h, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    int rc = for_each_sub(h, (hipStream_t)stream, [&](int, hipStream_t st) { return reset_one(h, st); });
+    if (rc) return rc;
+    h->parity ^= 1;
+    h->has_old = 1;
+    h->was_reset = 1;
+    return PCGRL_OK;
+}
+
+int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!actions) return PCGRL_EINVAL;
+    static const int kActionWidth[6] = {1, 3, 1, 2, 9, 2};
+    const int aw = kActionWidth[h->P.rep];
+    int rc = for_each_sub(h, (hipStream_t)stream, [&](int k, hipStream_t st) {
+        int lo = 0, hi = 0;
+        sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
+        return step_one(h, actions + (size_t)lo * aw, st);
+    });
+    if (rc) return rc;
+    h->parity ^= 1;
+    if (h->profiling) h->prof_steps++;
+    return PCGRL_OK;
+}
+
+int pcgrl_profile(pcgrl_env* h, int enable) {
+    if (!h) return PCGRL_EINVAL;
+    h->profiling = enable ? 1 : 0;
+    h->ev_used = 0;
+    h->prof_steps = 0;
+    return PCGRL_OK;
+}
+
+// Sums the per-phase GPU time (ms) of every step issued since pcgrl_profile(h, 1); synchronises.
+int pcgrl_profile_read(pcgrl_env* h, double* phase_ms, int32_t* steps) {
+    if (!h || !phase_ms || !steps) return PCGRL_EINVAL;
+    for (int k = 0; k < PCGRL_NPHASE; k++) phase_ms[k] = 0.0;
+    *steps = h->prof_steps;
+    if (h->ev_used == 0) return PCGRL_OK;
+    HIPCHK(hipEventSynchronize(h->events[h->ev_used - 1]));
+    const size_t per = PCGRL_NPHASE + 1;
+    for (size_t s0 = 0; s0 + per <= h->ev_used; s0 += per)
+        for (int k = 0; k < PCGRL_NPHASE; k++) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->events[s0 + k], h->events[s0 + k + 1]));
+            phase_ms[k] += ms;
+        }
+    return PCGRL_OK;
+}
+
+int pcgrl_observe(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!out || out_h < 1 || out_w < 1) return PCGRL_EINVAL;
+    if (centered && h->P.rep == PCGRL_REP_WIDE) return PCGRL_EINVAL;   // Cropped needs a cursor (wrappers.py:170)
+    const int depth = onehot ? h->P.ntiles : 1;
+    const size_t total = (size_t)h->P.num_envs * out_h * out_w;
+    const int grid = (int)((total + PCGRL_BLOCK - 1) / PCGRL_BLOCK < 16384 ? (total + PCGRL_BLOCK - 1) / PCGRL_BLOCK : 16384);
+    hipLaunchKernelGGL(k_obs_window, dim3(grid), dim3(PCGRL_BLOCK), 0, (hipStream_t)stream, h->P, h->B, out, out_h, out_w, centered, pad_value, depth);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+int pcgrl_action_map(pcgrl_env* h, const int32_t* flat, int32_t* xyv, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!flat || !xyv) return PCGRL_EINVAL;
+    const int n = h->P.num_envs;
+    hipLaunchKernelGGL(k_action_map, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, xyv, n, h->P.width, h->P.height, h->P.ntiles);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
+int pcgrl_status(pcgrl_env* h, void* stream, int32_t* status) {
+    if (!h || !h->bound || !status) return PCGRL_ESTATE;
+    HIPCHK(hipMemcpyAsync(status, h->B.status, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return PCGRL_OK;
+}
+
+static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const PcgrlParams& P = h->P;
+    const int n = P.num_envs, par = h->parity, cells = P.width * P.height;
+    const size_t lds = 4 * (size_t)((cells + 15) & ~15);
+    const int grid = grid_for(n, 4, 4096);
+    if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_planes_from_map<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
+    else
+        hipLaunchKernelGGL((k_planes_from_map<uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_CHG);
+    HIPCHK(hipGetLastError());
+    const bool sok = P.prob == PCGRL_PROB_SOKOBAN;
+    int rc = launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), st);
+    if (rc) return rc;
+    if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_SETMAP, par ^ 1, st))) return rc;
+    return PCGRL_OK;
+}
+
+int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!maps) return PCGRL_EINVAL;
+    const size_t cells = (size_t)h->P.width * h->P.height;
+    int rc = for_each_sub(h, (hipStream_t)stream, [&](int k, hipStream_t st) {
+        int lo = 0, hi = 0;
+        sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
+        return set_maps_one(h, maps + (size_t)lo * cells, st);
+    });
+    if (rc) return rc;
+    h->parity ^= 1;
+    return PCGRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Device buffers, sharded work lists and block-wide compaction shared by all kernels.
+// Part of the single translation unit pcgrl_abi.hip (see its header comment for the overall picture).
+#pragma once
+#define PCGRL_BLOCK 256
+enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
+
+// Work lists (changed environments, environments to reset, sokoban solver jobs).  A list is 64 shards,
+// each with its own counter on its own 64-byte line and its own segment of the item array, so appends
+// never pile up on one address (thousands of same-address atomics per step cost ~12 ns each);
+// consumers rebuild the dense index with a 64-entry prefix sum in LDS.  Counters are double-buffered
+// by step parity: the last kernel of a step zeroes the other parity's counters.
+#define WL_NSHARD 64
+#define WL_CSTRIDE 16
+enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_NLIST = 4 };   // SOL: solver jobs of the step, SOL2: of the resets
+
+struct DevBufs {
+    uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
+    int32_t* counters; int32_t* stats; int32_t* start_stats; int32_t* info;
+    double* reward; uint8_t* done; double* tile_p;
+    uint32_t* rng_rep; uint32_t* rng_prob; int32_t* rng_cur;
+    int32_t* wl_cnt;                 // [2 parities][WL_NLIST][WL_NSHARD * WL_CSTRIDE]
+    int32_t* wl_items[WL_NLIST];     // [WL_NSHARD][wl_cap[list]]
+    int32_t wl_cap[WL_NLIST];
+    // sokoban solver arena (per resident solver block) and sticky status word
+    SokNode* sok_pool; uint32_t* sok_heap; uint32_t* sok_table; int32_t* status;
+    int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
+};
+
+__device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {
+    return B.wl_cnt + (size_t)(parity * WL_NLIST + list) * WL_NSHARD * WL_CSTRIDE;
+}
+__device__ __forceinline__ void wl_push(const DevBufs& B, int parity, int list, int shard, int value) {
+    const int i = atomicAdd(wl_counters(B, parity, list) + shard * WL_CSTRIDE, 1);
+    B.wl_items[list][(size_t)shard * B.wl_cap[list] + i] = value;
+}
+// Every thread of the block calls this once; s_pref has WL_NSHARD + 1 entries.  Returns the list length.
+__device__ __forceinline__ int wl_load_prefix(const DevBufs& B, int parity, int list, int* s_pref) {
+    if (threadIdx.x < WL_NSHARD) {
+        int v = wl_counters(B, parity, list)[threadIdx.x * WL_CSTRIDE];
+        for (int o = 1; o < WL_NSHARD; o <<= 1) {
+            const int t = __shfl_up(v, o, 64);
+            if ((int)threadIdx.x >= o) v += t;
+        }
+        s_pref[threadIdx.x + 1] = v;
+        if (threadIdx.x == 0) s_pref[0] = 0;
+    }
+    __syncthreads();
+    return s_pref[WL_NSHARD];
+}
+__device__ __forceinline__ int wl_get(const DevBufs& B, int list, const int* s_pref, int i) {
+    int lo = 0;
+#pragma unroll
+    for (int step = WL_NSHARD / 2; step > 0; step >>= 1)
+        if (s_pref[lo + step] <= i) lo += step;
+    return B.wl_items[list][(size_t)lo * B.wl_cap[list] + (i - s_pref[lo])];
+}
+__device__ __forceinline__ void wl_clear(const DevBufs& B, int parity) {   // one block, any size
+    for (int i = threadIdx.x; i < WL_NLIST * WL_NSHARD; i += blockDim.x) wl_counters(B, parity, 0)[i * WL_CSTRIDE] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Block-wide stream compaction into a work list: every thread of the block must call this.
+__device__ __forceinline__ void block_append(bool flag, int value, const DevBufs& B, int parity, int list,
+                                             int* s_cnt, int* s_base) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int shard = blockIdx.x & (WL_NSHARD - 1);
+    const uint64_t m = __ballot(flag);
+    if (lane == 0) s_cnt[w] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        *s_base = tot ? atomicAdd(wl_counters(B, parity, list) + shard * WL_CSTRIDE, tot) : 0;
+    }
+    __syncthreads();
+    if (flag) {
+        int off = *s_base;
+        for (int i = 0; i < w; i++) off += s_cnt[i];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        B.wl_items[list][(size_t)shard * B.wl_cap[list] + off] = value;
+    }
+}
+
+// Changed environments are bucketed by how hard their statistics are expected to be (the previous
+// stats are a good predictor: one tile changed), one bucket per shard, so that the four maps sharing a
+// wavefront in k_stats have similar trip counts.  Every thread of the block must call this.
+__device__ __forceinline__ void block_append_bucketed(bool flag, int bucket, int value, const DevBufs& B, int parity, int list,
+                                                      int* s_hist, int* s_gbase) {
+    if (threadIdx.x < WL_NSHARD) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    int rank = 0;
+    if (flag) rank = atomicAdd(&s_hist[bucket], 1);
+    __syncthreads();
+    if (threadIdx.x < WL_NSHARD) {
+        const int c = s_hist[threadIdx.x];
+        if (c > 0) s_gbase[threadIdx.x] = atomicAdd(wl_counters(B, parity, list) + threadIdx.x * WL_CSTRIDE, c);
+    }
+    __syncthreads();
+    if (flag) B.wl_items[list][(size_t)bucket * B.wl_cap[list] + s_gbase[bucket] + rank] = value;
+}
+__device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int4& s0, const int4& s1) {
+    if (P.prob == PCGRL_PROB_BINARY) {   // (path-length / 6, regions / 3), 8 x 8
+        const int a = min(max(s0.y, 0) / 6, 7), b = min(max(s0.x, 0) / 3, 7);
+        return a * 8 + b;
+    }
+    const int regions = P.prob == PCGRL_PROB_ZELDA ? s1.x : s0.w;
+    return min(max(regions, 0), WL_NSHARD - 1);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
