@@ -9,8 +9,10 @@ __device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
     return lane < H ? full : (MaskT)0;
 }
 
-__device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
-                                              int mode, int parity, int shard) {
+// Returns true when the environment finished its episode and has to be reset; with push_reset the
+// environment is also appended to the reset list (consumed by k_reset), otherwise the caller resets it.
+__device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
+                                              int mode, int parity, int shard, bool push_reset = true) {
     int32_t* st = B.stats + (size_t)e * 8;
     int32_t* start = B.start_stats + (size_t)e * 8;
     if (mode == MODE_STEP) {
@@ -25,12 +27,14 @@ __device__ __forceinline__ void finalize_item(const PcgrlParams& P, const DevBuf
         for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
         if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
         inf[8] = c.x; inf[9] = c.y;
-        if (d && P.auto_reset) wl_push(B, parity, WL_RST, shard, e);
+        if (d && P.auto_reset && push_reset) wl_push(B, parity, WL_RST, shard, e);
+        return d && P.auto_reset;
     } else {
         for (int k = 0; k < 8; k++) st[k] = s[k];
         if (mode == MODE_START)
             for (int k = 0; k < 8; k++) start[k] = s[k];
     }
+    return false;
 }
 
 // Problem.get_stats on the row masks of one map (b0..b2 = bit planes of the tile id).  Returns true
@@ -48,8 +52,8 @@ __device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, M
 }
 
 // Lane 0 of the group: hand the item to the solver or finish it.
-__device__ __forceinline__ void finish_or_park(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s, bool need_solver,
-                                               int mode, int parity, int shard) {
+__device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s, bool need_solver,
+                                               int mode, int parity, int shard, bool push_reset = true) {
     if (need_solver) {
         // park the partial stats and hand the environment to the solver kernel.  STEP: in the info
         // row (the old stats are still needed for the reward); otherwise in the stats row itself
@@ -57,30 +61,79 @@ __device__ __forceinline__ void finish_or_park(const PcgrlParams& P, const DevBu
         int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
         for (int k = 0; k < 8; k++) park[k] = s[k];
         wl_push(B, parity, mode == MODE_STEP ? WL_SOL : WL_SOL2, shard, e);
-    } else {
-        finalize_item(P, B, e, s, mode, parity, shard);
+        return false;
     }
+    return finalize_item(P, B, e, s, mode, parity, shard, push_reset);
 }
 
+// inline_reset (kernel-uniform, STEP mode, every problem but Sokoban): an environment whose episode ended is
+// reset right here by the wavefront that found out -- wave_reset_env with all 64 lanes, then the start
+// stats on the regenerated rows -- instead of going through a reset list and another latency-bound launch.
+// The item loop is therefore wave-uniform: all groups of a wavefront iterate together, a group without
+// an item computes on an empty map.
 template <int PROB, int G, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity) {
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
+                                                        int inline_reset, int gen_map) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: per wave MT ring + tile bytes
     __shared__ int s_pref[WL_NSHARD + 1];
     // the last kernel of a step zeroes the *other* parity's work-list counters for the next step
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<G, MaskT> g;
-    constexpr int GPB = PCGRL_BLOCK / G;
+    constexpr int GPB = PCGRL_BLOCK / G, GPW = 64 / G;
     const int n = wl_load_prefix(B, parity, list, s_pref);
-    const int gi = threadIdx.x / G;
+    const int lane64 = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = lane64 / G;
     const int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
-    for (int item = blockIdx.x * GPB + gi; item < n; item += gridDim.x * GPB) {
-        const int e = wl_get(B, list, s_pref, item);
+    const int W = P.width, H = P.height;
+    const int tiles_bytes = (W * H + 15) & ~15;
+    uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)wv * (PCGRL_MT_N * 4 + tiles_bytes));
+    uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
+    const MaskT rowmask = row_valid<MaskT>(g.lane, W, H);
+    for (int base = blockIdx.x * GPB + wv * GPW; base < n; base += gridDim.x * GPB) {
+        const int item = base + gw;
+        const bool have = item < n;
+        const int raw = have ? wl_get(B, list, s_pref, item) : 0;
+        const bool reset_only = have && (raw & WL_RESET_ONLY) != 0;
+        const bool compute = have && !reset_only;
+        const int e = raw & ~WL_RESET_ONLY;
         const int shard = (item >> 4) & (WL_NSHARD - 1);
-        const MaskT* pl = reinterpret_cast<const MaskT*>(B.planes) + (size_t)e * NPL * G + g.lane;
-        const MaskT valid = row_valid<MaskT>(g.lane, P.width, P.height);
+        MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
+        MaskT b0 = 0, b1 = 0, b2 = 0;
+        if (compute) {
+            b0 = planes_e[g.lane];
+            if (NPL > 1) { b1 = planes_e[G + g.lane]; b2 = planes_e[2 * G + g.lane]; }
+        }
         int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const MaskT b0 = pl[0], b1 = NPL > 1 ? pl[G] : (MaskT)0, b2 = NPL > 1 ? pl[2 * G] : (MaskT)0;
-        const bool need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, valid, s);
-        if (g.lane == 0) finish_or_park(P, B, e, s, need_solver, mode, parity, shard);
+        bool need_solver = false;
+        if (compute) need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s);
+        int want_reset = 0;
+        if (g.lane == 0 && have) {
+            if (reset_only) want_reset = 1;
+            else want_reset = finish_or_park(P, B, e, s, need_solver, mode, parity, shard, !inline_reset) ? 1 : 0;
+        }
+        if (inline_reset) {
+            const uint64_t want = __ballot(want_reset != 0);     // one bit per group, at its lane 0
+            if (want) {
+                bool mine = false;
+#pragma unroll
+                for (int k = 0; k < GPW; k++) {
+                    if ((want >> (k * G)) & 1ull) {               // wave-uniform
+                        const int ek = __builtin_amdgcn_readlane(e, k * G);
+                        wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
+                        MaskT t0, t1, t2;
+                        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G,
+                                                 gw == k ? g.lane : -1, t0, t1, t2);
+                        if (gw == k) { b0 = t0; b1 = t1; b2 = t2; mine = true; }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                // start stats of the regenerated maps (pcgrl_env.py:70-71, problem.py:45-46)
+                if (mine) {
+                    int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st);
+                    if (g.lane == 0) finish_or_park(P, B, e, st, ns, MODE_START, parity, shard);
+                }
+            }
+        }
     }
 }
 

@@ -147,9 +147,13 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     }
     // bucketing pays where four maps share a wavefront and their cost varies a lot (binary); elsewhere the
     // plain per-block append is cheaper (kernel-uniform branch)
-    if (P.prob == PCGRL_PROB_BINARY && P.group == 16) block_append_bucketed(chg, bucket, e, B, parity, WL_CHG, s_hist, s_gbase);
-    else block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
-    block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+    // an unchanged environment whose episode ended rides the changed list flagged "reset only": k_stats resets
+    // in-kernel (every problem but Sokoban, whose resets wait for the solver and go through k_reset)
+    const bool inl = rst && B.inline_reset;
+    const int val = inl ? (e | WL_RESET_ONLY) : e;
+    if (P.prob == PCGRL_PROB_BINARY && P.group == 16) block_append_bucketed(chg || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase);
+    else block_append(chg || inl, val, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
             rst = d && P.auto_reset;
         }
     }
-    block_append(chg, e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
-    block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+    const bool inl = rst && B.inline_reset;   // see k_update
+    block_append(chg || inl, inl ? (e | WL_RESET_ONLY) : e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
 }

@@ -39,6 +39,7 @@
 
 #include "worklist.h"
 #include "kernels_update.h"
+#include "reset_env.h"
 #include "kernels_stats.h"
 #include "kernels_reset.h"
 #include "kernels_misc.h"
@@ -250,6 +251,10 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     }
     HIPCHK(hipMemsetAsync(B.wl_cnt, 0, WL_CNT_BYTES + 256, (hipStream_t)stream));
     B.sok_pool = nullptr; B.sok_heap = nullptr; B.sok_table = nullptr;
+    {   // PCGRL_INLINE_RESET=0 routes resets through the reset list + k_reset instead (A/B measurements)
+        const char* ir = getenv("PCGRL_INLINE_RESET");
+        B.inline_reset = (h->cfg.prob != PCGRL_SOKOBAN && !(ir && ir[0] == '0')) ? 1 : 0;
+    }
     if (h->cfg.prob == PCGRL_SOKOBAN) {
         // the arena is sized for the solver_power the buffers were allocated with
         const int power = h->alloc_solver_power = h->cfg.solver_power;
@@ -348,27 +353,29 @@ static int grid_for(int items, int per_block, int cap) {
 }
 
 template <int PROB>
-static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
+static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const int gpb = PCGRL_BLOCK / P.group;
-    // per-step reset lists are short: a small grid-stride grid avoids dispatching thousands of empty blocks
-    const int grid = grid_for(P.num_envs, gpb, (mode == MODE_START && h->was_reset) ? 512 : 8192);
+    const int grid = grid_for(P.num_envs, gpb, 8192);
+    // in-kernel reset: one MT ring + tile-byte staging area per wavefront
+    const size_t lds = inline_reset ? 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
+    const int gen = (P.random_start || !h->has_old) ? 1 : 0;
     if (P.group == 16 && P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
     else if (P.group == 16)
-        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
     else if (P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
     else
-        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, list, parity, mode, clr);
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
-static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
+static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, hipStream_t st) {
     switch (h->P.prob) {
-        case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, st);
-        case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, st);
-        default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, parity, mode, clr, st);
+        case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, inline_reset, st);
+        case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, inline_reset, st);
+        default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, parity, mode, clr, 0, st);
     }
 }
 
@@ -456,19 +463,23 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
     rc = (h->P.mask_bytes == 4) ? launch_update_m<uint32_t>(h, actions, par, st) : launch_update_m<uint64_t>(h, actions, par, st);
     if (rc) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    // the last kernel of the step clears the other parity's work-list counters
+    // The last kernel of the step clears the other parity's work-list counters.  Every problem but Sokoban is
+    // two launches: k_stats also resets the environments whose episode ended (auto_reset).  Sokoban parks the
+    // maps that need the solver, so its resets wait for k_sokoban and go through k_reset.
     const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN, ar = h->P.auto_reset != 0;
-    rc = launch_stats(h, WL_CHG, par, MODE_STEP, (ar || sok) ? -1 : (par ^ 1), st);
+    const bool inl = ar && h->B.inline_reset;   // (never for Sokoban)
+    const bool rst = ar && !inl;
+    rc = launch_stats(h, WL_CHG, par, MODE_STEP, (sok || rst) ? -1 : (par ^ 1), inl ? 1 : 0, st);
     if (rc) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     if (sok && (rc = launch_solver(h, WL_SOL, par, MODE_STEP, ar ? -1 : (par ^ 1), st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    if (ar) {
+    if (rst) {
         rc = launch_reset(h, par, sok ? -1 : (par ^ 1), st);
         if (rc) return rc;
     }
     if ((rc = prof_mark(h, st))) return rc;
-    if ((rc = prof_mark(h, st))) return rc;   // (the start stats are part of k_reset)
+    if ((rc = prof_mark(h, st))) return rc;   // (the start stats are part of k_reset / k_stats)
     if (ar && sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     return PCGRL_OK;
@@ -590,7 +601,7 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_CHG);
     HIPCHK(hipGetLastError());
     const bool sok = P.prob == PCGRL_PROB_SOKOBAN;
-    int rc = launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), st);
+    int rc = launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), 0, st);
     if (rc) return rc;
     if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_SETMAP, par ^ 1, st))) return rc;
     return PCGRL_OK;

@@ -1,0 +1,122 @@
+// Device functions of PcgrlEnv.reset shared by k_reset (kernels_reset.h) and the in-kernel reset of k_stats.
+// Part of the single translation unit pcgrl_abi.hip.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// Row bit planes from a tile byte map staged in LDS; lanes [0,G) of the wave each take one row.
+// `row` is the map row this lane owns (0 .. G-1) or -1 for a lane that does not take part.
+template <class MaskT>
+__device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const uint8_t* tiles, MaskT* planes_e, int row,
+                                                  MaskT& m0, MaskT& m1, MaskT& m2) {
+    const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
+    m0 = 0; m1 = 0; m2 = 0;
+    if (row >= 0 && row < G) {
+        const int lane = row;
+        if (lane < H) {
+            const uint8_t* row = tiles + lane * W;
+            for (int x = 0; x < W; x++) {
+                const MaskT t = row[x];
+                m0 |= (t & 1) << x;
+                m1 |= ((t >> 1) & 1) << x;
+                m2 |= ((t >> 2) & 1) << x;
+            }
+        }
+        planes_e[lane] = m0;
+        if (NPL > 1) { planes_e[G + lane] = m1; planes_e[2 * G + lane] = m2; }
+    }
+}
+
+// The whole-wavefront part of PcgrlEnv.reset (pcgrl_env.py:66-76) for environment e: new map (or the saved
+// first map), cursor, both MT19937 rings, heatmap, counters, BinaryProblem.reset.  All 64 lanes call it;
+// `mt` (624 words) and `tiles` (H*W bytes) are this wave's LDS scratch; the tile bytes of the new map are
+// left in `tiles` for the caller to turn into row planes.
+template <int PROB>
+__device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt,
+                                               uint8_t* tiles, int lane) {
+    const int W = P.width, H = P.height, cells = W * H;
+    uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
+    uint8_t* map_g = B.map + (size_t)e * cells;
+    uint8_t* old_g = B.old_map + (size_t)e * cells;
+    const int2 curs = reinterpret_cast<const int2*>(B.rng_cur)[e];
+    int cur = curs.x;
+    for (int i = lane; i < PCGRL_MT_N; i += 64) mt[i] = ring_g[i];
+    // BinaryProblem.reset (binary_prob.py:68-72) draws one double = two words from the *problem* stream
+    // after the map is made.  Its five operand words are fetched now, by five lanes, off the critical path.
+    const bool prob_draw = PROB == PCGRL_PROB_BINARY && P.random_probs;
+    uint32_t pw = 0;
+    if (prob_draw && lane < 5) {
+        const int off = lane < 3 ? lane : PCGRL_MT_M + (lane - 3);
+        int sl = curs.y + off; sl = sl >= PCGRL_MT_N ? sl - PCGRL_MT_N : sl;
+        pw = B.rng_prob[(size_t)e * PCGRL_MT_N + sl];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (gen_map) {
+        // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
+        double cdf[PCGRL_MAX_TILES];
+        if (PROB == PCGRL_PROB_BINARY) {
+            double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};
+            pcgrl_build_cdf(p, 2, cdf);
+        } else {
+            for (int i = 0; i < P.ntiles; i++) cdf[i] = P.cdf[i];
+        }
+        for (int c0 = 0; c0 < cells; c0 += 64) {
+            // cell c draws ring words 2c, 2c+1 of this episode: 128 new words per round, every
+            // operand is an *old* word (distance 397 > 128), so all reads come before all writes
+            const int c = c0 + lane;
+            int s = cur + 2 * lane; s = s >= PCGRL_MT_N ? s - PCGRL_MT_N : s;
+            const uint32_t x0 = mt[s], x1 = mt[mt_wrap(s + 1)], x2 = mt[mt_wrap(s + 2)];
+            const uint32_t xm0 = mt[mt_wrap(s + PCGRL_MT_M)], xm1 = mt[mt_wrap(s + PCGRL_MT_M + 1)];
+            const uint32_t ya = mt_twist(x0, x1, xm0), yb = mt_twist(x1, x2, xm1);
+            __builtin_amdgcn_wave_barrier();
+            if (c < cells) {
+                mt[s] = ya;
+                mt[mt_wrap(s + 1)] = yb;
+                const double u = mt_to_double(mt_temper(ya), mt_temper(yb));
+                const uint8_t t = (uint8_t)pcgrl_pick_tile(cdf, P.ntiles, u);
+                tiles[c] = t;
+                map_g[c] = t;
+                old_g[c] = t;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int adv = 2 * ((cells - c0) < 64 ? (cells - c0) : 64);
+            cur += adv; cur = cur >= PCGRL_MT_N ? cur - PCGRL_MT_N : cur;
+        }
+    } else {
+        // representation.py:44-45: restore the first map of this environment
+        for (int c = lane; c < cells; c += 64) { const uint8_t t = old_g[c]; tiles[c] = t; map_g[c] = t; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33
+        if (lane == 0) {
+            const int x = mt_randint(mt, cur, W);
+            const int y = mt_randint(mt, cur, H);
+            reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        }
+        cur = __shfl(cur, 0, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < PCGRL_MT_N; i += 64) ring_g[i] = mt[i];
+    uint16_t* heat_g = B.heat + (size_t)e * cells;
+    for (int c = lane; c < cells; c += 64) heat_g[c] = 0;        // pcgrl_env.py:72
+    if (lane == 0) {
+        B.rng_cur[2 * e] = cur;
+        reinterpret_cast<int2*>(B.counters)[e] = make_int2(0, 0);   // pcgrl_env.py:67-68
+    }
+    if (prob_draw) {
+        // two consecutive lazy-ring draws at cursor c: word c uses (c, c+1, c+397), word c+1 uses
+        // (c+1, c+2, c+398); none of those operands is the slot the first draw rewrites
+        const uint32_t x0 = __shfl(pw, 0, 64), x1 = __shfl(pw, 1, 64), x2 = __shfl(pw, 2, 64);
+        const uint32_t xm0 = __shfl(pw, 3, 64), xm1 = __shfl(pw, 4, 64);
+        if (lane == 0) {
+            const uint32_t ya = mt_twist(x0, x1, xm0), yb = mt_twist(x1, x2, xm1);
+            uint32_t* ring_p = B.rng_prob + (size_t)e * PCGRL_MT_N;
+            ring_p[curs.y] = ya;
+            ring_p[mt_wrap(curs.y + 1)] = yb;
+            B.rng_cur[2 * e + 1] = mt_wrap(mt_wrap(curs.y + 1) + 1);
+            const double pe = mt_to_double(mt_temper(ya), mt_temper(yb));
+            B.tile_p[2 * e] = pe;
+            B.tile_p[2 * e + 1] = 1 - pe;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+

@@ -11,7 +11,10 @@ enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
 // by step parity: the last kernel of a step zeroes the other parity's counters.
 #define WL_NSHARD 64
 #define WL_CSTRIDE 16
-enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_NLIST = 4 };   // SOL: solver jobs of the step, SOL2: of the resets
+enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_NLIST = 4 };
+// An item of the changed list with this bit set is an unchanged environment whose episode ended (iteration cap):
+// k_stats resets it without recomputing anything.
+#define WL_RESET_ONLY (1 << 30)   // SOL: solver jobs of the step, SOL2: of the resets
 
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
@@ -24,6 +27,7 @@ struct DevBufs {
     // sokoban solver arena (per resident solver block) and sticky status word
     SokNode* sok_pool; uint32_t* sok_heap; uint32_t* sok_table; int32_t* status;
     int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
+    int32_t inline_reset;   // k_stats resets finished environments itself (every problem but Sokoban)
 };
 
 __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {
