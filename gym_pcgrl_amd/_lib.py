@@ -45,7 +45,9 @@ EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "p
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
            "pcgrl_profile_read")
 NPHASE = 6
-PHASES = ("update", "stats_step", "solver_step", "mapgen", "stats_start", "solver_start")
+# the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
+# other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
+PHASES = ("update", "stats", "reset_or_idle", "solver_or_reset", "reset2", "solver2")
 
 
 def sources_newer_than_lib():

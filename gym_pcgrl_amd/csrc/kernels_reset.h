@@ -2,10 +2,10 @@
 // Part of the single translation unit pcgrl_abi.hip (see its header comment for the overall picture).
 #pragma once
 // k_reset: wavefront per environment on the reset list -- PcgrlEnv.reset including the start stats.  Used by
-// pcgrl_reset (every environment) and, for Sokoban, after the solver kernel; in a step the other problems
-// reset inside k_stats (kernels_stats.h).
+// pcgrl_reset (every environment) and by the Sokoban step (list = WL_RST before the solver kernel, WL_RST2 after
+// it; maps that need the solver are parked on park_list); in a step the other problems reset inside k_stats.
 template <int PROB, int G, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_reset(PcgrlParams P, DevBufs B, int parity, int gen_map, int clear_parity) {
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_reset(PcgrlParams P, DevBufs B, int list, int park_list, int parity, int gen_map, int clear_parity) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -14,9 +14,9 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_reset(PcgrlParams P, DevBufs B,
     uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)wv * (PCGRL_MT_N * 4 + tiles_bytes));
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
     __shared__ int s_pref[WL_NSHARD + 1];
-    const int n = wl_load_prefix(B, parity, WL_RST, s_pref);
+    const int n = wl_load_prefix(B, parity, list, s_pref);
     for (int item = blockIdx.x * 4 + wv; item < n; item += gridDim.x * 4) {
-        const int e = wl_get(B, WL_RST, s_pref, item);
+        const int e = wl_get(B, list, s_pref, item);
         wave_reset_env<PROB>(P, B, e, gen_map, mt, tiles, lane);
         MaskT b0, b1, b2;
         planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane < G ? lane : -1, b0, b1, b2);
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_reset(PcgrlParams P, DevBufs B,
         const MaskT valid = (lane < G) ? row_valid<MaskT>(g.lane, W, H) : (MaskT)0;
         int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         const bool need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, valid, st);
-        if (lane == 0) finish_or_park(P, B, e, st, need_solver, MODE_START, parity, item & (WL_NSHARD - 1));
+        if (lane == 0) finish_or_park(P, B, e, st, need_solver, MODE_START, parity, item & (WL_NSHARD - 1), true, park_list);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -1,0 +1,197 @@
+// k_sokoban: the solver jobs that k_stats / k_reset parked (sokoban_solver.h), one wavefront per search.
+// Part of the single translation unit pcgrl_abi.hip (see its header comment for the overall picture).
+//
+// SokobanProblem._run_game runs BFS, A*(1), A*(0.5), A*(0) one after the other and stops at the first
+// winner (sokoban_prob.py:104-122).  The agents are independent searches from the same root, so only the
+// *selection* is sequential.  A step of 131 072 environments almost always holds a few levels whose BFS
+// runs into the 5 000-pop cap, and those four back-to-back capped searches were the long pole of the whole
+// step.  Here a BFS that is still running after SOK_SPAWN_ITERS pops publishes its level on the "hard"
+// list; idle solver blocks pick up the three A* agents of that level and run them concurrently with the
+// BFS.  Every agent records (win, h, depth, exhausted); the last of the four to finish selects exactly
+// what the sequential loop would have returned.  An agent whose result cannot matter any more (an earlier
+// agent won, or BFS exhausted the state space: see the shortcut in sokoban_solver.h) is abandoned at its
+// next poll.  Short jobs (the median BFS ends after ~30 pops) never spawn anything.
+//
+// Scheduling is by tickets on words the host zeroes before the launch: BFS jobs are handed out with an
+// atomic counter; A* tickets are only ever taken for published levels (compare-and-swap), so no block
+// waits on work that may never come.  A block leaves when every BFS has finished (the hard list is then
+// final) and every A* ticket has been taken.  Blocks only ever wait for blocks that hold a ticket, i.e.
+// that are resident and running: no forward-progress assumption between unscheduled blocks.
+#pragma once
+
+enum { SOK_SY_TICKET_A = 0, SOK_SY_TICKET_B = 1, SOK_SY_HARD = 2, SOK_SY_BFS_DONE = 3, SOK_SY_WORDS = 16 };
+#define SOK_HARD_CAP 4096          /* published levels per launch; beyond it a BFS block runs its A* agents itself */
+#define SOK_SPAWN_ITERS 256
+#define SOK_POLL_MASK 31
+
+__device__ __forceinline__ int sok_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct SokSpawnHook {     // BFS: publish the level once the search has proven to be a long one
+    int32_t* sync; int32_t* hard; int spawn_at; int tag; int* spawned;
+    __device__ __forceinline__ bool operator()(int it) const {
+        if (it == spawn_at) {
+            const int idx = atomicAdd(sync + SOK_SY_HARD, 1);
+            if (idx < SOK_HARD_CAP) { __hip_atomic_store(hard + idx, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *spawned = 1; }
+        }
+        return false;
+    }
+};
+struct SokPollHook {      // A*: stop when the result cannot be selected any more
+    const int32_t* stop; int need;
+    __device__ __forceinline__ bool operator()(int it) const { return (it & SOK_POLL_MASK) == 0 && sok_ld(stop) >= need; }
+};
+
+// One agent of environment e is done.  The fourth report selects the result and finishes the item.
+__device__ __forceinline__ void sok_report(const PcgrlParams& P, const DevBufs& B, int e, int a, bool win, int hh, int dd, bool exhausted,
+                                           int mode, int parity, int rst_list) {
+    int32_t* r = B.sok_res + ((size_t)e * 4 + a) * 4;
+    __hip_atomic_store(r + 0, win ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 1, hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 2, dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 3, exhausted ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // agents after `a` are not needed once a wins (or BFS has expanded every reachable state): stop level 3 - a
+    if (win || (a == 0 && exhausted)) atomicMax(B.sok_stop + e, 3 - a);
+    __threadfence();
+    if (atomicAdd(B.sok_cnt + e, 1) != 3) return;
+    __threadfence();
+    int dist = 0, sol = 0;
+    bool chosen = false;
+    for (int k = 0; k < 4 && !chosen; k++) {
+        const int32_t* q = B.sok_res + ((size_t)e * 4 + k) * 4;
+        if (sok_ld(q + 0)) { dist = 0; sol = sok_ld(q + 2); chosen = true; }
+    }
+    if (!chosen) {
+        const int32_t* q0 = B.sok_res + (size_t)e * 16;
+        dist = sok_ld(q0 + 3) ? sok_ld(q0 + 1) : sok_ld(q0 + 12 + 1);   // exhausted BFS, else the last agent's best node
+    }
+    B.sok_cnt[e] = 0;      // ready for the next job of this environment (a later launch)
+    B.sok_stop[e] = 0;
+    int32_t s[PCGRL_MAX_STATS];
+    const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+    for (int k = 0; k < 8; k++) s[k] = park[k];
+    s[4] = dist; s[5] = sol;
+    finalize_item(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+}
+
+// Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  `sync`/`hard` are this launch's
+// zeroed scheduling words.  Environments that finish their episode here go to `rst_list`.
+__global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
+                                                int rst_list, int32_t* sync, int32_t* hard, int clear_parity) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sok_lds[];
+    __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    const int lane = threadIdx.x;
+    const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
+    const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
+    const int n = n_a + n_b;
+    __shared__ SokLevel s_L;             // level + node workspace in LDS: they are indexed dynamically
+    __shared__ SokNode s_root, s_work;
+    __shared__ int s_spawned;
+    SokNode* pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
+    uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
+    uint32_t* g_table = B.sok_use_lds ? nullptr : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
+    const int tsize = B.sok_use_lds ? SOK_LDS_TABLE : B.sok_table_size;
+    const int W = P.width, H = P.height;
+    const int KS[4] = {-1, 2, 1, 0};
+    for (;;) {
+        int kind = 0, t = 0;   // 0: nothing to do right now, 1: BFS job t, 2: A* ticket t, 3: leave
+        if (lane == 0) {
+            int hc = sok_ld(sync + SOK_SY_HARD);
+            hc = hc < SOK_HARD_CAP ? hc : SOK_HARD_CAP;
+            int tb = sok_ld(sync + SOK_SY_TICKET_B);
+            while (tb < 3 * hc) {
+                const int seen = atomicCAS(sync + SOK_SY_TICKET_B, tb, tb + 1);
+                if (seen == tb) { kind = 2; t = tb; break; }
+                tb = seen;
+            }
+            if (kind == 0 && sok_ld(sync + SOK_SY_TICKET_A) < n) {
+                const int ta = atomicAdd(sync + SOK_SY_TICKET_A, 1);
+                if (ta < n) { kind = 1; t = ta; }
+            }
+            if (kind == 0 && sok_ld(sync + SOK_SY_BFS_DONE) >= n) {
+                // every BFS has finished, so the hard list is final (the counter was read after the data it depends on)
+                int hf = sok_ld(sync + SOK_SY_HARD);
+                hf = hf < SOK_HARD_CAP ? hf : SOK_HARD_CAP;
+                if (sok_ld(sync + SOK_SY_TICKET_B) >= 3 * hf) kind = 3;
+            }
+        }
+        kind = __shfl(kind, 0, 64);
+        t = __shfl(t, 0, 64);
+        if (kind == 3) break;
+        if (kind == 0) { __builtin_amdgcn_s_sleep(127); continue; }
+
+        int e = 0, mode = 0, first = 0, last = 3;
+        if (kind == 1) {
+            if (t < n_a) { e = wl_get(B, list_a, s_pref_a, t); mode = mode_a; }
+            else { e = wl_get(B, list_b, s_pref_b, t - n_a); mode = mode_b; }
+        } else {
+            int tag = 0;
+            if (lane == 0) { while ((tag = sok_ld(hard + t / 3)) == 0) __builtin_amdgcn_s_sleep(8); }
+            tag = __shfl(tag, 0, 64);
+            e = (tag & 0x0FFFFFFF) - 1;
+            mode = (tag >> 28) & 3;
+            first = last = 1 + t % 3;
+        }
+        if (lane == 0) {
+            const int ncr = sok_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+            if (ncr > SOK_MAXC) atomicOr(B.status, 1);
+            sok_init_deadlocks(s_L);
+            s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
+            s_spawned = 0;
+        }
+        // BFS job: agent 0 and -- only if the level could not be published -- the other agents after it, with the
+        // exact exhausted-BFS shortcut.  A* ticket: that one agent.  The search is driven by lane 0; every lane
+        // helps to clear the visited table.
+        int dist = 0, sol = 0, go = 1, reported = 0;
+        for (int a = first; a <= last && go; a++) {
+            if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
+            else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
+            __threadfence_block();
+            if (lane == 0) {
+                int hh = 0, dd = 0, it = 0;
+                bool exhausted = false, win = false;
+                if (kind == 1 && a == 0) {
+                    int sp = P.solver_power < SOK_SPAWN_ITERS ? P.solver_power : SOK_SPAWN_ITERS;
+                    SokSpawnHook hook = {sync, hard, sp, (e + 1) | (mode << 28), &s_spawned};
+                    if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
+                        win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, -1, P.solver_power, hh, dd, it, exhausted, hook);
+                    else
+                        win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, -1, P.solver_power, hh, dd, it, exhausted, hook);
+                    if (s_spawned) { sok_report(P, B, e, 0, win, hh, dd, exhausted, mode, parity, rst_list); reported = 1; go = 0; }
+                    else go = !(win || exhausted);
+                } else if (kind == 1) {
+                    if (B.sok_use_lds)
+                        win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
+                    else
+                        win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
+                    go = !win;
+                } else {
+                    SokPollHook hook = {B.sok_stop + e, 4 - a};
+                    if (sok_ld(B.sok_stop + e) < 4 - a) {
+                        if (B.sok_use_lds)
+                            win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted, hook);
+                        else
+                            win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted, hook);
+                    }
+                    sok_report(P, B, e, a, win, hh, dd, false, mode, parity, rst_list);
+                    reported = 1;
+                }
+                dist = win ? 0 : hh;
+                sol = win ? dd : 0;
+            }
+            go = __shfl(go, 0, 64);
+            __threadfence_block();
+        }
+        if (lane == 0 && kind == 1) {
+            if (!reported) {
+                int32_t s[PCGRL_MAX_STATS];
+                const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+                for (int k = 0; k < 8; k++) s[k] = park[k];
+                s[4] = dist; s[5] = sol;
+                finalize_item(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+            }
+            __threadfence();
+            atomicAdd(sync + SOK_SY_BFS_DONE, 1);
+        }
+    }
+}

@@ -12,7 +12,7 @@ __device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
 // Returns true when the environment finished its episode and has to be reset; with push_reset the
 // environment is also appended to the reset list (consumed by k_reset), otherwise the caller resets it.
 __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
-                                              int mode, int parity, int shard, bool push_reset = true) {
+                                              int mode, int parity, int shard, bool push_reset = true, int rst_list = WL_RST) {
     int32_t* st = B.stats + (size_t)e * 8;
     int32_t* start = B.start_stats + (size_t)e * 8;
     if (mode == MODE_STEP) {
@@ -27,7 +27,7 @@ __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBuf
         for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
         if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
         inf[8] = c.x; inf[9] = c.y;
-        if (d && P.auto_reset && push_reset) wl_push(B, parity, WL_RST, shard, e);
+        if (d && P.auto_reset && push_reset) wl_push(B, parity, rst_list, shard, e);
         return d && P.auto_reset;
     } else {
         for (int k = 0; k < 8; k++) st[k] = s[k];
@@ -53,14 +53,14 @@ __device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, M
 
 // Lane 0 of the group: hand the item to the solver or finish it.
 __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s, bool need_solver,
-                                               int mode, int parity, int shard, bool push_reset = true) {
+                                               int mode, int parity, int shard, bool push_reset = true, int park_list = -1) {
     if (need_solver) {
         // park the partial stats and hand the environment to the solver kernel.  STEP: in the info
         // row (the old stats are still needed for the reward); otherwise in the stats row itself
         // (the info row keeps the terminal info of an environment that is being reset).
         int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
         for (int k = 0; k < 8; k++) park[k] = s[k];
-        wl_push(B, parity, mode == MODE_STEP ? WL_SOL : WL_SOL2, shard, e);
+        wl_push(B, parity, park_list >= 0 ? park_list : (mode == MODE_STEP ? WL_SOL : WL_SOL2), shard, e);
         return false;
     }
     return finalize_item(P, B, e, s, mode, parity, shard, push_reset);
@@ -137,58 +137,3 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// k_sokoban: one wavefront per solver job (sokoban_solver.h).  Finishes what k_stats parked.
-__global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t sok_lds[];
-    __shared__ int s_pref[WL_NSHARD + 1];
-    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
-    const int lane = threadIdx.x;
-    const int n = wl_load_prefix(B, parity, list, s_pref);
-    __shared__ SokLevel s_L;             // level + node workspace in LDS: they are indexed dynamically
-    __shared__ SokNode s_root, s_work;
-    SokNode* pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
-    uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
-    uint32_t* g_table = B.sok_use_lds ? nullptr : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
-    const int tsize = B.sok_use_lds ? SOK_LDS_TABLE : B.sok_table_size;
-    for (int item = blockIdx.x; item < n; item += gridDim.x) {
-        const int e = wl_get(B, list, s_pref, item);
-        const int W = P.width, H = P.height;
-        if (lane == 0) {
-            const int ncr = sok_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
-            if (ncr > SOK_MAXC) atomicOr(B.status, 1);
-            sok_init_deadlocks(s_L);
-            s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
-        }
-        int dist = 0, sol = 0;
-        // The four agents of _run_game, with the exact exhausted-BFS shortcut (sokoban_solver.h).  The search is
-        // driven by lane 0; every lane helps to clear the visited table between agents.
-        const int KS[4] = {-1, 2, 1, 0};
-        int go = 1;
-        for (int a = 0; a < 4 && go; a++) {
-            if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
-            else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
-            __threadfence_block();
-            if (lane == 0) {
-                int hh, dd, it;
-                bool exhausted = false, win;
-                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
-                    win = sok_search(s_L, pool, sok_lds, sok_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
-                else
-                    win = sok_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, hh, dd, it, exhausted);
-                dist = win ? 0 : hh;
-                sol = win ? dd : 0;
-                go = !(win || (a == 0 && exhausted));
-            }
-            go = __shfl(go, 0, 64);
-            __threadfence_block();
-        }
-        if (lane == 0) {
-            int32_t s[PCGRL_MAX_STATS];
-            const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
-            for (int k = 0; k < 8; k++) s[k] = park[k];
-            s[4] = dist; s[5] = sol;
-            finalize_item(P, B, e, s, mode, parity, item & (WL_NSHARD - 1));
-        }
-    }
-}

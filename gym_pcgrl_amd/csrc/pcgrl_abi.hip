@@ -42,6 +42,7 @@
 #include "reset_env.h"
 #include "kernels_stats.h"
 #include "kernels_reset.h"
+#include "kernels_sokoban.h"
 #include "kernels_misc.h"
 
 // ------------------------------------------------------------------------------------------
@@ -72,7 +73,7 @@ struct pcgrl_env {
     size_t ev_used;
     int prof_steps;
 };
-#define PCGRL_NPHASE 6   /* update, stats(step), solver(step), mapgen, stats(start), solver(start) */
+#define PCGRL_NPHASE 6   /* intervals between the 7 event marks of step_one (names: _lib.PHASES) */
 static int prof_mark(pcgrl_env* h, hipStream_t st) {
     if (!h->profiling) return PCGRL_OK;
     if (h->ev_used == h->events.size()) {
@@ -133,6 +134,9 @@ static size_t wl_bytes(const pcgrl_config* c) {
     for (int k = 0; k < WL_NLIST; k++) b += wl_list_bytes(c->num_envs, k);
     return b;
 }
+// per-environment agent results + counters, and the scheduling words of the two solver launches of a step
+static size_t sok_sync_bytes() { return align_up(2 * (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, 256); }
+static size_t sok_sched_bytes(int num_envs) { return align_up((size_t)num_envs * 18 * 4, 256) + sok_sync_bytes(); }
 static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<= 1; return t; }
 static int num_subbatches(const pcgrl_config* c) {
     const char* e = getenv("PCGRL_SUBBATCHES");
@@ -158,6 +162,7 @@ static size_t scratch_bytes(const pcgrl_config* c) {
     if (c->prob == PCGRL_SOKOBAN) {
         const size_t nodes = 4 * (size_t)c->solver_power + 4;
         b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
+        b += sok_sched_bytes(c->num_envs);
         if (c->solver_power > SOK_LDS_POWER) b += SOK_BLOCKS * (align_up(nodes * 4, 256) + (size_t)sok_table_size(c->solver_power) * 4);
     }
     return b;
@@ -263,6 +268,12 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         B.sok_pool = (SokNode*)a;
         B.sok_pool_stride = (int32_t)(align_up(nodes * sizeof(SokNode), 256) / sizeof(SokNode));
         a += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
+        B.sok_res = (int32_t*)a;
+        B.sok_cnt = B.sok_res + (size_t)h->cfg.num_envs * 16;
+        B.sok_stop = B.sok_cnt + h->cfg.num_envs;
+        B.sok_sync = (int32_t*)(a + align_up((size_t)h->cfg.num_envs * 18 * 4, 256));
+        HIPCHK(hipMemsetAsync(a, 0, sok_sched_bytes(h->cfg.num_envs), (hipStream_t)stream));
+        a += sok_sched_bytes(h->cfg.num_envs);
         B.sok_use_lds = power <= SOK_LDS_POWER;
         B.sok_table_size = sok_table_size(power);
         B.sok_heap_stride = (int32_t)(align_up(nodes * 4, 256) / 4);
@@ -401,7 +412,10 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
     return PCGRL_OK;
 }
 
-static int launch_solver(pcgrl_env* h, int list, int parity, int mode, int clr, hipStream_t st) {
+// One solver launch: the jobs of list_a (mode_a) and, if list_b >= 0, of list_b (mode_b).  `slot` selects the
+// scheduling words (two launches per step), zeroed here.  Episodes the solver ends go to rst_list.
+static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
+                         hipStream_t st) {
     const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
     static bool attr_set = false;
     if (!attr_set) {
@@ -409,35 +423,38 @@ static int launch_solver(pcgrl_env* h, int list, int parity, int mode, int clr, 
                                    (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_sokoban, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list, parity, mode, clr);
+    int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
+    HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
+    hipLaunchKernelGGL(k_sokoban, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
+                       sync, sync + SOK_SY_WORDS, clr);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
 
 template <int PROB>
-static int launch_reset_p(pcgrl_env* h, int parity, int clr, hipStream_t st) {
+static int launch_reset_p(pcgrl_env* h, int list, int park_list, int parity, int clr, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const int cells = P.width * P.height;
     const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((cells + 15) & ~15));
     const int grid = grid_for(P.num_envs, 4, h->was_reset ? 512 : 4096);
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
     if (P.group == 16 && P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_reset<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+        hipLaunchKernelGGL((k_reset<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, park_list, parity, gen, clr);
     else if (P.group == 16)
-        hipLaunchKernelGGL((k_reset<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+        hipLaunchKernelGGL((k_reset<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, park_list, parity, gen, clr);
     else if (P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_reset<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+        hipLaunchKernelGGL((k_reset<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, park_list, parity, gen, clr);
     else
-        hipLaunchKernelGGL((k_reset<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, parity, gen, clr);
+        hipLaunchKernelGGL((k_reset<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, park_list, parity, gen, clr);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
 // map generation + start stats of every environment on the reset list
-static int launch_reset(pcgrl_env* h, int parity, int clr, hipStream_t st) {
+static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int clr, hipStream_t st) {
     switch (h->P.prob) {
-        case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, parity, clr, st);
-        case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, parity, clr, st);
-        default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, parity, clr, st);
+        case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, list, park_list, parity, clr, st);
+        case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, list, park_list, parity, clr, st);
+        default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, list, park_list, parity, clr, st);
     }
 }
 
@@ -449,9 +466,9 @@ static int reset_one(pcgrl_env* h, void* stream) {
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_RST);
     HIPCHK(hipGetLastError());
     const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN;
-    int rc = launch_reset(h, par, sok ? -1 : (par ^ 1), st);
+    int rc = launch_reset(h, WL_RST, WL_SOL2, par, sok ? -1 : (par ^ 1), st);
     if (rc) return rc;
-    if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
+    if (sok && (rc = launch_solver(h, 0, WL_SOL2, MODE_START, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
     return PCGRL_OK;
 }
 
@@ -464,23 +481,32 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (rc) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     // The last kernel of the step clears the other parity's work-list counters.  Every problem but Sokoban is
-    // two launches: k_stats also resets the environments whose episode ended (auto_reset).  Sokoban parks the
-    // maps that need the solver, so its resets wait for k_sokoban and go through k_reset.
+    // two launches: k_stats also resets the environments whose episode ended (auto_reset).
     const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN, ar = h->P.auto_reset != 0;
-    const bool inl = ar && h->B.inline_reset;   // (never for Sokoban)
-    const bool rst = ar && !inl;
-    rc = launch_stats(h, WL_CHG, par, MODE_STEP, (sok || rst) ? -1 : (par ^ 1), inl ? 1 : 0, st);
+    if (!sok) {
+        const bool inl = ar && h->B.inline_reset;
+        rc = launch_stats(h, WL_CHG, par, MODE_STEP, (ar && !inl) ? -1 : (par ^ 1), inl ? 1 : 0, st);
+        if (rc) return rc;
+        if ((rc = prof_mark(h, st))) return rc;
+        if ((rc = prof_mark(h, st))) return rc;
+        if (ar && !inl && (rc = launch_reset(h, WL_RST, WL_SOL2, par, par ^ 1, st))) return rc;
+        for (int k = 0; k < 3; k++) if ((rc = prof_mark(h, st))) return rc;
+        return PCGRL_OK;
+    }
+    // Sokoban: k_stats parks the maps that need the solver (SOL) and sends finished episodes to RST; k_reset
+    // regenerates those and parks their solver jobs (SOL2); ONE solver launch then works on SOL and SOL2
+    // together, so that the step waits for its slowest search once, not twice.  The few episodes that only the
+    // solver could end (RST2) get a second, almost empty reset + solver pass.
+    rc = launch_stats(h, WL_CHG, par, MODE_STEP, -1, 0, st);
     if (rc) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    if (sok && (rc = launch_solver(h, WL_SOL, par, MODE_STEP, ar ? -1 : (par ^ 1), st))) return rc;
+    if (ar && (rc = launch_reset(h, WL_RST, WL_SOL2, par, -1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    if (rst) {
-        rc = launch_reset(h, par, sok ? -1 : (par ^ 1), st);
-        if (rc) return rc;
-    }
+    if ((rc = launch_solver(h, 0, WL_SOL, MODE_STEP, ar ? WL_SOL2 : -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    if ((rc = prof_mark(h, st))) return rc;   // (the start stats are part of k_reset / k_stats)
-    if (ar && sok && (rc = launch_solver(h, WL_SOL2, par, MODE_START, par ^ 1, st))) return rc;
+    if (ar && (rc = launch_reset(h, WL_RST2, WL_SOL3, par, -1, st))) return rc;
+    if ((rc = prof_mark(h, st))) return rc;
+    if (ar && (rc = launch_solver(h, 1, WL_SOL3, MODE_START, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     return PCGRL_OK;
 }
@@ -603,7 +629,7 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     const bool sok = P.prob == PCGRL_PROB_SOKOBAN;
     int rc = launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), 0, st);
     if (rc) return rc;
-    if (sok && (rc = launch_solver(h, WL_SOL2, par, MODE_SETMAP, par ^ 1, st))) return rc;
+    if (sok && (rc = launch_solver(h, 0, WL_SOL2, MODE_SETMAP, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
     return PCGRL_OK;
 }
 

@@ -213,11 +213,20 @@ PCGRL_D bool sok_same(const SokLevel& L, const SokNode& a, const SokNode& b) {
 // Returns win; out_h/out_depth describe the returned node (winner, or best node).
 // `out_exhausted` reports that the search ended because the queue ran empty (every reachable state was
 // expanded), not because of the iteration cap.
-template <class HP, class TP>
+// `hook(iterations)` is called at the top of every iteration; returning true abandons the search (the
+// caller knows its result is not needed: k_sokoban runs the agents of one level concurrently).
+// The node that will be popped next is fetched from the pool one iteration ahead whenever it is already
+// known (BFS: the next queue entry; A*: the heap top after the repair), which takes the global-memory
+// latency of the pop off the serial chain.
+struct SokNoHook { PCGRL_D bool operator()(int) const { return false; } };
+template <class HP, class TP, class Hook>
 PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int table_mask, SokNode& w,
                         const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
-                        bool& out_exhausted) {
+                        bool& out_exhausted, Hook hook) {
     int npool = 0, head = 0, heapn = 0, iterations = 0, best = -1, best_h = 0, best_depth = 0;
+    SokRaw ahead = sok_load(&root);
+    int ahead_idx = 0;
+    bool aborted = false;
     sok_store(pool, sok_load(&root));
     npool = 1;
     if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth) << 16) | 0u; heapn = 1; }
@@ -225,16 +234,24 @@ PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int
     int result_h = root.h, result_depth = 0;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
         iterations++;
+        if (hook(iterations)) { aborted = true; break; }
         int cur;
         if (k >= 0) {
             const uint32_t last = heap[--heapn];
             cur = (int)((heapn > 0 ? heap[0] : last) & 0xFFFFu);
-            const SokRaw fetched = sok_load(pool + cur);   // global load in flight while the heap is repaired
+            SokRaw fetched = ahead;
+            if (cur != ahead_idx) fetched = sok_load(pool + cur);   // global load in flight while the heap is repaired
             if (heapn > 0) { heap[0] = last; sok_siftup(heap, 0, heapn); }
             sok_store(&w, fetched);
+            ahead_idx = -1;
+            if (heapn > 0) { ahead_idx = (int)(heap[0] & 0xFFFFu); ahead = sok_load(pool + ahead_idx); }
         } else {
             cur = head++;
-            sok_store(&w, sok_load(pool + cur));
+            SokRaw fetched = ahead;
+            if (cur != ahead_idx) fetched = sok_load(pool + cur);
+            sok_store(&w, fetched);
+            ahead_idx = -1;
+            if (head < npool) { ahead_idx = head; ahead = sok_load(pool + head); }
         }
         const int node_h = w.h, node_depth = w.depth, node_player = w.player;
         if (sok_win(L, w.crate)) { win = true; result_h = node_h; result_depth = node_depth; break; }
@@ -287,8 +304,14 @@ PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int
     }
     if (!win) { result_h = best_h; result_depth = best_depth; }
     out_h = result_h; out_depth = result_depth; out_iters = iterations;
-    out_exhausted = !win && !(k >= 0 ? heapn > 0 : head < npool);
+    out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < npool);
     return win;
+}
+template <class HP, class TP>
+PCGRL_D bool sok_search(const SokLevel& L, SokNode* pool, HP heap, TP table, int table_mask, SokNode& w,
+                        const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
+                        bool& out_exhausted) {
+    return sok_search(L, pool, heap, table, table_mask, w, root, k, power, out_h, out_depth, out_iters, out_exhausted, SokNoHook());
 }
 
 // SokobanProblem._run_game (sokoban_prob.py:104-122): BFS, then A* with balance 1, 0.5, 0; first winner gives

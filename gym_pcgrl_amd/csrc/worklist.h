@@ -11,10 +11,12 @@ enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
 // by step parity: the last kernel of a step zeroes the other parity's counters.
 #define WL_NSHARD 64
 #define WL_CSTRIDE 16
-enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_NLIST = 4 };
+// CHG: changed environments; RST: to reset; SOL: solver jobs of the step; SOL2: of the resets.  Sokoban only: RST2 =
+// environments whose episode the solver kernel ended, SOL3 = solver jobs of *their* resets.
+enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5, WL_NLIST = 6 };
 // An item of the changed list with this bit set is an unchanged environment whose episode ended (iteration cap):
 // k_stats resets it without recomputing anything.
-#define WL_RESET_ONLY (1 << 30)   // SOL: solver jobs of the step, SOL2: of the resets
+#define WL_RESET_ONLY (1 << 30)
 
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
@@ -26,6 +28,9 @@ struct DevBufs {
     int32_t wl_cap[WL_NLIST];
     // sokoban solver arena (per resident solver block) and sticky status word
     SokNode* sok_pool; uint32_t* sok_heap; uint32_t* sok_table; int32_t* status;
+    int32_t* sok_res;                // [num_envs][4 agents][win, h, depth, exhausted]
+    int32_t* sok_cnt; int32_t* sok_stop;   // [num_envs] agents reported / stop level (kernels_sokoban.h)
+    int32_t* sok_sync;               // [2 launches per step][SOK_SY_WORDS + SOK_HARD_CAP] scheduling words
     int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
     int32_t inline_reset;   // k_stats resets finished environments itself (every problem but Sokoban)
 };
