@@ -36,6 +36,7 @@
 #include "mt19937.h"
 #include "pcgrl_algos.h"
 #include "sokoban_solver.h"
+#include "sokoban_fast.h"
 
 #include "worklist.h"
 #include "kernels_update.h"
@@ -416,11 +417,11 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
 // scheduling words (two launches per step), zeroed here.  Episodes the solver ends go to rst_list.
 static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
                          hipStream_t st) {
-    const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
+    const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sokoban), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
+                                   (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4)));
         attr_set = true;
     }
     int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);

@@ -1,0 +1,237 @@
+// Register-resident Sokoban search: the same agents as sok_search (sokoban_solver.h), for levels with at
+// most SOKF_MAXC crates -- every level the benchmark ever sees; the rest take sok_search.
+//
+// sok_search keeps the node under expansion and the level in LDS because their arrays are indexed
+// dynamically; on one lane that is a chain of ~100 dependent LDS reads per pop (measured on MI355X:
+// 3 900 cycles per BFS pop, 8 000 per A* pop).  Here a state is two registers -- the ordered crate list as
+// the bytes of a 64-bit word and the player cell -- plus a crate bitboard, and the level is a handful of
+// 64-bit masks, so a pop is register arithmetic around three memory structures:
+//   * pool   16-byte nodes in global memory (one dwordx4 load/store; the next pop is fetched ahead),
+//   * table  visited set in LDS, open addressing on the *exact* 64-bit key (player | crates << 8): a hit
+//            needs no look at the pool,
+//   * heap   CPython heapq on packed (priority << 16 | node) words in LDS.  The sift loops fetch two
+//            levels per round trip; slots past the end hold an "infinite" sentinel so the bounds tests of
+//            heapq turn into ordinary comparisons and the loads need no guards.
+// Order of exploration, visited-on-pop, iteration counting and best-node rules are those of sok_search.
+#pragma once
+#include "sokoban_solver.h"
+
+#define SOKF_MAXC 7
+#define SOKF_SENTINEL 0xFFFFFFFFu
+
+struct alignas(16) SokFastNode { uint64_t cr; uint32_t ph; uint32_t depth; };   // ph = player | h << 16
+
+template <int NW>
+struct SokFastLevel {
+    uint64_t solid[NW], dead[NW], tmask[NW];
+    uint64_t tx, ty;        // x / y of target i in byte i
+    uint32_t inv_w;         // ceil(2^16 / w): p / w == (p * inv_w) >> 16 for p < 256
+    int w, h, nc;
+};
+
+template <int NW>
+PCGRL_D bool sokf_bit(const uint64_t* m, int p) {
+    if (NW == 1) return (m[0] >> p) & 1ull;
+    const uint64_t lo = (p & 64) ? m[1] : m[0], hi = (p & 64) ? m[3] : m[2];
+    return (((p & 128) ? hi : lo) >> (p & 63)) & 1ull;
+}
+template <int NW>
+PCGRL_D void sokf_flip(uint64_t* m, int p) {
+    if (NW == 1) { m[0] ^= 1ull << p; return; }
+    const uint64_t b = 1ull << (p & 63);
+    const int wd = p >> 6;
+    m[0] ^= wd == 0 ? b : 0; m[1] ^= wd == 1 ? b : 0; m[2] ^= wd == 2 ? b : 0; m[3] ^= wd == 3 ? b : 0;
+}
+template <int NW>
+PCGRL_D bool sokf_any_and(const uint64_t* a, const uint64_t* b) {
+    uint64_t r = a[0] & b[0];
+    for (int i = 1; i < NW; i++) r |= a[i] & b[i];
+    return r != 0;
+}
+template <int NW>
+PCGRL_D bool sokf_covers(const uint64_t* a, const uint64_t* t) {    // every bit of t set in a
+    uint64_t r = ~a[0] & t[0];
+    for (int i = 1; i < NW; i++) r |= ~a[i] & t[i];
+    return r == 0;
+}
+
+template <int NW>
+PCGRL_D void sokf_level(const SokLevel& L, SokFastLevel<NW>& F) {
+    for (int i = 0; i < NW; i++) { F.solid[i] = L.solid[i]; F.dead[i] = L.dead[i]; F.tmask[i] = L.targetmask[i]; }
+    F.w = L.w; F.h = L.h; F.nc = L.nc;
+    F.inv_w = (65536u + (uint32_t)L.w - 1u) / (uint32_t)L.w;
+    F.tx = 0; F.ty = 0;
+    for (int i = 0; i < L.nc; i++) {
+        F.tx |= (uint64_t)L.cx[L.target[i]] << (8 * i);
+        F.ty |= (uint64_t)L.cy[L.target[i]] << (8 * i);
+    }
+}
+PCGRL_D int sokf_absdiff(int a, int b) { return a > b ? a - b : b - a; }
+// engine.py:282-296 (same greedy matching as sok_heuristic) on the packed crate list
+template <int NW>
+PCGRL_D int sokf_heuristic(const SokFastLevel<NW>& F, uint64_t cr) {
+    uint32_t used = 0;
+    int distance = 0;
+    for (int c = 0; c < F.nc; c++) {
+        const int p = (int)((cr >> (8 * c)) & 0xFF);
+        const int cy = (int)(((uint32_t)p * F.inv_w) >> 16), cx = p - cy * F.w;
+        int best = F.w + F.h, match = -1, firstfree = -1, matchd = 0, firstd = 0;
+        for (int i = 0; i < F.nc; i++) {
+            if ((used >> i) & 1u) continue;
+            const int d = sokf_absdiff(cx, (int)((F.tx >> (8 * i)) & 0xFF)) + sokf_absdiff(cy, (int)((F.ty >> (8 * i)) & 0xFF));
+            if (firstfree < 0) { firstfree = i; firstd = d; }
+            if (best > d) { match = i; best = d; matchd = d; }
+        }
+        if (match < 0) { match = firstfree; matchd = firstd; }
+        distance += matchd;
+        used |= 1u << match;
+    }
+    return distance;
+}
+// index of the crate standing on cell p (p != 0; unused bytes of cr are 0), known to exist
+PCGRL_D int sokf_crate_index(uint64_t cr, int p) {
+    const uint64_t x = cr ^ (0x0101010101010101ull * (uint64_t)p);
+    const uint64_t t = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // lowest marked byte is exact
+#if defined(__HIPCC__)
+    return (__ffsll((unsigned long long)t) - 1) >> 3;
+#else
+    return __builtin_ctzll(t) >> 3;
+#endif
+}
+
+// heapq with a sentinel tail.  cap1 = index of the last slot of the heap array (always a sentinel).
+template <class HP>
+PCGRL_D void sokf_siftdown(HP heap, int pos) {
+    const uint32_t newitem = heap[pos];
+    while (pos > 0) {
+        const int p1 = (pos - 1) >> 1;
+        const int p2 = p1 > 0 ? (p1 - 1) >> 1 : 0;
+        const uint32_t v1 = heap[p1], v2 = heap[p2];
+        if (!sok_lt(newitem, v1)) break;
+        heap[pos] = v1; pos = p1;
+        if (pos == 0 || !sok_lt(newitem, v2)) break;
+        heap[pos] = v2; pos = p2;
+    }
+    heap[pos] = newitem;
+}
+template <class HP>
+PCGRL_D void sokf_siftup_root(HP heap, int endpos, int cap1) {
+    int pos = 0;
+    const uint32_t newitem = heap[0];
+    for (;;) {
+        const int c1 = 2 * pos + 1;
+        if (c1 >= endpos) break;
+        const int g = 2 * c1 + 1;
+        const int i1 = c1 + 1 < cap1 ? c1 + 1 : cap1;
+        const int j0 = g < cap1 ? g : cap1, j1 = g + 1 < cap1 ? g + 1 : cap1, j2 = g + 2 < cap1 ? g + 2 : cap1, j3 = g + 3 < cap1 ? g + 3 : cap1;
+        const uint32_t a0 = heap[c1], a1 = heap[i1], g0 = heap[j0], g1 = heap[j1], g2 = heap[j2], g3 = heap[j3];
+        const bool right1 = !sok_lt(a0, a1);      // a sentinel on the right never wins: same as heapq's bounds test
+        heap[pos] = right1 ? a1 : a0;
+        pos = right1 ? c1 + 1 : c1;
+        const int c2 = 2 * pos + 1;
+        if (c2 >= endpos) break;
+        const uint32_t b0 = right1 ? g2 : g0, b1 = right1 ? g3 : g1;
+        const bool right2 = !sok_lt(b0, b1);
+        heap[pos] = right2 ? b1 : b0;
+        pos = right2 ? c2 + 1 : c2;
+    }
+    heap[pos] = newitem;
+    sokf_siftdown(heap, pos);
+}
+
+// One search.  `heap` must hold SOKF_SENTINEL in every slot (A* only; [0, heap_cap)), `table` zeros.
+// Same contract as sok_search otherwise.
+template <int NW, class HP, class TP, class Hook>
+PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, int heap_cap, TP table, int table_mask,
+                             const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
+                             bool& out_exhausted, Hook hook) {
+    SokFastLevel<NW> F;
+    sokf_level(L, F);
+    const int cap1 = heap_cap - 1;
+    const int nc = F.nc;
+    int npool = 0, head = 0, heapn = 0, iterations = 0, best_h = 0, best_depth = 0;
+    bool have_best = false, aborted = false, win = false;
+    SokFastNode n0;
+    n0.cr = 0;
+    for (int i = 0; i < nc; i++) n0.cr |= (uint64_t)root.crate[i] << (8 * i);
+    n0.ph = (uint32_t)root.player | ((uint32_t)root.h << 16);
+    n0.depth = 0;
+    pool[0] = n0;
+    npool = 1;
+    if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth) << 16) | 0u; heapn = 1; }
+    SokFastNode ahead = n0;
+    int ahead_idx = 0;
+    int result_h = root.h, result_depth = 0;
+    while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
+        iterations++;
+        if (hook(iterations)) { aborted = true; break; }
+        int cur;
+        SokFastNode nd = ahead;
+        if (k >= 0) {
+            const uint32_t top = heap[0];
+            const uint32_t last = heap[--heapn];
+            heap[heapn] = SOKF_SENTINEL;
+            cur = (int)(top & 0xFFFFu);
+            if (cur != ahead_idx) nd = pool[cur];
+            if (heapn > 0) { heap[0] = last; sokf_siftup_root(heap, heapn, cap1); }
+            ahead_idx = -1;
+            if (heapn > 0) { ahead_idx = (int)(heap[0] & 0xFFFFu); ahead = pool[ahead_idx]; }
+        } else {
+            cur = head++;
+            if (cur != ahead_idx) nd = pool[cur];
+            ahead_idx = -1;
+            if (head < npool) { ahead_idx = head; ahead = pool[head]; }
+        }
+        const uint64_t cr = nd.cr;
+        const int node_player = (int)(nd.ph & 0xFFu), node_h = (int)(nd.ph >> 16), node_depth = (int)nd.depth;
+        uint64_t cb[NW];
+        for (int i = 0; i < NW; i++) cb[i] = 0;
+        for (int i = 0; i < nc; i++) sokf_flip<NW>(cb, (int)((cr >> (8 * i)) & 0xFF));
+        if (sokf_covers<NW>(cb, F.tmask)) { win = true; result_h = node_h; result_depth = node_depth; break; }   // engine.py:272-280
+        // visited test-and-add on the exact key
+        const uint64_t key = (cr << 8) | (uint64_t)node_player;
+        uint64_t hs = key * 0x9E3779B97F4A7C15ull;
+        uint32_t slot = (uint32_t)(hs >> 40) & (uint32_t)table_mask;
+        bool seen = false;
+        for (;;) {
+            const uint64_t v = table[slot];
+            if (v == 0) break;
+            if (v == key) { seen = true; break; }
+            slot = (slot + 1) & (uint32_t)table_mask;
+        }
+        if (seen) continue;
+        table[slot] = key;
+        if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) { have_best = true; best_h = node_h; best_depth = node_depth; }
+        for (int d = 0; d < 4; d++) {          // Node.getChildren: L, R, U, D (State.update engine.py:298-327)
+            const int dir = d == 0 ? -1 : (d == 1 ? 1 : (d == 2 ? -F.w : F.w));
+            const int np = node_player + dir;
+            if (sokf_bit<NW>(F.solid, np)) continue;                 // player did not move
+            uint64_t ncr = cr;
+            int nh = node_h;
+            if (sokf_bit<NW>(cb, np)) {
+                const int cp = np + dir;
+                if (sokf_bit<NW>(F.solid, cp) || sokf_bit<NW>(cb, cp)) continue;   // blocked crate: no move
+                const int c = sokf_crate_index(cr, np);
+                ncr = cr ^ ((uint64_t)(np ^ cp) << (8 * c));
+                uint64_t nb[NW];
+                for (int i = 0; i < NW; i++) nb[i] = cb[i];
+                sokf_flip<NW>(nb, np); sokf_flip<NW>(nb, cp);
+                if (sokf_any_and<NW>(nb, F.dead)) continue;          // checkDeadlock looks at every crate
+                nh = sokf_heuristic(F, ncr);
+            }
+            SokFastNode ch;
+            ch.cr = ncr; ch.ph = (uint32_t)np | ((uint32_t)nh << 16); ch.depth = (uint32_t)(node_depth + 1);
+            pool[npool] = ch;
+            if (k >= 0) {
+                heap[heapn] = ((uint32_t)(2 * nh + k * (node_depth + 1)) << 16) | (uint32_t)npool;
+                heapn++;
+                sokf_siftdown(heap, heapn - 1);
+            }
+            npool++;
+        }
+    }
+    if (!win) { result_h = best_h; result_depth = best_depth; }
+    out_h = result_h; out_depth = result_depth; out_iters = iterations;
+    out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < npool);
+    return win;
+}

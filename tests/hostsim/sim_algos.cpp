@@ -13,6 +13,7 @@ static int g_trace_site[4096], g_trace_rounds[4096], g_trace_n = 0;
 #include "../../gym_pcgrl_amd/csrc/mt19937.h"
 #include "../../gym_pcgrl_amd/csrc/pcgrl_algos.h"
 #include "../../gym_pcgrl_amd/csrc/sokoban_solver.h"
+#include "../../gym_pcgrl_amd/csrc/sokoban_fast.h"
 #include <vector>
 
 template <class T, int G>
@@ -97,23 +98,50 @@ static void run(int prob, const uint8_t* map, int h, int w, int pw, int ph, int3
 }
 
 extern "C" {
-// the device solver (sokoban_solver.h) run on the host: same pool/heap/table layout as k_sokoban
-int sim_sokoban_solve(const uint8_t* map, int h, int w, int power, int shortcut, int* dist, int* sol, int* iters) {
+// the device solver (sokoban_solver.h / sokoban_fast.h) run on the host: same pool/heap/table layout as k_sokoban.
+// fast = 1 takes the register-resident search for levels with at most SOKF_MAXC crates (what the kernel does),
+// fast = 0 forces the generic one.
+int sim_sokoban_solve2(const uint8_t* map, int h, int w, int power, int shortcut, int fast, int* dist, int* sol, int* iters) {
     SokLevel L; SokNode root;
     int ncr = sok_build_level(map, w, h, L, root);
     if (ncr > SOK_MAXC) return -1;
     sok_init_deadlocks(L);
     root.h = (uint16_t)sok_heuristic(L, root.crate);
     std::vector<SokNode> pool(4 * (size_t)power + 4);
-    std::vector<uint32_t> heap(4 * (size_t)power + 4);
+    const int heap_cap = 4 * power + 4;
+    std::vector<uint32_t> heap(heap_cap);
     int tsize = 1024; while (tsize < 2 * power) tsize <<= 1;
     if (power <= SOK_LDS_POWER) tsize = SOK_LDS_TABLE;
-    std::vector<uint32_t> table(tsize);
-    SokNode work;
-    uint32_t* tp = table.data();
-    sok_run_game(L, pool.data(), heap.data(), tp, tsize, work, root, power, shortcut != 0,
-                 [tp](int n) { for (int i = 0; i < n; i++) tp[i] = 0; }, *dist, *sol, iters);
+    if (!(fast && L.nc <= SOKF_MAXC)) {
+        std::vector<uint32_t> table(tsize);
+        SokNode work;
+        uint32_t* tp = table.data();
+        sok_run_game(L, pool.data(), heap.data(), tp, tsize, work, root, power, shortcut != 0,
+                     [tp](int n) { for (int i = 0; i < n; i++) tp[i] = 0; }, *dist, *sol, iters);
+        return 0;
+    }
+    std::vector<uint64_t> table(tsize);
+    const int KS[4] = {-1, 2, 1, 0};
+    bool win = false;
+    int hh = 0, dd = 0;
+    for (int a = 0; a < 4; a++) iters[a] = 0;
+    for (int a = 0; a < 4 && !win; a++) {
+        for (int i = 0; i < tsize; i++) table[i] = 0;
+        for (int i = 0; i < heap_cap; i++) heap[i] = SOKF_SENTINEL;
+        bool exhausted = false;
+        SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool.data());
+        if (L.cells <= 64)
+            win = sok_search_fast<1>(L, fp, heap.data(), heap_cap, table.data(), tsize - 1, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
+        else
+            win = sok_search_fast<4>(L, fp, heap.data(), heap_cap, table.data(), tsize - 1, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
+        if (a == 0 && !win && exhausted && shortcut) break;
+    }
+    *dist = win ? 0 : hh;
+    *sol = win ? dd : 0;
     return 0;
+}
+int sim_sokoban_solve(const uint8_t* map, int h, int w, int power, int shortcut, int* dist, int* sol, int* iters) {
+    return sim_sokoban_solve2(map, h, w, power, shortcut, 0, dist, sol, iters);
 }
 long sim_iters_reset() { long v = g_sim_iters; g_sim_iters = 0; return v; }
 void sim_set_spurious(int n) { g_spurious = n; }

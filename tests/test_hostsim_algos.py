@@ -63,12 +63,13 @@ def test_bitboard_stats_vs_golden(sim, path):
                 assert np.array_equal(out[:ns], exp), (i, variant, out, exp, m)
 
 
-def test_device_sokoban_solver_vs_golden(sim):
-    """gym_pcgrl_amd/csrc/sokoban_solver.h (the code k_sokoban runs) compiled for the host.  Without the
-    exhausted-BFS shortcut the per-agent iteration counts must equal the reference's; with it (what the GPU
-    runs) dist-win and sol-length must still be equal, and the A* agents are skipped exactly when BFS
+@pytest.mark.parametrize("fast", [0, 1], ids=["generic", "register-resident"])
+def test_device_sokoban_solver_vs_golden(sim, fast):
+    """gym_pcgrl_amd/csrc/sokoban_solver.h and sokoban_fast.h (the code k_sokoban runs) compiled for the host.
+    Without the exhausted-BFS shortcut the per-agent iteration counts must equal the reference's; with it (what
+    the GPU runs) dist-win and sol-length must still be equal, and the A* agents are skipped exactly when BFS
     exhausted the state space without a win."""
-    sim.sim_sokoban_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    sim.sim_sokoban_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     n = skipped = 0
     for path in sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz"))):
         d = np.load(path)
@@ -79,11 +80,11 @@ def test_device_sokoban_solver_vs_golden(sim):
             m = np.ascontiguousarray(m)
             dist, sol = C.c_int(), C.c_int()
             it = np.zeros(4, np.int32)
-            assert sim.sim_sokoban_solve(_p(m), m.shape[0], m.shape[1], power, 0, C.byref(dist), C.byref(sol), _p(it)) == 0
+            assert sim.sim_sokoban_solve2(_p(m), m.shape[0], m.shape[1], power, 0, fast, C.byref(dist), C.byref(sol), _p(it)) == 0
             assert (dist.value, sol.value) == (d["stats"][i, 4], d["stats"][i, 5]), (path, i)
             assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
             it2 = np.zeros(4, np.int32)
-            assert sim.sim_sokoban_solve(_p(m), m.shape[0], m.shape[1], power, 1, C.byref(dist), C.byref(sol), _p(it2)) == 0
+            assert sim.sim_sokoban_solve2(_p(m), m.shape[0], m.shape[1], power, 1, fast, C.byref(dist), C.byref(sol), _p(it2)) == 0
             assert (dist.value, sol.value) == (d["stats"][i, 4], d["stats"][i, 5]), ("shortcut", path, i)
             if it2[1] == 0 and it[1] > 0:
                 skipped += 1
