@@ -77,13 +77,13 @@ __device__ __forceinline__ void sok_report(const PcgrlParams& P, const DevBufs& 
 // level qualifies, else the generic one (LDS or global-arena heap/table).  Called by lane 0.
 template <class Hook>
 __device__ __forceinline__ bool sok_run_agent(const DevBufs& B, int power, const SokLevel& L, SokNode& work, const SokNode& root, SokNode* pool,
-                                              uint32_t* lds, uint32_t* g_heap, uint32_t* g_table, int tsize, int fast, int k,
+                                              uint32_t* lds, SokFastNode* cache, uint32_t* g_heap, uint32_t* g_table, int tsize, int fast, int k,
                                               int& hh, int& dd, int& it, bool& exhausted, Hook hook) {
     if (fast) {
         uint64_t* tab = reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP);
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool);
-        if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, SOK_LDS_HEAP, tab, tsize - 1, root, k, power, hh, dd, it, exhausted, hook);
-        return sok_search_fast<4>(L, fp, lds, SOK_LDS_HEAP, tab, tsize - 1, root, k, power, hh, dd, it, exhausted, hook);
+        if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook);
+        return sok_search_fast<4>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook);
     }
     if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
         return sok_search(L, pool, lds, lds + SOK_LDS_HEAP, tsize - 1, work, root, k, power, hh, dd, it, exhausted, hook);
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
     __shared__ SokLevel s_L;             // level + node workspace in LDS: they are indexed dynamically
     __shared__ SokNode s_root, s_work;
     __shared__ int s_spawned, s_fast;
+    __shared__ SokFastNode s_cache[4];
     SokNode* pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
     uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
     uint32_t* g_table = B.sok_use_lds ? nullptr : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
@@ -164,10 +165,7 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
         // helps to clear the visited table.
         int dist = 0, sol = 0, go = 1, reported = 0;
         for (int a = first; a <= last && go; a++) {
-            if (fast) {   // 64-bit keys; the heap of an A* agent starts as all sentinels
-                for (int i = lane; i < 2 * tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0;
-                if (a > 0) for (int i = lane; i < SOK_LDS_HEAP; i += 64) sok_lds[i] = SOKF_SENTINEL;
-            } else if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
+            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }   // 64-bit keys else if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
             else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
             __threadfence_block();
             if (lane == 0) {
@@ -176,16 +174,16 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
                 if (kind == 1 && a == 0) {
                     int sp = P.solver_power < SOK_SPAWN_ITERS ? P.solver_power : SOK_SPAWN_ITERS;
                     SokSpawnHook hook = {sync, hard, sp, (e + 1) | (mode << 28), &s_spawned};
-                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, g_heap, g_table, tsize, fast, -1, hh, dd, it, exhausted, hook);
+                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, -1, hh, dd, it, exhausted, hook);
                     if (s_spawned) { sok_report(P, B, e, 0, win, hh, dd, exhausted, mode, parity, rst_list); reported = 1; go = 0; }
                     else go = !(win || exhausted);
                 } else if (kind == 1) {
-                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, SokNoHook());
+                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, SokNoHook());
                     go = !win;
                 } else {
                     SokPollHook hook = {B.sok_stop + e, 4 - a};
                     if (sok_ld(B.sok_stop + e) < 4 - a) {
-                        win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, hook);
+                        win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, hook);
                     }
                     sok_report(P, B, e, a, win, hh, dd, false, mode, parity, rst_list);
                     reported = 1;

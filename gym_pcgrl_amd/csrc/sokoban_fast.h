@@ -6,18 +6,18 @@
 // 3 900 cycles per BFS pop, 8 000 per A* pop).  Here a state is two registers -- the ordered crate list as
 // the bytes of a 64-bit word and the player cell -- plus a crate bitboard, and the level is a handful of
 // 64-bit masks, so a pop is register arithmetic around three memory structures:
-//   * pool   16-byte nodes in global memory (one dwordx4 load/store; the next pop is fetched ahead),
+//   * pool   16-byte nodes in global memory (one dwordx4 load/store).  A pop never waits for it: the next
+//            node to be popped is either the heap top left by the repair (fetched ahead, in flight while
+//            the children are made) or one of the up to four children just pushed (kept in `cache`),
 //   * table  visited set in LDS, open addressing on the *exact* 64-bit key (player | crates << 8): a hit
 //            needs no look at the pool,
-//   * heap   CPython heapq on packed (priority << 16 | node) words in LDS.  The sift loops fetch two
-//            levels per round trip; slots past the end hold an "infinite" sentinel so the bounds tests of
-//            heapq turn into ordinary comparisons and the loads need no guards.
+//   * heap   CPython heapq on packed (priority << 16 | node) words in LDS; the sift loops walk two
+//            levels per round with no bounds tests while the grandchildren exist.
 // Order of exploration, visited-on-pop, iteration counting and best-node rules are those of sok_search.
 #pragma once
 #include "sokoban_solver.h"
 
 #define SOKF_MAXC 7
-#define SOKF_SENTINEL 0xFFFFFFFFu
 
 struct alignas(16) SokFastNode { uint64_t cr; uint32_t ph; uint32_t depth; };   // ph = player | h << 16
 
@@ -99,7 +99,9 @@ PCGRL_D int sokf_crate_index(uint64_t cr, int p) {
 #endif
 }
 
-// heapq with a sentinel tail.  cap1 = index of the last slot of the heap array (always a sentinel).
+// heapq on packed words.  A lone lane executes about one instruction every 5-6 cycles, so the sift loops are
+// written for instruction count: while both children and all four grandchildren exist, two levels are
+// walked per round without any bounds test (paired LDS reads); the last level or two use plain heapq.
 template <class HP>
 PCGRL_D void sokf_siftdown(HP heap, int pos) {
     const uint32_t newitem = heap[pos];
@@ -115,39 +117,45 @@ PCGRL_D void sokf_siftdown(HP heap, int pos) {
     heap[pos] = newitem;
 }
 template <class HP>
-PCGRL_D void sokf_siftup_root(HP heap, int endpos, int cap1) {
+PCGRL_D void sokf_siftup_root(HP heap, int endpos) {
     int pos = 0;
     const uint32_t newitem = heap[0];
-    for (;;) {
-        const int c1 = 2 * pos + 1;
-        if (c1 >= endpos) break;
-        const int g = 2 * c1 + 1;
-        const int i1 = c1 + 1 < cap1 ? c1 + 1 : cap1;
-        const int j0 = g < cap1 ? g : cap1, j1 = g + 1 < cap1 ? g + 1 : cap1, j2 = g + 2 < cap1 ? g + 2 : cap1, j3 = g + 3 < cap1 ? g + 3 : cap1;
-        const uint32_t a0 = heap[c1], a1 = heap[i1], g0 = heap[j0], g1 = heap[j1], g2 = heap[j2], g3 = heap[j3];
-        const bool right1 = !sok_lt(a0, a1);      // a sentinel on the right never wins: same as heapq's bounds test
-        heap[pos] = right1 ? a1 : a0;
-        pos = right1 ? c1 + 1 : c1;
-        const int c2 = 2 * pos + 1;
-        if (c2 >= endpos) break;
-        const uint32_t b0 = right1 ? g2 : g0, b1 = right1 ? g3 : g1;
-        const bool right2 = !sok_lt(b0, b1);
-        heap[pos] = right2 ? b1 : b0;
-        pos = right2 ? c2 + 1 : c2;
+    while (4 * pos + 6 < endpos) {
+        const int c1 = 2 * pos + 1, g = 4 * pos + 3;
+        const uint32_t a0 = heap[c1], a1 = heap[c1 + 1];
+        const uint32_t g0 = heap[g], g1 = heap[g + 1], g2 = heap[g + 2], g3 = heap[g + 3];
+        const bool r1 = !sok_lt(a0, a1);
+        heap[pos] = r1 ? a1 : a0;
+        const int p1 = c1 + (r1 ? 1 : 0);
+        const uint32_t b0 = r1 ? g2 : g0, b1 = r1 ? g3 : g1;
+        const bool r2 = !sok_lt(b0, b1);
+        heap[p1] = r2 ? b1 : b0;
+        pos = 2 * p1 + 1 + (r2 ? 1 : 0);
+    }
+    int childpos = 2 * pos + 1;
+    while (childpos < endpos) {
+        const int rightpos = childpos + 1;
+        uint32_t c = heap[childpos];
+        if (rightpos < endpos) {
+            const uint32_t r = heap[rightpos];
+            if (!sok_lt(c, r)) { childpos = rightpos; c = r; }
+        }
+        heap[pos] = c;
+        pos = childpos;
+        childpos = 2 * pos + 1;
     }
     heap[pos] = newitem;
     sokf_siftdown(heap, pos);
 }
 
-// One search.  `heap` must hold SOKF_SENTINEL in every slot (A* only; [0, heap_cap)), `table` zeros.
-// Same contract as sok_search otherwise.
+// One search.  `table` must be all zeros; `cache`
+// is room for four nodes (LDS on the device).  Same contract as sok_search otherwise.
 template <int NW, class HP, class TP, class Hook>
-PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, int heap_cap, TP table, int table_mask,
-                             const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
+PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP table, int table_mask,
+                             SokFastNode* cache, const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
                              bool& out_exhausted, Hook hook) {
     SokFastLevel<NW> F;
     sokf_level(L, F);
-    const int cap1 = heap_cap - 1;
     const int nc = F.nc;
     int npool = 0, head = 0, heapn = 0, iterations = 0, best_h = 0, best_depth = 0;
     bool have_best = false, aborted = false, win = false;
@@ -160,7 +168,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, int 
     npool = 1;
     if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth) << 16) | 0u; heapn = 1; }
     SokFastNode ahead = n0;
-    int ahead_idx = 0;
+    int ahead_idx = 0, cache_base = 0, cache_n = 0;   // cache[j] = pool[cache_base + j], j < cache_n
     int result_h = root.h, result_depth = 0;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
         iterations++;
@@ -170,10 +178,12 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, int 
         if (k >= 0) {
             const uint32_t top = heap[0];
             const uint32_t last = heap[--heapn];
-            heap[heapn] = SOKF_SENTINEL;
             cur = (int)(top & 0xFFFFu);
-            if (cur != ahead_idx) nd = pool[cur];
-            if (heapn > 0) { heap[0] = last; sokf_siftup_root(heap, heapn, cap1); }
+            if (cur != ahead_idx) {
+                if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
+                else nd = pool[cur];
+            }
+            if (heapn > 0) { heap[0] = last; sokf_siftup_root(heap, heapn); }
             ahead_idx = -1;
             if (heapn > 0) { ahead_idx = (int)(heap[0] & 0xFFFFu); ahead = pool[ahead_idx]; }
         } else {
@@ -201,6 +211,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, int 
         }
         if (seen) continue;
         table[slot] = key;
+        cache_base = npool; cache_n = 0;
         if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) { have_best = true; best_h = node_h; best_depth = node_depth; }
         for (int d = 0; d < 4; d++) {          // Node.getChildren: L, R, U, D (State.update engine.py:298-327)
             const int dir = d == 0 ? -1 : (d == 1 ? 1 : (d == 2 ? -F.w : F.w));
@@ -223,6 +234,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, int 
             ch.cr = ncr; ch.ph = (uint32_t)np | ((uint32_t)nh << 16); ch.depth = (uint32_t)(node_depth + 1);
             pool[npool] = ch;
             if (k >= 0) {
+                cache[cache_n++] = ch;
                 heap[heapn] = ((uint32_t)(2 * nh + k * (node_depth + 1)) << 16) | (uint32_t)npool;
                 heapn++;
                 sokf_siftdown(heap, heapn - 1);

@@ -127,13 +127,13 @@ int sim_sokoban_solve2(const uint8_t* map, int h, int w, int power, int shortcut
     for (int a = 0; a < 4; a++) iters[a] = 0;
     for (int a = 0; a < 4 && !win; a++) {
         for (int i = 0; i < tsize; i++) table[i] = 0;
-        for (int i = 0; i < heap_cap; i++) heap[i] = SOKF_SENTINEL;
         bool exhausted = false;
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool.data());
+        SokFastNode cache[4];
         if (L.cells <= 64)
-            win = sok_search_fast<1>(L, fp, heap.data(), heap_cap, table.data(), tsize - 1, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
+            win = sok_search_fast<1>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
         else
-            win = sok_search_fast<4>(L, fp, heap.data(), heap_cap, table.data(), tsize - 1, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
+            win = sok_search_fast<4>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
         if (a == 0 && !win && exhausted && shortcut) break;
     }
     *dist = win ? 0 : hh;
