@@ -58,6 +58,17 @@ def measured_traffic(workload):
     return d["fetch_bytes_per_step"] + d["write_bytes_per_step"], os.path.relpath(files[-1], ROOT)
 
 
+def measured_valu(workload, kernel="k_stats"):
+    """Wave-level VALU instructions per dispatch of `kernel` from the last committed rocprofv3 SQ pass
+    (profiles/*/<W>_pmc.json), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", workload + "_pmc.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))["per_dispatch"].get(kernel)
+    return (d.get("SQ_INSTS_VALU") if d else None), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(prob, rep, calls, budget_s=12.0):
     """Oracle (kind 'port') on every host core: one environment per thread, random actions."""
     import concurrent.futures as cf
@@ -176,6 +187,20 @@ def main():
         env.profile(False)
 
     if rank == 0:
+        # dominant kernel (k_stats; for sokoban the solver): its share of the step from the event pass -- the idle
+        # intervals of that pass measure the cost of an event pair, which is subtracted -- and, from the committed
+        # SQ counters, how close it runs to the VALU issue limit (one wave64 VALU instruction per SIMD per 4 cycles)
+        ph = {k: 1e3 * v / max(prof_steps, 1) for k, v in phase_ms.items()}
+        ev_us = min(ph.values()) if ph else 0.0
+        dom_name = "k_sokoban" if prob == "sokoban" else "k_stats"
+        dom_us = max((ph.get("solver_or_reset", 0.0) if prob == "sokoban" else ph.get("stats", 0.0)) - ev_us, 0.0)
+        valu, valu_src = measured_valu(a.workload) if n == n_default else (None, None)
+        dominant = {"name": dom_name, "avg_us": dom_us, "event_pair_overhead_us": ev_us}
+        if valu and dom_us > 0 and prob != "sokoban":
+            peak = 256 * 4 * 2.4e9 / 4          # SIMDs x clock / 4 cycles per wave64 VALU instruction
+            dominant.update({"valu_wave_instr_per_launch": valu, "valu_source": valu_src,
+                             "valu_issue_rate": valu / (dom_us * 1e-6), "valu_issue_peak": peak,
+                             "valu_issue_frac": valu / (dom_us * 1e-6) / peak})
         total_steps = float(n) * world * a.steps
         value = total_steps / dt
         b_alg = 2 * H * W + 64
@@ -192,9 +217,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": n * b_alg,
-                         "kernel": "step pipeline (k_update, k_stats, k_reset [+ k_sokoban]; dominant: k_stats)",
+                         "kernel": "one step = k_update + k_stats (binary/zelda: resets inside k_stats); sokoban adds k_reset + k_sokoban",
+                         "dominant_kernel": dominant,
                          "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
-                         "phase_us_per_step_with_event_overhead": {k: 1e3 * v / max(prof_steps, 1) for k, v in phase_ms.items()}},
+                         "phase_us_per_step_with_event_overhead": ph},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, rep, calls)

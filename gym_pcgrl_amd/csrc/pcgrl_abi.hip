@@ -1,23 +1,23 @@
 // C ABI of the batched PCGRL environment and, through the kernels_*.h headers it includes, its HIP
 // kernels (gfx950 / CDNA4): one translation unit.
 //
-// One `pcgrl_step` is three launches on the caller's stream (five for Sokoban):
+// One `pcgrl_step` is two launches on the caller's stream (binary, zelda); Sokoban adds its solver passes:
 //
 //   k_update   thread per environment.  Representation.update (narrow_rep.py:99-114, wide_rep.py:67-70,
 //              turtle_rep.py:101-129), counters + heatmap (pcgrl_env.py:130-137).  Unchanged
-//              environments are finished here (reward 0, done, info); changed ones are compacted into
-//              a sharded work list, bucketed by expected difficulty (LDS histogram, one atomic per bucket
-//              per 256-thread block).
+//              environments are finished here (reward 0, done, info); changed ones -- and unchanged ones
+//              whose episode ended, flagged "reset only" -- are compacted into a sharded work list,
+//              bucketed by expected difficulty (LDS histogram, one atomic per bucket per 256-thread block).
 //   k_stats    one lane group (16 lanes = one DPP row, or a full wavefront for maps taller than 16) per
-//              changed environment: Problem.get_stats as row-bitboard programs (pcgrl_algos.h), get_reward,
-//              get_episode_over, get_debug_info (pcgrl_env.py:138-148).  Done environments go to the
-//              reset list.
-//   k_sokoban  (Sokoban only) one wavefront per solver job parked by k_stats / k_reset.
-//   k_reset    one wavefront per environment to reset: PcgrlEnv.reset (pcgrl_env.py:66-76): the MT19937
-//              ring is staged in LDS and the wave produces 128 words per round, tiles are drawn with
-//              numpy's choice() rule, written coalesced as uint8 and transposed through LDS into the
-//              row bit planes; cursor draw; BinaryProblem.reset (binary_prob.py:68-72); start stats
-//              (problem.py:45-46) on the rows that are already in registers.
+//              work item: Problem.get_stats as row-bitboard programs (pcgrl_algos.h), get_reward,
+//              get_episode_over, get_debug_info (pcgrl_env.py:138-148).  An environment whose episode ended
+//              is reset right there by its wavefront (reset_env.h): PcgrlEnv.reset (pcgrl_env.py:66-76) --
+//              the MT19937 ring is staged in LDS and the wave produces 128 words per round, tiles are drawn
+//              with numpy's choice() rule, written coalesced as uint8 and turned into row bit planes; cursor
+//              draw; BinaryProblem.reset (binary_prob.py:68-72); start stats (problem.py:45-46) on the rows
+//              that are already in registers.
+//   k_reset    one wavefront per environment on a reset list: pcgrl_reset, and the Sokoban step.
+//   k_sokoban  (Sokoban only) the solver jobs parked by k_stats / k_reset: kernels_sokoban.h.
 //
 // State is structure-of-arrays over the environment axis, all in HBM, owned by the caller
 // (include/pcgrl_hip.h).  The uint8 map is the observation; the kernels compute on `planes`

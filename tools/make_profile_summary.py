@@ -45,6 +45,13 @@ for W in workloads:
         out.append("HBM traffic per step (sum over the step's kernels, as reported: rocprofv3 KB; FETCH_SIZE may under-report wide coalesced reads by 2x on gfx950, "
                    "these kernels issue mostly narrow scattered accesses, so the figure is uncalibrated): fetch %.1f MB + write %.1f MB.\n" % (tot_f / 1024, tot_w / 1024))
         json.dump({"workload": W, "fetch_bytes_per_step": tot_f * 1024, "write_bytes_per_step": tot_w * 1024}, open(os.path.join(dst, W + "_traffic.json"), "w"))
+        # per-kernel counter averages, read back by bench.py for the VALU-issue figure of the dominant kernel
+        pm = {}
+        for k, v in sq.items():
+            if k.startswith(("void k_", "k_")) and len(v[cols[0]]) >= 4:
+                kk = k.replace("void ", "").split("<")[0]
+                pm[kk] = {c: sum(v[c]) / len(v[c]) for c in cols if c in v}
+        json.dump({"workload": W, "per_dispatch": pm}, open(os.path.join(dst, W + "_pmc.json"), "w"))
     for cand in ("bench_%s.json" % W, "bench_%s.log" % W):
         b = os.path.join(G, cand)
         if os.path.exists(b) and os.path.getsize(b) > 10:
