@@ -125,7 +125,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         // ---- round trip 3
         if (chg) {
             changes += 1;
-            B.heat[((size_t)e * H + hy) * W + hx] += 1;
+            heat_increment(B, B.heat + ((size_t)e * H + hy) * W + hx);
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
         if (REP != PCGRL_REP_WIDE) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
         if (change > 0) {
             chg = true;
             changes += change;
-            B.heat[((size_t)e * H + y) * W + x] += 1;
+            heat_increment(B, B.heat + ((size_t)e * H + y) * W + x);
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
         reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);

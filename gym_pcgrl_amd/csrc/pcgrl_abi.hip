@@ -240,6 +240,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     if (h->cfg.prob == PCGRL_BINARY && !b->rng_prob) return PCGRL_EINVAL;
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
+    B.heat_end = B.heat + (size_t)h->cfg.num_envs * h->cfg.width * h->cfg.height;
     B.planes = b->planes; B.counters = (int32_t*)b->counters; B.stats = (int32_t*)b->stats;
     B.start_stats = (int32_t*)b->start_stats; B.info = (int32_t*)b->info; B.reward = (double*)b->reward;
     B.done = (uint8_t*)b->done; B.tile_p = (double*)b->tile_p; B.rng_rep = (uint32_t*)b->rng_rep;

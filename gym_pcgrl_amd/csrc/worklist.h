@@ -20,6 +20,7 @@ enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5
 
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
+    const uint16_t* heat_end;        // end of the caller's whole heatmap buffer (also in sub-batch views)
     int32_t* counters; int32_t* stats; int32_t* start_stats; int32_t* info;
     double* reward; uint8_t* done; double* tile_p;
     uint32_t* rng_rep; uint32_t* rng_prob; int32_t* rng_cur;
@@ -113,6 +114,16 @@ __device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int
     }
     const int regions = P.prob == PCGRL_PROB_ZELDA ? s1.x : s0.w;
     return min(max(regions, 0), WL_NSHARD - 1);
+}
+
+// heatmap[cell] += 1 (pcgrl_env.py:137) without waiting for the old value: a no-return 32-bit atomic add on the
+// word that holds the 16-bit counter (counts stay below 2^16, so a half never carries into the other).  Only the
+// very last counter of a buffer with an odd number of cells has no complete word; it takes the plain path.
+__device__ __forceinline__ void heat_increment(const DevBufs& B, uint16_t* cell) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(cell);
+    uint32_t* word = reinterpret_cast<uint32_t*>(a & ~(uintptr_t)3);
+    if (reinterpret_cast<uintptr_t>(word) + 4 <= reinterpret_cast<uintptr_t>(B.heat_end)) atomicAdd(word, 1u << ((a & 2) * 8));
+    else *cell += 1;
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
