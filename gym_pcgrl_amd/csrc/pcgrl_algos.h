@@ -187,8 +187,21 @@ PCGRL_D typename B::mask_t pcg_fill_cols(B& g, typename B::mask_t f, const PcgFi
 template <class B>
 PCGRL_D typename B::mask_t pcg_component(B& g, typename B::mask_t seed, const PcgFillCtx<B>& c) {
     typedef typename B::mask_t M;
-    M f = pcg_fill_rows(g, seed, c.pass, c.rpass);
     PCGRL_TRACE(g, 1);
+    if (B::kGroup != 16) {
+        // Whole-wavefront groups (tall maps): a fill round costs ~100 instructions there (64-bit masks, the extra
+        // block hop) and most components of a large random map are small, so plain flood steps go first -- two per
+        // exit test, eight at most -- and the run/column fills only take over for what is still growing.
+        M f = seed;
+        for (int i = 0; i < 4; i++) {
+            M n = pcg_expand(g, f) & c.pass;
+            n = pcg_expand(g, n) & c.pass;
+            if (!g.wave_any(n ^ f)) return f;
+            f = n;
+        }
+        seed = f;
+    }
+    M f = pcg_fill_rows(g, seed, c.pass, c.rpass);
     for (;;) {
         M n = pcg_fill_cols(g, f, c);
         n = pcg_fill_rows(g, n, c.pass, c.rpass);
@@ -284,11 +297,13 @@ PCGRL_D int count_regions(B& g, typename B::mask_t pass) {
 }
 
 // helper.py:250-264 for one component: sweep from its first cell in row-major order, np.argmax == first
-// bit of the last frontier, second sweep; returns the second eccentricity.
+// bit of the last frontier, second sweep; returns the second eccentricity (or 0 when it provably cannot exceed `best`).
 template <class B>
-PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp) {
+PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
     typename B::mask_t last, unused;
-    bfs_levels(g, g.first_bit(comp), comp, last);
+    const int e1 = bfs_levels(g, g.first_bit(comp), comp, last);
+    // the second sweep measures an eccentricity, which cannot exceed the diameter <= 2 * e1
+    if (2 * e1 <= best) return 0;
     return bfs_levels(g, g.first_bit(last), comp, unused);
 }
 
@@ -318,7 +333,7 @@ PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& region
             const M comp = pcg_component(g, seed, ctx);
             rest = rest & ~comp;
             ++regions;
-            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp); path = e > path ? e : path; }
+            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); path = e > path ? e : path; }
             seed = g.first_bit(rest);
         }
         return;
@@ -334,14 +349,14 @@ PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& region
         else if (size > size2) { size3 = size2; size2 = size; big2 = comp; }
         else if (size > size3) size3 = size;
     }
-    if (size1 - 1 > path) { const int e = pcg_double_sweep(g, big1); path = e > path ? e : path; }
-    if (size2 - 1 > path) { const int e = pcg_double_sweep(g, big2); path = e > path ? e : path; }
+    if (size1 - 1 > path) { const int e = pcg_double_sweep(g, big1, path); path = e > path ? e : path; }
+    if (size2 - 1 > path) { const int e = pcg_double_sweep(g, big2, path); path = e > path ? e : path; }
     if (size3 - 1 > path) {   // rare: a third component is still large enough to matter
         rest = nontiny & ~big1 & ~big2;
         while (g.any(rest)) {
             const M comp = pcg_component(g, g.first_bit(rest), ctx);
             rest = rest & ~comp;
-            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp); path = e > path ? e : path; }
+            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); path = e > path ? e : path; }
         }
     }
 }
