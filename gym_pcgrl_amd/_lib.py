@@ -43,7 +43,7 @@ class Buffers(C.Structure):
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
-           "pcgrl_profile_read")
+           "pcgrl_profile_read", "pcgrl_bind_episode_stats")
 NPHASE = 6
 # the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
 # other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
@@ -108,6 +108,7 @@ def load():
     L.pcgrl_action_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     L.pcgrl_profile.argtypes = [C.c_void_p, C.c_int]
+    L.pcgrl_bind_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _lib = L
     return L

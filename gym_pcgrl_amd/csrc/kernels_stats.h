@@ -23,6 +23,7 @@ __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBuf
         const bool d = episode_over(P, s, sv) || c.y >= P.max_changes || c.x >= P.max_iterations;
         B.reward[e] = r;
         B.done[e] = d ? 1 : 0;
+        episode_account(B, e, r, d);
         int32_t* inf = B.info + (size_t)e * 10;
         for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
         if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)

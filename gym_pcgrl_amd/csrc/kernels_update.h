@@ -137,6 +137,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             const bool d = episode_over(P, s, st) || changes >= P.max_changes || iter >= P.max_iterations;
             B.reward[e] = 0.0;
             B.done[e] = d ? 1 : 0;
+            episode_account(B, e, 0.0, d);
             int32_t* inf = B.info + (size_t)e * 10;
             inf[0] = s0.x; inf[1] = s0.y; inf[2] = s0.z; inf[3] = s0.w;
             inf[4] = s1.x; inf[5] = s1.y; inf[6] = s1.z; inf[7] = s1.w;
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
             const bool d = episode_over(P, s, st) || changes >= P.max_changes || iter >= P.max_iterations;
             B.reward[e] = 0.0;
             B.done[e] = d ? 1 : 0;
+            episode_account(B, e, 0.0, d);
             if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - st[1];
             inf[8] = iter; inf[9] = changes;
             rst = d && P.auto_reset;

@@ -241,6 +241,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
     B.heat_end = B.heat + (size_t)h->cfg.num_envs * h->cfg.width * h->cfg.height;
+    B.ep_return = nullptr; B.ep_length = nullptr; B.last_return = nullptr; B.last_length = nullptr;
     B.planes = b->planes; B.counters = (int32_t*)b->counters; B.stats = (int32_t*)b->stats;
     B.start_stats = (int32_t*)b->start_stats; B.info = (int32_t*)b->info; B.reward = (double*)b->reward;
     B.done = (uint8_t*)b->done; B.tile_p = (double*)b->tile_p; B.rng_rep = (uint32_t*)b->rng_rep;
@@ -559,6 +560,31 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (rc) return rc;
     h->parity ^= 1;
     if (h->profiling) h->prof_steps++;
+    return PCGRL_OK;
+}
+
+// Optional per-environment episode statistics, kept by the step kernels.  All four DEVICE pointers or all NULL
+// (off, the default).  Call after pcgrl_bind; the buffers are zeroed here.
+int pcgrl_bind_episode_stats(pcgrl_env* h, double* ep_return, int32_t* ep_length, double* last_return, int32_t* last_length,
+                             void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    const int any = (ep_return != nullptr) + (ep_length != nullptr) + (last_return != nullptr) + (last_length != nullptr);
+    if (any != 0 && any != 4) return PCGRL_EINVAL;
+    const size_t n = (size_t)h->cfg.num_envs;
+    if (any) {
+        HIPCHK(hipMemsetAsync(ep_return, 0, n * 8, (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(ep_length, 0, n * 4, (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(last_return, 0, n * 8, (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(last_length, 0, n * 4, (hipStream_t)stream));
+    }
+    h->B.ep_return = ep_return; h->B.ep_length = ep_length; h->B.last_return = last_return; h->B.last_length = last_length;
+    for (int k = 0; k < h->nsub && h->nsub > 1; k++) {
+        int lo, hi;
+        sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
+        DevBufs& S = h->subB[k];
+        S.ep_return = any ? ep_return + lo : nullptr; S.ep_length = any ? ep_length + lo : nullptr;
+        S.last_return = any ? last_return + lo : nullptr; S.last_length = any ? last_length + lo : nullptr;
+    }
     return PCGRL_OK;
 }
 

@@ -21,6 +21,8 @@ enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     const uint16_t* heat_end;        // end of the caller's whole heatmap buffer (also in sub-batch views)
+    // optional episode statistics (pcgrl_bind_episode_stats): running return/length, latched at the end of an episode
+    double* ep_return; int32_t* ep_length; double* last_return; int32_t* last_length;
     int32_t* counters; int32_t* stats; int32_t* start_stats; int32_t* info;
     double* reward; uint8_t* done; double* tile_p;
     uint32_t* rng_rep; uint32_t* rng_prob; int32_t* rng_cur;
@@ -114,6 +116,16 @@ __device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int
     }
     const int regions = P.prob == PCGRL_PROB_ZELDA ? s1.x : s0.w;
     return min(max(regions, 0), WL_NSHARD - 1);
+}
+
+// What stable-baselines' Monitor does around the reference env (utils.py:13-29, 60-71): sum the rewards of the running
+// episode in step order and count its steps; when the episode ends, latch both and start over.
+__device__ __forceinline__ void episode_account(const DevBufs& B, int e, double r, bool d) {
+    if (!B.ep_return) return;
+    double R = B.ep_return[e] + r;
+    int L = B.ep_length[e] + 1;
+    if (d) { B.last_return[e] = R; B.last_length[e] = L; R = 0.0; L = 0; }
+    B.ep_return[e] = R; B.ep_length[e] = L;
 }
 
 // heatmap[cell] += 1 (pcgrl_env.py:137) without waiting for the old value: a no-return 32-bit atomic add on the

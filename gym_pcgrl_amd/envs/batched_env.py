@@ -70,7 +70,8 @@ class BatchedPcgrlEnv:
         self._max_iterations = self._max_changes * self._prob._width * self._prob._height
         self._handle = None
         self._bufs = None
-        self._rng = None          # RNG tensors survive re-allocation on width/height changes
+        self._rng = None
+        self._episode = None          # RNG tensors survive re-allocation on width/height changes
         self._needs_reset = True
         self._alloc_dims = None
         self._probs_dirty = False
@@ -167,6 +168,8 @@ class BatchedPcgrlEnv:
             self._probs_dirty = False
         if not self._rng_seeded:
             self._upload_seeds()
+        if self._episode is not None:      # rebinding after a reallocation keeps the running episodes' sums
+            self._bind_episode_stats()
 
     def _upload_seeds(self):
         keys = np.ascontiguousarray(self._seed_keys, dtype=np.uint32)
@@ -265,6 +268,41 @@ class BatchedPcgrlEnv:
 
     def step_wait(self):
         return self._pending
+
+    # ---- episode statistics (stable-baselines Monitor as wrapped around the reference env, utils.py:13-29)
+    def enable_episode_stats(self, enable=True):
+        """Keep per-environment episode return/length on the device (updated by the step kernels).  After a step,
+        `episode_stats()` gives the values of the episodes that just ended (where done is set)."""
+        if enable:
+            if self._handle is None:
+                self._allocate()
+            if self._episode is None:
+                torch, n, dev = self._torch, self.num_envs, self.device
+                self._episode = OrderedDict(
+                    ep_return=torch.zeros(n, dtype=torch.float64, device=dev), ep_length=torch.zeros(n, dtype=torch.int32, device=dev),
+                    last_return=torch.zeros(n, dtype=torch.float64, device=dev), last_length=torch.zeros(n, dtype=torch.int32, device=dev))
+                self._bind_episode_stats(zero=True)
+        elif self._episode is not None:
+            self._episode = None
+            if self._handle is not None:
+                _lib.check(self._lib.pcgrl_bind_episode_stats(self._handle, None, None, None, None, self._stream()), "pcgrl_bind_episode_stats")
+
+    def _bind_episode_stats(self, zero=False):
+        e = self._episode
+        keep = None if zero else {k: v.clone() for k, v in e.items()}
+        _lib.check(self._lib.pcgrl_bind_episode_stats(self._handle, e["ep_return"].data_ptr(), e["ep_length"].data_ptr(),
+                                                     e["last_return"].data_ptr(), e["last_length"].data_ptr(), self._stream()),
+                   "pcgrl_bind_episode_stats")
+        if keep is not None:           # the ABI call zeroes the buffers
+            for k, v in keep.items():
+                e[k].copy_(v)
+
+    def episode_stats(self):
+        """-> dict of device tensors: running `ep_return`/`ep_length`, and `last_return`/`last_length` of the most
+        recently finished episode of every environment (valid where the last step returned done)."""
+        if self._episode is None:
+            raise RuntimeError("call enable_episode_stats() first")
+        return self._episode
 
     def set_maps(self, maps):
         """Overwrite every map (uint8 [N,H,W]) and recompute the current stats on the device."""

@@ -1,0 +1,68 @@
+"""Device-resident rollout collection for an on-policy trainer (the role of stable-baselines' runner behind the
+reference's `train.py:86-94`: `model.learn` steps a VecEnv `n_steps` at a time and hands PPO the stacked
+observations, actions, rewards and episode starts).
+
+Everything stays on the GPU: the batched environment writes rewards/dones into its own tensors, the wrapped
+observation is one uint8 image tensor, and this module only copies them into preallocated `[T, N, ...]` storage.
+No policy or optimiser lives here (out of scope): `policy(obs) -> actions` is any callable on device
+tensors.
+"""
+from collections import OrderedDict
+
+
+class RolloutBuffer:
+    """Preallocated `[T, N, ...]` device storage of one rollout."""
+
+    def __init__(self, torch, n_steps, num_envs, obs_shape, action_shape, device):
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        self.n_steps, self.num_envs = n_steps, num_envs
+        self.obs = z((n_steps, num_envs) + tuple(obs_shape), torch.uint8)
+        self.actions = z((n_steps, num_envs) + tuple(action_shape), torch.int64)
+        self.rewards = z((n_steps, num_envs), torch.float64)
+        self.dones = z((n_steps, num_envs), torch.bool)
+        self.episode_starts = z((n_steps, num_envs), torch.bool)     # obs[t] is the first observation of an episode
+        self.last_obs = z((num_envs,) + tuple(obs_shape), torch.uint8)
+
+    def as_dict(self):
+        return OrderedDict(obs=self.obs, actions=self.actions, rewards=self.rewards, dones=self.dones,
+                           episode_starts=self.episode_starts, last_obs=self.last_obs)
+
+
+class RolloutCollector:
+    """Steps a `BatchedVecEnv` (utils.make_vec_envs) with `policy` and fills a RolloutBuffer.
+
+    collect() continues from where the previous call stopped (like a SB runner: the environment is only reset
+    once), so consecutive rollouts tile the same trajectories.  With `vec_env.monitor` the finished episodes'
+    returns/lengths accumulate in `episode_returns` / `episode_lengths` (device tensors, no host sync)."""
+
+    def __init__(self, vec_env, n_steps):
+        self.env = vec_env
+        self.torch = vec_env.env.pcgrl_env._torch
+        dev = vec_env.env.pcgrl_env.device
+        a = vec_env.action_space
+        ashape = () if hasattr(a, "n") else (len(a.nvec),)
+        self.buffer = RolloutBuffer(self.torch, n_steps, vec_env.num_envs, vec_env.observation_space.shape, ashape, dev)
+        self._obs = None
+        self._start = self.torch.ones(vec_env.num_envs, dtype=self.torch.bool, device=dev)
+        self.episode_returns, self.episode_lengths = [], []
+
+    def collect(self, policy):
+        torch, b = self.torch, self.buffer
+        if self._obs is None:
+            self._obs = self.env.reset()
+        for t in range(b.n_steps):
+            b.obs[t].copy_(self._obs)
+            b.episode_starts[t].copy_(self._start)
+            actions = policy(self._obs)
+            b.actions[t].copy_(actions)
+            self._obs, rew, done, _ = self.env.env.step(actions)     # the wrapper below the Monitor layer: no host sync
+            b.rewards[t].copy_(rew)
+            b.dones[t].copy_(done)
+            self._start = done.to(torch.bool).clone()
+            if self.env.monitor:
+                st = self.env.episode_stats()
+                m = b.dones[t]
+                self.episode_returns.append(torch.where(m, st["last_return"], torch.full_like(st["last_return"], float("nan"))))
+                self.episode_lengths.append(torch.where(m, st["last_length"], torch.zeros_like(st["last_length"])))
+        b.last_obs.copy_(self._obs)
+        return b

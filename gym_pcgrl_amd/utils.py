@@ -5,8 +5,12 @@ SubprocVecEnv workers of wrapped single environments, this returns ONE batched, 
 observations are one uint8 image tensor [n_cpu, h, w, depth] (the reference's wrapped observation), done
 environments are reset inside `step` like SubprocVecEnv does.
 
-`log_dir`, `render` and `max_step` belong to the trainer's RenderMonitor (utils.py:13-29) and are accepted but
-ignored: monitoring/rendering is outside the accelerated path.
+The reference wraps every worker in RenderMonitor (a stable-baselines Monitor, utils.py:13-29) whose product is
+`info["episode"] = {"r": return, "l": length}` on the step that ends an episode.  Here the step kernels keep those
+sums per environment (`BatchedPcgrlEnv.enable_episode_stats`); `monitor=True` (the default when `log_dir` is given,
+as in the reference) adds the same `episode` entry to the infos of finished environments and `episode_stats()`
+returns them as device tensors without any host round trip.  `render` and `max_step` are accepted and ignored
+(rendering is outside the accelerated path; `max_step` is unused by the reference wrapper too, utils.py:21-29).
 """
 import numpy as np
 
@@ -15,9 +19,12 @@ from .wrappers import ActionMapImagePCGRLWrapper, CroppedImagePCGRLWrapper
 
 
 class BatchedVecEnv:
-    def __init__(self, wrapped, image_shape, n_actions):
+    def __init__(self, wrapped, image_shape, n_actions, monitor=False):
         self.env = wrapped
         self.num_envs = wrapped.num_envs
+        self.monitor = bool(monitor)
+        if self.monitor:
+            wrapped.pcgrl_env.enable_episode_stats()
         self.observation_space = spaces.Box(low=0, high=255, shape=image_shape, dtype=np.uint8)
         self.action_space = spaces.Discrete(n_actions) if np.ndim(n_actions) == 0 else spaces.MultiDiscrete(n_actions)
         self._pending = None
@@ -26,10 +33,24 @@ class BatchedVecEnv:
         return self.env.reset()
 
     def step(self, actions):
-        return self.env.step(actions)
+        out = self.env.step(actions)
+        if not self.monitor:
+            return out
+        obs, rew, done, infos = out
+        idx = done.nonzero().flatten()
+        if idx.numel():                      # Monitor.step: ep_info = {"r": round(sum(rewards), 6), "l": len(rewards)}
+            st = self.env.pcgrl_env.episode_stats()
+            r = st["last_return"][idx].cpu().numpy()
+            l = st["last_length"][idx].cpu().numpy()
+            infos = _EpisodeInfos(infos, {int(i): {"r": round(float(a), 6), "l": int(b)} for i, a, b in zip(idx.cpu().numpy(), r, l)})
+        return obs, rew, done, infos
+
+    def episode_stats(self):
+        """Device tensors of the in-kernel episode statistics (see BatchedPcgrlEnv.episode_stats)."""
+        return self.env.pcgrl_env.episode_stats()
 
     def step_async(self, actions):
-        self._pending = self.env.step(actions)
+        self._pending = self.step(actions)
 
     def step_wait(self):
         return self._pending
@@ -41,8 +62,28 @@ class BatchedVecEnv:
         self.env.close()
 
 
-def make_vec_envs(env_name, representation, log_dir=None, n_cpu=1, seed=None, device=None, **kwargs):
+class _EpisodeInfos:
+    """The batched info object of the step plus Monitor's per-environment `episode` entries."""
+
+    def __init__(self, base, episodes):
+        self._base, self.episodes = base, episodes
+
+    def __getitem__(self, key):
+        return self._base[key]
+
+    def __getattr__(self, name):
+        return getattr(self._base, name)
+
+    def to_list(self):
+        out = self._base.to_list()
+        for i, ep in self.episodes.items():
+            out[i]["episode"] = ep
+        return out
+
+
+def make_vec_envs(env_name, representation, log_dir=None, n_cpu=1, seed=None, device=None, monitor=None, **kwargs):
     kwargs = dict(kwargs)
+    monitor = (log_dir is not None) if monitor is None else monitor
     kwargs.pop("render", None)
     kwargs.pop("max_step", None)
     crop_size = kwargs.pop("cropped_size", 28)
@@ -50,8 +91,8 @@ def make_vec_envs(env_name, representation, log_dir=None, n_cpu=1, seed=None, de
         w = ActionMapImagePCGRLWrapper(env_name, num_envs=n_cpu, seed=seed, device=device, **kwargs)
         p = w.pcgrl_env._prob
         h_, w_, d_ = int(p._height), int(p._width), (w.pcgrl_env.get_num_tiles() if w.one_hot else 1)
-        return BatchedVecEnv(w, (h_, w_, d_), h_ * w_ * w.pcgrl_env.get_num_tiles())
+        return BatchedVecEnv(w, (h_, w_, d_), h_ * w_ * w.pcgrl_env.get_num_tiles(), monitor)
     w = CroppedImagePCGRLWrapper(env_name, crop_size, num_envs=n_cpu, seed=seed, device=device, **kwargs)   # utils.py:51-53
     d_ = w.pcgrl_env.get_num_tiles() if w.one_hot else 1
     a = w.pcgrl_env.action_space
-    return BatchedVecEnv(w, (crop_size, crop_size, d_), a.n if hasattr(a, "n") else [int(v) for v in a.nvec])
+    return BatchedVecEnv(w, (crop_size, crop_size, d_), a.n if hasattr(a, "n") else [int(v) for v in a.nvec], monitor)

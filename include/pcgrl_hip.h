@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PCGRL_ABI_VERSION 1
+#define PCGRL_ABI_VERSION 2
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -119,6 +119,13 @@ int pcgrl_observe(pcgrl_env* env, uint8_t* out, int32_t out_h, int32_t out_w, in
 /* ActionMap.step for the wide representation (wrappers.py:139-154): flat DEVICE i32 [N] index into
  * (H, W, tiles) -> xyv DEVICE i32 [N,3] = (x, y, tile), the action pcgrl_step takes. */
 int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* stream);
+/* Episode statistics kept by the step kernels -- what stable-baselines' Monitor keeps around the reference env in
+ * utils.make_env / make_vec_envs (utils.py:13-29, 60-71).  ep_return f64 [N], ep_length i32 [N]: reward sum (in step
+ * order) and step count of the running episode; last_return / last_length: the same, latched when an episode ends
+ * (read them where done == 1).  DEVICE pointers, zeroed by the call; pass four NULLs to switch the feature off (the
+ * default).  Call after pcgrl_bind. */
+int pcgrl_bind_episode_stats(pcgrl_env* env, double* ep_return, int32_t* ep_length, double* last_return,
+                             int32_t* last_length, void* stream);
 /* Sticky device status word (0 = fine; bit 0: a sokoban level had more crates than the solver supports).
  * Synchronises the stream. */
 int pcgrl_status(pcgrl_env* env, void* stream, int32_t* status);

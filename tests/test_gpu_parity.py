@@ -357,3 +357,82 @@ def test_make_vec_envs_surface():
     obs, r, d, info = v.step_wait()
     assert tuple(obs.shape) == (32, 14, 14, 1)
     v.close()
+
+
+# ------------------------------------------------------------------ episode statistics + rollout collection
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-wide-v0", "sokoban-turtle-v0"])
+def test_episode_stats_match_oracle_sums(env_id):
+    """The in-kernel Monitor (pcgrl_bind_episode_stats): return and length latched when an episode ends must equal
+    the sums over the oracle's rewards of that episode, for every environment and every episode."""
+    import gym_pcgrl_amd as gp
+    torch = _torch()
+    prob, rep = env_id.split("-")[0], env_id.split("-")[1]
+    N, T = 48, 160
+    env = gp.make_batched(env_id, num_envs=N, seed=700)
+    env.enable_episode_stats()
+    env.reset()
+    rs = np.random.RandomState(11)
+    sp = env.single_action_space
+    if hasattr(sp, "n"):
+        acts = rs.randint(0, sp.n, size=(T, N)).astype(np.int32)
+    else:
+        acts = np.stack([rs.randint(0, int(k), size=(T, N)) for k in sp.nvec], -1).astype(np.int32)
+    got_r, got_l, got_d = [], [], []
+    for t in range(T):
+        _, _, done, _ = env.step(torch.as_tensor(acts[t], device="cuda"))
+        st = env.episode_stats()
+        got_r.append(st["last_return"].cpu().numpy().copy()); got_l.append(st["last_length"].cpu().numpy().copy())
+        got_d.append(done.cpu().numpy().astype(bool).copy())
+    checked = 0
+    for i in range(N):
+        e = ol.OracleEnv(prob, rep)
+        e.seed(700 + i)
+        e.reset()
+        out = e.rollout(acts[:, i])
+        ret, length = 0.0, 0
+        for t in range(T):
+            ret += float(out["reward"][t]); length += 1
+            assert bool(out["done"][t]) == bool(got_d[t][i])
+            if out["done"][t]:
+                assert got_r[t][i] == ret and got_l[t][i] == length, (i, t, got_r[t][i], ret, got_l[t][i], length)
+                ret, length = 0.0, 0
+                checked += 1
+    assert checked >= N
+
+
+@pytest.mark.gpu
+def test_vec_env_monitor_and_rollout_collector():
+    from gym_pcgrl_amd.rollout import RolloutCollector
+    from gym_pcgrl_amd.utils import make_vec_envs
+    torch = _torch()
+    venv = make_vec_envs("binary-narrow-v0", "narrow", log_dir="unused", n_cpu=64, seed=5)
+    assert venv.monitor
+    n_act = venv.action_space.n
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    policy = lambda obs: torch.randint(0, n_act, (obs.shape[0],), device=obs.device, generator=g)
+    col = RolloutCollector(venv, n_steps=120)
+    b = col.collect(policy)
+    assert b.obs.shape[:2] == (120, 64) and b.obs.dtype == torch.uint8
+    assert bool(b.episode_starts[0].all()) and torch.equal(b.episode_starts[1:], b.dones[:-1])
+    # the Monitor sums equal the sums of the collected rewards per episode
+    rew, done = b.rewards.cpu().numpy(), b.dones.cpu().numpy()
+    ep_r = torch.stack(col.episode_returns).cpu().numpy()
+    ep_l = torch.stack(col.episode_lengths).cpu().numpy()
+    n_ep = 0
+    for i in range(64):
+        acc, ln = 0.0, 0
+        for t in range(120):
+            acc += rew[t, i]; ln += 1
+            if done[t, i]:
+                assert ep_r[t, i] == acc and ep_l[t, i] == ln
+                acc, ln = 0.0, 0
+                n_ep += 1
+    assert n_ep > 0
+    # second rollout continues the same trajectories; the Monitor layer of the VecEnv reports `episode` infos
+    b2 = col.collect(policy)
+    assert torch.equal(b2.episode_starts[0], torch.as_tensor(done[-1], device="cuda"))
+    obs, r, d, infos = venv.step(policy(b2.last_obs))
+    lst = infos.to_list()
+    for i in np.nonzero(d.cpu().numpy())[0]:
+        assert set(lst[i]["episode"]) == {"r", "l"}
