@@ -27,9 +27,9 @@ enum { SOK_SY_TICKET_A = 0, SOK_SY_TICKET_B = 1, SOK_SY_HARD = 2, SOK_SY_BFS_DON
 __device__ __forceinline__ int sok_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct SokSpawnHook {     // BFS: publish the level once the search has proven to be a long one
-    int32_t* sync; int32_t* hard; int spawn_at; int tag; int* spawned;
+    int32_t* sync; int32_t* hard; int spawn_at; int tag; int* spawned; int lane;
     __device__ __forceinline__ bool operator()(int it) const {
-        if (it == spawn_at) {
+        if (it == spawn_at && lane == 0) {
             const int idx = atomicAdd(sync + SOK_SY_HARD, 1);
             if (idx < SOK_HARD_CAP) { __hip_atomic_store(hard + idx, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *spawned = 1; }
         }
@@ -39,6 +39,25 @@ struct SokSpawnHook {     // BFS: publish the level once the search has proven t
 struct SokPollHook {      // A*: stop when the result cannot be selected any more
     const int32_t* stop; int need;
     __device__ __forceinline__ bool operator()(int it) const { return (it & SOK_POLL_MASK) == 0 && sok_ld(stop) >= need; }
+};
+
+// The four children of a pop, one per lane (lanes 0..3 run the search in lockstep; everything else in it is
+// uniform across them).  The results come back through v_readlane, i.e. as scalars.
+struct SokKidsLanes {
+    int lane;
+    template <int NW>
+    __device__ __forceinline__ void operator()(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, SokChild* out) const {
+        const SokChild mine = sokf_child<NW>(F, cr, cb, player, h, lane & 3);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.cr, d);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.cr >> 32), d);
+            out[d].cr = ((uint64_t)hi << 32) | lo;
+            out[d].np = __builtin_amdgcn_readlane(mine.np, d);
+            out[d].h = __builtin_amdgcn_readlane(mine.h, d);
+            out[d].ok = __builtin_amdgcn_readlane(mine.ok, d);
+        }
+    }
 };
 
 // One agent of environment e is done.  The fourth report selects the result and finishes the item.
@@ -74,17 +93,20 @@ __device__ __forceinline__ void sok_report(const PcgrlParams& P, const DevBufs& 
 }
 
 // One agent on the level in L: the register-resident search (sokoban_fast.h; LDS heap + 64-bit-key table) when the
-// level qualifies, else the generic one (LDS or global-arena heap/table).  Called by lane 0.
+// level qualifies, else the generic one (LDS or global-arena heap/table).  Called by lanes 0..3 for the former (the
+// four children of a pop are made side by side), by lane 0 for the latter.
 template <class Hook>
 __device__ __forceinline__ bool sok_run_agent(const DevBufs& B, int power, const SokLevel& L, SokNode& work, const SokNode& root, SokNode* pool,
                                               uint32_t* lds, SokFastNode* cache, uint32_t* g_heap, uint32_t* g_table, int tsize, int fast, int k,
-                                              int& hh, int& dd, int& it, bool& exhausted, Hook hook) {
+                                              int& hh, int& dd, int& it, bool& exhausted, Hook hook, int lane) {
     if (fast) {
+        const SokKidsLanes kids = {lane};
         uint64_t* tab = reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP);
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool);
-        if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook);
-        return sok_search_fast<4>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook);
+        if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids);
+        return sok_search_fast<4>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids);
     }
+    if (lane != 0) return false;
     if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
         return sok_search(L, pool, lds, lds + SOK_LDS_HEAP, tsize - 1, work, root, k, power, hh, dd, it, exhausted, hook);
     return sok_search(L, pool, g_heap, g_table, tsize - 1, work, root, k, power, hh, dd, it, exhausted, hook);
@@ -156,36 +178,39 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
             sok_init_deadlocks(s_L);
             s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
             s_spawned = 0;
-            s_fast = (B.sok_use_lds && s_L.nc <= SOKF_MAXC) ? 1 : 0;
+            s_fast = (B.sok_use_lds && s_L.nc <= B.sok_fast_maxc) ? 1 : 0;
         }
         __threadfence_block();
         const int fast = s_fast;
         // BFS job: agent 0 and -- only if the level could not be published -- the other agents after it, with the
-        // exact exhausted-BFS shortcut.  A* ticket: that one agent.  The search is driven by lane 0; every lane
-        // helps to clear the visited table.
+        // exact exhausted-BFS shortcut.  A* ticket: that one agent.  The search runs on lanes 0..3 (register-resident
+        // path: uniform except for the four children of a pop) or on lane 0 (generic path); every lane helps to clear
+        // the visited table.
         int dist = 0, sol = 0, go = 1, reported = 0;
         for (int a = first; a <= last && go; a++) {
-            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }   // 64-bit keys else if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
+            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }   // 64-bit keys
+            else if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) sok_lds[SOK_LDS_HEAP + i] = 0; }
             else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
             __threadfence_block();
-            if (lane == 0) {
+            if (lane < (fast ? 4 : 1)) {
                 int hh = 0, dd = 0, it = 0;
                 bool exhausted = false, win = false;
                 if (kind == 1 && a == 0) {
                     int sp = P.solver_power < SOK_SPAWN_ITERS ? P.solver_power : SOK_SPAWN_ITERS;
-                    SokSpawnHook hook = {sync, hard, sp, (e + 1) | (mode << 28), &s_spawned};
-                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, -1, hh, dd, it, exhausted, hook);
-                    if (s_spawned) { sok_report(P, B, e, 0, win, hh, dd, exhausted, mode, parity, rst_list); reported = 1; go = 0; }
+                    SokSpawnHook hook = {sync, hard, sp, (e + 1) | (mode << 28), &s_spawned, lane};
+                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, -1, hh, dd, it, exhausted, hook, lane);
+                    __threadfence_block();
+                    if (s_spawned) { if (lane == 0) sok_report(P, B, e, 0, win, hh, dd, exhausted, mode, parity, rst_list); reported = 1; go = 0; }
                     else go = !(win || exhausted);
                 } else if (kind == 1) {
-                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, SokNoHook());
+                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, SokNoHook(), lane);
                     go = !win;
                 } else {
                     SokPollHook hook = {B.sok_stop + e, 4 - a};
                     if (sok_ld(B.sok_stop + e) < 4 - a) {
-                        win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, hook);
+                        win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, hook, lane);
                     }
-                    sok_report(P, B, e, a, win, hh, dd, false, mode, parity, rst_list);
+                    if (lane == 0) sok_report(P, B, e, a, win, hh, dd, false, mode, parity, rst_list);
                     reported = 1;
                 }
                 dist = win ? 0 : hh;

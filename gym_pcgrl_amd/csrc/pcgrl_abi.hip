@@ -278,6 +278,10 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         HIPCHK(hipMemsetAsync(a, 0, sok_sched_bytes(h->cfg.num_envs), (hipStream_t)stream));
         a += sok_sched_bytes(h->cfg.num_envs);
         B.sok_use_lds = power <= SOK_LDS_POWER;
+        {   // PCGRL_SOK_GENERIC=1: every level takes the generic search (tests)
+            const char* sg = getenv("PCGRL_SOK_GENERIC");
+            B.sok_fast_maxc = (sg && sg[0] == '1') ? -1 : SOKF_MAXC;
+        }
         B.sok_table_size = sok_table_size(power);
         B.sok_heap_stride = (int32_t)(align_up(nodes * 4, 256) / 4);
         if (!B.sok_use_lds) {

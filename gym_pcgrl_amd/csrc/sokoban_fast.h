@@ -99,6 +99,39 @@ PCGRL_D int sokf_crate_index(uint64_t cr, int p) {
 #endif
 }
 
+// One child of Node.getChildren (State.update engine.py:298-327) for direction d = 0..3 (L, R, U, D): dropped if the
+// player did not move, if the pushed crate is blocked, or if after the push any crate stands on a deadlock cell.
+struct SokChild { uint64_t cr; int np, h, ok; };
+template <int NW>
+PCGRL_D SokChild sokf_child(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, int d) {
+    SokChild c;
+    const int dir = d == 0 ? -1 : (d == 1 ? 1 : (d == 2 ? -F.w : F.w));
+    const int np = player + dir;
+    c.cr = cr; c.np = np; c.h = h; c.ok = 0;
+    if (sokf_bit<NW>(F.solid, np)) return c;                     // player did not move
+    if (sokf_bit<NW>(cb, np)) {
+        const int cp = np + dir;
+        if (sokf_bit<NW>(F.solid, cp) || sokf_bit<NW>(cb, cp)) return c;   // blocked crate: no move
+        const int i = sokf_crate_index(cr, np);
+        c.cr = cr ^ ((uint64_t)(np ^ cp) << (8 * i));
+        uint64_t nb[NW];
+        for (int j = 0; j < NW; j++) nb[j] = cb[j];
+        sokf_flip<NW>(nb, np); sokf_flip<NW>(nb, cp);
+        if (sokf_any_and<NW>(nb, F.dead)) return c;              // checkDeadlock looks at every crate
+        c.h = sokf_heuristic(F, c.cr);
+    }
+    c.ok = 1;
+    return c;
+}
+// How the four children of a pop get made: one after the other (host, generic), or -- on the device -- by four
+// lanes at once (SokKidsLanes in kernels_sokoban.h), the rest of the search being uniform across those lanes.
+struct SokKidsSerial {
+    template <int NW>
+    PCGRL_D void operator()(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, SokChild* out) const {
+        for (int d = 0; d < 4; d++) out[d] = sokf_child<NW>(F, cr, cb, player, h, d);
+    }
+};
+
 // heapq on packed words.  A lone lane executes about one instruction every 5-6 cycles, so the sift loops are
 // written for instruction count: while both children and all four grandchildren exist, two levels are
 // walked per round without any bounds test (paired LDS reads); the last level or two use plain heapq.
@@ -150,10 +183,10 @@ PCGRL_D void sokf_siftup_root(HP heap, int endpos) {
 
 // One search.  `table` must be all zeros; `cache`
 // is room for four nodes (LDS on the device).  Same contract as sok_search otherwise.
-template <int NW, class HP, class TP, class Hook>
+template <int NW, class HP, class TP, class Hook, class Kids>
 PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP table, int table_mask,
                              SokFastNode* cache, const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
-                             bool& out_exhausted, Hook hook) {
+                             bool& out_exhausted, Hook hook, Kids kids) {
     SokFastLevel<NW> F;
     sokf_level(L, F);
     const int nc = F.nc;
@@ -213,29 +246,19 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
         table[slot] = key;
         cache_base = npool; cache_n = 0;
         if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) { have_best = true; best_h = node_h; best_depth = node_depth; }
-        for (int d = 0; d < 4; d++) {          // Node.getChildren: L, R, U, D (State.update engine.py:298-327)
-            const int dir = d == 0 ? -1 : (d == 1 ? 1 : (d == 2 ? -F.w : F.w));
-            const int np = node_player + dir;
-            if (sokf_bit<NW>(F.solid, np)) continue;                 // player did not move
-            uint64_t ncr = cr;
-            int nh = node_h;
-            if (sokf_bit<NW>(cb, np)) {
-                const int cp = np + dir;
-                if (sokf_bit<NW>(F.solid, cp) || sokf_bit<NW>(cb, cp)) continue;   // blocked crate: no move
-                const int c = sokf_crate_index(cr, np);
-                ncr = cr ^ ((uint64_t)(np ^ cp) << (8 * c));
-                uint64_t nb[NW];
-                for (int i = 0; i < NW; i++) nb[i] = cb[i];
-                sokf_flip<NW>(nb, np); sokf_flip<NW>(nb, cp);
-                if (sokf_any_and<NW>(nb, F.dead)) continue;          // checkDeadlock looks at every crate
-                nh = sokf_heuristic(F, ncr);
-            }
+        SokChild kid[4];                        // Node.getChildren: L, R, U, D
+        kids(F, cr, cb, node_player, node_h, kid);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int d = 0; d < 4; d++) {
+            if (!kid[d].ok) continue;
             SokFastNode ch;
-            ch.cr = ncr; ch.ph = (uint32_t)np | ((uint32_t)nh << 16); ch.depth = (uint32_t)(node_depth + 1);
+            ch.cr = kid[d].cr; ch.ph = (uint32_t)kid[d].np | ((uint32_t)kid[d].h << 16); ch.depth = (uint32_t)(node_depth + 1);
             pool[npool] = ch;
             if (k >= 0) {
                 cache[cache_n++] = ch;
-                heap[heapn] = ((uint32_t)(2 * nh + k * (node_depth + 1)) << 16) | (uint32_t)npool;
+                heap[heapn] = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1)) << 16) | (uint32_t)npool;
                 heapn++;
                 sokf_siftdown(heap, heapn - 1);
             }

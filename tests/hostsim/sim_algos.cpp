@@ -131,9 +131,9 @@ int sim_sokoban_solve2(const uint8_t* map, int h, int w, int power, int shortcut
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool.data());
         SokFastNode cache[4];
         if (L.cells <= 64)
-            win = sok_search_fast<1>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
+            win = sok_search_fast<1>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook(), SokKidsSerial());
         else
-            win = sok_search_fast<4>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook());
+            win = sok_search_fast<4>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook(), SokKidsSerial());
         if (a == 0 && !win && exhausted && shortcut) break;
     }
     *dist = win ? 0 : hh;

@@ -436,3 +436,52 @@ def test_vec_env_monitor_and_rollout_collector():
     lst = infos.to_list()
     for i in np.nonzero(d.cpu().numpy())[0]:
         assert set(lst[i]["episode"]) == {"r", "l"}
+
+
+# ------------------------------------------------------------------ both Sokoban search implementations on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz"))), ids=os.path.basename)
+def test_sokoban_generic_search_path(path, monkeypatch):
+    """k_sokoban picks the register-resident search for levels with <= 7 crates, which is every fixture level; the
+    generic search (more crates, LDS workspace) must give the same answers: PCGRL_SOK_GENERIC=1 routes every level
+    through it."""
+    _torch()
+    monkeypatch.setenv("PCGRL_SOK_GENERIC", "1")
+    d = np.load(path)
+    maps = d["maps"]
+    n, h, w = maps.shape
+    env = _make("sokoban", "wide", n, [dict(width=w, height=h), dict(solver_power=int(d["solver_power"]))])
+    env.reset()
+    env.set_maps(maps)
+    got = env.stats.cpu().numpy().astype(np.int64)
+    assert env.check_status() == 0
+    assert np.array_equal(got, d["stats"])
+
+
+@pytest.mark.gpu
+def test_sokoban_many_crates_vs_oracle():
+    """Levels with 8..12 crates (beyond the register-resident search) against the oracle: engineered 8x8 levels,
+    crates next to their targets in open space, small solver_power so that every agent runs into the cap or wins."""
+    _torch()
+    rs = np.random.RandomState(21)
+    maps = []
+    while len(maps) < 24:
+        m = np.zeros((8, 8), np.uint8)
+        k = rs.randint(8, 13)
+        cells = rs.permutation(64)
+        m.flat[cells[0]] = 2
+        m.flat[cells[1:1 + k]] = 3
+        m.flat[cells[1 + k:1 + 2 * k]] = 4
+        m.flat[cells[1 + 2 * k:1 + 2 * k + rs.randint(0, 6)]] = 1
+        maps.append(m)
+    maps = np.stack(maps)
+    power = 400
+    exp = np.stack([ol.get_stats("sokoban", m, solver_power=power) for m in maps])
+    ran = sum(1 for m in maps if ol.get_stats("sokoban", m, solver_power=power, with_iters=True)[1][0] > 0)
+    assert ran >= 12          # the solver precondition (one region) holds for most of them
+    env = _make("sokoban", "wide", len(maps), [dict(width=8, height=8), dict(solver_power=power)])
+    env.reset()
+    env.set_maps(maps)
+    got = env.stats.cpu().numpy().astype(np.int64)
+    assert env.check_status() == 0
+    assert np.array_equal(got, exp), (got, exp)
