@@ -138,3 +138,101 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_stats_wide: binary problem on maps of more than 16 rows -- one block of four wavefronts per work item.
+// A 64x64 map costs one wavefront ~30k dependent instructions and a step only has ~1 400 such items for 1 024 SIMDs:
+// with a wavefront per item the launch lasts as long as the unluckiest SIMD (two heavy items).  Here the four
+// wavefronts of a block all hold the map and work through its components together (pcgrl_algos.h, "one map, several
+// cooperating lane groups"): the set of unretired cells and the running path maximum live in LDS.  Same work list,
+// same in-kernel reset as k_stats.
+template <class MaskT>
+struct LdsShared {
+    MaskT* rest; int* bestp; int lane;
+    __device__ __forceinline__ MaskT load_rest() const { return *reinterpret_cast<volatile MaskT*>(rest + lane); }
+    template <class G>
+    __device__ __forceinline__ bool retire(G& g, MaskT comp) const {
+        const MaskT fb = g.first_bit(comp);                     // non-zero in one lane only: the component's first cell
+        MaskT old = 0;
+        if (fb) old = atomicAnd(rest + lane, ~fb);
+        const bool won = __ballot((old & fb) != 0) != 0;
+        if (comp) atomicAnd(rest + lane, ~comp);
+        return won;
+    }
+    __device__ __forceinline__ int best() const { return *reinterpret_cast<volatile int*>(bestp); }
+    __device__ __forceinline__ void raise(int v) const { if (lane == 0 && v > 0) atomicMax(bestp, v); }
+};
+// regions + longest path of the map whose rows are in `pass`, by the four wavefronts of the block.  Results in
+// s_regions / s_best after the trailing barrier.  Every thread of the block calls this.
+template <class MaskT>
+__device__ __forceinline__ void block_regions_and_path(DevGroup<64, MaskT>& g, MaskT pass, int wv, int lane, int row_lo, int row_hi,
+                                                       MaskT* s_rest, int* s_regions, int* s_best) {
+    int tiny_regions, tiny_path;
+    const MaskT nontiny = rlp_prepare(g, pass, tiny_regions, tiny_path);
+    if (wv == 0) {
+        s_rest[lane] = nontiny;
+        if (lane == 0) { *s_regions = tiny_regions; *s_best = tiny_path; }
+    }
+    __syncthreads();
+    LdsShared<MaskT> sh = {s_rest, s_best, lane};
+    int regions = 0;
+    MaskT rest = sh.load_rest();
+    if (g.any(rest)) {
+        const PcgFillCtx<DevGroup<64, MaskT>> ctx = pcg_fill_ctx(g, pass);
+        do {
+            rlp_process_seed(g, rlp_choose_seed(g, rest, row_lo, row_hi), ctx, sh, regions);
+            rest = sh.load_rest();
+        } while (g.any(rest));
+    }
+    if (lane == 0 && regions) atomicAdd(s_regions, regions);
+    __syncthreads();
+}
+
+template <class MaskT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
+                                                             int inline_reset, int gen_map) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: MT ring + tile bytes of one environment
+    __shared__ int s_pref[WL_NSHARD + 1];
+    __shared__ MaskT s_rest[64];
+    __shared__ int s_regions, s_best, s_flag;
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    DevGroup<64, MaskT> g;
+    const int n = wl_load_prefix(B, parity, list, s_pref);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W = P.width, H = P.height;
+    const int bh = (H + NWAVES - 1) / NWAVES;
+    const int row_lo = wv * bh, row_hi = (row_lo + bh < H) ? row_lo + bh : H;
+    uint32_t* mt = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
+    const MaskT rowmask = row_valid<MaskT>(lane, W, H);
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        const int raw = wl_get(B, list, s_pref, item);
+        const bool reset_only = (raw & WL_RESET_ONLY) != 0;
+        const int e = raw & ~WL_RESET_ONLY;
+        const int shard = (item >> 4) & (WL_NSHARD - 1);
+        MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * 64;
+        if (threadIdx.x == 0) s_flag = reset_only ? 1 : 0;
+        if (!reset_only) {
+            const MaskT b0 = planes_e[lane];
+            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best);
+            if (threadIdx.x == 0) {
+                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, 0, 0, 0, 0, 0, 0};
+                const bool want = finalize_item(P, B, e, s, mode, parity, shard, !inline_reset);
+                s_flag = (want && inline_reset) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (inline_reset && s_flag) {   // block-uniform: PcgrlEnv.reset of this environment, then its start stats
+            if (wv == 0) wave_reset_env<PCGRL_PROB_BINARY>(P, B, e, gen_map, mt, tiles, lane);
+            __syncthreads();
+            MaskT b0, b1, b2;
+            planes_from_tiles<MaskT>(P, tiles, planes_e, lane, b0, b1, b2, wv == 0);
+            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best);
+            if (threadIdx.x == 0) {
+                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, 0, 0, 0, 0, 0, 0};
+                finalize_item(P, B, e, s, MODE_START, parity, shard);
+            }
+        }
+        __syncthreads();
+    }
+}
+

@@ -67,6 +67,8 @@ struct DevGroup<16, MaskT> : DevLaneOps<MaskT> {
         return (uint32_t)(__ballot(p) >> shift) & 0xFFFFu;
     }
     __device__ __forceinline__ bool any(mask_t m) const { return ballot(m != 0) != 0; }
+    __device__ __forceinline__ mask_t rows_between(mask_t m, int lo, int hi) const { return (lane >= lo && lane < hi) ? m : (mask_t)0; }
+    __device__ __forceinline__ int first_row(mask_t m) const { return __ffs((int)ballot(m != 0)) - 1; }
     __device__ __forceinline__ bool any_ne(mask_t a, mask_t b) const { return ballot(a != b) != 0; }
     __device__ __forceinline__ mask_t first_bit(mask_t m) const {
         uint32_t b = ballot(m != 0);
@@ -108,6 +110,8 @@ struct DevGroup<64, MaskT> : DevLaneOps<MaskT> {
         switch (k) { case 0: return dpp_mov0<0x101>(m); case 1: return dpp_mov0<0x102>(m); case 2: return dpp_mov0<0x104>(m); default: return dpp_mov0<0x108>(m); }
     }
     __device__ __forceinline__ bool any(mask_t m) const { return __ballot(m != 0) != 0; }
+    __device__ __forceinline__ mask_t rows_between(mask_t m, int lo, int hi) const { return (lane >= lo && lane < hi) ? m : (mask_t)0; }
+    __device__ __forceinline__ int first_row(mask_t m) const { return __ffsll((unsigned long long)__ballot(m != 0)) - 1; }
     __device__ __forceinline__ bool any_ne(mask_t a, mask_t b) const { return __ballot(a != b) != 0; }
     __device__ __forceinline__ mask_t first_bit(mask_t m) const {
         uint64_t b = __ballot(m != 0);

@@ -378,6 +378,17 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     // in-kernel reset: one MT ring + tile-byte staging area per wavefront
     const size_t lds = inline_reset ? 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
+    if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !getenv("PCGRL_NO_WIDE")) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
+        const size_t lds1 = inline_reset ? (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
+        const int gridw = P.num_envs < 16384 ? P.num_envs : 16384;
+        // four wavefronts per map: measured on C5 -- 2: 150 us/step, 4: 130, 8: 151 (one wavefront per map: 176)
+        if (P.mask_bytes == 4)
+            hipLaunchKernelGGL((k_stats_wide<uint32_t, 4>), dim3(gridw), dim3(256), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
+        else
+            hipLaunchKernelGGL((k_stats_wide<uint64_t, 4>), dim3(gridw), dim3(256), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
+        HIPCHK(hipGetLastError());
+        return PCGRL_OK;
+    }
     if (P.group == 16 && P.mask_bytes == 4)
         hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
     else if (P.group == 16)

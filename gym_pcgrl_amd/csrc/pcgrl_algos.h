@@ -362,6 +362,35 @@ PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& region
 }
 
 // Row masks of each tile class from the bit planes of the tile id (plane b = bit b of the id).
+// ---------------------------------------------------------------- one map, several cooperating lane groups
+// The same result computed by several groups (wavefronts on the device) that all hold the whole map in their
+// registers and share, through `sh`, the set of cells whose component has not been retired yet plus the running
+// maximum.  A group picks a seed -- from its own band of rows first, anywhere once that is used up -- extracts
+// the component and retires it; two groups that started in the same component both extract it, and the one
+// whose atomic test-and-clear of the component's first cell finds the bit still set owns it (counts it, sweeps
+// it if its size says it can still raise the maximum).  Timing changes who does what, never the result.
+//   Shared: M load_rest(); bool retire(B&, M comp) [uniform]; int best(); void raise(int)
+template <class B>
+PCGRL_D typename B::mask_t rlp_choose_seed(B& g, typename B::mask_t rest, int row_lo, int row_hi) {
+    const typename B::mask_t mine = g.rows_between(rest, row_lo, row_hi);
+    return g.first_bit(g.any(mine) ? mine : rest);
+}
+template <class B, class Shared>
+PCGRL_D void rlp_process_seed(B& g, typename B::mask_t seed, const PcgFillCtx<B>& ctx, Shared& sh, int& regions) {
+    typedef typename B::mask_t M;
+    const M comp = pcg_component(g, seed, ctx);
+    if (!sh.retire(g, comp)) return;
+    ++regions;
+    const int best = sh.best();
+    if (g.popcount_sum(comp) - 1 > best) sh.raise(pcg_double_sweep(g, comp, best));
+}
+// What every group does before the shared loop; returns the non-tiny cells (identical in every group).
+template <class B>
+PCGRL_D typename B::mask_t rlp_prepare(B& g, typename B::mask_t pass, int& tiny_regions, int& tiny_path) {
+    tiny_regions = 0; tiny_path = 0;
+    return pass & ~pcg_tiny_components(g, pass, tiny_regions, tiny_path);
+}
+
 template <class M>
 struct ZeldaMasks {
     M empty, solid, player, key, door, enemy;

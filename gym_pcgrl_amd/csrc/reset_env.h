@@ -6,7 +6,7 @@
 // `row` is the map row this lane owns (0 .. G-1) or -1 for a lane that does not take part.
 template <class MaskT>
 __device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const uint8_t* tiles, MaskT* planes_e, int row,
-                                                  MaskT& m0, MaskT& m1, MaskT& m2) {
+                                                  MaskT& m0, MaskT& m1, MaskT& m2, bool store = true) {
     const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
     m0 = 0; m1 = 0; m2 = 0;
     if (row >= 0 && row < G) {
@@ -20,8 +20,10 @@ __device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const ui
                 m2 |= ((t >> 2) & 1) << x;
             }
         }
-        planes_e[lane] = m0;
-        if (NPL > 1) { planes_e[G + lane] = m1; planes_e[2 * G + lane] = m2; }
+        if (store) {
+            planes_e[lane] = m0;
+            if (NPL > 1) { planes_e[G + lane] = m1; planes_e[2 * G + lane] = m2; }
+        }
     }
 }
 

@@ -60,6 +60,8 @@ struct SimGroup {
     mask_t up(const mask_t& m) const { mask_t r; for (int i = 1; i < G; i++) r.v[i] = m.v[i - 1]; return r; }
     mask_t down(const mask_t& m) const { mask_t r; for (int i = 0; i + 1 < G; i++) r.v[i] = m.v[i + 1]; return r; }
     bool any(const mask_t& m) const { for (int i = 0; i < G; i++) if (m.v[i]) return true; return false; }
+    mask_t rows_between(const mask_t& m, int lo, int hi) const { mask_t r; for (int i = 0; i < G; i++) if (i >= lo && i < hi) r.v[i] = m.v[i]; return r; }
+    int first_row(const mask_t& m) const { for (int i = 0; i < G; i++) if (m.v[i]) return i; return -1; }
     bool any_ne(const mask_t& a, const mask_t& b) const { g_sim_iters++; for (int i = 0; i < G; i++) if (a.v[i] != b.v[i]) return true; return false; }
     mask_t first_bit(const mask_t& m) const {
         mask_t r;
@@ -97,7 +99,61 @@ static void run(int prob, const uint8_t* map, int h, int w, int pw, int ph, int3
     }
 }
 
+// binary stats the way k_stats_wide computes them: `ngroups` cooperating groups sharing the rest set.  The groups
+// take turns; in every turn ALL of them choose their seed from the same snapshot before any of them retires its
+// component (the worst interleaving: as many duplicate extractions as possible).
+template <int G, class T>
+struct SimShared {
+    typedef SimGroup<G, T> Gp;
+    typedef typename Gp::mask_t M;
+    M rest; int bestv; long dup;
+    M load_rest() const { return rest; }
+    bool retire(Gp& g, const M& comp) {
+        const M fb = g.first_bit(comp);
+        bool won = false;
+        for (int i = 0; i < G; i++) if (fb.v[i] && (rest.v[i] & fb.v[i])) won = true;
+        for (int i = 0; i < G; i++) rest.v[i] &= ~comp.v[i];
+        if (!won) dup++;
+        return won;
+    }
+    int best() const { return bestv; }
+    void raise(int v) { if (v > bestv) bestv = v; }
+};
+template <int G, class T>
+static long run_shared(const uint8_t* map, int h, int w, int ngroups, int32_t* out) {
+    typedef SimGroup<G, T> Gp;
+    typedef typename Gp::mask_t M;
+    Gp g;
+    M b0, valid;
+    for (int y = 0; y < h; y++) {
+        valid.v[y] = (w >= (int)(8 * sizeof(T))) ? ~(T)0 : (((T)1 << w) - 1);
+        for (int x = 0; x < w; x++) b0.v[y] |= (T)(map[y * w + x] & 1) << x;
+    }
+    const M pass = ~b0 & valid;
+    SimShared<G, T> sh;
+    int tr, tp, regions = 0;
+    sh.rest = rlp_prepare(g, pass, tr, tp);
+    sh.bestv = tp; sh.dup = 0;
+    regions = tr;
+    const PcgFillCtx<Gp> ctx = pcg_fill_ctx(g, pass);
+    const int bh = (h + ngroups - 1) / ngroups;
+    while (g.any(sh.rest)) {
+        std::vector<M> seeds;
+        for (int k = 0; k < ngroups; k++) {
+            const int lo = k * bh, hi = (lo + bh < h) ? lo + bh : h;
+            seeds.push_back(rlp_choose_seed(g, sh.rest, lo, hi));
+        }
+        for (int k = 0; k < ngroups; k++) rlp_process_seed(g, seeds[k], ctx, sh, regions);
+    }
+    out[0] = regions; out[1] = sh.bestv;
+    return sh.dup;
+}
+
 extern "C" {
+long sim_stats_shared(const uint8_t* map, int h, int w, int ngroups, int32_t* out) {
+    if (w > 32) return run_shared<64, uint64_t>(map, h, w, ngroups, out);
+    return run_shared<64, uint32_t>(map, h, w, ngroups, out);
+}
 // the device solver (sokoban_solver.h / sokoban_fast.h) run on the host: same pool/heap/table layout as k_sokoban.
 // fast = 1 takes the register-resident search for levels with at most SOKF_MAXC crates (what the kernel does),
 // fast = 0 forces the generic one.

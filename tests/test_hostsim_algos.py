@@ -134,6 +134,27 @@ def test_extra_wave_rounds_are_harmless(sim):
         sim.sim_set_spurious(0)
 
 
+def test_shared_rest_binary_stats(sim):
+    """The cooperative form of regions + longest path (k_stats_wide: four wavefronts per tall map sharing the set
+    of unretired cells) against the oracle, under the interleaving with the most duplicate extractions."""
+    sim.sim_stats_shared.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    sim.sim_stats_shared.restype = C.c_long
+    rs = np.random.RandomState(5)
+    cases = [m for m in np.load(os.path.join(G, "stats_binary_64x64.npz"))["maps"]]
+    for shape in ((64, 64), (40, 33), (17, 9), (33, 64), (64, 20)):
+        for dens in (0.3, 0.5, 0.62, 0.8, 1.0):
+            cases.append((rs.random_sample(shape) >= dens).astype(np.uint8))
+    dups = 0
+    for m in cases:
+        m = np.ascontiguousarray(m, np.uint8)
+        exp = ol.get_stats("binary", m)
+        for ng in (4, 3, 1):
+            out = np.zeros(8, np.int32)
+            dups += sim.sim_stats_shared(_p(m), m.shape[0], m.shape[1], ng, _p(out))
+            assert np.array_equal(out[:2], exp), (m.shape, ng, out[:2], exp)
+    assert dups > 0      # the retire rule was exercised
+
+
 def test_range_reward_table(sim):
     sim.sim_range_reward_i.argtypes = [C.c_int] * 4
     enc = lambda b: 2147483647 if b == np.inf else (-2147483648 if b == -np.inf else int(b))
