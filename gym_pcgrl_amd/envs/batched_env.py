@@ -339,8 +339,35 @@ class BatchedPcgrlEnv:
         self._torch.cuda.synchronize(self.device)
         return {k: (v.clone() if v is not None else None) for k, v in self._bufs.items() if k != "scratch"}
 
-    def render(self, mode="human"):
-        raise NotImplementedError("rendering is out of scope for the batched environment (SURVEY.md 8f-4)")
+    def render(self, mode="rgb_array", index=0):
+        """Image of environment `index` with the reference's layout (pcgrl_env.py:161-175): 16-pixel tiles, a one-tile
+        border of the border tile (problem.py:142-156), a two-pixel red frame on the cursor cell for narrow/turtle
+        (narrow_rep.py:128-142).  The tile pictures are the reference's *fallback* graphics -- grey level
+        i*255/len(tiles), problem.py:136-140 -- its PNG assets are not part of this package.  Host side, one
+        device->host map copy; returns a PIL image when PIL is importable (like the reference), else an ndarray."""
+        if mode not in ("rgb_array", "human"):
+            raise ValueError("unsupported render mode %r" % (mode,))
+        tiles = self._prob.tiles
+        ts = int(self._prob._tile_size)
+        bx, by = self._prob._border_size
+        m = self._bufs["map"][index].cpu().numpy()
+        h, w = m.shape
+        full = np.full((h + 2 * by, w + 2 * bx), tiles.index(self._prob._border_tile), dtype=np.int64)
+        full[by:by + h, bx:bx + w] = m
+        grey = np.array([int(i * 255 / len(tiles)) for i in range(len(tiles))], dtype=np.uint8)
+        img = np.repeat(np.repeat(grey[full], ts, axis=0), ts, axis=1)
+        img = np.stack([img, img, img], -1)
+        if self._rep.has_pos:
+            x, y = [int(v) for v in self._bufs["pos"][index].cpu().numpy()]
+            y0, x0 = (y + by) * ts, (x + bx) * ts
+            cell = img[y0:y0 + ts, x0:x0 + ts]
+            for sl in (np.s_[:2, :], np.s_[-2:, :], np.s_[:, :2], np.s_[:, -2:]):
+                cell[sl] = (255, 0, 0)
+        try:
+            from PIL import Image
+            return Image.fromarray(img, "RGB")
+        except ImportError:
+            return img
 
     def close(self):
         self._free()

@@ -64,7 +64,9 @@ class PcgrlEnv:
         return self._np_obs(obs), r, bool(done[0].item()), info.to_list()[0]
 
     def render(self, mode="human"):
-        raise NotImplementedError("rendering is outside the accelerated hot path (SURVEY.md 8f-4)")
+        """pcgrl_env.py:161-175.  'rgb_array' returns the image; 'human' has no viewer here (gym's classic_control
+        viewer is not a dependency) and returns the image as well."""
+        return self._batched.render("rgb_array", 0)
 
     def close(self):
         self._batched.close()
