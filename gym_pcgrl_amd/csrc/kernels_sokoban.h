@@ -27,11 +27,11 @@ enum { SOK_SY_TICKET_A = 0, SOK_SY_TICKET_B = 1, SOK_SY_HARD = 2, SOK_SY_BFS_DON
 __device__ __forceinline__ int sok_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct SokSpawnHook {     // BFS: publish the level once the search has proven to be a long one
-    int32_t* sync; int32_t* hard; int spawn_at; int tag; int* spawned; int lane;
+    int32_t* sync; int32_t* hard; int spawn_at; int tag; int* spawned; int lane; int cap;
     __device__ __forceinline__ bool operator()(int it) const {
         if (it == spawn_at && lane == 0) {
             const int idx = atomicAdd(sync + SOK_SY_HARD, 1);
-            if (idx < SOK_HARD_CAP) { __hip_atomic_store(hard + idx, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *spawned = 1; }
+            if (idx < cap) { __hip_atomic_store(hard + idx, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *spawned = 1; }
         }
         return false;
     }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
         int kind = 0, t = 0;   // 0: nothing to do right now, 1: BFS job t, 2: A* ticket t, 3: leave
         if (lane == 0) {
             int hc = sok_ld(sync + SOK_SY_HARD);
-            hc = hc < SOK_HARD_CAP ? hc : SOK_HARD_CAP;
+            hc = hc < B.sok_hard_cap ? hc : B.sok_hard_cap;
             int tb = sok_ld(sync + SOK_SY_TICKET_B);
             while (tb < 3 * hc) {
                 const int seen = atomicCAS(sync + SOK_SY_TICKET_B, tb, tb + 1);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
             if (kind == 0 && sok_ld(sync + SOK_SY_BFS_DONE) >= n) {
                 // every BFS has finished, so the hard list is final (the counter was read after the data it depends on)
                 int hf = sok_ld(sync + SOK_SY_HARD);
-                hf = hf < SOK_HARD_CAP ? hf : SOK_HARD_CAP;
+                hf = hf < B.sok_hard_cap ? hf : B.sok_hard_cap;
                 if (sok_ld(sync + SOK_SY_TICKET_B) >= 3 * hf) kind = 3;
             }
         }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
                 bool exhausted = false, win = false;
                 if (kind == 1 && a == 0) {
                     int sp = P.solver_power < SOK_SPAWN_ITERS ? P.solver_power : SOK_SPAWN_ITERS;
-                    SokSpawnHook hook = {sync, hard, sp, (e + 1) | (mode << 28), &s_spawned, lane};
+                    SokSpawnHook hook = {sync, hard, sp, (e + 1) | (mode << 28), &s_spawned, lane, B.sok_hard_cap};
                     win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, -1, hh, dd, it, exhausted, hook, lane);
                     __threadfence_block();
                     if (s_spawned) { if (lane == 0) sok_report(P, B, e, 0, win, hh, dd, exhausted, mode, parity, rst_list); reported = 1; go = 0; }

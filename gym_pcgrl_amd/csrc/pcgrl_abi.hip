@@ -281,6 +281,9 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         {   // PCGRL_SOK_GENERIC=1: every level takes the generic search (tests)
             const char* sg = getenv("PCGRL_SOK_GENERIC");
             B.sok_fast_maxc = (sg && sg[0] == '1') ? -1 : SOKF_MAXC;
+            const char* hc = getenv("PCGRL_SOK_HARD_CAP");
+            B.sok_hard_cap = hc ? atoi(hc) : SOK_HARD_CAP;
+            if (B.sok_hard_cap < 0 || B.sok_hard_cap > SOK_HARD_CAP) B.sok_hard_cap = SOK_HARD_CAP;
         }
         B.sok_table_size = sok_table_size(power);
         B.sok_heap_stride = (int32_t)(align_up(nodes * 4, 256) / 4);

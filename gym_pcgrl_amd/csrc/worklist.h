@@ -35,6 +35,7 @@ struct DevBufs {
     int32_t* sok_cnt; int32_t* sok_stop;   // [num_envs] agents reported / stop level (kernels_sokoban.h)
     int32_t* sok_sync;               // [2 launches per step][SOK_SY_WORDS + SOK_HARD_CAP] scheduling words
     int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
+    int32_t sok_hard_cap;            // levels k_sokoban may publish per launch (SOK_HARD_CAP; PCGRL_SOK_HARD_CAP lowers it for tests)
     int32_t sok_fast_maxc;           // most crates the register-resident search takes (SOKF_MAXC; -1: PCGRL_SOK_GENERIC=1 forces the generic one)
     int32_t inline_reset;   // k_stats resets finished environments itself (every problem but Sokoban)
 };

@@ -509,3 +509,20 @@ def test_render_layout():
     wide = gp.make("binary-wide-v0")
     wide.reset()
     assert (np.asarray(wide.render()) != np.array([255, 0, 0])).any(-1).all()   # no cursor for wide
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", ["0", "1"])
+def test_sokoban_hard_list_overflow(cap, monkeypatch):
+    """k_sokoban publishes long levels so that their A* agents run on other blocks; when the list is full the block
+    that ran the BFS runs them itself.  With the list shrunk to 0 / 1 entries the capped fixture levels take both
+    routes at once; the answers must not change."""
+    _torch()
+    monkeypatch.setenv("PCGRL_SOK_HARD_CAP", cap)
+    d = np.load(os.path.join(G, "stats_sokoban_5x5.npz"))
+    maps, n = d["maps"], len(d["maps"])
+    env = _make("sokoban", "wide", n, [dict(width=5, height=5), dict(solver_power=int(d["solver_power"]))])
+    env.reset()
+    for _ in range(2):
+        env.set_maps(maps)
+        assert np.array_equal(env.stats.cpu().numpy().astype(np.int64), d["stats"])
