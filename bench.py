@@ -65,7 +65,8 @@ def measured_valu(workload, kernel="k_stats"):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", workload + "_pmc.json")))
     if not files:
         return None, None
-    d = json.load(open(files[-1]))["per_dispatch"].get(kernel)
+    per = json.load(open(files[-1]))["per_dispatch"]
+    d = per.get(kernel + "_wide") or per.get(kernel)      # tall binary maps run k_stats_wide
     return (d.get("SQ_INSTS_VALU") if d else None), os.path.relpath(files[-1], ROOT)
 
 
@@ -192,7 +193,7 @@ def main():
         # SQ counters, how close it runs to the VALU issue limit (one wave64 VALU instruction per SIMD per 4 cycles)
         ph = {k: 1e3 * v / max(prof_steps, 1) for k, v in phase_ms.items()}
         ev_us = min(ph.values()) if ph else 0.0
-        dom_name = "k_sokoban" if prob == "sokoban" else "k_stats"
+        dom_name = "k_sokoban" if prob == "sokoban" else ("k_stats_wide" if (prob == "binary" and H > 16) else "k_stats")
         dom_us = max((ph.get("solver_or_reset", 0.0) if prob == "sokoban" else ph.get("stats", 0.0)) - ev_us, 0.0)
         valu, valu_src = measured_valu(a.workload) if n == n_default else (None, None)
         dominant = {"name": dom_name, "avg_us": dom_us, "event_pair_overhead_us": ev_us}

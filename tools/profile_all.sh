@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 timeout 600 tools/profile_gpu.sh C2 trace sq mem
 timeout 400 tools/profile_gpu.sh C3 trace sq mem
 timeout 400 tools/profile_gpu.sh C5 trace sq mem
-timeout 400 tools/profile_gpu.sh C4 trace
+timeout 600 tools/profile_gpu.sh C4 trace sq mem
 for w in C2 C3 C4 C5; do
   timeout 400 python bench.py --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
   tail -c 400 gpurun_out/bench_$w.json
