@@ -40,16 +40,25 @@ __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBuf
 
 // Problem.get_stats on the row masks of one map (b0..b2 = bit planes of the tile id).  Returns true
 // when the Sokoban solver has to finish the job.
+// Binary: `champ` receives the rows of the champion component (pcgrl_algos.h) and s[2] says whether there is one --
+// a slot of the stats row the binary problem does not use otherwise; k_update reads it to route the next change.
 template <int PROB, class G, class MaskT>
-__device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, MaskT b0, MaskT b1, MaskT b2, MaskT valid, int32_t* s) {
+__device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, MaskT b0, MaskT b1, MaskT b2, MaskT valid, int32_t* s,
+                                                   MaskT& champ) {
+    champ = 0;
     if (PROB == PCGRL_PROB_BINARY) {
         int regions, path;
-        regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path);
-        s[0] = regions; s[1] = path;
+        regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path, champ);
+        s[0] = regions; s[1] = path; s[2] = g.any(champ) ? 1 : 0;
         return false;
     }
     if (PROB == PCGRL_PROB_ZELDA) { zelda_stats(g, P, b0, b1, b2, valid, s); return false; }
     return sokoban_stats(g, P, b0, b1, b2, valid, s);
+}
+template <int PROB, class G, class MaskT>
+__device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, MaskT b0, MaskT b1, MaskT b2, MaskT valid, int32_t* s) {
+    MaskT champ;
+    return compute_item_stats<PROB>(g, P, b0, b1, b2, valid, s, champ);
 }
 
 // Lane 0 of the group: hand the item to the solver or finish it.
@@ -76,12 +85,20 @@ template <int PROB, int G, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
                                                         int inline_reset, int gen_map) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: per wave MT ring + tile bytes
-    __shared__ int s_pref[WL_NSHARD + 1];
+    __shared__ int s_pref[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
     // the last kernel of a step zeroes the *other* parity's work-list counters for the next step
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<G, MaskT> g;
     constexpr int GPB = PCGRL_BLOCK / G, GPW = 64 / G;
-    const int n = wl_load_prefix(B, parity, list, s_pref);
+    // Binary 16-row maps in a step: after the items of the changed list (padded to whole wavefronts) come the items of
+    // the incremental list -- a wavefront works on one kind only.
+    constexpr bool kInc = PROB == PCGRL_PROB_BINARY && G == 16 && sizeof(MaskT) == 4;
+    const bool with_inc = kInc && mode == MODE_STEP && B.champ != nullptr;
+    const int n_full = wl_load_prefix(B, parity, list, s_pref);
+    const int n_full_pad = (n_full + GPW - 1) / GPW * GPW;
+    const int n_inc = with_inc ? wl_load_prefix(B, parity, WL_INC, s_pref_inc) : 0;
+    const int n = with_inc ? n_full_pad + n_inc : n_full;
+    MaskT* champ_base = reinterpret_cast<MaskT*>(B.champ);
     const int lane64 = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = lane64 / G;
     const int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
     const int W = P.width, H = P.height;
@@ -90,12 +107,13 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
     const MaskT rowmask = row_valid<MaskT>(g.lane, W, H);
     for (int base = blockIdx.x * GPB + wv * GPW; base < n; base += gridDim.x * GPB) {
-        const int item = base + gw;
-        const bool have = item < n;
-        const int raw = have ? wl_get(B, list, s_pref, item) : 0;
-        const bool reset_only = have && (raw & WL_RESET_ONLY) != 0;
+        const bool inc = with_inc && base >= n_full_pad;          // wave-uniform
+        const int item = inc ? base - n_full_pad + gw : base + gw;
+        const bool have = item < (inc ? n_inc : n_full);
+        const int raw = have ? (inc ? wl_get(B, WL_INC, s_pref_inc, item) : wl_get(B, list, s_pref, item)) : 0;
+        const bool reset_only = have && !inc && (raw & WL_RESET_ONLY) != 0;
         const bool compute = have && !reset_only;
-        const int e = raw & ~WL_RESET_ONLY;
+        const int e = inc ? (raw & WL_INC_ENV_MASK) : (raw & ~WL_RESET_ONLY);
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
         MaskT b0 = 0, b1 = 0, b2 = 0;
@@ -105,7 +123,21 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
         }
         int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool need_solver = false;
-        if (compute) need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s);
+        MaskT champ = 0;
+        if (kInc && inc) {
+            if (compute) {      // one cell changed away from the champion: update the previous answer
+                const int cell = (raw >> 21) & 511;
+                const MaskT cbit = (g.lane == (cell >> 5)) ? (MaskT)1 << (cell & 31) : (MaskT)0;
+                const MaskT champ_old = champ_base[(size_t)e * G + g.lane];
+                const int2 old = *reinterpret_cast<const int2*>(B.stats + (size_t)e * 8);
+                int regions, path;
+                binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, ((raw >> 30) & 1) != 0, old.x, old.y, champ_old, regions, path, champ);
+                s[0] = regions; s[1] = path; s[2] = 1;
+            }
+        } else if (compute) {
+            need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ);
+        }
+        if (kInc && compute && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
         int want_reset = 0;
         if (g.lane == 0 && have) {
             if (reset_only) want_reset = 1;
@@ -130,7 +162,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
                 // start stats of the regenerated maps (pcgrl_env.py:70-71, problem.py:45-46)
                 if (mine) {
                     int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st);
+                    const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st, champ);
+                    if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
                     if (g.lane == 0) finish_or_park(P, B, e, st, ns, MODE_START, parity, shard);
                 }
             }

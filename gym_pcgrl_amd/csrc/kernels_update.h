@@ -10,13 +10,13 @@
 #define PCGRL_SPEC_DRAWS 6
 template <int REP, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
-    __shared__ int s_cnt[2][4];
-    __shared__ int s_base[2];
+    __shared__ int s_cnt[3][4];
+    __shared__ int s_base[3];
     __shared__ int s_hist[WL_NSHARD], s_gbase[WL_NSHARD];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
     const bool act = e < P.num_envs;
-    bool chg = false, rst = false;
-    int bucket = 0;
+    bool chg = false, rst = false, cheap = false;
+    int bucket = 0, inc_item = 0;
     if (act) {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
         // ---- round trip 1
@@ -66,6 +66,15 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
         MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G + wy;
         const int old = *cell;
+        // binary, 16-row maps: the three champion rows around the cell, for the routing decision below
+        const bool inc_on = sizeof(MaskT) == 4 && P.prob == PCGRL_PROB_BINARY && B.champ != nullptr;
+        uint32_t ch0 = 0, chu = 0, chd = 0;
+        if (inc_on) {
+            const uint32_t* ch = reinterpret_cast<const uint32_t*>(B.champ) + (size_t)e * 16;
+            ch0 = ch[wy];
+            chu = ch[wy > 0 ? wy - 1 : wy];
+            chd = ch[wy < 15 ? wy + 1 : wy];
+        }
         MaskT m0 = pl[0], m1 = 0, m2 = 0;
         if (NPL > 1) { m1 = pl[G]; m2 = pl[2 * G]; }
         uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
@@ -78,6 +87,14 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         }
         if (tile >= 0 && old != tile) {
             chg = true;
+            if (inc_on && s0.z != 0) {
+                // the statistics can be updated from the previous ones when the cell is neither in the champion component
+                // nor next to it (binary_incremental); s0.z = "there is a champion"
+                const uint32_t bit = 1u << wx;
+                const uint32_t touch = ((ch0 | chu | chd) & bit) | (ch0 & ((bit << 1) | (bit >> 1)));
+                cheap = touch == 0;
+                inc_item = e | ((wy * 32 + wx) << 21) | ((tile == 0 ? 1 : 0) << 30);
+            }
             *cell = (uint8_t)tile;
             const MaskT bit = (MaskT)1 << wx;
             pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
@@ -152,8 +169,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     // in-kernel (every problem but Sokoban, whose resets wait for the solver and go through k_reset)
     const bool inl = rst && B.inline_reset;
     const int val = inl ? (e | WL_RESET_ONLY) : e;
-    if (P.prob == PCGRL_PROB_BINARY && P.group == 16) block_append_bucketed(chg || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase);
-    else block_append(chg || inl, val, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
+    if (P.prob == PCGRL_PROB_BINARY && P.group == 16) {
+        block_append_bucketed((chg && !cheap) || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase);
+        if (B.champ != nullptr) block_append(cheap, inc_item, B, parity, WL_INC, s_cnt[2], &s_base[2]);
+    } else block_append(chg || inl, val, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
     if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
 }
 

@@ -155,7 +155,13 @@ static void sub_range(int num_envs, int nsub, int k, int* lo, int* hi) {
     *lo = k * base + (k < extra ? k : extra);
     *hi = *lo + base + (k < extra ? 1 : 0);
 }
-static size_t scratch_bytes(const pcgrl_config* c) {
+// rows of the champion component per environment (binary, maps of at most 16 x 32): the incremental statistics path
+static size_t champ_bytes(const pcgrl_config* c) {
+    return (c->prob == PCGRL_BINARY && c->height <= 16 && c->width <= 32 && c->num_envs <= WL_INC_ENV_MASK) ? align_up((size_t)c->num_envs * 64, 256) : 0;
+}
+static size_t scratch_bytes_base(const pcgrl_config* c);
+static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c); }
+static size_t scratch_bytes_base(const pcgrl_config* c) {
     const int nsub = num_subbatches(c);
     pcgrl_config cc = *c;
     cc.num_envs = (c->num_envs + nsub - 1) / nsub;
@@ -259,6 +265,11 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     }
     HIPCHK(hipMemsetAsync(B.wl_cnt, 0, WL_CNT_BYTES + 256, (hipStream_t)stream));
     B.sok_pool = nullptr; B.sok_heap = nullptr; B.sok_table = nullptr;
+    B.champ = nullptr;
+    if (champ_bytes(&h->cfg) && !getenv("PCGRL_NO_INC")) {      // PCGRL_NO_INC=1: every change takes the full statistics (A/B, tests)
+        B.champ = s + scratch_bytes_base(&h->cfg);
+        HIPCHK(hipMemsetAsync(B.champ, 0, champ_bytes(&h->cfg), (hipStream_t)stream));
+    }
     {   // PCGRL_INLINE_RESET=0 routes resets through the reset list + k_reset instead (A/B measurements)
         const char* ir = getenv("PCGRL_INLINE_RESET");
         B.inline_reset = (h->cfg.prob != PCGRL_SOKOBAN && !(ir && ir[0] == '0')) ? 1 : 0;
@@ -313,6 +324,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
             S.info = B.info + 10 * (size_t)lo; S.reward = B.reward + lo; S.done = B.done + lo; S.tile_p = B.tile_p + 2 * (size_t)lo;
             S.rng_rep = B.rng_rep + (size_t)lo * PCGRL_MT_N; S.rng_prob = B.rng_prob ? B.rng_prob + (size_t)lo * PCGRL_MT_N : nullptr;
             S.rng_cur = B.rng_cur + 2 * (size_t)lo;
+            S.champ = B.champ ? (uint8_t*)B.champ + (size_t)lo * 64 : nullptr;
             uint8_t* q = s + (size_t)k * wlb;
             S.wl_cnt = (int32_t*)q;
             q += WL_CNT_BYTES + 256;

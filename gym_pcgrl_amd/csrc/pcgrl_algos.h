@@ -314,11 +314,14 @@ PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
 // keeps the lockstep cost near max-over-maps instead of sum-over-maps; the second largest and, rarely,
 // the rest are swept only if their size says they could still raise the maximum (a k-cell component
 // cannot hold a shortest path longer than k-1).  Whole-wave groups sweep as they go.
+// `champ` receives a component whose sweep produced the returned path (the "champion"), or an empty mask when the
+// path comes from the closed-form tiny components: binary_incremental below builds on it.
 template <class B>
-PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path) {
+PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path, typename B::mask_t& champ) {
     typedef typename B::mask_t M;
     regions = 0;
     path = 0;
+    champ = pass ^ pass;
     const M nontiny = pass & ~pcg_tiny_components(g, pass, regions, path);
     if (!g.any(nontiny)) return;
     const PcgFillCtx<B> ctx = pcg_fill_ctx(g, pass);    // components never touch, so the full mask is safe
@@ -333,7 +336,7 @@ PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& region
             const M comp = pcg_component(g, seed, ctx);
             rest = rest & ~comp;
             ++regions;
-            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); path = e > path ? e : path; }
+            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); if (e > path) { path = e; champ = comp; } }
             seed = g.first_bit(rest);
         }
         return;
@@ -349,19 +352,62 @@ PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& region
         else if (size > size2) { size3 = size2; size2 = size; big2 = comp; }
         else if (size > size3) size3 = size;
     }
-    if (size1 - 1 > path) { const int e = pcg_double_sweep(g, big1, path); path = e > path ? e : path; }
-    if (size2 - 1 > path) { const int e = pcg_double_sweep(g, big2, path); path = e > path ? e : path; }
+    if (size1 - 1 > path) { const int e = pcg_double_sweep(g, big1, path); if (e > path) { path = e; champ = big1; } }
+    if (size2 - 1 > path) { const int e = pcg_double_sweep(g, big2, path); if (e > path) { path = e; champ = big2; } }
     if (size3 - 1 > path) {   // rare: a third component is still large enough to matter
         rest = nontiny & ~big1 & ~big2;
         while (g.any(rest)) {
             const M comp = pcg_component(g, g.first_bit(rest), ctx);
             rest = rest & ~comp;
-            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); path = e > path ? e : path; }
+            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); if (e > path) { path = e; champ = comp; } }
         }
     }
 }
+template <class B>
+PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path) {
+    typename B::mask_t champ;
+    regions_and_longest_path(g, pass, regions, path, champ);
+}
 
-// Row masks of each tile class from the bit planes of the tile id (plane b = bit b of the id).
+// The same two statistics after ONE cell `c` changed, from the previous answer -- exact, and a fraction of the work.
+// Preconditions (the caller routes everything else to the full computation): the previous map had a champion
+// (a component `champ_old` whose double sweep gave path_old) and the changed cell is neither in it nor 4-adjacent
+// to it.  Then the champion is still a component of the new map, every component that does not touch c is
+// unchanged and cannot beat it, and only the components around c need looking at:
+//   * count the distinct components k of (new map minus c) among the up to four neighbours of c;
+//   * c became passable (`added`): they merge with c into one component -- regions + 1 - k, and that union is
+//     swept if its size says it could beat the champion;
+//   * c became impassable: its old component fell into those k pieces -- regions + k - 1, each piece swept if its
+//     size allows (removing a cell can lengthen the shortest paths around it).
+// `cbit` has the bit of c in the lane of its row and is zero elsewhere; pass_new is the new passable mask.
+template <class B>
+PCGRL_D void binary_incremental(B& g, typename B::mask_t pass_new, typename B::mask_t cbit, bool added, int regions_old, int path_old,
+                                typename B::mask_t champ_old, int& regions, int& path, typename B::mask_t& champ) {
+    typedef typename B::mask_t M;
+    const M base = pass_new & ~cbit;                 // the new map with c impassable
+    M rest = pcg_neighbours(g, cbit) & base;
+    path = path_old;
+    champ = champ_old;
+    int k = 0;
+    M uni = cbit;
+    if (g.any(rest)) {
+        const PcgFillCtx<B> ctx = pcg_fill_ctx(g, base);
+        while (g.any(rest)) {
+            const M comp = pcg_component(g, g.first_bit(rest), ctx);
+            rest = rest & ~comp;
+            ++k;
+            if (added) uni = uni | comp;
+            else if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); if (e > path) { path = e; champ = comp; } }
+        }
+    }
+    if (added) {
+        regions = regions_old + 1 - k;
+        if (g.popcount_sum(uni) - 1 > path) { const int e = pcg_double_sweep(g, uni, path); if (e > path) { path = e; champ = uni; } }
+    } else {
+        regions = regions_old + k - 1;
+    }
+}
+
 // ---------------------------------------------------------------- one map, several cooperating lane groups
 // The same result computed by several groups (wavefronts on the device) that all hold the whole map in their
 // registers and share, through `sh`, the set of cells whose component has not been retired yet plus the running
@@ -391,6 +437,7 @@ PCGRL_D typename B::mask_t rlp_prepare(B& g, typename B::mask_t pass, int& tiny_
     return pass & ~pcg_tiny_components(g, pass, tiny_regions, tiny_path);
 }
 
+// Row masks of each tile class from the bit planes of the tile id (plane b = bit b of the id).
 template <class M>
 struct ZeldaMasks {
     M empty, solid, player, key, door, enemy;

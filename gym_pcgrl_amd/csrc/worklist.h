@@ -13,13 +13,17 @@ enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
 #define WL_CSTRIDE 16
 // CHG: changed environments; RST: to reset; SOL: solver jobs of the step; SOL2: of the resets.  Sokoban only: RST2 =
 // environments whose episode the solver kernel ended, SOL3 = solver jobs of *their* resets.
-enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5, WL_NLIST = 6 };
+// INC (binary, 16-row maps): changed environments whose statistics can be updated incrementally (binary_incremental).
+enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5, WL_INC = 6, WL_NLIST = 7 };
+// An INC item: environment in bits 0..20, changed cell (row * 32 + column) in bits 21..29, bit 30 = the cell became passable.
+#define WL_INC_ENV_MASK 0x1FFFFF
 // An item of the changed list with this bit set is an unchanged environment whose episode ended (iteration cap):
 // k_stats resets it without recomputing anything.
 #define WL_RESET_ONLY (1 << 30)
 
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
+    void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
     const uint16_t* heat_end;        // end of the caller's whole heatmap buffer (also in sub-batch views)
     // optional episode statistics (pcgrl_bind_episode_stats): running return/length, latched at the end of an episode
     double* ep_return; int32_t* ep_length; double* last_return; int32_t* last_length;

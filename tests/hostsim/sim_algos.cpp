@@ -149,7 +149,48 @@ static long run_shared(const uint8_t* map, int h, int w, int ngroups, int32_t* o
     return sh.dup;
 }
 
+// Binary statistics along a sequence of single-cell changes the way the step kernels compute them: full
+// computation when there is no champion or the change touches it, binary_incremental otherwise.
+// flips: cell indices (y * w + x) toggled one after the other; out: [nflips + 1][2] (regions, path); returns the
+// number of incremental updates.
+template <int G, class T>
+static int run_incremental(const uint8_t* map0, int h, int w, const int* flips, int nflips, int32_t* out) {
+    typedef SimGroup<G, T> Gp;
+    typedef typename Gp::mask_t M;
+    Gp g;
+    M pass, valid;
+    for (int y = 0; y < h; y++) {
+        valid.v[y] = (w >= (int)(8 * sizeof(T))) ? ~(T)0 : (((T)1 << w) - 1);
+        for (int x = 0; x < w; x++) if (!(map0[y * w + x] & 1)) pass.v[y] |= (T)1 << x;
+    }
+    int regions, path, ninc = 0;
+    M champ;
+    regions_and_longest_path(g, pass, regions, path, champ);
+    out[0] = regions; out[1] = path;
+    for (int f = 0; f < nflips; f++) {
+        const int y = flips[f] / w, x = flips[f] % w;
+        M cbit; cbit.v[y] = (T)1 << x;
+        const bool added = !(pass.v[y] >> x & 1);
+        pass.v[y] ^= (T)1 << x;
+        M touch = (pcg_expand(g, cbit)) & champ;
+        if (!g.any(champ) || g.any(touch)) {
+            regions_and_longest_path(g, pass, regions, path, champ);
+        } else {
+            int r2, p2; M c2;
+            binary_incremental(g, pass, cbit, added, regions, path, champ, r2, p2, c2);
+            regions = r2; path = p2; champ = c2;
+            ninc++;
+        }
+        out[2 * (f + 1)] = regions; out[2 * (f + 1) + 1] = path;
+    }
+    return ninc;
+}
+
 extern "C" {
+int sim_binary_incremental(const uint8_t* map0, int h, int w, const int* flips, int nflips, int32_t* out) {
+    if (w > 32) return run_incremental<16, uint64_t>(map0, h, w, flips, nflips, out);
+    return run_incremental<16, uint32_t>(map0, h, w, flips, nflips, out);
+}
 long sim_stats_shared(const uint8_t* map, int h, int w, int ngroups, int32_t* out) {
     if (w > 32) return run_shared<64, uint64_t>(map, h, w, ngroups, out);
     return run_shared<64, uint32_t>(map, h, w, ngroups, out);

@@ -134,6 +134,33 @@ def test_extra_wave_rounds_are_harmless(sim):
         sim.sim_set_spurious(0)
 
 
+def test_binary_incremental_update(sim):
+    """binary_incremental (pcgrl_algos.h): regions and path after single-cell changes from the previous answer and
+    the cached champion component, against the oracle on the full map after every change -- long random walks
+    at several shapes and densities, with spurious wave rounds injected."""
+    sim.sim_binary_incremental.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    sim.sim_set_spurious.argtypes = [C.c_int]
+    rs = np.random.RandomState(17)
+    total = ninc = 0
+    for (h, w) in ((14, 14), (16, 11), (5, 5), (9, 32), (3, 7), (16, 40), (1, 9)):
+        for dens in (0.3, 0.5, 0.65):
+            for rep in range(3):
+                m = (rs.random_sample((h, w)) < dens).astype(np.uint8)
+                T = 120
+                flips = rs.randint(0, h * w, size=T).astype(np.int32)
+                out = np.zeros((T + 1, 2), np.int32)
+                sim.sim_set_spurious(int(rs.randint(0, 30)))
+                ninc += sim.sim_binary_incremental(_p(m), h, w, _p(flips), T, _p(out))
+                sim.sim_set_spurious(0)
+                cur = m.copy()
+                assert np.array_equal(out[0], ol.get_stats("binary", cur))
+                for t in range(T):
+                    cur.flat[flips[t]] ^= 1
+                    assert np.array_equal(out[t + 1], ol.get_stats("binary", cur)), ((h, w), dens, t, out[t + 1], ol.get_stats("binary", cur))
+                total += T
+    assert ninc > total // 3          # the incremental route is the common one
+
+
 def test_shared_rest_binary_stats(sim):
     """The cooperative form of regions + longest path (k_stats_wide: four wavefronts per tall map sharing the set
     of unretired cells) against the oracle, under the interleaving with the most duplicate extractions."""
