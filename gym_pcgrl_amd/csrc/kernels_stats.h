@@ -82,7 +82,7 @@ __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBu
 // The item loop is therefore wave-uniform: all groups of a wavefront iterate together, a group without
 // an item computes on an empty map.
 template <int PROB, int G, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
+__global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
                                                         int inline_reset, int gen_map) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: per wave MT ring + tile bytes
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_stats(PcgrlParams P, DevBufs B,
     // the incremental list -- a wavefront works on one kind only.
     constexpr bool kInc = PROB == PCGRL_PROB_BINARY && G == 16 && sizeof(MaskT) == 4;
     const bool with_inc = kInc && mode == MODE_STEP && B.champ != nullptr;
-    const int n_full = wl_load_prefix(B, parity, list, s_pref);
+    int n_inc = 0;
+    const int n_full = with_inc ? wl_load_prefix2(B, parity, list, WL_INC, s_pref, s_pref_inc, &n_inc) : wl_load_prefix(B, parity, list, s_pref);
     const int n_full_pad = (n_full + GPW - 1) / GPW * GPW;
-    const int n_inc = with_inc ? wl_load_prefix(B, parity, WL_INC, s_pref_inc) : 0;
     const int n = with_inc ? n_full_pad + n_inc : n_full;
     MaskT* champ_base = reinterpret_cast<MaskT*>(B.champ);
     const int lane64 = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = lane64 / G;
