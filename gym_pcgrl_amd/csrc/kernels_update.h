@@ -10,9 +10,9 @@
 #define PCGRL_SPEC_DRAWS 6
 template <int REP, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
-    __shared__ int s_cnt[3][4];
-    __shared__ int s_base[3];
-    __shared__ int s_hist[WL_NSHARD], s_gbase[WL_NSHARD];
+    __shared__ int s_cnt[2][4];
+    __shared__ int s_base[2];
+    __shared__ int s_hist[WL_NSHARD + 1], s_gbase[WL_NSHARD + 1];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
     const bool act = e < P.num_envs;
     bool chg = false, rst = false, cheap = false;
@@ -170,8 +170,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     const bool inl = rst && B.inline_reset;
     const int val = inl ? (e | WL_RESET_ONLY) : e;
     if (P.prob == PCGRL_PROB_BINARY && P.group == 16) {
-        block_append_bucketed((chg && !cheap) || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase);
-        if (B.champ != nullptr) block_append(cheap, inc_item, B, parity, WL_INC, s_cnt[2], &s_base[2]);
+        block_append_bucketed((chg && !cheap) || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase, cheap, inc_item, B.champ != nullptr ? WL_INC : -1);
     } else block_append(chg || inl, val, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
     if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
 }

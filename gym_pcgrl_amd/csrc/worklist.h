@@ -121,18 +121,26 @@ __device__ __forceinline__ void block_append(bool flag, int value, const DevBufs
 // stats are a good predictor: one tile changed), one bucket per shard, so that the four maps sharing a
 // wavefront in k_stats have similar trip counts.  Every thread of the block must call this.
 __device__ __forceinline__ void block_append_bucketed(bool flag, int bucket, int value, const DevBufs& B, int parity, int list,
-                                                      int* s_hist, int* s_gbase) {
-    if (threadIdx.x < WL_NSHARD) s_hist[threadIdx.x] = 0;
+                                                      int* s_hist, int* s_gbase, bool flag2 = false, int value2 = 0, int list2 = -1) {
+    // s_hist / s_gbase have WL_NSHARD + 1 entries: the last one serves the optional second list (plain, one shard per
+    // block like block_append), whose global atomic shares the round trip of the bucket atomics.
+    if (threadIdx.x <= WL_NSHARD) s_hist[threadIdx.x] = 0;
     __syncthreads();
     int rank = 0;
     if (flag) rank = atomicAdd(&s_hist[bucket], 1);
+    else if (flag2) rank = atomicAdd(&s_hist[WL_NSHARD], 1);
     __syncthreads();
+    const int shard2 = blockIdx.x & (WL_NSHARD - 1);
     if (threadIdx.x < WL_NSHARD) {
         const int c = s_hist[threadIdx.x];
         if (c > 0) s_gbase[threadIdx.x] = atomicAdd(wl_counters(B, parity, list) + threadIdx.x * WL_CSTRIDE, c);
+    } else if (threadIdx.x == WL_NSHARD && list2 >= 0) {
+        const int c = s_hist[WL_NSHARD];
+        if (c > 0) s_gbase[WL_NSHARD] = atomicAdd(wl_counters(B, parity, list2) + shard2 * WL_CSTRIDE, c);
     }
     __syncthreads();
     if (flag) B.wl_items[list][(size_t)bucket * B.wl_cap[list] + s_gbase[bucket] + rank] = value;
+    else if (flag2) B.wl_items[list2][(size_t)shard2 * B.wl_cap[list2] + s_gbase[WL_NSHARD] + rank] = value2;
 }
 __device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int4& s0, const int4& s1) {
     if (P.prob == PCGRL_PROB_BINARY) {   // (path-length / 6, regions / 3), 8 x 8
