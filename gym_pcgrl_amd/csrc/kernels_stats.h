@@ -83,7 +83,7 @@ __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBu
 // an item computes on an empty map.
 template <int PROB, int G, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
-                                                        int inline_reset, int gen_map) {
+                                                        int inline_reset, int gen_map, int lone0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: per wave MT ring + tile bytes
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
     // the last kernel of a step zeroes the *other* parity's work-list counters for the next step
@@ -96,8 +96,12 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     const bool with_inc = kInc && mode == MODE_STEP && B.champ != nullptr;
     int n_inc = 0;
     const int n_full = with_inc ? wl_load_prefix2(B, parity, list, WL_INC, s_pref, s_pref_inc, &n_inc) : wl_load_prefix(B, parity, list, s_pref);
-    const int n_full_pad = (n_full + GPW - 1) / GPW * GPW;
-    const int n = with_inc ? n_full_pad + n_inc : n_full;
+    // lone0: shard 0 of the list holds the environments that are certain to be reset in this launch (k_update puts them
+    // there).  Stats + reset + start stats is the longest chain of dependent steps in the kernel, so those items come
+    // first and get a wavefront each: the chains start at once and none waits behind another reset of its wavefront.
+    const int n0 = lone0 ? s_pref[1] : 0;
+    const int w_full = (n_full - n0 + GPW - 1) / GPW;             // wavefronts of the remaining full items
+    const int w_total = n0 + w_full + (n_inc + GPW - 1) / GPW;
     MaskT* champ_base = reinterpret_cast<MaskT*>(B.champ);
     const int lane64 = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = lane64 / G;
     const int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
@@ -106,10 +110,11 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)wv * (PCGRL_MT_N * 4 + tiles_bytes));
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
     const MaskT rowmask = row_valid<MaskT>(g.lane, W, H);
-    for (int base = blockIdx.x * GPB + wv * GPW; base < n; base += gridDim.x * GPB) {
-        const bool inc = with_inc && base >= n_full_pad;          // wave-uniform
-        const int item = inc ? base - n_full_pad + gw : base + gw;
-        const bool have = item < (inc ? n_inc : n_full);
+    for (int wid = blockIdx.x * (PCGRL_BLOCK / 64) + wv; wid < w_total; wid += gridDim.x * (PCGRL_BLOCK / 64)) {
+        const bool lone = wid < n0;                                // wave-uniform, like inc
+        const bool inc = wid >= n0 + w_full;
+        const int item = lone ? wid : (inc ? (wid - n0 - w_full) * GPW + gw : n0 + (wid - n0) * GPW + gw);
+        const bool have = lone ? gw == 0 : item < (inc ? n_inc : n_full);
         const int raw = have ? (inc ? wl_get(B, WL_INC, s_pref_inc, item) : wl_get(B, list, s_pref, item)) : 0;
         const bool reset_only = have && !inc && (raw & WL_RESET_ONLY) != 0;
         const bool compute = have && !reset_only;

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     __shared__ int s_hist[WL_NSHARD + 1], s_gbase[WL_NSHARD + 1];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
     const bool act = e < P.num_envs;
-    bool chg = false, rst = false, cheap = false;
+    bool chg = false, rst = false, cheap = false, sure_done = false;
     int bucket = 0, inc_item = 0;
     if (act) {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
@@ -146,6 +146,9 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
         if (REP != PCGRL_REP_WIDE) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        // the episode ends whatever the new statistics are (pcgrl_env.py:143): the reset is certain
+        sure_done = chg && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
+        if (sure_done) cheap = false;
         if (!chg) {
             // new_stats is old_stats (pcgrl_env.py:132-142): reward 0, done/info from the current stats
             int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
@@ -170,6 +173,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     const bool inl = rst && B.inline_reset;
     const int val = inl ? (e | WL_RESET_ONLY) : e;
     if (P.prob == PCGRL_PROB_BINARY && P.group == 16) {
+        // bucket 0 = environments that k_stats is certain to reset (k_stats starts those first, a wavefront each)
+        bucket = (inl || sure_done) ? 0 : (bucket < 1 ? 1 : bucket);
         block_append_bucketed((chg && !cheap) || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase, cheap, inc_item, B.champ != nullptr ? WL_INC : -1);
     } else block_append(chg || inl, val, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
     if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);

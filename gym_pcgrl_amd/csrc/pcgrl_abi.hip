@@ -393,6 +393,8 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     // in-kernel reset: one MT ring + tile-byte staging area per wavefront
     const size_t lds = inline_reset ? 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
+    // shard 0 of the bucketed changed list = certain resets (k_update, single-cell representations of the binary problem)
+    const int lone0 = (PROB == PCGRL_PROB_BINARY && P.group == 16 && mode == MODE_STEP && inline_reset && P.rep <= PCGRL_REP_TURTLE) ? 1 : 0;
     if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !getenv("PCGRL_NO_WIDE")) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
         const size_t lds1 = inline_reset ? (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
         const int gridw = P.num_envs < 16384 ? P.num_envs : 16384;
@@ -405,13 +407,13 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
         return PCGRL_OK;
     }
     if (P.group == 16 && P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen, lone0);
     else if (P.group == 16)
-        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
+        hipLaunchKernelGGL((k_stats<PROB, 16, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen, lone0);
     else if (P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen, lone0);
     else
-        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
+        hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen, lone0);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
