@@ -94,13 +94,18 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     // the incremental list -- a wavefront works on one kind only.
     constexpr bool kInc = PROB == PCGRL_PROB_BINARY && G == 16 && sizeof(MaskT) == 4;
     const bool with_inc = kInc && mode == MODE_STEP && B.champ != nullptr;
-    int n_inc = 0;
-    const int n_full = with_inc ? wl_load_prefix2(B, parity, list, WL_INC, s_pref, s_pref_inc, &n_inc) : wl_load_prefix(B, parity, list, s_pref);
+    // lone0 = 1: the certain resets are shard 0 of `list` (bucketed list of the binary problem); 2: they are the list
+    // WL_RST (its prefix shares s_pref_inc with the incremental list, which such a launch does not have)
+    int n_second = 0;
+    const int n_full = (with_inc || lone0 == 2) ? wl_load_prefix2(B, parity, list, with_inc ? WL_INC : WL_RST, s_pref, s_pref_inc, &n_second)
+                                                 : wl_load_prefix(B, parity, list, s_pref);
+    const int n_inc = with_inc ? n_second : 0;
     // lone0: shard 0 of the list holds the environments that are certain to be reset in this launch (k_update puts them
     // there).  Stats + reset + start stats is the longest chain of dependent steps in the kernel, so those items come
     // first and get a wavefront each: the chains start at once and none waits behind another reset of its wavefront.
-    const int n0 = lone0 ? s_pref[1] : 0;
-    const int w_full = (n_full - n0 + GPW - 1) / GPW;             // wavefronts of the remaining full items
+    const int n0 = lone0 == 1 ? s_pref[1] : (lone0 == 2 ? n_second : 0);
+    const int f0 = lone0 == 1 ? n0 : 0;                           // items of `list` that the lone wavefronts take
+    const int w_full = (n_full - f0 + GPW - 1) / GPW;             // wavefronts of the remaining full items
     const int w_total = n0 + w_full + (n_inc + GPW - 1) / GPW;
     MaskT* champ_base = reinterpret_cast<MaskT*>(B.champ);
     const int lane64 = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = lane64 / G;
@@ -113,9 +118,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     for (int wid = blockIdx.x * (PCGRL_BLOCK / 64) + wv; wid < w_total; wid += gridDim.x * (PCGRL_BLOCK / 64)) {
         const bool lone = wid < n0;                                // wave-uniform, like inc
         const bool inc = wid >= n0 + w_full;
-        const int item = lone ? wid : (inc ? (wid - n0 - w_full) * GPW + gw : n0 + (wid - n0) * GPW + gw);
+        const int item = lone ? wid : (inc ? (wid - n0 - w_full) * GPW + gw : f0 + (wid - n0) * GPW + gw);
         const bool have = lone ? gw == 0 : item < (inc ? n_inc : n_full);
-        const int raw = have ? (inc ? wl_get(B, WL_INC, s_pref_inc, item) : wl_get(B, list, s_pref, item)) : 0;
+        const bool second = inc || (lone && lone0 == 2);
+        const int raw = have ? (second ? wl_get(B, inc ? WL_INC : WL_RST, s_pref_inc, item) : wl_get(B, list, s_pref, item)) : 0;
         const bool reset_only = have && !inc && (raw & WL_RESET_ONLY) != 0;
         const bool compute = have && !reset_only;
         const int e = inc ? (raw & WL_INC_ENV_MASK) : (raw & ~WL_RESET_ONLY);
@@ -229,12 +235,15 @@ template <class MaskT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
                                                              int inline_reset, int gen_map) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: MT ring + tile bytes of one environment
-    __shared__ int s_pref[WL_NSHARD + 1];
+    __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1];
     __shared__ MaskT s_rest[64];
     __shared__ int s_regions, s_best, s_flag;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<64, MaskT> g;
-    const int n = wl_load_prefix(B, parity, list, s_pref);
+    // with the in-kernel reset, k_update puts the environments that are certain to be reset on WL_RST: those come first
+    int n_rst = 0;
+    const int n_chg = inline_reset ? wl_load_prefix2(B, parity, list, WL_RST, s_pref, s_pref_rst, &n_rst) : wl_load_prefix(B, parity, list, s_pref);
+    const int n = n_rst + n_chg;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int W = P.width, H = P.height;
     const int bh = (H + NWAVES - 1) / NWAVES;
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
     const MaskT rowmask = row_valid<MaskT>(lane, W, H);
     for (int item = blockIdx.x; item < n; item += gridDim.x) {
-        const int raw = wl_get(B, list, s_pref, item);
+        const int raw = item < n_rst ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item - n_rst);
         const bool reset_only = (raw & WL_RESET_ONLY) != 0;
         const int e = raw & ~WL_RESET_ONLY;
         const int shard = (item >> 4) & (WL_NSHARD - 1);

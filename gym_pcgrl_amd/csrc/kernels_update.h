@@ -145,6 +145,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             heat_increment(B, B.heat + ((size_t)e * H + hy) * W + hx);
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
+        sure_done = chg && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
         if (REP != PCGRL_REP_WIDE) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
         // the episode ends whatever the new statistics are (pcgrl_env.py:143): the reset is certain
         sure_done = chg && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
@@ -176,8 +177,14 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         // bucket 0 = environments that k_stats is certain to reset (k_stats starts those first, a wavefront each)
         bucket = (inl || sure_done) ? 0 : (bucket < 1 ? 1 : bucket);
         block_append_bucketed((chg && !cheap) || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase, cheap, inc_item, B.champ != nullptr ? WL_INC : -1);
-    } else block_append(chg || inl, val, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
-    if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+        if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+    } else if (B.inline_reset) {
+        // same idea without buckets: the certain resets go to their own list, which k_stats works through first
+        const bool first = inl || sure_done;
+        block_append2(chg && !first, e, WL_CHG, first, val, WL_RST, B, parity, s_cnt, s_base);
+    } else {
+        block_append2(chg, e, WL_CHG, rst, e, WL_RST, B, parity, s_cnt, s_base);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
     __shared__ int s_base[2];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
     const bool act = e < P.num_envs;
-    bool chg = false, rst = false;
+    bool chg = false, rst = false, sure_done = false;
     if (act) {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes, NT = P.ntiles;
         const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
@@ -284,6 +291,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
         }
     }
     const bool inl = rst && B.inline_reset;   // see k_update
-    block_append(chg || inl, inl ? (e | WL_RESET_ONLY) : e, B, parity, WL_CHG, s_cnt[0], &s_base[0]);
-    if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
+    if (B.inline_reset) {
+        const bool first = inl || sure_done;
+        block_append2(chg && !first, e, WL_CHG, first, inl ? (e | WL_RESET_ONLY) : e, WL_RST, B, parity, s_cnt, s_base);
+    } else {
+        block_append2(chg, e, WL_CHG, rst, e, WL_RST, B, parity, s_cnt, s_base);
+    }
 }

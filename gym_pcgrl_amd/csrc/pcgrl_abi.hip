@@ -393,8 +393,10 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     // in-kernel reset: one MT ring + tile-byte staging area per wavefront
     const size_t lds = inline_reset ? 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
-    // shard 0 of the bucketed changed list = certain resets (k_update, single-cell representations of the binary problem)
-    const int lone0 = (PROB == PCGRL_PROB_BINARY && P.group == 16 && mode == MODE_STEP && inline_reset && P.rep <= PCGRL_REP_TURTLE) ? 1 : 0;
+    // where k_update put the environments that are certain to be reset in this launch
+    // (1: shard 0 of the bucketed changed list -- single-cell representations of the binary problem on 16-row maps;
+    //  2: the list WL_RST -- everything else that resets in k_stats)
+    const int lone0 = !(mode == MODE_STEP && inline_reset) ? 0 : ((PROB == PCGRL_PROB_BINARY && P.group == 16 && P.rep <= PCGRL_REP_TURTLE) ? 1 : 2);
     if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !getenv("PCGRL_NO_WIDE")) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
         const size_t lds1 = inline_reset ? (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
         const int gridw = P.num_envs < 16384 ? P.num_envs : 16384;

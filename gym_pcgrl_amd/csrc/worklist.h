@@ -117,6 +117,30 @@ __device__ __forceinline__ void block_append(bool flag, int value, const DevBufs
     }
 }
 
+// Two lists in one pass: the two global atomics share a round trip.  Every thread of the block must call this.
+__device__ __forceinline__ void block_append2(bool flag_a, int value_a, int list_a, bool flag_b, int value_b, int list_b,
+                                              const DevBufs& B, int parity, int (*s_cnt)[4], int* s_base) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int shard = blockIdx.x & (WL_NSHARD - 1);
+    const uint64_t ma = __ballot(flag_a), mb = __ballot(flag_b);
+    if (lane == 0) { s_cnt[0][w] = __popcll(ma); s_cnt[1][w] = __popcll(mb); }
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+        const int k = threadIdx.x >> 6;
+        const int tot = s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+        s_base[k] = tot ? atomicAdd(wl_counters(B, parity, k ? list_b : list_a) + shard * WL_CSTRIDE, tot) : 0;
+    }
+    __syncthreads();
+    if (flag_a || flag_b) {
+        const int k = flag_a ? 0 : 1;
+        const int list = k ? list_b : list_a;
+        int off = s_base[k];
+        for (int i = 0; i < w; i++) off += s_cnt[k][i];
+        off += __popcll((k ? mb : ma) & ((1ull << lane) - 1ull));
+        B.wl_items[list][(size_t)shard * B.wl_cap[list] + off] = k ? value_b : value_a;
+    }
+}
+
 // Changed environments are bucketed by how hard their statistics are expected to be (the previous
 // stats are a good predictor: one tile changed), one bucket per shard, so that the four maps sharing a
 // wavefront in k_stats have similar trip counts.  Every thread of the block must call this.
