@@ -65,7 +65,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         // ---- round trip 2: everything addressed by the cursor cell and by the ring cursor
         uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
         MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G + wy;
-        const int old = *cell;
+        // the old tile: from the plane word when there is a single plane (one scattered read less), else from the byte map
+        const int old_byte = (NPL > 1) ? (int)*cell : 0;
         // binary, 16-row maps: the three champion rows around the cell, for the routing decision below
         const bool inc_on = sizeof(MaskT) == 4 && P.prob == PCGRL_PROB_BINARY && B.champ != nullptr;
         uint32_t ch0 = 0, chu = 0, chd = 0;
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         }
         MaskT m0 = pl[0], m1 = 0, m2 = 0;
         if (NPL > 1) { m1 = pl[G]; m2 = pl[2 * G]; }
+        const int old = (NPL > 1) ? old_byte : (int)((m0 >> wx) & 1);
         uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
         if (draws) {
