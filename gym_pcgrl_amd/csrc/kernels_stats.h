@@ -11,14 +11,17 @@ __device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
 
 // Returns true when the environment finished its episode and has to be reset; with push_reset the
 // environment is also appended to the reset list (consumed by k_reset), otherwise the caller resets it.
+// `pre` (STEP): iteration/changes read before the environment's counters were reset (k_stats resets an environment that
+// is certain to end its episode *before* it finishes the step).
 __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
-                                              int mode, int parity, int shard, bool push_reset = true, int rst_list = WL_RST) {
+                                              int mode, int parity, int shard, bool push_reset = true, int rst_list = WL_RST,
+                                              const int2* pre = nullptr) {
     int32_t* st = B.stats + (size_t)e * 8;
     int32_t* start = B.start_stats + (size_t)e * 8;
     if (mode == MODE_STEP) {
         int32_t old[PCGRL_MAX_STATS], sv[PCGRL_MAX_STATS];
         for (int k = 0; k < 8; k++) { old[k] = st[k]; sv[k] = start[k]; }
-        const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
+        const int2 c = pre ? *pre : reinterpret_cast<const int2*>(B.counters)[e];
         const double r = compute_reward(P, s, old);
         const bool d = episode_over(P, s, sv) || c.y >= P.max_changes || c.x >= P.max_iterations;
         B.reward[e] = r;
@@ -131,6 +134,34 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
         if (compute) {
             b0 = planes_e[g.lane];
             if (NPL > 1) { b1 = planes_e[G + g.lane]; b2 = planes_e[2 * G + g.lane]; }
+        }
+        if (GPW >= 2 && lone && inline_reset) {
+            // A certain reset.  The new map does not depend on the statistics of the old one, so the environment is reset
+            // first and then both statistics -- of the map the step ended on (rows already in registers, group 0) and
+            // of the regenerated one (group 1) -- are computed side by side: the chain is one statistics computation
+            // long instead of two.  The step is finished with the counters read before the reset zeroed them.
+            const int e0 = __builtin_amdgcn_readlane(e, 0);
+            const bool ro = __builtin_amdgcn_readlane((int)reset_only, 0) != 0;
+            int2 pre = make_int2(0, 0);
+            if (lane64 == 0) pre = reinterpret_cast<const int2*>(B.counters)[e0];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // old planes and counters are in registers
+            wave_reset_env<PROB>(P, B, e0, gen_map, mt, tiles, lane64);
+            MaskT t0, t1, t2;
+            planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e0 * NPL * G, gw == 1 ? g.lane : -1, t0, t1, t2);
+            if (gw == 1) { b0 = t0; b1 = t1; b2 = t2; }
+            __builtin_amdgcn_wave_barrier();
+            const bool act = (gw == 0 && !ro) || gw == 1;
+            int32_t sl[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+            MaskT champ_l = 0;
+            bool ns = false;
+            if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l);
+            if (lane64 == 0 && !ro) finalize_item(P, B, e0, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
+            __builtin_amdgcn_wave_barrier();
+            if (gw == 1) {
+                if (kInc && champ_base) champ_base[(size_t)e0 * G + g.lane] = champ_l;
+                if (g.lane == 0) finish_or_park(P, B, e0, sl, ns, MODE_START, parity, shard);
+            }
+            continue;
         }
         int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool need_solver = false;
