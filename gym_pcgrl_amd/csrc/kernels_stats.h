@@ -88,7 +88,7 @@ template <int PROB, int G, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
                                                         int inline_reset, int gen_map, int lone0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: per wave MT ring + tile bytes
-    __shared__ int s_pref[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
+    __shared__ int s_pref[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1];
     // the last kernel of a step zeroes the *other* parity's work-list counters for the next step
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<G, MaskT> g;
@@ -96,17 +96,20 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     // Binary 16-row maps in a step: after the items of the changed list (padded to whole wavefronts) come the items of
     // the incremental list -- a wavefront works on one kind only.
     constexpr bool kInc = PROB == PCGRL_PROB_BINARY && G == 16 && sizeof(MaskT) == 4;
-    const bool with_inc = kInc && mode == MODE_STEP && B.champ != nullptr;
-    // lone0 = 1: the certain resets are shard 0 of `list` (bucketed list of the binary problem); 2: they are the list
-    // WL_RST (its prefix shares s_pref_inc with the incremental list, which such a launch does not have)
-    int n_second = 0;
-    const int n_full = (with_inc || lone0 == 2) ? wl_load_prefix2(B, parity, list, with_inc ? WL_INC : WL_RST, s_pref, s_pref_inc, &n_second)
+    // Zelda (same restriction on the map size): every changed item of a step carries the cell and what happened to its
+    // passability; the region count is updated (items of `list`) or simply kept (items of WL_INC).
+    constexpr bool kZinc = PROB == PCGRL_PROB_ZELDA && G == 16 && sizeof(MaskT) == 4;
+    const bool zinc = kZinc && mode == MODE_STEP && B.zelda_inc;
+    const bool with_inc = (kInc && mode == MODE_STEP && B.champ != nullptr) || zinc;
+    // lone0 = 1: the certain resets are shard 0 of `list` (bucketed list of the binary problem); 2: they are the list WL_RST
+    int n_inc = 0, n_rst = 0;
+    const int n_full = (with_inc || lone0 == 2) ? wl_load_prefix3(B, parity, list, with_inc ? WL_INC : -1, lone0 == 2 ? WL_RST : -1, s_pref,
+                                                                  s_pref_inc, s_pref_rst, &n_inc, &n_rst)
                                                  : wl_load_prefix(B, parity, list, s_pref);
-    const int n_inc = with_inc ? n_second : 0;
     // lone0: shard 0 of the list holds the environments that are certain to be reset in this launch (k_update puts them
     // there).  Stats + reset + start stats is the longest chain of dependent steps in the kernel, so those items come
     // first and get a wavefront each: the chains start at once and none waits behind another reset of its wavefront.
-    const int n0 = lone0 == 1 ? s_pref[1] : (lone0 == 2 ? n_second : 0);
+    const int n0 = lone0 == 1 ? s_pref[1] : (lone0 == 2 ? n_rst : 0);
     const int f0 = lone0 == 1 ? n0 : 0;                           // items of `list` that the lone wavefronts take
     const int w_full = (n_full - f0 + GPW - 1) / GPW;             // wavefronts of the remaining full items
     const int w_total = n0 + w_full + (n_inc + GPW - 1) / GPW;
@@ -123,11 +126,12 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
         const bool inc = wid >= n0 + w_full;
         const int item = lone ? wid : (inc ? (wid - n0 - w_full) * GPW + gw : f0 + (wid - n0) * GPW + gw);
         const bool have = lone ? gw == 0 : item < (inc ? n_inc : n_full);
-        const bool second = inc || (lone && lone0 == 2);
-        const int raw = have ? (second ? wl_get(B, inc ? WL_INC : WL_RST, s_pref_inc, item) : wl_get(B, list, s_pref, item)) : 0;
-        const bool reset_only = have && !inc && (raw & WL_RESET_ONLY) != 0;
+        const bool from_rst = lone && lone0 == 2;
+        const int raw = !have ? 0 : (inc ? wl_get(B, WL_INC, s_pref_inc, item) : (from_rst ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item)));
+        const bool packed = inc || (kZinc && zinc && !lone);        // (environment, cell, passability change) in one word
+        const bool reset_only = have && !packed && (raw & WL_RESET_ONLY) != 0;
         const bool compute = have && !reset_only;
-        const int e = inc ? (raw & WL_INC_ENV_MASK) : (raw & ~WL_RESET_ONLY);
+        const int e = packed ? (raw & WL_INC_ENV_MASK) : (raw & ~WL_RESET_ONLY);
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
         MaskT b0 = 0, b1 = 0, b2 = 0;
@@ -175,6 +179,12 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
                 int regions, path;
                 binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, ((raw >> 30) & 1) != 0, old.x, old.y, champ_old, regions, path, champ);
                 s[0] = regions; s[1] = path; s[2] = 1;
+            }
+        } else if (kZinc && packed) {
+            if (compute) {      // zelda: one cell was written; keep or update the region count
+                const int cell = (raw >> 21) & 511;
+                const MaskT cbit = (g.lane == (cell >> 5)) ? (MaskT)1 << (cell & 31) : (MaskT)0;
+                zelda_stats(g, P, b0, b1, b2, rowmask, s, (int)(((uint32_t)raw >> 30) & 3u), cbit, B.stats[(size_t)e * 8 + 4]);
             }
         } else if (compute) {
             need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ);

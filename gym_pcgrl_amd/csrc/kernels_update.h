@@ -10,8 +10,8 @@
 #define PCGRL_SPEC_DRAWS 6
 template <int REP, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
-    __shared__ int s_cnt[2][4];
-    __shared__ int s_base[2];
+    __shared__ int s_cnt[3][4];
+    __shared__ int s_base[3];
     __shared__ int s_hist[WL_NSHARD + 1], s_gbase[WL_NSHARD + 1];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
     const bool act = e < P.num_envs;
@@ -97,6 +97,13 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
                 cheap = touch == 0;
                 inc_item = e | ((wy * 32 + wx) << 21) | ((tile == 0 ? 1 : 0) << 30);
             }
+            if (B.zelda_inc) {
+                // zelda: what the write does to the cell's passability for the region count (zelda_prob.py:93: everything
+                // but solid = 1 and door = 4), so that k_stats can update the count instead of recounting
+                const bool po = old != 1 && old != 4, pn = tile != 1 && tile != 4;
+                inc_item = e | ((wy * 32 + wx) << 21) | (int)((po == pn ? 0u : (pn ? 1u : 2u)) << 30);
+                cheap = po == pn;
+            }
             *cell = (uint8_t)tile;
             const MaskT bit = (MaskT)1 << wx;
             pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
@@ -180,12 +187,15 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         bucket = (inl || sure_done) ? 0 : (bucket < 1 ? 1 : bucket);
         block_append_bucketed((chg && !cheap) || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase, cheap, inc_item, B.champ != nullptr ? WL_INC : -1);
         if (!B.inline_reset) block_append(rst, e, B, parity, WL_RST, s_cnt[1], &s_base[1]);
-    } else if (B.inline_reset) {
-        // same idea without buckets: the certain resets go to their own list, which k_stats works through first
-        const bool first = inl || sure_done;
-        block_append2(chg && !first, e, WL_CHG, first, val, WL_RST, B, parity, s_cnt, s_base);
     } else {
-        block_append2(chg, e, WL_CHG, rst, e, WL_RST, B, parity, s_cnt, s_base);
+        // same idea without buckets: the certain resets go to their own list, which k_stats works through first (without the
+        // in-kernel reset WL_RST is simply the reset list of k_reset).  Zelda: changed environments are split by what their
+        // statistics will cost -- the region count has to be updated (WL_CHG) or not (WL_INC) -- and carry the cell.
+        const bool first = B.inline_reset ? (inl || sure_done) : rst;
+        int dest = -1, v = e;
+        if (first) { dest = 2; v = val; }
+        else if (chg) { dest = (B.zelda_inc && cheap) ? 1 : 0; v = B.zelda_inc ? inc_item : e; }
+        block_append3(dest, v, B, parity, s_cnt, s_base);
     }
 }
 

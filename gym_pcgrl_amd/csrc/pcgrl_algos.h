@@ -455,16 +455,43 @@ PCGRL_D ZeldaMasks<M> zelda_masks(M b0, M b1, M b2, M valid) {
     return z;
 }
 
-// zelda_prob.py:80-112.  out: player,key,door,enemies,regions,nearest-enemy,path-length
+// The number of 4-connected components after ONE cell changed its passability, from the previous count (the same local
+// argument as binary_incremental): with k = the number of distinct components of (new map minus the cell) among the
+// cell's up to four neighbours, a cell that became passable merges them into one (regions + 1 - k), a cell that became
+// impassable leaves its component in k pieces (regions - 1 + k).  `cbit` has the cell's bit in the lane of its row.
+template <class B>
+PCGRL_D int regions_incremental(B& g, typename B::mask_t pass_new, typename B::mask_t cbit, bool added, int regions_old) {
+    typedef typename B::mask_t M;
+    const M base = pass_new & ~cbit;
+    M rest = pcg_neighbours(g, cbit) & base;
+    int k = 0;
+    if (g.any(rest)) {
+        const PcgFillCtx<B> ctx = pcg_fill_ctx(g, base);
+        while (g.any(rest)) {
+            rest = rest & ~pcg_component(g, g.first_bit(rest), ctx);
+            ++k;
+        }
+    }
+    return added ? regions_old + 1 - k : regions_old - 1 + k;
+}
+
+// zelda_prob.py:80-112.  out: player,key,door,enemies,regions,nearest-enemy,path-length.
+// pass_change < 0: count the regions from scratch; otherwise one cell (`cbit`) changed since the map had `regions_old`
+// regions: 0 = its passability (zelda_prob.py:93: everything but solid and door) did not change, 1 = it became
+// passable, 2 = it became impassable.
 template <class B>
 PCGRL_D void zelda_stats(B& g, const PcgrlParams& P, typename B::mask_t b0, typename B::mask_t b1,
-                         typename B::mask_t b2, typename B::mask_t valid, int32_t* out) {
+                         typename B::mask_t b2, typename B::mask_t valid, int32_t* out,
+                         int pass_change = -1, typename B::mask_t cbit = typename B::mask_t(), int regions_old = 0) {
     typedef typename B::mask_t M;
     ZeldaMasks<M> z = zelda_masks(b0, b1, b2, valid);
     int player = g.popcount_sum(z.player), key = g.popcount_sum(z.key), door = g.popcount_sum(z.door);
     int enemies = g.popcount_sum(z.enemy);
     M walk = z.empty | z.player | z.key | z.enemy;          // regions / player->key passable set
-    int regions = count_regions(g, walk);
+    int regions;
+    if (pass_change < 0) regions = count_regions(g, walk);
+    else if (pass_change == 0) regions = regions_old;
+    else regions = regions_incremental(g, walk, cbit, pass_change == 1, regions_old);
     int nearest = 0, path = 0;
     if (player == 1 && regions == 1) {
         if (enemies > 0) {

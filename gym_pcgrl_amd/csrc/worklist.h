@@ -15,7 +15,9 @@ enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
 // environments whose episode the solver kernel ended, SOL3 = solver jobs of *their* resets.
 // INC (binary, 16-row maps): changed environments whose statistics can be updated incrementally (binary_incremental).
 enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5, WL_INC = 6, WL_NLIST = 7 };
-// An INC item: environment in bits 0..20, changed cell (row * 32 + column) in bits 21..29, bit 30 = the cell became passable.
+// An INC item (and, for zelda, a CHG item too): environment in bits 0..20, changed cell (row * 32 + column) in bits 21..29,
+// bits 30..31 = what happened to the cell's passability (binary: 1 = became passable, 0 = impassable; zelda: 0 = unchanged,
+// 1 = became passable, 2 = impassable).
 #define WL_INC_ENV_MASK 0x1FFFFF
 // An item of the changed list with this bit set is an unchanged environment whose episode ended (iteration cap):
 // k_stats resets it without recomputing anything.
@@ -42,6 +44,7 @@ struct DevBufs {
     int32_t sok_hard_cap;            // levels k_sokoban may publish per launch (SOK_HARD_CAP; PCGRL_SOK_HARD_CAP lowers it for tests)
     int32_t sok_fast_maxc;           // most crates the register-resident search takes (SOKF_MAXC; -1: PCGRL_SOK_GENERIC=1 forces the generic one)
     int32_t inline_reset;   // k_stats resets finished environments itself (every problem but Sokoban)
+    int32_t zelda_inc;      // zelda, single-cell representations, maps of at most 16 x 32: changed/incremental items carry (cell, passability change)
 };
 
 __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {
@@ -65,8 +68,27 @@ __device__ __forceinline__ int wl_load_prefix(const DevBufs& B, int parity, int 
     __syncthreads();
     return s_pref[WL_NSHARD];
 }
-// Two lists at once (one barrier, the counter loads of both in flight together): threads 0..63 take list_a, 64..127
-// list_b.  Block of at least 128 threads; returns the length of list_a, *n_b = length of list_b.
+// Up to three lists at once (one barrier, the counter loads of all in flight together): wavefront k of the block takes
+// list k (a negative id = no list: length 0).  Block of at least 192 threads; returns the length of list_a.
+__device__ __forceinline__ int wl_load_prefix3(const DevBufs& B, int parity, int list_a, int list_b, int list_c, int* s_pref_a,
+                                               int* s_pref_b, int* s_pref_c, int* n_b, int* n_c) {
+    if (threadIdx.x < 3 * WL_NSHARD) {
+        const int t = threadIdx.x & (WL_NSHARD - 1), k = threadIdx.x >> 6;
+        const int list = k == 0 ? list_a : (k == 1 ? list_b : list_c);
+        int v = list >= 0 ? wl_counters(B, parity, list)[t * WL_CSTRIDE] : 0;
+        for (int o = 1; o < WL_NSHARD; o <<= 1) {
+            const int u = __shfl_up(v, o, 64);
+            if (t >= o) v += u;
+        }
+        int* sp = k == 0 ? s_pref_a : (k == 1 ? s_pref_b : s_pref_c);
+        sp[t + 1] = v;
+        if (t == 0) sp[0] = 0;
+    }
+    __syncthreads();
+    *n_b = s_pref_b[WL_NSHARD];
+    *n_c = s_pref_c[WL_NSHARD];
+    return s_pref_a[WL_NSHARD];
+}
 __device__ __forceinline__ int wl_load_prefix2(const DevBufs& B, int parity, int list_a, int list_b, int* s_pref_a, int* s_pref_b, int* n_b) {
     if (threadIdx.x < 2 * WL_NSHARD) {
         const int t = threadIdx.x & (WL_NSHARD - 1);
@@ -138,6 +160,30 @@ __device__ __forceinline__ void block_append2(bool flag_a, int value_a, int list
         for (int i = 0; i < w; i++) off += s_cnt[k][i];
         off += __popcll((k ? mb : ma) & ((1ull << lane) - 1ull));
         B.wl_items[list][(size_t)shard * B.wl_cap[list] + off] = k ? value_b : value_a;
+    }
+}
+
+// Three lists (changed, incremental, certain resets) in one pass.  dest: -1 none, 0 = WL_CHG, 1 = WL_INC, 2 = WL_RST.
+__device__ __forceinline__ void block_append3(int dest, int value, const DevBufs& B, int parity, int (*s_cnt)[4], int* s_base) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int shard = blockIdx.x & (WL_NSHARD - 1);
+    const uint64_t m0 = __ballot(dest == 0), m1 = __ballot(dest == 1), m2 = __ballot(dest == 2);
+    if (lane == 0) { s_cnt[0][w] = __popcll(m0); s_cnt[1][w] = __popcll(m1); s_cnt[2][w] = __popcll(m2); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 192) {
+        const int k = threadIdx.x >> 6;
+        const int list = k == 0 ? WL_CHG : (k == 1 ? WL_INC : WL_RST);
+        const int tot = s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+        s_base[k] = tot ? atomicAdd(wl_counters(B, parity, list) + shard * WL_CSTRIDE, tot) : 0;
+    }
+    __syncthreads();
+    if (dest >= 0) {
+        const int list = dest == 0 ? WL_CHG : (dest == 1 ? WL_INC : WL_RST);
+        const uint64_t m = dest == 0 ? m0 : (dest == 1 ? m1 : m2);
+        int off = s_base[dest];
+        for (int i = 0; i < w; i++) off += s_cnt[dest][i];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        B.wl_items[list][(size_t)shard * B.wl_cap[list] + off] = value;
     }
 }
 

@@ -186,7 +186,45 @@ static int run_incremental(const uint8_t* map0, int h, int w, const int* flips, 
     return ninc;
 }
 
+// Zelda statistics along a sequence of single-tile writes: the first map from scratch, every following one with the
+// incremental region count.  writes: [n][2] = (cell, tile); out: [n + 1][7]
+template <int G, class T>
+static void run_zelda_incremental(const uint8_t* map0, int h, int w, const int* writes, int n, int32_t* out) {
+    typedef SimGroup<G, T> Gp;
+    typedef typename Gp::mask_t M;
+    Gp g;
+    std::vector<uint8_t> map(map0, map0 + h * w);
+    PcgrlParams P; memset(&P, 0, sizeof(P));
+    P.prob = PCGRL_PROB_ZELDA; P.width = w; P.height = h; P.prob_width = w; P.prob_height = h;
+    auto planes = [&](M& b0, M& b1, M& b2, M& valid) {
+        b0 = M(); b1 = M(); b2 = M(); valid = M();
+        for (int y = 0; y < h; y++) {
+            valid.v[y] = (w >= (int)(8 * sizeof(T))) ? ~(T)0 : (((T)1 << w) - 1);
+            for (int x = 0; x < w; x++) {
+                T t = map[y * w + x];
+                b0.v[y] |= (t & 1) << x; b1.v[y] |= ((t >> 1) & 1) << x; b2.v[y] |= ((t >> 2) & 1) << x;
+            }
+        }
+    };
+    M b0, b1, b2, valid;
+    planes(b0, b1, b2, valid);
+    zelda_stats(g, P, b0, b1, b2, valid, out);
+    for (int i = 0; i < n; i++) {
+        const int cell = writes[2 * i], tile = writes[2 * i + 1];
+        const int old = map[cell];
+        map[cell] = (uint8_t)tile;
+        planes(b0, b1, b2, valid);
+        const bool po = old != 1 && old != 4, pn = tile != 1 && tile != 4;
+        M cbit; cbit.v[cell / w] = (T)1 << (cell % w);
+        zelda_stats(g, P, b0, b1, b2, valid, out + 7 * (i + 1), po == pn ? 0 : (pn ? 1 : 2), cbit, out[7 * i + 4]);
+    }
+}
+
 extern "C" {
+void sim_zelda_incremental(const uint8_t* map0, int h, int w, const int* writes, int n, int32_t* out) {
+    if (w > 32) run_zelda_incremental<16, uint64_t>(map0, h, w, writes, n, out);
+    else run_zelda_incremental<16, uint32_t>(map0, h, w, writes, n, out);
+}
 int sim_binary_incremental(const uint8_t* map0, int h, int w, const int* flips, int nflips, int32_t* out) {
     if (w > 32) return run_incremental<16, uint64_t>(map0, h, w, flips, nflips, out);
     return run_incremental<16, uint32_t>(map0, h, w, flips, nflips, out);

@@ -161,6 +161,27 @@ def test_binary_incremental_update(sim):
     assert ninc > total // 3          # the incremental route is the common one
 
 
+def test_zelda_incremental_regions(sim):
+    """zelda_stats with the incremental region count (regions_incremental) along random tile writes, every step
+    against the oracle on the full map."""
+    sim.sim_zelda_incremental.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rs = np.random.RandomState(23)
+    p = np.array([0.58, 0.3, 0.02, 0.02, 0.02, 0.02, 0.02, 0.02])
+    for (h, w) in ((16, 11), (7, 11), (5, 5), (16, 32), (3, 40), (1, 6)):
+        for psolid in (0.3, 0.1, 0.6):
+            q = p.copy(); q[1] = psolid; q[0] = 1 - q[1:].sum()
+            m = rs.choice(8, size=(h, w), p=q).astype(np.uint8)
+            T = 150
+            writes = np.stack([rs.randint(0, h * w, size=T), rs.choice(8, size=T, p=q)], 1).astype(np.int32)
+            out = np.zeros((T + 1, 7), np.int32)
+            sim.sim_zelda_incremental(_p(m), h, w, _p(writes), T, _p(out))
+            cur = m.copy()
+            assert np.array_equal(out[0], ol.get_stats("zelda", cur))
+            for t in range(T):
+                cur.flat[writes[t, 0]] = writes[t, 1]
+                assert np.array_equal(out[t + 1], ol.get_stats("zelda", cur)), ((h, w), psolid, t, out[t + 1], ol.get_stats("zelda", cur))
+
+
 def test_shared_rest_binary_stats(sim):
     """The cooperative form of regions + longest path (k_stats_wide: four wavefronts per tall map sharing the set
     of unretired cells) against the oracle, under the interleaving with the most duplicate extractions."""
