@@ -93,9 +93,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<G, MaskT> g;
     constexpr int GPB = PCGRL_BLOCK / G, GPW = 64 / G;
-    // Binary 16-row maps in a step: after the items of the changed list (padded to whole wavefronts) come the items of
-    // the incremental list -- a wavefront works on one kind only.
-    constexpr bool kInc = PROB == PCGRL_PROB_BINARY && G == 16 && sizeof(MaskT) == 4;
+    // Binary in a step: after the items of the changed list (padded to whole wavefronts) come the items of the
+    // incremental list -- a wavefront works on one kind only.  (Maps taller than 16 rows: `list` < 0, the full
+    // recomputations run in k_stats_wide and this launch only has the incremental items.)
+    constexpr bool kInc = PROB == PCGRL_PROB_BINARY;
     // Zelda (same restriction on the map size): every changed item of a step carries the cell and what happened to its
     // passability; the region count is updated (items of `list`) or simply kept (items of WL_INC).
     constexpr bool kZinc = PROB == PCGRL_PROB_ZELDA && G == 16 && sizeof(MaskT) == 4;
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     const bool with_inc = (kInc && mode == MODE_STEP && B.champ != nullptr) || zinc;
     // lone0 = 1: the certain resets are shard 0 of `list` (bucketed list of the binary problem); 2: they are the list WL_RST
     int n_inc = 0, n_rst = 0;
-    const int n_full = (with_inc || lone0 == 2) ? wl_load_prefix3(B, parity, list, with_inc ? WL_INC : -1, lone0 == 2 ? WL_RST : -1, s_pref,
-                                                                  s_pref_inc, s_pref_rst, &n_inc, &n_rst)
-                                                 : wl_load_prefix(B, parity, list, s_pref);
+    const int n_full = (with_inc || lone0 == 2 || list < 0) ? wl_load_prefix3(B, parity, list, with_inc ? WL_INC : -1, lone0 == 2 ? WL_RST : -1,
+                                                                              s_pref, s_pref_inc, s_pref_rst, &n_inc, &n_rst)
+                                                             : wl_load_prefix(B, parity, list, s_pref);
     // lone0: shard 0 of the list holds the environments that are certain to be reset in this launch (k_update puts them
     // there).  Stats + reset + start stats is the longest chain of dependent steps in the kernel, so those items come
     // first and get a wavefront each: the chains start at once and none waits behind another reset of its wavefront.
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
         const bool packed = inc || (kZinc && zinc && !lone);        // (environment, cell, passability change) in one word
         const bool reset_only = have && !packed && (raw & WL_RESET_ONLY) != 0;
         const bool compute = have && !reset_only;
-        const int e = packed ? (raw & WL_INC_ENV_MASK) : (raw & ~WL_RESET_ONLY);
+        const int e = packed ? wl_inc_env<G>(raw) : (raw & ~WL_RESET_ONLY);
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
         MaskT b0 = 0, b1 = 0, b2 = 0;
@@ -172,19 +173,17 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
         MaskT champ = 0;
         if (kInc && inc) {
             if (compute) {      // one cell changed away from the champion: update the previous answer
-                const int cell = (raw >> 21) & 511;
-                const MaskT cbit = (g.lane == (cell >> 5)) ? (MaskT)1 << (cell & 31) : (MaskT)0;
+                const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
                 const MaskT champ_old = champ_base[(size_t)e * G + g.lane];
                 const int2 old = *reinterpret_cast<const int2*>(B.stats + (size_t)e * 8);
                 int regions, path;
-                binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, ((raw >> 30) & 1) != 0, old.x, old.y, champ_old, regions, path, champ);
+                binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, wl_inc_code<G>(raw) != 0, old.x, old.y, champ_old, regions, path, champ);
                 s[0] = regions; s[1] = path; s[2] = 1;
             }
         } else if (kZinc && packed) {
             if (compute) {      // zelda: one cell was written; keep or update the region count
-                const int cell = (raw >> 21) & 511;
-                const MaskT cbit = (g.lane == (cell >> 5)) ? (MaskT)1 << (cell & 31) : (MaskT)0;
-                zelda_stats(g, P, b0, b1, b2, rowmask, s, (int)(((uint32_t)raw >> 30) & 3u), cbit, B.stats[(size_t)e * 8 + 4]);
+                const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
+                zelda_stats(g, P, b0, b1, b2, rowmask, s, (int)wl_inc_code<G>(raw), cbit, B.stats[(size_t)e * 8 + 4]);
             }
         } else if (compute) {
             need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ);
@@ -248,28 +247,38 @@ struct LdsShared {
 };
 // regions + longest path of the map whose rows are in `pass`, by the four wavefronts of the block.  Results in
 // s_regions / s_best after the trailing barrier.  Every thread of the block calls this.
+// `champ_e` (may be null): receives the rows of a champion component -- one whose sweep gave the final maximum -- or
+// zeros when the path comes from the closed-form tiny components; *s_owner tells which wavefront wrote it (-1: none).
 template <class MaskT>
 __device__ __forceinline__ void block_regions_and_path(DevGroup<64, MaskT>& g, MaskT pass, int wv, int lane, int row_lo, int row_hi,
-                                                       MaskT* s_rest, int* s_regions, int* s_best) {
+                                                       MaskT* s_rest, int* s_regions, int* s_best, int* s_owner, MaskT* champ_e) {
     int tiny_regions, tiny_path;
     const MaskT nontiny = rlp_prepare(g, pass, tiny_regions, tiny_path);
     if (wv == 0) {
         s_rest[lane] = nontiny;
-        if (lane == 0) { *s_regions = tiny_regions; *s_best = tiny_path; }
+        if (lane == 0) { *s_regions = tiny_regions; *s_best = tiny_path; *s_owner = -1; }
     }
     __syncthreads();
     LdsShared<MaskT> sh = {s_rest, s_best, lane};
-    int regions = 0;
+    int regions = 0, my_best = 0;
+    MaskT my_champ = 0;
     MaskT rest = sh.load_rest();
     if (g.any(rest)) {
         const PcgFillCtx<DevGroup<64, MaskT>> ctx = pcg_fill_ctx(g, pass);
         do {
-            rlp_process_seed(g, rlp_choose_seed(g, rest, row_lo, row_hi), ctx, sh, regions);
+            rlp_process_seed(g, rlp_choose_seed(g, rest, row_lo, row_hi), ctx, sh, regions, my_best, my_champ);
             rest = sh.load_rest();
         } while (g.any(rest));
     }
     if (lane == 0 && regions) atomicAdd(s_regions, regions);
     __syncthreads();
+    if (champ_e) {
+        // one of the wavefronts whose own best sweep equals the final maximum writes its component
+        if (lane == 0 && my_best > tiny_path && my_best == *s_best) atomicCAS(s_owner, -1, wv);
+        __syncthreads();
+        const int owner = *s_owner;
+        if (wv == (owner < 0 ? 0 : owner)) champ_e[lane] = owner < 0 ? (MaskT)0 : my_champ;
+    }
 }
 
 template <class MaskT, int NWAVES>
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: MT ring + tile bytes of one environment
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1];
     __shared__ MaskT s_rest[64];
-    __shared__ int s_regions, s_best, s_flag;
+    __shared__ int s_regions, s_best, s_flag, s_owner;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<64, MaskT> g;
     // with the in-kernel reset, k_update puts the environments that are certain to be reset on WL_RST: those come first
@@ -298,12 +307,13 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         const int e = raw & ~WL_RESET_ONLY;
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * 64;
+        MaskT* champ_e = B.champ ? reinterpret_cast<MaskT*>(B.champ) + (size_t)e * 64 : nullptr;
         if (threadIdx.x == 0) s_flag = reset_only ? 1 : 0;
         if (!reset_only) {
             const MaskT b0 = planes_e[lane];
-            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best);
+            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best, &s_owner, champ_e);
             if (threadIdx.x == 0) {
-                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, 0, 0, 0, 0, 0, 0};
+                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, s_owner >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
                 const bool want = finalize_item(P, B, e, s, mode, parity, shard, !inline_reset);
                 s_flag = (want && inline_reset) ? 1 : 0;
             }
@@ -314,9 +324,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             __syncthreads();
             MaskT b0, b1, b2;
             planes_from_tiles<MaskT>(P, tiles, planes_e, lane, b0, b1, b2, wv == 0);
-            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best);
+            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best, &s_owner, champ_e);
             if (threadIdx.x == 0) {
-                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, 0, 0, 0, 0, 0, 0};
+                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, s_owner >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
                 finalize_item(P, B, e, s, MODE_START, parity, shard);
             }
         }

@@ -68,13 +68,13 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         // the old tile: from the plane word when there is a single plane (one scattered read less), else from the byte map
         const int old_byte = (NPL > 1) ? (int)*cell : 0;
         // binary, 16-row maps: the three champion rows around the cell, for the routing decision below
-        const bool inc_on = sizeof(MaskT) == 4 && P.prob == PCGRL_PROB_BINARY && B.champ != nullptr;
-        uint32_t ch0 = 0, chu = 0, chd = 0;
+        const bool inc_on = P.prob == PCGRL_PROB_BINARY && B.champ != nullptr;
+        MaskT ch0 = 0, chu = 0, chd = 0;
         if (inc_on) {
-            const uint32_t* ch = reinterpret_cast<const uint32_t*>(B.champ) + (size_t)e * 16;
+            const MaskT* ch = reinterpret_cast<const MaskT*>(B.champ) + (size_t)e * G;
             ch0 = ch[wy];
             chu = ch[wy > 0 ? wy - 1 : wy];
-            chd = ch[wy < 15 ? wy + 1 : wy];
+            chd = ch[wy < G - 1 ? wy + 1 : wy];
         }
         MaskT m0 = pl[0], m1 = 0, m2 = 0;
         if (NPL > 1) { m1 = pl[G]; m2 = pl[2 * G]; }
@@ -92,16 +92,16 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             if (inc_on && s0.z != 0) {
                 // the statistics can be updated from the previous ones when the cell is neither in the champion component
                 // nor next to it (binary_incremental); s0.z = "there is a champion"
-                const uint32_t bit = 1u << wx;
-                const uint32_t touch = ((ch0 | chu | chd) & bit) | (ch0 & ((bit << 1) | (bit >> 1)));
+                const MaskT bit = (MaskT)1 << wx;
+                const MaskT touch = ((ch0 | chu | chd) & bit) | (ch0 & ((bit << 1) | (bit >> 1)));
                 cheap = touch == 0;
-                inc_item = e | ((wy * 32 + wx) << 21) | ((tile == 0 ? 1 : 0) << 30);
+                inc_item = wl_inc_pack(G, e, wy, wx, tile == 0 ? 1u : 0u);
             }
             if (B.zelda_inc) {
                 // zelda: what the write does to the cell's passability for the region count (zelda_prob.py:93: everything
                 // but solid = 1 and door = 4), so that k_stats can update the count instead of recounting
                 const bool po = old != 1 && old != 4, pn = tile != 1 && tile != 4;
-                inc_item = e | ((wy * 32 + wx) << 21) | (int)((po == pn ? 0u : (pn ? 1u : 2u)) << 30);
+                inc_item = wl_inc_pack(16, e, wy, wx, po == pn ? 0u : (pn ? 1u : 2u));
                 cheap = po == pn;
             }
             *cell = (uint8_t)tile;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         const bool first = B.inline_reset ? (inl || sure_done) : rst;
         int dest = -1, v = e;
         if (first) { dest = 2; v = val; }
-        else if (chg) { dest = (B.zelda_inc && cheap) ? 1 : 0; v = B.zelda_inc ? inc_item : e; }
+        else if (chg) { dest = cheap ? 1 : 0; v = (cheap || B.zelda_inc) ? inc_item : e; }
         block_append3(dest, v, B, parity, s_cnt, s_base);
     }
 }

@@ -157,7 +157,9 @@ static void sub_range(int num_envs, int nsub, int k, int* lo, int* hi) {
 }
 // rows of the champion component per environment (binary, maps of at most 16 x 32): the incremental statistics path
 static size_t champ_bytes(const pcgrl_config* c) {
-    return (c->prob == PCGRL_BINARY && c->height <= 16 && c->width <= 32 && c->num_envs <= WL_INC_ENV_MASK) ? align_up((size_t)c->num_envs * 64, 256) : 0;
+    if (c->prob != PCGRL_BINARY) return 0;
+    if (c->height <= 16) return (c->width <= 32 && c->num_envs <= WL_INC_ENV_MASK) ? align_up((size_t)c->num_envs * 64, 256) : 0;
+    return c->num_envs <= WL_INC64_ENV_MASK ? align_up((size_t)c->num_envs * 64 * (c->width > 32 ? 8 : 4), 256) : 0;
 }
 static size_t scratch_bytes_base(const pcgrl_config* c);
 static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c); }
@@ -326,7 +328,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
             S.info = B.info + 10 * (size_t)lo; S.reward = B.reward + lo; S.done = B.done + lo; S.tile_p = B.tile_p + 2 * (size_t)lo;
             S.rng_rep = B.rng_rep + (size_t)lo * PCGRL_MT_N; S.rng_prob = B.rng_prob ? B.rng_prob + (size_t)lo * PCGRL_MT_N : nullptr;
             S.rng_cur = B.rng_cur + 2 * (size_t)lo;
-            S.champ = B.champ ? (uint8_t*)B.champ + (size_t)lo * 64 : nullptr;
+            S.champ = B.champ ? (uint8_t*)B.champ + (size_t)lo * P0.group * P0.mask_bytes : nullptr;
             uint8_t* q = s + (size_t)k * wlb;
             S.wl_cnt = (int32_t*)q;
             q += WL_CNT_BYTES + 256;
@@ -402,12 +404,25 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !getenv("PCGRL_NO_WIDE")) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
         const size_t lds1 = inline_reset ? (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
         const int gridw = P.num_envs < 16384 ? P.num_envs : 16384;
-        // four wavefronts per map: measured on C5 -- 2: 150 us/step, 4: 130, 8: 151 (one wavefront per map: 176)
-        if (P.mask_bytes == 4)
-            hipLaunchKernelGGL((k_stats_wide<uint32_t, 4>), dim3(gridw), dim3(256), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
-        else
-            hipLaunchKernelGGL((k_stats_wide<uint64_t, 4>), dim3(gridw), dim3(256), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen);
+        // wavefronts per map: with the incremental route only ~10 % of the changes (and the resets) come here, so the launch
+        // is latency-bound and more wavefronts per map pay (PCGRL_WIDE_WAVES overrides for experiments)
+        const char* wvs = getenv("PCGRL_WIDE_WAVES");
+        const int nw = wvs ? atoi(wvs) : 8;   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
+#define LAUNCH_WIDE(NW) do { if (P.mask_bytes == 4) hipLaunchKernelGGL((k_stats_wide<uint32_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); \
+                             else hipLaunchKernelGGL((k_stats_wide<uint64_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); } while (0)
+        if (nw == 16) LAUNCH_WIDE(16); else if (nw == 8) LAUNCH_WIDE(8); else LAUNCH_WIDE(4);
+#undef LAUNCH_WIDE
         HIPCHK(hipGetLastError());
+        if (mode == MODE_STEP && h->B.champ) {
+            // the incremental items of the step (binary_incremental), a wavefront each: k_stats with no "full" list
+            const size_t ldsw = inline_reset ? 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
+            const int gridi = grid_for(P.num_envs, 4, 8192);
+            if (P.mask_bytes == 4)
+                hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(gridi), dim3(PCGRL_BLOCK), ldsw, st, P, h->B, -1, parity, mode, -1, inline_reset, gen, 0);
+            else
+                hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(gridi), dim3(PCGRL_BLOCK), ldsw, st, P, h->B, -1, parity, mode, -1, inline_reset, gen, 0);
+            HIPCHK(hipGetLastError());
+        }
         return PCGRL_OK;
     }
     if (P.group == 16 && P.mask_bytes == 4)

@@ -421,14 +421,27 @@ PCGRL_D typename B::mask_t rlp_choose_seed(B& g, typename B::mask_t rest, int ro
     const typename B::mask_t mine = g.rows_between(rest, row_lo, row_hi);
     return g.first_bit(g.any(mine) ? mine : rest);
 }
+// my_best / my_champ: the longest sweep result of THIS group so far and its component (the group whose my_best equals
+// the final shared maximum holds a champion component for binary_incremental).
 template <class B, class Shared>
-PCGRL_D void rlp_process_seed(B& g, typename B::mask_t seed, const PcgFillCtx<B>& ctx, Shared& sh, int& regions) {
+PCGRL_D void rlp_process_seed(B& g, typename B::mask_t seed, const PcgFillCtx<B>& ctx, Shared& sh, int& regions, int& my_best,
+                              typename B::mask_t& my_champ) {
     typedef typename B::mask_t M;
     const M comp = pcg_component(g, seed, ctx);
     if (!sh.retire(g, comp)) return;
     ++regions;
     const int best = sh.best();
-    if (g.popcount_sum(comp) - 1 > best) sh.raise(pcg_double_sweep(g, comp, best));
+    if (g.popcount_sum(comp) - 1 > best) {
+        const int e = pcg_double_sweep(g, comp, best);
+        if (e > my_best) { my_best = e; my_champ = comp; }
+        sh.raise(e);
+    }
+}
+template <class B, class Shared>
+PCGRL_D void rlp_process_seed(B& g, typename B::mask_t seed, const PcgFillCtx<B>& ctx, Shared& sh, int& regions) {
+    int my_best = 0;
+    typename B::mask_t my_champ = seed ^ seed;
+    rlp_process_seed(g, seed, ctx, sh, regions, my_best, my_champ);
 }
 // What every group does before the shared loop; returns the non-tiny cells (identical in every group).
 template <class B>

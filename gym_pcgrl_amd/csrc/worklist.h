@@ -19,6 +19,17 @@ enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5
 // bits 30..31 = what happened to the cell's passability (binary: 1 = became passable, 0 = impassable; zelda: 0 = unchanged,
 // 1 = became passable, 2 = impassable).
 #define WL_INC_ENV_MASK 0x1FFFFF
+// 64-lane groups (maps taller than 16 rows, binary only): environment in bits 0..18, cell (row * 64 + column) in bits 19..30,
+// bit 31 = the cell became passable.
+#define WL_INC64_ENV_MASK 0x7FFFF
+__device__ __forceinline__ int wl_inc_pack(int group, int e, int row, int col, unsigned code) {
+    return group == 16 ? (int)((unsigned)e | ((unsigned)(row * 32 + col) << 21) | (code << 30))
+                       : (int)((unsigned)e | ((unsigned)(row * 64 + col) << 19) | ((code & 1u) << 31));
+}
+template <int G> __device__ __forceinline__ int wl_inc_env(int raw) { return raw & (G == 16 ? WL_INC_ENV_MASK : WL_INC64_ENV_MASK); }
+template <int G> __device__ __forceinline__ int wl_inc_row(int raw) { return G == 16 ? ((raw >> 26) & 15) : ((raw >> 25) & 63); }
+template <int G> __device__ __forceinline__ int wl_inc_col(int raw) { return G == 16 ? ((raw >> 21) & 31) : ((raw >> 19) & 63); }
+template <int G> __device__ __forceinline__ unsigned wl_inc_code(int raw) { return G == 16 ? (((unsigned)raw >> 30) & 3u) : ((unsigned)raw >> 31); }
 // An item of the changed list with this bit set is an unchanged environment whose episode ended (iteration cap):
 // k_stats resets it without recomputing anything.
 #define WL_RESET_ONLY (1 << 30)
@@ -75,7 +86,7 @@ __device__ __forceinline__ int wl_load_prefix3(const DevBufs& B, int parity, int
     if (threadIdx.x < 3 * WL_NSHARD) {
         const int t = threadIdx.x & (WL_NSHARD - 1), k = threadIdx.x >> 6;
         const int list = k == 0 ? list_a : (k == 1 ? list_b : list_c);
-        int v = list >= 0 ? wl_counters(B, parity, list)[t * WL_CSTRIDE] : 0;
+        int v = list >= 0 ? wl_counters(B, parity, list)[t * WL_CSTRIDE] : 0;   // (also list_a may be absent)
         for (int o = 1; o < WL_NSHARD; o <<= 1) {
             const int u = __shfl_up(v, o, 64);
             if (t >= o) v += u;
