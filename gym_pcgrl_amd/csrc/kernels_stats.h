@@ -247,14 +247,20 @@ struct LdsShared {
 };
 // regions + longest path of the map whose rows are in `pass`, by the four wavefronts of the block.  Results in
 // s_regions / s_best after the trailing barrier.  Every thread of the block calls this.
-// `champ_e` (may be null): receives the rows of a champion component -- one whose sweep gave the final maximum -- or
-// zeros when the path comes from the closed-form tiny components; *s_owner tells which wavefront wrote it (-1: none).
+// The wavefronts of a block work as one team of NWAVES or -- for an environment that is certain to be reset -- as two teams
+// of NWAVES / 2 on two maps at once (the one the step ended on and the regenerated one).  `tw` / `ts`: index in the team and
+// team size; the s_* pointers are the team's own shared words.  `champ_e` (may be null): receives the rows of a champion
+// component -- one whose sweep gave the final maximum -- or zeros when the path comes from the closed-form tiny
+// components; *s_owner tells which wavefront of the team wrote it (-1: none).  Every thread of the block calls this (the
+// barriers are block-wide: both teams pass them together).
 template <class MaskT>
-__device__ __forceinline__ void block_regions_and_path(DevGroup<64, MaskT>& g, MaskT pass, int wv, int lane, int row_lo, int row_hi,
+__device__ __forceinline__ void block_regions_and_path(DevGroup<64, MaskT>& g, MaskT pass, int tw, int ts, int lane, int H,
                                                        MaskT* s_rest, int* s_regions, int* s_best, int* s_owner, MaskT* champ_e) {
+    const int bh = (H + ts - 1) / ts;
+    const int row_lo = tw * bh, row_hi = (row_lo + bh < H) ? row_lo + bh : H;
     int tiny_regions, tiny_path;
     const MaskT nontiny = rlp_prepare(g, pass, tiny_regions, tiny_path);
-    if (wv == 0) {
+    if (tw == 0) {
         s_rest[lane] = nontiny;
         if (lane == 0) { *s_regions = tiny_regions; *s_best = tiny_path; *s_owner = -1; }
     }
@@ -272,48 +278,112 @@ __device__ __forceinline__ void block_regions_and_path(DevGroup<64, MaskT>& g, M
     }
     if (lane == 0 && regions) atomicAdd(s_regions, regions);
     __syncthreads();
+    // one of the wavefronts whose own best sweep equals the final maximum writes its component
+    if (lane == 0 && my_best > tiny_path && my_best == *s_best) atomicCAS(s_owner, -1, tw);
+    __syncthreads();
     if (champ_e) {
-        // one of the wavefronts whose own best sweep equals the final maximum writes its component
-        if (lane == 0 && my_best > tiny_path && my_best == *s_best) atomicCAS(s_owner, -1, wv);
-        __syncthreads();
         const int owner = *s_owner;
-        if (wv == (owner < 0 ? 0 : owner)) champ_e[lane] = owner < 0 ? (MaskT)0 : my_champ;
+        if (tw == (owner < 0 ? 0 : owner)) champ_e[lane] = owner < 0 ? (MaskT)0 : my_champ;
+    }
+}
+
+// One incremental item by one wavefront (binary_incremental), with the wavefront-level reset for the rare episode that
+// ends on it (episodes that are certain to end are not routed here).
+template <class MaskT>
+__device__ __forceinline__ void wave_incremental_item(const PcgrlParams& P, const DevBufs& B, DevGroup<64, MaskT>& g, int raw, int parity,
+                                                      int inline_reset, int gen_map, uint32_t* mt, uint8_t* tiles, int lane, MaskT rowmask) {
+    const int e = wl_inc_env<64>(raw);
+    MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * 64;
+    MaskT* champ_e = reinterpret_cast<MaskT*>(B.champ) + (size_t)e * 64;
+    const MaskT b0 = planes_e[lane];
+    const MaskT champ_old = champ_e[lane];
+    const int2 old = *reinterpret_cast<const int2*>(B.stats + (size_t)e * 8);
+    const MaskT cbit = (lane == wl_inc_row<64>(raw)) ? (MaskT)1 << wl_inc_col<64>(raw) : (MaskT)0;
+    int regions, path;
+    MaskT champ;
+    binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, wl_inc_code<64>(raw) != 0, old.x, old.y, champ_old, regions, path, champ);
+    champ_e[lane] = champ;
+    int want = 0;
+    if (lane == 0) {
+        int32_t s[PCGRL_MAX_STATS] = {regions, path, 1, 0, 0, 0, 0, 0};
+        want = finalize_item(P, B, e, s, MODE_STEP, parity, e & (WL_NSHARD - 1), !inline_reset) ? 1 : 0;
+    }
+    want = __builtin_amdgcn_readfirstlane(want);
+    if (inline_reset && want) {
+        wave_reset_env<PCGRL_PROB_BINARY>(P, B, e, gen_map, mt, tiles, lane);
+        MaskT n0, n1, n2;
+        planes_from_tiles<MaskT>(P, tiles, planes_e, lane, n0, n1, n2);
+        int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        compute_item_stats<PCGRL_PROB_BINARY>(g, P, n0, n1, n2, rowmask, st, champ);
+        champ_e[lane] = champ;
+        if (lane == 0) finalize_item(P, B, e, st, MODE_START, parity, e & (WL_NSHARD - 1));
     }
 }
 
 template <class MaskT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
                                                              int inline_reset, int gen_map) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: MT ring + tile bytes of one environment
-    __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1];
-    __shared__ MaskT s_rest[64];
-    __shared__ int s_regions, s_best, s_flag, s_owner;
+    // inline_reset: MT ring + tile bytes, one set per wavefront (the block-wide reset uses the first)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
+    __shared__ MaskT s_rest[2][64];
+    __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag;
+    __shared__ int2 s_pre;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<64, MaskT> g;
-    // with the in-kernel reset, k_update puts the environments that are certain to be reset on WL_RST: those come first
-    int n_rst = 0;
-    const int n_chg = inline_reset ? wl_load_prefix2(B, parity, list, WL_RST, s_pref, s_pref_rst, &n_rst) : wl_load_prefix(B, parity, list, s_pref);
+    // with the in-kernel reset, k_update puts the environments that are certain to be reset on WL_RST: those come first;
+    // the incremental items of a step (WL_INC) are taken, a wavefront each, by the blocks that have no full item
+    const bool with_inc = mode == MODE_STEP && B.champ != nullptr;
+    int n_rst = 0, n_inc = 0;
+    const int n_chg = wl_load_prefix3(B, parity, list, with_inc ? WL_INC : -1, inline_reset ? WL_RST : -1, s_pref, s_pref_inc, s_pref_rst, &n_inc, &n_rst);
     const int n = n_rst + n_chg;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int W = P.width, H = P.height;
-    const int bh = (H + NWAVES - 1) / NWAVES;
-    const int row_lo = wv * bh, row_hi = (row_lo + bh < H) ? row_lo + bh : H;
+    const int wave_lds = PCGRL_MT_N * 4 + ((W * H + 15) & ~15);
     uint32_t* mt = reinterpret_cast<uint32_t*>(smem);
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
     const MaskT rowmask = row_valid<MaskT>(lane, W, H);
     for (int item = blockIdx.x; item < n; item += gridDim.x) {
-        const int raw = item < n_rst ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item - n_rst);
+        const bool lone = item < n_rst;                      // certain reset (block-uniform)
+        const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item - n_rst);
         const bool reset_only = (raw & WL_RESET_ONLY) != 0;
         const int e = raw & ~WL_RESET_ONLY;
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * 64;
         MaskT* champ_e = B.champ ? reinterpret_cast<MaskT*>(B.champ) + (size_t)e * 64 : nullptr;
+        if (lone) {
+            // Reset first, then the statistics of the map the step ended on (team 0, rows already in registers) and of the
+            // regenerated map (team 1) side by side; the step is finished with the counters read before the reset.
+            const MaskT b_old = reset_only ? (MaskT)0 : planes_e[lane];
+            if (threadIdx.x == 0) s_pre = reinterpret_cast<const int2*>(B.counters)[e];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wv == 0) wave_reset_env<PCGRL_PROB_BINARY>(P, B, e, gen_map, mt, tiles, lane);
+            __syncthreads();
+            MaskT n0, n1, n2;
+            planes_from_tiles<MaskT>(P, tiles, planes_e, lane, n0, n1, n2, wv == 0);
+            constexpr int TS = NWAVES / 2;
+            const int team = wv / TS, tw = wv % TS;
+            const MaskT pass = team == 0 ? (reset_only ? (MaskT)0 : (MaskT)(~b_old & rowmask)) : (MaskT)(~n0 & rowmask);
+            block_regions_and_path(g, pass, tw, TS, lane, H, s_rest[team], &s_regions[team], &s_best[team], &s_owner[team],
+                                   team == 1 ? champ_e : (MaskT*)nullptr);
+            if (threadIdx.x == 0) {
+                if (!reset_only) {
+                    int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], 0, 0, 0, 0, 0, 0};
+                    finalize_item(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &s_pre);
+                }
+                int32_t st[PCGRL_MAX_STATS] = {s_regions[1], s_best[1], s_owner[1] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
+                finalize_item(P, B, e, st, MODE_START, parity, shard);
+            }
+            __syncthreads();
+            continue;
+        }
         if (threadIdx.x == 0) s_flag = reset_only ? 1 : 0;
         if (!reset_only) {
             const MaskT b0 = planes_e[lane];
-            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best, &s_owner, champ_e);
+            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);
             if (threadIdx.x == 0) {
-                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, s_owner >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
+                int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
                 const bool want = finalize_item(P, B, e, s, mode, parity, shard, !inline_reset);
                 s_flag = (want && inline_reset) ? 1 : 0;
             }
@@ -324,13 +394,23 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             __syncthreads();
             MaskT b0, b1, b2;
             planes_from_tiles<MaskT>(P, tiles, planes_e, lane, b0, b1, b2, wv == 0);
-            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, lane, row_lo, row_hi, s_rest, &s_regions, &s_best, &s_owner, champ_e);
+            block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);
             if (threadIdx.x == 0) {
-                int32_t s[PCGRL_MAX_STATS] = {s_regions, s_best, s_owner >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
+                int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
                 finalize_item(P, B, e, s, MODE_START, parity, shard);
             }
         }
         __syncthreads();
     }
+    if (n_inc > 0) {
+        // incremental items: by the blocks beyond the full items if there are any, else by all
+        const int first = ((int)gridDim.x > n) ? n : 0;
+        const int nblk = (int)gridDim.x - first;
+        if ((int)blockIdx.x >= first) {
+            uint32_t* mtw = reinterpret_cast<uint32_t*>(smem + (size_t)wv * wave_lds);
+            uint8_t* tilesw = reinterpret_cast<uint8_t*>(mtw + PCGRL_MT_N);
+            for (int j = ((int)blockIdx.x - first) * NWAVES + wv; j < n_inc; j += nblk * NWAVES)
+                wave_incremental_item<MaskT>(P, B, g, wl_get(B, WL_INC, s_pref_inc, j), parity, inline_reset, gen_map, mtw, tilesw, lane, rowmask);
+        }
+    }
 }
-

@@ -402,27 +402,17 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     //  2: the list WL_RST -- everything else that resets in k_stats)
     const int lone0 = !(mode == MODE_STEP && inline_reset) ? 0 : ((PROB == PCGRL_PROB_BINARY && P.group == 16 && P.rep <= PCGRL_REP_TURTLE) ? 1 : 2);
     if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !getenv("PCGRL_NO_WIDE")) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
-        const size_t lds1 = inline_reset ? (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
+        const char* wvs = getenv("PCGRL_WIDE_WAVES");
+        const int nw = wvs ? atoi(wvs) : 8;   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
+        const size_t lds1 = inline_reset ? (size_t)(nw == 8 ? 8 : 4) * (PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
         const int gridw = P.num_envs < 16384 ? P.num_envs : 16384;
         // wavefronts per map: with the incremental route only ~10 % of the changes (and the resets) come here, so the launch
         // is latency-bound and more wavefronts per map pay (PCGRL_WIDE_WAVES overrides for experiments)
-        const char* wvs = getenv("PCGRL_WIDE_WAVES");
-        const int nw = wvs ? atoi(wvs) : 8;   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
 #define LAUNCH_WIDE(NW) do { if (P.mask_bytes == 4) hipLaunchKernelGGL((k_stats_wide<uint32_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); \
                              else hipLaunchKernelGGL((k_stats_wide<uint64_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); } while (0)
-        if (nw == 16) LAUNCH_WIDE(16); else if (nw == 8) LAUNCH_WIDE(8); else LAUNCH_WIDE(4);
+        if (nw == 8) LAUNCH_WIDE(8); else LAUNCH_WIDE(4);
 #undef LAUNCH_WIDE
         HIPCHK(hipGetLastError());
-        if (mode == MODE_STEP && h->B.champ) {
-            // the incremental items of the step (binary_incremental), a wavefront each: k_stats with no "full" list
-            const size_t ldsw = inline_reset ? 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
-            const int gridi = grid_for(P.num_envs, 4, 8192);
-            if (P.mask_bytes == 4)
-                hipLaunchKernelGGL((k_stats<PROB, 64, uint32_t>), dim3(gridi), dim3(PCGRL_BLOCK), ldsw, st, P, h->B, -1, parity, mode, -1, inline_reset, gen, 0);
-            else
-                hipLaunchKernelGGL((k_stats<PROB, 64, uint64_t>), dim3(gridi), dim3(PCGRL_BLOCK), ldsw, st, P, h->B, -1, parity, mode, -1, inline_reset, gen, 0);
-            HIPCHK(hipGetLastError());
-        }
         return PCGRL_OK;
     }
     if (P.group == 16 && P.mask_bytes == 4)
