@@ -28,7 +28,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <functional>
 #include <vector>
 
 #include "../../include/pcgrl_hip.h"
@@ -48,7 +47,6 @@
 
 // ------------------------------------------------------------------------------------------
 // Host side of the ABI
-#define PCGRL_MAX_SUB 4
 struct pcgrl_env {
     pcgrl_config cfg;
     PcgrlParams P;
@@ -61,14 +59,6 @@ struct pcgrl_env {
     int device;
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
     int alloc_solver_power;
-    // Sub-batches: the environment axis is cut into nsub contiguous slices whose kernel chains run on
-    // separate HIP streams (slice 0 on the caller's stream), so that one slice's latency-bound kernels
-    // (k_update, k_reset) overlap another slice's throughput-bound k_stats.  Fork/join with events.
-    int nsub;
-    PcgrlParams subP[PCGRL_MAX_SUB];
-    DevBufs subB[PCGRL_MAX_SUB];
-    hipStream_t sub_stream[PCGRL_MAX_SUB];
-    hipEvent_t ev_fork, ev_join[PCGRL_MAX_SUB];
     int profiling;
     std::vector<hipEvent_t> events;
     size_t ev_used;
@@ -139,22 +129,6 @@ static size_t wl_bytes(const pcgrl_config* c) {
 static size_t sok_sync_bytes() { return align_up(2 * (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, 256); }
 static size_t sok_sched_bytes(int num_envs) { return align_up((size_t)num_envs * 18 * 4, 256) + sok_sync_bytes(); }
 static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<= 1; return t; }
-static int num_subbatches(const pcgrl_config* c) {
-    const char* e = getenv("PCGRL_SUBBATCHES");
-    // Measured on MI355X (C2/C3, 65 536 envs): 1 slice 61 us/step, 2 slices 74, 4 slices 113 -- the
-    // cross-stream event fork/join costs more than the overlap wins, so slicing is opt-in only.
-    int n = e ? atoi(e) : 1;
-    if (c->prob == PCGRL_SOKOBAN) n = 1;          // the solver arena is per handle
-    if (n < 1) n = 1;
-    if (n > PCGRL_MAX_SUB) n = PCGRL_MAX_SUB;
-    while (n > 1 && c->num_envs / n < 1024) n--;
-    return n;
-}
-static void sub_range(int num_envs, int nsub, int k, int* lo, int* hi) {
-    const int base = num_envs / nsub, extra = num_envs % nsub;
-    *lo = k * base + (k < extra ? k : extra);
-    *hi = *lo + base + (k < extra ? 1 : 0);
-}
 // rows of the champion component per environment (binary, maps of at most 16 x 32): the incremental statistics path
 static size_t champ_bytes(const pcgrl_config* c) {
     if (c->prob != PCGRL_BINARY) return 0;
@@ -164,10 +138,7 @@ static size_t champ_bytes(const pcgrl_config* c) {
 static size_t scratch_bytes_base(const pcgrl_config* c);
 static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c); }
 static size_t scratch_bytes_base(const pcgrl_config* c) {
-    const int nsub = num_subbatches(c);
-    pcgrl_config cc = *c;
-    cc.num_envs = (c->num_envs + nsub - 1) / nsub;
-    size_t b = nsub * wl_bytes(&cc);
+    size_t b = wl_bytes(c);
     if (c->prob == PCGRL_SOKOBAN) {
         const size_t nodes = 4 * (size_t)c->solver_power + 4;
         b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
@@ -217,8 +188,6 @@ int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
     pcgrl_env* h = new pcgrl_env();
     h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
     h->profiling = 0; h->ev_used = 0; h->prof_steps = 0;
-    h->nsub = 1; h->ev_fork = nullptr;
-    for (int k = 0; k < PCGRL_MAX_SUB; k++) { h->sub_stream[k] = nullptr; h->ev_join[k] = nullptr; }
     memset(&h->B, 0, sizeof(h->B));
     h->cfg = *c;
     fill_params(c, &h->P);
@@ -230,11 +199,6 @@ int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
 int pcgrl_destroy(pcgrl_env* h) {
     if (h) {
         for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-        for (int k = 0; k < PCGRL_MAX_SUB; k++) {
-            if (h->sub_stream[k]) { (void)hipStreamSynchronize(h->sub_stream[k]); (void)hipStreamDestroy(h->sub_stream[k]); }
-            if (h->ev_join[k]) (void)hipEventDestroy(h->ev_join[k]);
-        }
-        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     }
     delete h;
     return PCGRL_OK;
@@ -282,7 +246,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         // the arena is sized for the solver_power the buffers were allocated with
         const int power = h->alloc_solver_power = h->cfg.solver_power;
         const size_t nodes = 4 * (size_t)power + 4;
-        uint8_t* a = s + wl_bytes(&h->cfg);   // (nsub == 1 for sokoban)
+        uint8_t* a = s + wl_bytes(&h->cfg);
         B.sok_pool = (SokNode*)a;
         B.sok_pool_stride = (int32_t)(align_up(nodes * sizeof(SokNode), 256) / sizeof(SokNode));
         a += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
@@ -308,39 +272,6 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
             B.sok_table = (uint32_t*)a;
         }
     }
-    // sub-batch views: every per-environment pointer offset to the slice, private work lists
-    h->nsub = num_subbatches(&h->cfg);
-    if (h->nsub > 1) {
-        const PcgrlParams& P0 = h->P;
-        const size_t cells = (size_t)P0.width * P0.height;
-        pcgrl_config cc = h->cfg;
-        cc.num_envs = (h->cfg.num_envs + h->nsub - 1) / h->nsub;
-        const size_t wlb = wl_bytes(&cc);
-        for (int k = 0; k < h->nsub; k++) {
-            int lo, hi;
-            sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
-            PcgrlParams& P = h->subP[k]; DevBufs& S = h->subB[k];
-            P = P0; P.num_envs = hi - lo;
-            S = B;
-            S.map = B.map + lo * cells; S.old_map = B.old_map + lo * cells; S.heat = B.heat + lo * cells; S.pos = B.pos + 2 * (size_t)lo;
-            S.planes = (uint8_t*)B.planes + (size_t)lo * P0.nplanes * P0.group * P0.mask_bytes;
-            S.counters = B.counters + 2 * (size_t)lo; S.stats = B.stats + 8 * (size_t)lo; S.start_stats = B.start_stats + 8 * (size_t)lo;
-            S.info = B.info + 10 * (size_t)lo; S.reward = B.reward + lo; S.done = B.done + lo; S.tile_p = B.tile_p + 2 * (size_t)lo;
-            S.rng_rep = B.rng_rep + (size_t)lo * PCGRL_MT_N; S.rng_prob = B.rng_prob ? B.rng_prob + (size_t)lo * PCGRL_MT_N : nullptr;
-            S.rng_cur = B.rng_cur + 2 * (size_t)lo;
-            S.champ = B.champ ? (uint8_t*)B.champ + (size_t)lo * P0.group * P0.mask_bytes : nullptr;
-            uint8_t* q = s + (size_t)k * wlb;
-            S.wl_cnt = (int32_t*)q;
-            q += WL_CNT_BYTES + 256;
-            for (int l = 0; l < WL_NLIST; l++) { S.wl_cap[l] = wl_capacity(cc.num_envs, l); S.wl_items[l] = (int32_t*)q; q += wl_list_bytes(cc.num_envs, l); }
-            if (k > 0 && !h->sub_stream[k]) {
-                HIPCHK(hipStreamCreateWithFlags(&h->sub_stream[k], hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
-            }
-        }
-        if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipMemsetAsync(s, 0, h->nsub * wlb, (hipStream_t)stream));
-    }
     h->bound = 1; h->has_old = 0; h->was_reset = 0; h->parity = 0;
     return PCGRL_OK;   // tile_p is caller state: call pcgrl_set_tile_probs once after the first bind
 }
@@ -355,7 +286,6 @@ int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
     if (h->bound && c->prob == PCGRL_SOKOBAN && c->solver_power > h->alloc_solver_power) return PCGRL_EINVAL;   // arena too small: re-create
     h->cfg = *c;
     fill_params(c, &h->P);
-    for (int k = 0; k < h->nsub && h->nsub > 1; k++) { const int n = h->subP[k].num_envs; h->subP[k] = h->P; h->subP[k].num_envs = n; }
     return PCGRL_OK;
 }
 
@@ -506,7 +436,7 @@ extern "C" {
 
 static int reset_one(pcgrl_env* h, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const int n = h->P.num_envs, par = h->parity;   // (h->P is the sub-batch view here)
+    const int n = h->P.num_envs, par = h->parity;
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_RST);
     HIPCHK(hipGetLastError());
     const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN;
@@ -555,32 +485,9 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
     return PCGRL_OK;
 }
 
-// Run `fn` once per sub-batch: slice 0 on the caller's stream, the others on their own streams between a
-// fork event and join events; h->P / h->B are swapped to the slice's view for the duration of the call.
-static int for_each_sub(pcgrl_env* h, hipStream_t caller, const std::function<int(int, hipStream_t)>& fn) {
-    if (h->nsub <= 1) return fn(0, caller);
-    const PcgrlParams P0 = h->P;
-    const DevBufs B0 = h->B;
-    const int prof = h->profiling;
-    int rc = PCGRL_OK;
-    if (hipEventRecord(h->ev_fork, caller) != hipSuccess) return PCGRL_EHIP;
-    for (int k = h->nsub - 1; k >= 0 && rc == PCGRL_OK; k--) {   // side streams first, the caller's slice last
-        hipStream_t st = k == 0 ? caller : h->sub_stream[k];
-        if (k > 0 && hipStreamWaitEvent(st, h->ev_fork, 0) != hipSuccess) { rc = PCGRL_EHIP; break; }
-        h->P = h->subP[k]; h->B = h->subB[k];
-        h->profiling = (k == 0) ? prof : 0;          // phase timing follows slice 0
-        rc = fn(k, st);
-        if (rc == PCGRL_OK && k > 0 && hipEventRecord(h->ev_join[k], st) != hipSuccess) rc = PCGRL_EHIP;
-    }
-    h->P = P0; h->B = B0; h->profiling = prof;
-    for (int k = 1; k < h->nsub && rc == PCGRL_OK; k++)
-        if (hipStreamWaitEvent(caller, h->ev_join[k], 0) != hipSuccess) rc = PCGRL_EHIP;
-    return rc;
-}
-
 int pcgrl_reset(pcgrl_env* h, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
-    int rc = for_each_sub(h, (hipStream_t)stream, [&](int, hipStream_t st) { return reset_one(h, st); });
+    int rc = reset_one(h, stream);
     if (rc) return rc;
     h->parity ^= 1;
     h->has_old = 1;
@@ -591,13 +498,7 @@ int pcgrl_reset(pcgrl_env* h, void* stream) {
 int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!actions) return PCGRL_EINVAL;
-    static const int kActionWidth[6] = {1, 3, 1, 2, 9, 2};
-    const int aw = kActionWidth[h->P.rep];
-    int rc = for_each_sub(h, (hipStream_t)stream, [&](int k, hipStream_t st) {
-        int lo = 0, hi = 0;
-        sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
-        return step_one(h, actions + (size_t)lo * aw, st);
-    });
+    int rc = step_one(h, actions, stream);
     if (rc) return rc;
     h->parity ^= 1;
     if (h->profiling) h->prof_steps++;
@@ -619,13 +520,6 @@ int pcgrl_bind_episode_stats(pcgrl_env* h, double* ep_return, int32_t* ep_length
         HIPCHK(hipMemsetAsync(last_length, 0, n * 4, (hipStream_t)stream));
     }
     h->B.ep_return = ep_return; h->B.ep_length = ep_length; h->B.last_return = last_return; h->B.last_length = last_length;
-    for (int k = 0; k < h->nsub && h->nsub > 1; k++) {
-        int lo, hi;
-        sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
-        DevBufs& S = h->subB[k];
-        S.ep_return = any ? ep_return + lo : nullptr; S.ep_length = any ? ep_length + lo : nullptr;
-        S.last_return = any ? last_return + lo : nullptr; S.last_length = any ? last_length + lo : nullptr;
-    }
     return PCGRL_OK;
 }
 
@@ -705,12 +599,7 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
 int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!maps) return PCGRL_EINVAL;
-    const size_t cells = (size_t)h->P.width * h->P.height;
-    int rc = for_each_sub(h, (hipStream_t)stream, [&](int k, hipStream_t st) {
-        int lo = 0, hi = 0;
-        sub_range(h->cfg.num_envs, h->nsub, k, &lo, &hi);
-        return set_maps_one(h, maps + (size_t)lo * cells, st);
-    });
+    int rc = set_maps_one(h, maps, stream);
     if (rc) return rc;
     h->parity ^= 1;
     return PCGRL_OK;

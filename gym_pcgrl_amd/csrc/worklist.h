@@ -37,7 +37,7 @@ template <int G> __device__ __forceinline__ unsigned wl_inc_code(int raw) { retu
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
-    const uint16_t* heat_end;        // end of the caller's whole heatmap buffer (also in sub-batch views)
+    const uint16_t* heat_end;        // end of the caller's heatmap buffer
     // optional episode statistics (pcgrl_bind_episode_stats): running return/length, latched at the end of an episode
     double* ep_return; int32_t* ep_length; double* last_return; int32_t* last_length;
     int32_t* counters; int32_t* stats; int32_t* start_stats; int32_t* info;
