@@ -526,3 +526,59 @@ def test_sokoban_hard_list_overflow(cap, monkeypatch):
     for _ in range(2):
         env.set_maps(maps)
         assert np.array_equal(env.stats.cpu().numpy().astype(np.int64), d["stats"])
+
+
+# ------------------------------------------------------------------ long runs through the incremental statistics routes
+SOAK_CASES = [
+    ("binary", "narrow", (dict(change_percentage=1.0),), 256, 400),                      # long episodes: long chains of incremental updates
+    ("binary", "wide", (dict(width=32, height=16), dict(change_percentage=0.6)), 64, 300),   # widest map of the 32-bit route
+    ("binary", "narrow", (dict(width=5, height=5), dict(change_percentage=1.0)), 256, 300),  # tiny components: often no champion
+    ("binary", "turtle", (dict(width=33, height=16), dict(change_percentage=0.5)), 48, 300),  # 64-bit rows: full route only
+    ("binary", "turtle", (dict(width=64, height=40), dict(change_percentage=0.3), dict(warp=True)), 12, 400),  # tall map: k_stats_wide + incremental
+    ("binary", "wide", (dict(width=20, height=30), dict(change_percentage=0.5)), 24, 300),   # tall, 32-bit rows
+    ("zelda", "narrow", (dict(width=32, height=16), dict(change_percentage=0.5)), 64, 300),
+    ("zelda", "wide", (dict(width=11, height=16), dict(change_percentage=1.0)), 128, 400),
+    ("zelda", "turtle", (dict(width=5, height=4), dict(change_percentage=1.0)), 128, 300),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob,rep,calls,E,T", SOAK_CASES, ids=lambda v: str(v) if isinstance(v, (str, int)) else "cfg")
+def test_incremental_routes_soak(prob, rep, calls, E, T):
+    """Hundreds of consecutive steps per environment against the oracle: the incremental statistics (binary champion
+    cache on 16-row and on tall maps, zelda region count) carry state from step to step, so errors would accumulate."""
+    torch = _torch()
+    seed0 = 4242
+    env = _make(prob, rep, E, calls, seed=seed0)
+    obs = env.reset()
+    W, H = env._prob._width, env._prob._height
+    nt = env.get_num_tiles()
+    rs = np.random.RandomState(5)
+    if rep == "narrow":
+        acts = rs.randint(0, nt + 1, size=(T, E, 1))
+    elif rep == "turtle":
+        acts = rs.randint(0, nt + 4, size=(T, E, 1))
+    else:
+        acts = np.stack([rs.randint(0, W, size=(T, E)), rs.randint(0, H, size=(T, E)), rs.randint(0, nt, size=(T, E))], -1)
+    acts = acts.astype(np.int32)
+    exp = []
+    for i in range(E):
+        o = ol.OracleEnv(prob, rep)
+        for kw in calls:
+            o.adjust_param(**kw)
+        o.seed(seed0 + i)
+        o.reset()
+        a3 = np.zeros((T, 3), np.int32)
+        a3[:, :acts.shape[2]] = acts[:, i]
+        exp.append(o.rollout(a3, want_heat=False))
+    keys = list(env._prob.info_keys) + ["iterations", "changes"]
+    for t in range(T):
+        obs, rew, done, info = env.step(acts[t] if rep == "wide" else acts[t, :, 0])
+        assert np.array_equal(done.cpu().numpy(), np.array([x["done"][t] for x in exp])), ("done", t)
+        assert np.array_equal(rew.cpu().numpy(), np.array([x["reward"][t] for x in exp])), ("reward", t)
+        got_info = np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64)
+        e_info = np.stack([x["info"][t] for x in exp])
+        assert np.array_equal(got_info, e_info), ("info", t, np.nonzero((got_info != e_info).any(1))[0][:4])
+        if t % 50 == 49 or t == T - 1:
+            assert np.array_equal(obs["map"].cpu().numpy(), np.stack([x["maps"][t] for x in exp])), ("map", t)
+    assert env.check_status() == 0
