@@ -40,6 +40,7 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
 
 
+ABI_VERSION = 2          # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
@@ -91,6 +92,8 @@ def load():
         if not hasattr(L, name):
             raise RuntimeError("gym_pcgrl_amd: %s does not export %s (stale build?)" % (SO, name))
     L.pcgrl_abi_version.restype = C.c_int
+    if L.pcgrl_abi_version() != ABI_VERSION:
+        raise RuntimeError("gym_pcgrl_amd: %s has ABI version %d, this package needs %d (stale build?)" % (SO, L.pcgrl_abi_version(), ABI_VERSION))
     L.pcgrl_error_string.restype = C.c_char_p
     L.pcgrl_error_string.argtypes = [C.c_int]
     L.pcgrl_last_hip_error.restype = C.c_int
