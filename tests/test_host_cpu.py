@@ -105,3 +105,10 @@ def test_no_gpu_means_loud_failure():
         env.reset()
     with pytest.raises(RuntimeError):
         gym_pcgrl_amd.make_batched("binary-narrow-v0", num_envs=2, seed=0, device="cpu")
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() must succeed on a GPU-less host (cross-compiles, loads the
+    library, checks the ABI version, builds the oracle)."""
+    import __graft_entry__ as g
+    g.build()
