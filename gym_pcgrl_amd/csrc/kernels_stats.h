@@ -113,7 +113,11 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     const int n0 = lone0 == 1 ? s_pref[1] : (lone0 == 2 ? n_rst : 0);
     const int f0 = lone0 == 1 ? n0 : 0;                           // items of `list` that the lone wavefronts take
     const int w_full = (n_full - f0 + GPW - 1) / GPW;             // wavefronts of the remaining full items
-    const int w_total = n0 + w_full + (n_inc + GPW - 1) / GPW;
+    // With many certain resets (zelda: thousands per step) the launch is throughput-bound and a wavefront takes two of
+    // them: four statistics side by side instead of two.  With few, one each keeps the chain short.
+    const bool pair = GPW >= 4 && n0 >= B.pair_min;
+    const int w_lone = pair ? (n0 + 1) >> 1 : n0;
+    const int w_total = w_lone + w_full + (n_inc + GPW - 1) / GPW;
     MaskT* champ_base = reinterpret_cast<MaskT*>(B.champ);
     const int lane64 = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = lane64 / G;
     const int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
@@ -123,15 +127,17 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
     const MaskT rowmask = row_valid<MaskT>(g.lane, W, H);
     for (int wid = blockIdx.x * (PCGRL_BLOCK / 64) + wv; wid < w_total; wid += gridDim.x * (PCGRL_BLOCK / 64)) {
-        const bool lone = wid < n0;                                // wave-uniform, like inc
-        const bool inc = wid >= n0 + w_full;
-        const int item = lone ? wid : (inc ? (wid - n0 - w_full) * GPW + gw : f0 + (wid - n0) * GPW + gw);
-        const bool have = lone ? gw == 0 : item < (inc ? n_inc : n_full);
+        const bool lone = wid < w_lone;                            // wave-uniform, like inc
+        const bool inc = wid >= w_lone + w_full;
+        // a certain reset occupies two lane groups: an even one for the map the step ended on, the odd one next to it for
+        // the regenerated map
+        const int item = lone ? (pair ? 2 * wid + (gw >> 1) : wid) : (inc ? (wid - w_lone - w_full) * GPW + gw : f0 + (wid - w_lone) * GPW + gw);
+        const bool have = lone ? (item < n0 && (pair || gw < 2)) : item < (inc ? n_inc : n_full);
         const bool from_rst = lone && lone0 == 2;
         const int raw = !have ? 0 : (inc ? wl_get(B, WL_INC, s_pref_inc, item) : (from_rst ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item)));
         const bool packed = inc || (kZinc && zinc && !lone);        // (environment, cell, passability change) in one word
         const bool reset_only = have && !packed && (raw & WL_RESET_ONLY) != 0;
-        const bool compute = have && !reset_only;
+        const bool compute = have && !reset_only && !(lone && (gw & 1));
         const int e = packed ? wl_inc_env<G>(raw) : (raw & ~WL_RESET_ONLY);
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
@@ -141,30 +147,35 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
             if (NPL > 1) { b1 = planes_e[G + g.lane]; b2 = planes_e[2 * G + g.lane]; }
         }
         if (GPW >= 2 && lone && inline_reset) {
-            // A certain reset.  The new map does not depend on the statistics of the old one, so the environment is reset
-            // first and then both statistics -- of the map the step ended on (rows already in registers, group 0) and
-            // of the regenerated one (group 1) -- are computed side by side: the chain is one statistics computation
+            // Certain resets.  The new map does not depend on the statistics of the old one, so the environment is reset
+            // first and then both statistics -- of the map the step ended on (rows already in registers, even group) and
+            // of the regenerated one (odd group) -- are computed side by side: the chain is one statistics computation
             // long instead of two.  The step is finished with the counters read before the reset zeroed them.
-            const int e0 = __builtin_amdgcn_readlane(e, 0);
-            const bool ro = __builtin_amdgcn_readlane((int)reset_only, 0) != 0;
+            const int role = gw & 1;
             int2 pre = make_int2(0, 0);
-            if (lane64 == 0) pre = reinterpret_cast<const int2*>(B.counters)[e0];
+            if (g.lane == 0 && role == 0 && have) pre = reinterpret_cast<const int2*>(B.counters)[e];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // old planes and counters are in registers
-            wave_reset_env<PROB>(P, B, e0, gen_map, mt, tiles, lane64);
-            MaskT t0, t1, t2;
-            planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e0 * NPL * G, gw == 1 ? g.lane : -1, t0, t1, t2);
-            if (gw == 1) { b0 = t0; b1 = t1; b2 = t2; }
-            __builtin_amdgcn_wave_barrier();
-            const bool act = (gw == 0 && !ro) || gw == 1;
+#pragma unroll
+            for (int k = 0; k < GPW / 2; k++) {
+                if (k > 0 && !pair) break;                        // wave-uniform
+                if (!__builtin_amdgcn_readlane((int)have, 2 * k * G)) continue;
+                const int ek = __builtin_amdgcn_readlane(e, 2 * k * G);
+                wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
+                MaskT t0, t1, t2;
+                planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == 2 * k + 1 ? g.lane : -1, t0, t1, t2);
+                if (gw == 2 * k + 1) { b0 = t0; b1 = t1; b2 = t2; }
+                __builtin_amdgcn_wave_barrier();
+            }
+            const bool act = have && (role == 1 || !reset_only);
             int32_t sl[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
             MaskT champ_l = 0;
             bool ns = false;
             if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l);
-            if (lane64 == 0 && !ro) finalize_item(P, B, e0, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
+            if (g.lane == 0 && role == 0 && act) finalize_item(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
             __builtin_amdgcn_wave_barrier();
-            if (gw == 1) {
-                if (kInc && champ_base) champ_base[(size_t)e0 * G + g.lane] = champ_l;
-                if (g.lane == 0) finish_or_park(P, B, e0, sl, ns, MODE_START, parity, shard);
+            if (role == 1 && have) {
+                if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ_l;
+                if (g.lane == 0) finish_or_park(P, B, e, sl, ns, MODE_START, parity, shard);
             }
             continue;
         }

@@ -233,6 +233,10 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     B.sok_pool = nullptr; B.sok_heap = nullptr; B.sok_table = nullptr;
     B.zelda_inc = (h->cfg.prob == PCGRL_ZELDA && h->cfg.rep <= PCGRL_REP_TURTLE && h->cfg.height <= 16 && h->cfg.width <= 32 &&
                    h->cfg.num_envs <= WL_INC_ENV_MASK && !getenv("PCGRL_NO_INC")) ? 1 : 0;
+    {
+        const char* pm = getenv("PCGRL_PAIR_MIN");
+        B.pair_min = pm ? atoi(pm) : 2048;
+    }
     B.champ = nullptr;
     if (champ_bytes(&h->cfg) && !getenv("PCGRL_NO_INC")) {      // PCGRL_NO_INC=1: every change takes the full statistics (A/B, tests)
         B.champ = s + scratch_bytes_base(&h->cfg);

@@ -55,6 +55,7 @@ struct DevBufs {
     int32_t sok_hard_cap;            // levels k_sokoban may publish per launch (SOK_HARD_CAP; PCGRL_SOK_HARD_CAP lowers it for tests)
     int32_t sok_fast_maxc;           // most crates the register-resident search takes (SOKF_MAXC; -1: PCGRL_SOK_GENERIC=1 forces the generic one)
     int32_t inline_reset;   // k_stats resets finished environments itself (every problem but Sokoban)
+    int32_t pair_min;       // from this many certain resets per launch on, a wavefront of k_stats takes two of them (PCGRL_PAIR_MIN)
     int32_t zelda_inc;      // zelda, single-cell representations, maps of at most 16 x 32: changed/incremental items carry (cell, passability change)
 };
 

@@ -582,3 +582,16 @@ def test_incremental_routes_soak(prob, rep, calls, E, T):
         if t % 50 == 49 or t == T - 1:
             assert np.array_equal(obs["map"].cpu().numpy(), np.stack([x["maps"][t] for x in exp])), ("map", t)
     assert env.check_status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob,rep,calls,E,T", [
+    ("zelda", "wide", (dict(width=11, height=16),), 192, 150),
+    ("binary", "narrow", (), 192, 200),
+    ("binary", "turtle", (dict(change_percentage=0.1),), 128, 200),
+], ids=lambda v: str(v) if isinstance(v, (str, int)) else "cfg")
+def test_paired_certain_resets(prob, rep, calls, E, T, monkeypatch):
+    """With thousands of certain resets per launch a wavefront of k_stats takes two of them (four statistics side by
+    side).  PCGRL_PAIR_MIN=1 forces that mode on small batches; the rollout must still equal the oracle's."""
+    monkeypatch.setenv("PCGRL_PAIR_MIN", "1")
+    test_rollout_vs_oracle(prob, rep, calls, E, T)
