@@ -101,23 +101,6 @@ __device__ __forceinline__ int wl_load_prefix3(const DevBufs& B, int parity, int
     *n_c = s_pref_c[WL_NSHARD];
     return s_pref_a[WL_NSHARD];
 }
-__device__ __forceinline__ int wl_load_prefix2(const DevBufs& B, int parity, int list_a, int list_b, int* s_pref_a, int* s_pref_b, int* n_b) {
-    if (threadIdx.x < 2 * WL_NSHARD) {
-        const int t = threadIdx.x & (WL_NSHARD - 1);
-        const bool second = threadIdx.x >= WL_NSHARD;
-        int v = wl_counters(B, parity, second ? list_b : list_a)[t * WL_CSTRIDE];
-        for (int o = 1; o < WL_NSHARD; o <<= 1) {
-            const int u = __shfl_up(v, o, 64);
-            if (t >= o) v += u;
-        }
-        int* sp = second ? s_pref_b : s_pref_a;
-        sp[t + 1] = v;
-        if (t == 0) sp[0] = 0;
-    }
-    __syncthreads();
-    *n_b = s_pref_b[WL_NSHARD];
-    return s_pref_a[WL_NSHARD];
-}
 __device__ __forceinline__ int wl_get(const DevBufs& B, int list, const int* s_pref, int i) {
     int lo = 0;
 #pragma unroll
