@@ -143,8 +143,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
         MaskT b0 = 0, b1 = 0, b2 = 0;
         if (compute) {
-            b0 = planes_e[g.lane];
-            if (NPL > 1) { b1 = planes_e[G + g.lane]; b2 = planes_e[2 * G + g.lane]; }
+            b0 = planes_e[g.lane * NPL];
+            if (NPL > 1) { b1 = planes_e[g.lane * NPL + 1]; b2 = planes_e[g.lane * NPL + 2]; }
         }
         if (GPW >= 2 && lone && inline_reset) {
             // Certain resets.  The new map does not depend on the statistics of the old one, so the environment is reset

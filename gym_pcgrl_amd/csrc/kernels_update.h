@@ -64,7 +64,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         }
         // ---- round trip 2: everything addressed by the cursor cell and by the ring cursor
         uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
-        MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G + wy;
+        MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + ((size_t)e * G + wy) * NPL;   // the planes of one row are adjacent
         // the old tile: from the plane word when there is a single plane (one scattered read less), else from the byte map
         const int old_byte = (NPL > 1) ? (int)*cell : 0;
         // binary, 16-row maps: the three champion rows around the cell, for the routing decision below
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             chd = ch[wy < G - 1 ? wy + 1 : wy];
         }
         MaskT m0 = pl[0], m1 = 0, m2 = 0;
-        if (NPL > 1) { m1 = pl[G]; m2 = pl[2 * G]; }
+        if (NPL > 1) { m1 = pl[1]; m2 = pl[2]; }
         const int old = (NPL > 1) ? old_byte : (int)((m0 >> wx) & 1);
         uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             const MaskT bit = (MaskT)1 << wx;
             pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
             if (NPL > 1) {
-                pl[G] = (tile & 2) ? (m1 | bit) : (m1 & ~bit);
-                pl[2 * G] = (tile & 4) ? (m2 | bit) : (m2 & ~bit);
+                pl[1] = (tile & 2) ? (m1 | bit) : (m1 & ~bit);
+                pl[2] = (tile & 4) ? (m2 | bit) : (m2 & ~bit);
             }
         }
         if (REP == PCGRL_REP_NARROW) {   // the cursor moves on every step (narrow_rep.py:104-113)
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
             const int yy = y + dy;
             if (yy < 0 || yy >= H) continue;
             if (vals[(dy + 1) * 3] < 0 && vals[(dy + 1) * 3 + 1] < 0 && vals[(dy + 1) * 3 + 2] < 0) continue;
-            MaskT m0 = pl_e[yy], m1 = NPL > 1 ? pl_e[G + yy] : (MaskT)0, m2 = NPL > 1 ? pl_e[2 * G + yy] : (MaskT)0;
+            MaskT m0 = pl_e[yy * NPL], m1 = NPL > 1 ? pl_e[yy * NPL + 1] : (MaskT)0, m2 = NPL > 1 ? pl_e[yy * NPL + 2] : (MaskT)0;
             bool touched = false;
 #pragma unroll
             for (int dx = -1; dx <= 1; dx++) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
                     m2 = (v & 4) ? (m2 | bit) : (m2 & ~bit);
                 }
             }
-            if (touched) { pl_e[yy] = m0; if (NPL > 1) { pl_e[G + yy] = m1; pl_e[2 * G + yy] = m2; } }
+            if (touched) { pl_e[yy * NPL] = m0; if (NPL > 1) { pl_e[yy * NPL + 1] = m1; pl_e[yy * NPL + 2] = m2; } }
         }
         if (REP != PCGRL_REP_TURTLE_CAST) {   // narrow cursor move (narrow_rep.py:104-113), after the write
             if (P.random_tile) {

@@ -21,7 +21,7 @@
 //
 // State is structure-of-arrays over the environment axis, all in HBM, owned by the caller
 // (include/pcgrl_hip.h).  The uint8 map is the observation; the kernels compute on `planes`
-// (row bitboards of the tile-id bits, [N][nplanes][group]) which k_update keeps in sync, so the
+// (row bitboards of the tile-id bits, [N][group][nplanes]) which k_update keeps in sync, so the
 // statistics never re-read or transpose the byte map.  No MFMA: integer/bit work only.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -21,8 +21,8 @@ __device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const ui
             }
         }
         if (store) {
-            planes_e[lane] = m0;
-            if (NPL > 1) { planes_e[G + lane] = m1; planes_e[2 * G + lane] = m2; }
+            planes_e[lane * NPL] = m0;
+            if (NPL > 1) { planes_e[lane * NPL + 1] = m1; planes_e[lane * NPL + 2] = m2; }
         }
     }
 }

@@ -66,7 +66,7 @@ typedef struct pcgrl_layout {
     size_t old_map;       /* u8  [N,H,W]   Representation._old_map */
     size_t heatmap;       /* i16 [N,H,W]   observation "heatmap" (counts) */
     size_t pos;           /* u8  [N,2]     observation "pos" (x,y); unused for wide */
-    size_t planes;        /* mask[N,nplanes,group] row bitboards of the tile-id bits */
+    size_t planes;        /* mask[N,group,nplanes] row bitboards of the tile-id bits (the planes of a row are adjacent) */
     size_t counters;      /* i32 [N,2]     iteration, changes */
     size_t stats;         /* i32 [N,8]     current _rep_stats */
     size_t start_stats;   /* i32 [N,8]     Problem._start_stats */

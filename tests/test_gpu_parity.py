@@ -250,9 +250,9 @@ def test_full_size_properties(prob, rep, calls, N):
     m = obs["map"].long()
     planes = env._bufs["planes"].long()
     xs = torch.arange(W, device="cuda")
-    for b in range(planes.shape[1]):
+    for b in range(planes.shape[2]):
         rows = (((m >> b) & 1) << xs).sum(-1)
-        got = planes[:, b, :H]
+        got = planes[:, :H, b]
         if env._bufs["planes"].dtype == torch.int32:
             got = got & 0xFFFFFFFF
         assert torch.equal(rows, got), ("plane", b)
