@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define PCGRL_ABI_VERSION 2
+/* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]). */
+#define PCGRL_ABI_VERSION 3
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
