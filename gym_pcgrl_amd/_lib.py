@@ -44,7 +44,7 @@ ABI_VERSION = 3          # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
-           "pcgrl_profile_read", "pcgrl_bind_episode_stats")
+           "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words")
 NPHASE = 6
 # the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
 # other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
@@ -103,6 +103,7 @@ def load():
     L.pcgrl_bind.argtypes = [C.c_void_p, C.POINTER(Buffers), C.c_void_p]
     L.pcgrl_configure.argtypes = [C.c_void_p, C.POINTER(Config)]
     L.pcgrl_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.pcgrl_seed_words.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.pcgrl_set_tile_probs.argtypes = [C.c_void_p, C.c_void_p]
     L.pcgrl_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.pcgrl_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

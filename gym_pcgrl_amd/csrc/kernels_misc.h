@@ -55,3 +55,40 @@ __global__ void k_zero_cursors(int32_t* cur, int first, int count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) { cur[2 * (first + i)] = 0; cur[2 * (first + i) + 1] = 0; }
 }
+
+// MT19937 init_by_array (Matsumoto & Nishimura 2002; numpy RandomState.seed(list) as used by gym's seeding.np_random,
+// reps/representation.py:28-30, probs/problem.py:34-36) for `count` environments, thread per environment: the key words
+// (1 or 2) and their number were uploaded into words 0..2 of the environment's ring.  1 247 dependent steps per
+// environment on its own 2.5 KB ring in global memory; environments run side by side.
+__device__ uint32_t g_mt_genrand[PCGRL_MT_N];      // init_genrand(19650218), the same for every key: filled by the host once
+__global__ void k_init_by_array(uint32_t* __restrict__ rng_rep, uint32_t* __restrict__ rng_prob, int32_t* __restrict__ cur, int first, int count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const size_t e = (size_t)first + t;
+    uint32_t* mt = rng_rep + e * PCGRL_MT_N;
+    const uint32_t key[2] = {mt[0], mt[1]};
+    const int klen = (int)mt[2] == 1 ? 1 : 2;
+    for (int i = 0; i < PCGRL_MT_N; i++) mt[i] = g_mt_genrand[i];
+    uint32_t prev = g_mt_genrand[0];
+    int i = 1, j = 0;
+    for (int k = 0; k < PCGRL_MT_N; k++) {
+        prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        mt[i] = prev;
+        i++; j++;
+        if (i >= PCGRL_MT_N) { mt[0] = prev; i = 1; }
+        if (j >= klen) j = 0;
+    }
+    for (int k = 0; k < PCGRL_MT_N - 1; k++) {
+        prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+        mt[i] = prev;
+        i++;
+        if (i >= PCGRL_MT_N) { mt[0] = prev; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+    if (rng_prob) {
+        uint32_t* mp = rng_prob + e * PCGRL_MT_N;
+        for (int q = 0; q < PCGRL_MT_N; q++) mp[q] = mt[q];
+    }
+    cur[2 * e] = 0; cur[2 * e + 1] = 0;
+}
+

@@ -314,6 +314,28 @@ int pcgrl_seed(pcgrl_env* h, const uint32_t* keys, int32_t first, int32_t count,
     return PCGRL_OK;
 }
 
+// The same seeding with the MT19937 states computed on the device: words HOST u32 [count][3] = (key word 0, key word 1,
+// number of key words: 1 or 2) per environment -- what gym's hash_seed leaves of `seed` (gym_pcgrl_amd/seeding.py
+// hash_seed_words).  8 bytes of key per environment cross PCIe instead of a 2.5 KB state.
+int pcgrl_seed_words(pcgrl_env* h, const uint32_t* words, int32_t first, int32_t count, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!words || first < 0 || count < 1 || first + count > h->cfg.num_envs) return PCGRL_EINVAL;
+    static bool table_ready = false;
+    if (!table_ready) {
+        uint32_t tab[PCGRL_MT_N];
+        tab[0] = 19650218u;
+        for (int i = 1; i < PCGRL_MT_N; i++) tab[i] = 1812433253u * (tab[i - 1] ^ (tab[i - 1] >> 30)) + (uint32_t)i;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_mt_genrand), tab, sizeof(tab)));
+        table_ready = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpy2DAsync(h->B.rng_rep + (size_t)first * PCGRL_MT_N, PCGRL_MT_N * 4, words, 12, 12, (size_t)count, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_init_by_array, dim3((count + 63) / 64), dim3(64), 0, st, h->B.rng_rep, h->B.rng_prob, h->B.rng_cur, first, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));   // `words` may be pageable host memory
+    return PCGRL_OK;
+}
+
 }  // extern "C"
 
 // ---- launch helpers ------------------------------------------------------------------------

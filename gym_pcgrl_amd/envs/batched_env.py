@@ -172,8 +172,8 @@ class BatchedPcgrlEnv:
             self._bind_episode_stats()
 
     def _upload_seeds(self):
-        keys = np.ascontiguousarray(self._seed_keys, dtype=np.uint32)
-        _lib.check(self._lib.pcgrl_seed(self._handle, keys.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()), "pcgrl_seed")
+        words = np.ascontiguousarray(self._seed_keys, dtype=np.uint32)      # [N, 3]: the MT19937 states are made on the device
+        _lib.check(self._lib.pcgrl_seed_words(self._handle, words.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()), "pcgrl_seed_words")
         self._rng_seeded = True
 
     # ------------------------------------------------------------------ reference surface
@@ -192,7 +192,7 @@ class BatchedPcgrlEnv:
             if s < 0:
                 raise ValueError("Seed must be a non-negative integer or omitted, not %r" % (s,))
         self._seeds = seeds
-        self._seed_keys = seeding.mt_states_for_seeds(seeds)
+        self._seed_keys = seeding.key_words_for_seeds(seeds)
         self._rng_seeded = False
         if self._handle is not None:
             self._upload_seeds()

@@ -136,6 +136,17 @@ def mt_states_for_seeds(seeds):
     return out
 
 
+def key_words_for_seeds(seeds):
+    """[len(seeds), 3] uint32: (key word 0, key word 1, number of key words) of `np_random(seed)` for every seed -- the
+    input of the device-side init_by_array (pcgrl_seed_words)."""
+    out = np.zeros((len(seeds), 3), dtype=np.uint32)
+    for k, sd in enumerate(seeds):
+        w = hash_seed_words(create_seed(int(sd)))
+        out[k, :len(w)] = w
+        out[k, 2] = len(w)
+    return out
+
+
 def np_random(seed=None):
     """Drop-in for gym<=0.21 `seeding.np_random`: (RandomState, seed)."""
     if seed is not None and not (isinstance(seed, (int, np.integer)) and 0 <= seed):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-/* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]). */
+/* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]); + pcgrl_seed_words. */
 #define PCGRL_ABI_VERSION 3
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -101,6 +101,9 @@ int pcgrl_configure(pcgrl_env* env, const pcgrl_config* cfg);
 /* keys: HOST pointer, [count,624] u32 = MT19937 init_by_array state of environment first..first+count-1;
  * seeds both streams identically (pcgrl_env.py:54-57). */
 int pcgrl_seed(pcgrl_env* env, const uint32_t* keys, int32_t first, int32_t count, void* stream);
+/* The same, with the MT19937 states computed on the device (init_by_array): words HOST u32 [count][3] = (key word 0,
+ * key word 1, number of key words 1|2) -- the key gym's seeding.hash_seed derives from the integer seed. */
+int pcgrl_seed_words(pcgrl_env* env, const uint32_t* words, int32_t first, int32_t count, void* stream);
 /* Broadcast cfg.tile_probs[0..1] into tile_p (binary); call once after the first bind and whenever
  * adjust_param(probs=...) touched them.  tile_p otherwise persists (it carries BinaryProblem._prob). */
 int pcgrl_set_tile_probs(pcgrl_env* env, void* stream);

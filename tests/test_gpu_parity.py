@@ -595,3 +595,33 @@ def test_paired_certain_resets(prob, rep, calls, E, T, monkeypatch):
     side).  PCGRL_PAIR_MIN=1 forces that mode on small batches; the rollout must still equal the oracle's."""
     monkeypatch.setenv("PCGRL_PAIR_MIN", "1")
     test_rollout_vs_oracle(prob, rep, calls, E, T)
+
+
+@pytest.mark.gpu
+def test_device_seeding_matches_numpy():
+    """pcgrl_seed_words: MT19937 init_by_array on the device against numpy's RandomState.seed(list) -- keys of two words
+    (what gym's hash_seed gives) and of one word."""
+    import ctypes as C
+    torch = _torch()
+    from gym_pcgrl_amd import _lib, seeding
+    N = 300
+    env = _make("binary", "narrow", N, seed=123456)
+    env.reset()                                           # allocates, seeds through pcgrl_seed_words
+    exp = seeding.mt_states_for_seeds([123456 + i for i in range(N)])
+    # the reset consumed draws in place, so re-seed and look at the untouched rings
+    env.seed(123456)
+    torch.cuda.synchronize()
+    got = env._bufs["rng_rep"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(env._bufs["rng_prob"].cpu().numpy().view(np.uint32), exp)
+    assert int(env._bufs["rng_cursor"].abs().sum().item()) == 0
+    words = np.zeros((N, 3), np.uint32)
+    words[:, 0] = ((np.arange(N, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.uint32)
+    words[:, 2] = 1
+    words[0, 0] = 0                                       # the key [0]
+    _lib.check(env._lib.pcgrl_seed_words(env._handle, words.ctypes.data_as(C.c_void_p), 0, N, env._stream()), "pcgrl_seed_words")
+    got = env._bufs["rng_rep"].cpu().numpy().view(np.uint32)
+    for i in (0, 1, 17, N - 1):
+        rs = np.random.RandomState()
+        rs.seed([int(words[i, 0])])
+        assert np.array_equal(got[i], rs.get_state()[1])
