@@ -66,18 +66,23 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         uint8_t* cell = B.map + ((size_t)e * H + wy) * W + wx;
         MaskT* pl = reinterpret_cast<MaskT*>(B.planes) + ((size_t)e * G + wy) * NPL;   // the planes of one row are adjacent
         // the old tile: from the plane word when there is a single plane (one scattered read less), else from the byte map
-        const int old_byte = (NPL > 1) ? (int)*cell : 0;
+        // (nothing of the cell is needed when the action writes no tile: a third of the narrow actions, the moves of turtle)
+        const bool writes = tile >= 0;
+        const int old_byte = (NPL > 1 && writes) ? (int)*cell : 0;
         // binary, 16-row maps: the three champion rows around the cell, for the routing decision below
         const bool inc_on = P.prob == PCGRL_PROB_BINARY && B.champ != nullptr;
         MaskT ch0 = 0, chu = 0, chd = 0;
-        if (inc_on) {
+        if (inc_on && writes) {
             const MaskT* ch = reinterpret_cast<const MaskT*>(B.champ) + (size_t)e * G;
             ch0 = ch[wy];
             chu = ch[wy > 0 ? wy - 1 : wy];
             chd = ch[wy < G - 1 ? wy + 1 : wy];
         }
-        MaskT m0 = pl[0], m1 = 0, m2 = 0;
-        if (NPL > 1) { m1 = pl[1]; m2 = pl[2]; }
+        MaskT m0 = 0, m1 = 0, m2 = 0;
+        if (writes) {
+            m0 = pl[0];
+            if (NPL > 1) { m1 = pl[1]; m2 = pl[2]; }
+        }
         const int old = (NPL > 1) ? old_byte : (int)((m0 >> wx) & 1);
         uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
