@@ -336,8 +336,37 @@ class BatchedPcgrlEnv:
         return self._bufs["stats"][:, :len(self._prob.stat_keys)]
 
     def state_dict(self):
+        """Everything a batch of environments carries between steps (checkpoint / resume): maps, first maps,
+        heatmaps, cursors, counters, current and start stats, last step outputs, binary tile probabilities, both MT19937
+        rings with their cursors, and the episode statistics when they are on.  Device tensors (clones)."""
         self._torch.cuda.synchronize(self.device)
-        return {k: (v.clone() if v is not None else None) for k, v in self._bufs.items() if k != "scratch"}
+        sd = {k: (v.clone() if v is not None else None) for k, v in self._bufs.items() if k not in ("scratch", "planes")}
+        if self._episode is not None:
+            sd.update({"episode_" + k: v.clone() for k, v in self._episode.items()})
+        return sd
+
+    def load_state_dict(self, sd):
+        """Restore `state_dict()` of an environment batch with the same problem, representation, size and parameters.
+        The derived state (row planes, cached champion components) is rebuilt from the maps on the device."""
+        if self._handle is None:
+            raise RuntimeError("call reset() once before load_state_dict() (buffers are allocated lazily)")
+        for k, v in sd.items():
+            if v is None or k.startswith("episode_"):
+                continue
+            dst = self._bufs[k]
+            if tuple(dst.shape) != tuple(v.shape) or dst.dtype != v.dtype:
+                raise ValueError("state_dict entry %r does not fit this environment: %s %s vs %s %s" % (k, tuple(v.shape), v.dtype, tuple(dst.shape), dst.dtype))
+            dst.copy_(v)
+        if any(k.startswith("episode_") for k in sd):
+            self.enable_episode_stats()
+            for k, v in self._episode.items():
+                v.copy_(sd["episode_" + k])
+        stats = self._bufs["stats"].clone()
+        self.set_maps(self._bufs["map"].clone())       # planes + champion cache from the maps; recomputes the current stats ...
+        self._torch.cuda.synchronize(self.device)
+        n = len(self._prob.stat_keys)
+        if not self._torch.equal(self._bufs["stats"][:, :n], stats[:, :n]):   # ... which must be the ones that were saved
+            raise ValueError("state_dict is inconsistent: the saved stats are not the stats of the saved maps")
 
     def render(self, mode="rgb_array", index=0):
         """Image of environment `index` with the reference's layout (pcgrl_env.py:161-175): 16-pixel tiles, a one-tile
