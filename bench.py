@@ -138,12 +138,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
     assert world == a.gpus or not use_dist, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    # PCGRL_BENCH_SAME_GPU=1 (tests on a one-GPU box): every rank uses cuda:0 and the ranks meet over gloo
+    same_gpu = os.environ.get("PCGRL_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)   # RCCL; only used for the barrier and the max-over-ranks time
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)   # RCCL; only used for the barrier and the max-over-ranks time
 
     from gym_pcgrl_amd.envs import BatchedPcgrlEnv
     prob, rep, calls, n_default, desc = WORKLOADS[a.workload]
@@ -174,7 +181,7 @@ def main():
     dt = time.perf_counter() - t0
     gpu_ms_per_step = ev0.elapsed_time(ev1) / a.steps
     if use_dist:
-        tt = torch.tensor([dt, gpu_ms_per_step], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt, gpu_ms_per_step], device="cpu" if same_gpu else device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, gpu_ms_per_step = float(tt[0].item()), float(tt[1].item())
     # informational per-kernel breakdown: a second pass with HIP events around every launch

@@ -654,3 +654,21 @@ def test_state_dict_round_trip(env_id):
         assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ia.table, ib.table)
         for k in oa:
             assert torch.equal(oa[k], ob[k]), k
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-process path (rank-sharded environments, barrier, max-over-ranks time, one JSON line from rank 0),
+    with both ranks on cuda:0 and gloo instead of RCCL (PCGRL_BENCH_SAME_GPU=1) so that it runs on a one-GPU box."""
+    import json, subprocess, sys
+    _torch()
+    root = os.path.dirname(HERE) if "HERE" in globals() else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCGRL_BENCH_SAME_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                          "--envs", "4096"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 4096 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-6
