@@ -110,7 +110,10 @@ class OracleEnv:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+            try:
+                lib().orc_destroy(self._h)
+            except Exception:        # interpreter shutdown: the module globals are already gone
+                pass
             self._h = None
 
     def seed(self, seed):
