@@ -79,6 +79,114 @@ __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBu
     return finalize_item(P, B, e, s, mode, parity, shard, push_reset);
 }
 
+// What one wavefront does with its share of the work of a launch (k_stats, and the fused step kernel k_step): `lone` -- a
+// certain reset (two when `pair`), an even lane group for the map the step ended on and the odd one next to it for the
+// regenerated map; `inc` -- incremental items; else full recomputations.  `have` / `raw`: this lane group's item.
+template <int PROB, int G, class MaskT>
+__device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevBufs& B, DevGroup<G, MaskT>& g, int lane64, int gw, bool lone,
+                                                bool inc, bool pair, bool zinc, bool have, int raw, int shard, int mode, int parity,
+                                                int inline_reset, int gen_map, uint32_t* mt, uint8_t* tiles, MaskT rowmask) {
+    constexpr int GPW = 64 / G;
+    constexpr bool kInc = PROB == PCGRL_PROB_BINARY;
+    constexpr bool kZinc = PROB == PCGRL_PROB_ZELDA && G == 16 && sizeof(MaskT) == 4;
+    constexpr int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
+    MaskT* champ_base = reinterpret_cast<MaskT*>(B.champ);
+    const bool packed = inc || (kZinc && zinc && !lone);        // (environment, cell, passability change) in one word
+    const bool reset_only = have && !packed && (raw & WL_RESET_ONLY) != 0;
+    const bool compute = have && !reset_only && !(lone && (gw & 1));
+    const int e = packed ? wl_inc_env<G>(raw) : (raw & ~WL_RESET_ONLY);
+    MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
+    MaskT b0 = 0, b1 = 0, b2 = 0;
+    if (compute) {
+        b0 = planes_e[g.lane * NPL];
+        if (NPL > 1) { b1 = planes_e[g.lane * NPL + 1]; b2 = planes_e[g.lane * NPL + 2]; }
+    }
+    if (GPW >= 2 && lone && inline_reset) {
+        // Certain resets.  The new map does not depend on the statistics of the old one, so the environment is reset
+        // first and then both statistics -- of the map the step ended on (rows already in registers, even group) and
+        // of the regenerated one (odd group) -- are computed side by side: the chain is one statistics computation
+        // long instead of two.  The step is finished with the counters read before the reset zeroed them.
+        const int role = gw & 1;
+        int2 pre = make_int2(0, 0);
+        if (g.lane == 0 && role == 0 && have) pre = reinterpret_cast<const int2*>(B.counters)[e];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // old planes and counters are in registers
+#pragma unroll
+        for (int k = 0; k < GPW / 2; k++) {
+            if (k > 0 && !pair) break;                        // wave-uniform
+            if (!__builtin_amdgcn_readlane((int)have, 2 * k * G)) continue;
+            const int ek = __builtin_amdgcn_readlane(e, 2 * k * G);
+            wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
+            MaskT t0, t1, t2;
+            planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == 2 * k + 1 ? g.lane : -1, t0, t1, t2);
+            if (gw == 2 * k + 1) { b0 = t0; b1 = t1; b2 = t2; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool act = have && (role == 1 || !reset_only);
+        int32_t sl[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        MaskT champ_l = 0;
+        bool ns = false;
+        if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l);
+        if (g.lane == 0 && role == 0 && act) finalize_item(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
+        __builtin_amdgcn_wave_barrier();
+        if (role == 1 && have) {
+            if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ_l;
+            if (g.lane == 0) finish_or_park(P, B, e, sl, ns, MODE_START, parity, shard);
+        }
+        return;
+    }
+    int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool need_solver = false;
+    MaskT champ = 0;
+    if (kInc && inc) {
+        if (compute) {      // one cell changed away from the champion: update the previous answer
+            const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
+            const MaskT champ_old = champ_base[(size_t)e * G + g.lane];
+            const int2 old = *reinterpret_cast<const int2*>(B.stats + (size_t)e * 8);
+            int regions, path;
+            binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, wl_inc_code<G>(raw) != 0, old.x, old.y, champ_old, regions, path, champ);
+            s[0] = regions; s[1] = path; s[2] = 1;
+        }
+    } else if (kZinc && packed) {
+        if (compute) {      // zelda: one cell was written; keep or update the region count
+            const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
+            zelda_stats(g, P, b0, b1, b2, rowmask, s, (int)wl_inc_code<G>(raw), cbit, B.stats[(size_t)e * 8 + 4]);
+        }
+    } else if (compute) {
+        need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ);
+    }
+    if (kInc && compute && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
+    int want_reset = 0;
+    if (g.lane == 0 && have) {
+        if (reset_only) want_reset = 1;
+        else want_reset = finish_or_park(P, B, e, s, need_solver, mode, parity, shard, !inline_reset) ? 1 : 0;
+    }
+    if (inline_reset) {
+        const uint64_t want = __ballot(want_reset != 0);     // one bit per group, at its lane 0
+        if (want) {
+            bool mine = false;
+#pragma unroll
+            for (int k = 0; k < GPW; k++) {
+                if ((want >> (k * G)) & 1ull) {               // wave-uniform
+                    const int ek = __builtin_amdgcn_readlane(e, k * G);
+                    wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
+                    MaskT t0, t1, t2;
+                    planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G,
+                                             gw == k ? g.lane : -1, t0, t1, t2);
+                    if (gw == k) { b0 = t0; b1 = t1; b2 = t2; mine = true; }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            // start stats of the regenerated maps (pcgrl_env.py:70-71, problem.py:45-46)
+            if (mine) {
+                int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st, champ);
+                if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
+                if (g.lane == 0) finish_or_park(P, B, e, st, ns, MODE_START, parity, shard);
+            }
+        }
+    }
+}
+
 // inline_reset (kernel-uniform, STEP mode, every problem but Sokoban): an environment whose episode ended is
 // reset right here by the wavefront that found out -- wave_reset_env with all 64 lanes, then the start
 // stats on the regenerated rows -- instead of going through a reset list and another latency-bound launch.
@@ -135,101 +243,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
         const bool have = lone ? (item < n0 && (pair || gw < 2)) : item < (inc ? n_inc : n_full);
         const bool from_rst = lone && lone0 == 2;
         const int raw = !have ? 0 : (inc ? wl_get(B, WL_INC, s_pref_inc, item) : (from_rst ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item)));
-        const bool packed = inc || (kZinc && zinc && !lone);        // (environment, cell, passability change) in one word
-        const bool reset_only = have && !packed && (raw & WL_RESET_ONLY) != 0;
-        const bool compute = have && !reset_only && !(lone && (gw & 1));
-        const int e = packed ? wl_inc_env<G>(raw) : (raw & ~WL_RESET_ONLY);
         const int shard = (item >> 4) & (WL_NSHARD - 1);
-        MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * NPL * G;
-        MaskT b0 = 0, b1 = 0, b2 = 0;
-        if (compute) {
-            b0 = planes_e[g.lane * NPL];
-            if (NPL > 1) { b1 = planes_e[g.lane * NPL + 1]; b2 = planes_e[g.lane * NPL + 2]; }
-        }
-        if (GPW >= 2 && lone && inline_reset) {
-            // Certain resets.  The new map does not depend on the statistics of the old one, so the environment is reset
-            // first and then both statistics -- of the map the step ended on (rows already in registers, even group) and
-            // of the regenerated one (odd group) -- are computed side by side: the chain is one statistics computation
-            // long instead of two.  The step is finished with the counters read before the reset zeroed them.
-            const int role = gw & 1;
-            int2 pre = make_int2(0, 0);
-            if (g.lane == 0 && role == 0 && have) pre = reinterpret_cast<const int2*>(B.counters)[e];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // old planes and counters are in registers
-#pragma unroll
-            for (int k = 0; k < GPW / 2; k++) {
-                if (k > 0 && !pair) break;                        // wave-uniform
-                if (!__builtin_amdgcn_readlane((int)have, 2 * k * G)) continue;
-                const int ek = __builtin_amdgcn_readlane(e, 2 * k * G);
-                wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
-                MaskT t0, t1, t2;
-                planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == 2 * k + 1 ? g.lane : -1, t0, t1, t2);
-                if (gw == 2 * k + 1) { b0 = t0; b1 = t1; b2 = t2; }
-                __builtin_amdgcn_wave_barrier();
-            }
-            const bool act = have && (role == 1 || !reset_only);
-            int32_t sl[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-            MaskT champ_l = 0;
-            bool ns = false;
-            if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l);
-            if (g.lane == 0 && role == 0 && act) finalize_item(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
-            __builtin_amdgcn_wave_barrier();
-            if (role == 1 && have) {
-                if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ_l;
-                if (g.lane == 0) finish_or_park(P, B, e, sl, ns, MODE_START, parity, shard);
-            }
-            continue;
-        }
-        int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-        bool need_solver = false;
-        MaskT champ = 0;
-        if (kInc && inc) {
-            if (compute) {      // one cell changed away from the champion: update the previous answer
-                const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
-                const MaskT champ_old = champ_base[(size_t)e * G + g.lane];
-                const int2 old = *reinterpret_cast<const int2*>(B.stats + (size_t)e * 8);
-                int regions, path;
-                binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, wl_inc_code<G>(raw) != 0, old.x, old.y, champ_old, regions, path, champ);
-                s[0] = regions; s[1] = path; s[2] = 1;
-            }
-        } else if (kZinc && packed) {
-            if (compute) {      // zelda: one cell was written; keep or update the region count
-                const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
-                zelda_stats(g, P, b0, b1, b2, rowmask, s, (int)wl_inc_code<G>(raw), cbit, B.stats[(size_t)e * 8 + 4]);
-            }
-        } else if (compute) {
-            need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ);
-        }
-        if (kInc && compute && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
-        int want_reset = 0;
-        if (g.lane == 0 && have) {
-            if (reset_only) want_reset = 1;
-            else want_reset = finish_or_park(P, B, e, s, need_solver, mode, parity, shard, !inline_reset) ? 1 : 0;
-        }
-        if (inline_reset) {
-            const uint64_t want = __ballot(want_reset != 0);     // one bit per group, at its lane 0
-            if (want) {
-                bool mine = false;
-#pragma unroll
-                for (int k = 0; k < GPW; k++) {
-                    if ((want >> (k * G)) & 1ull) {               // wave-uniform
-                        const int ek = __builtin_amdgcn_readlane(e, k * G);
-                        wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
-                        MaskT t0, t1, t2;
-                        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G,
-                                                 gw == k ? g.lane : -1, t0, t1, t2);
-                        if (gw == k) { b0 = t0; b1 = t1; b2 = t2; mine = true; }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-                // start stats of the regenerated maps (pcgrl_env.py:70-71, problem.py:45-46)
-                if (mine) {
-                    int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st, champ);
-                    if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
-                    if (g.lane == 0) finish_or_park(P, B, e, st, ns, MODE_START, parity, shard);
-                }
-            }
-        }
+        stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, pair, zinc, have, raw, shard, mode, parity, inline_reset, gen_map, mt, tiles, rowmask);
     }
 }
 
