@@ -8,16 +8,21 @@
 // cell, its plane words and the MT19937 ring words of up to PCGRL_SPEC_DRAWS speculative draws (every
 // operand of draw i is an *old* word: distance 397); (3) the heatmap cell of the new cursor.
 #define PCGRL_SPEC_DRAWS 6
+// What Representation.update + the bookkeeping of PcgrlEnv.step did to one environment, for the routing of its statistics.
+struct UpdateOut {
+    bool chg;          // a tile changed: the statistics have to be recomputed (or updated)
+    bool rst;          // nothing changed and the episode ended (auto_reset): reset only
+    bool cheap;        // binary: incremental update possible; zelda: the cell's passability did not change
+    bool sure_done;    // a tile changed and the episode ends whatever the new statistics are
+    int bucket;        // difficulty bucket (binary)
+    int inc_item;      // packed (environment, cell, passability change) for the incremental routes
+};
+// One environment of k_update (thread per environment; also the first phase of the fused step kernel k_step).
 template <int REP, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
-    __shared__ int s_cnt[3][4];
-    __shared__ int s_base[3];
-    __shared__ int s_hist[WL_NSHARD + 1], s_gbase[WL_NSHARD + 1];
-    const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
-    const bool act = e < P.num_envs;
+__device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevBufs& B, const int32_t* __restrict__ actions, int e) {
     bool chg = false, rst = false, cheap = false, sure_done = false;
     int bucket = 0, inc_item = 0;
-    if (act) {
+    {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
         // ---- round trip 1
         const int2 c = reinterpret_cast<const int2*>(B.counters)[e];
@@ -181,6 +186,22 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             rst = d && P.auto_reset;
         }
     }
+    UpdateOut o;
+    o.chg = chg; o.rst = rst; o.cheap = cheap; o.sure_done = sure_done; o.bucket = bucket; o.inc_item = inc_item;
+    return o;
+}
+
+template <int REP, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
+    __shared__ int s_cnt[3][4];
+    __shared__ int s_base[3];
+    __shared__ int s_hist[WL_NSHARD + 1], s_gbase[WL_NSHARD + 1];
+    const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
+    UpdateOut u = {false, false, false, false, 0, 0};
+    if (e < P.num_envs) u = update_env<REP, MaskT>(P, B, actions, e);
+    const bool chg = u.chg, rst = u.rst, cheap = u.cheap, sure_done = u.sure_done;
+    int bucket = u.bucket;
+    const int inc_item = u.inc_item;
     // bucketing pays where four maps share a wavefront and their cost varies a lot (binary); elsewhere the
     // plain per-block append is cheaper (kernel-uniform branch)
     // an unchanged environment whose episode ended rides the changed list flagged "reset only": k_stats resets

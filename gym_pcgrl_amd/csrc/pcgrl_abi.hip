@@ -42,6 +42,7 @@
 #include "reset_env.h"
 #include "kernels_stats.h"
 #include "kernels_reset.h"
+#include "kernels_step.h"
 #include "kernels_sokoban.h"
 #include "kernels_misc.h"
 
@@ -414,6 +415,37 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
 
 // One solver launch: the jobs of list_a (mode_a) and, if list_b >= 0, of list_b (mode_b).  `slot` selects the
 // scheduling words (two launches per step), zeroed here.  Episodes the solver ends go to rst_list.
+// One fused launch per step (kernels_step.h) where it applies: binary, maps of at most 16 rows, single-cell
+// representations, auto-reset with the in-kernel reset.  PCGRL_NO_FUSED=1 keeps the two-launch pipeline (A/B, tests).
+static bool env_is_one(const char* name) { const char* v = getenv(name); return v && v[0] == '1'; }
+static bool fused_step_applies(const pcgrl_env* h) {
+    const PcgrlParams& P = h->P;
+    // (zelda changes 7 of 8 environments per step: a block then has ~18 wavefront tasks for its four wavefronts and the global
+    //  work lists balance better -- measured 48 vs 42.6 us/step on C3; PCGRL_FUSED_ZELDA=1 takes the fused kernel anyway)
+    const bool prob_ok = P.prob == PCGRL_PROB_BINARY || (P.prob == PCGRL_PROB_ZELDA && env_is_one("PCGRL_FUSED_ZELDA"));
+    return prob_ok && P.group == 16 && P.rep <= PCGRL_REP_TURTLE && P.auto_reset &&
+           h->B.inline_reset && !env_is_one("PCGRL_NO_FUSED");
+}
+template <int PROB, class MaskT>
+static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
+    const int grid = (P.num_envs + 63) / 64;
+    const int gen = (P.random_start || !h->has_old) ? 1 : 0;
+    switch (P.rep) {
+        case PCGRL_REP_NARROW: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen); break;
+        case PCGRL_REP_WIDE: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_WIDE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen); break;
+        default: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_TURTLE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen); break;
+    }
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+static int launch_step(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
+    const bool m4 = h->P.mask_bytes == 4;
+    if (h->P.prob == PCGRL_PROB_BINARY) return m4 ? launch_step_pm<PCGRL_PROB_BINARY, uint32_t>(h, actions, parity, st) : launch_step_pm<PCGRL_PROB_BINARY, uint64_t>(h, actions, parity, st);
+    return m4 ? launch_step_pm<PCGRL_PROB_ZELDA, uint32_t>(h, actions, parity, st) : launch_step_pm<PCGRL_PROB_ZELDA, uint64_t>(h, actions, parity, st);
+}
+
 static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
                          hipStream_t st) {
     const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
@@ -477,6 +509,11 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
     const int par = h->parity;
     int rc;
     if ((rc = prof_mark(h, st))) return rc;
+    if (fused_step_applies(h)) {      // the whole step in one launch
+        if ((rc = launch_step(h, actions, par, st))) return rc;
+        for (int k = 0; k < 6; k++) if ((rc = prof_mark(h, st))) return rc;
+        return PCGRL_OK;
+    }
     rc = (h->P.mask_bytes == 4) ? launch_update_m<uint32_t>(h, actions, par, st) : launch_update_m<uint64_t>(h, actions, par, st);
     if (rc) return rc;
     if ((rc = prof_mark(h, st))) return rc;
