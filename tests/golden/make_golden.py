@@ -40,11 +40,15 @@ INFO_KEYS = {
     "binary": ["regions", "path-length", "path-imp"],
     "zelda": ["player", "key", "door", "enemies", "regions", "nearest-enemy", "path-length"],
     "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
+    "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
+                 "dist-win", "sol-length"],
 }
 STAT_KEYS = {
     "binary": ["regions", "path-length"],
     "zelda": ["player", "key", "door", "enemies", "regions", "nearest-enemy", "path-length"],
     "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
+    "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
+                 "dist-win", "sol-length"],
 }
 
 
@@ -305,6 +309,106 @@ def gen_stats_sokoban():
              solver_power=np.array(power), keys=np.array(STAT_KEYS["sokoban"]))
 
 
+# ----------------------------------------------------------------------------- mdungeon
+def engineer_mdungeon(rs, h, w, n, solid_max=0.35, guard=0.25):
+    """Maps with one player and one exit (often connected), a sprinkle of potions / treasures / goblins / ogres, and
+    now and then an exit walled in by ogres so that the planner cannot win and runs into its iteration cap."""
+    maps = []
+    for _ in range(n):
+        solid = rs.uniform(0.0, solid_max)
+        m = (rs.random_sample((h, w)) < solid).astype(np.uint8)
+        cells = rs.permutation(h * w)
+        c = 0
+        def put(tile, cnt):
+            nonlocal c
+            for _ in range(cnt):
+                if c < len(cells):
+                    m.flat[cells[c]] = tile
+                    c += 1
+        put(2, 1 if rs.random_sample() < 0.92 else rs.randint(0, 3))
+        put(3, 1 if rs.random_sample() < 0.92 else rs.randint(0, 3))
+        dens = rs.uniform(0.0, 1.0)
+        for t in (4, 5, 6, 7):
+            put(t, rs.randint(0, 1 + int(dens * 4)))
+        if rs.random_sample() < guard:
+            ys, xs = np.where(m == 3)
+            R = rs.randint(1, 4)           # rings of monsters around the exit: 2-3 of them cost more than 5 health
+            strong = rs.uniform(0.6, 1.0)
+            for y, x in zip(ys, xs):
+                for dy in range(-R, R + 1):
+                    for dx in range(-R, R + 1):
+                        yy, xx = y + dy, x + dx
+                        if (dy or dx) and 0 <= yy < h and 0 <= xx < w and m[yy, xx] not in (2, 3):
+                            m[yy, xx] = 7 if rs.random_sample() < strong else 6
+        maps.append(m)
+    return maps
+
+
+def run_agents_mdungeon(prob, m):
+    """What MDungeonProblem._run_game does (mdungeon_prob.py:91-126), keeping the agents' iteration counts."""
+    from gym_pcgrl.envs.probs.mdungeon.engine import AStarAgent as MA, BFSAgent as MB, State as MS
+    smap = get_string_map(m, prob.get_tile_types())
+    chars = " #@H*$go"
+    s2c = dict((s, chars[i]) for i, s in enumerate(prob.get_tile_types()))
+    W = prob._width
+    lvl = "#" * (W + 2) + "\n"
+    for row in smap:
+        lvl += "#" + "".join(s2c[c] for c in row) + "#\n"
+    lvl += "#" * (W + 2) + "\n"
+    state = MS()
+    state.stringInitialize(lvl.split("\n"))
+    iters, win = [], -1
+    for k, bal in enumerate((1, 0.5, 0)):
+        sol, st, it = MA().getSolution(state, bal, prob._solver_power)
+        iters.append(it)
+        if st.checkWin():
+            win = k
+            break
+    if win < 0:
+        sol, st, it = MB().getSolution(state, prob._solver_power)
+        iters.append(it)
+        if st.checkWin():
+            win = 3
+    while len(iters) < 4:
+        iters.append(0)
+    gs = st.getGameStatus()
+    return iters, win, (0 if win >= 0 else st.getHeuristic()), (len(sol) if win >= 0 else 0), gs
+
+
+def gen_stats_mdungeon():
+    rs = np.random.RandomState(17)
+    prob = PROBLEMS["mdungeon"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng, power, smax, guard) in [(11, 7, 120, 260, 5000, 0.35, 0.25), (7, 11, 20, 80, 5000, 0.3, 0.3),
+                                                     (5, 5, 40, 120, 5000, 0.3, 0.3), (6, 9, 10, 80, 300, 0.25, 0.5),
+                                                     (11, 7, 0, 60, 1200, 0.1, 0.9), (14, 14, 0, 24, 5000, 0.2, 0.5),
+                                                     (1, 6, 0, 30, 5000, 0.1, 0.2)]:
+        prob._width, prob._height, prob._solver_power = w, h, power
+        maps = [np.zeros((h, w), np.uint8), np.ones((h, w), np.uint8)]
+        maps += random_maps(rs, nrand, h, w, 8, pr) + engineer_mdungeon(rs, h, w, neng, smax, guard)
+        t0 = time.time()
+        res, agents = [], []
+        for m in maps:
+            st = stats_of(prob, m)
+            row = [int(st[k]) for k in STAT_KEYS["mdungeon"]]
+            res.append(row)
+            if st["player"] == 1 and st["exit"] == 1 and st["regions"] == 1:
+                iters, win, dist, sl, gs = run_agents_mdungeon(prob, m)
+                assert dist == row[9] and sl == row[10], (dist, sl, row)
+                assert [gs["col_potions"], gs["col_treasures"], gs["col_enemies"]] == row[6:9]
+                agents.append(iters + [win])
+            else:
+                agents.append([0, 0, 0, 0, -2])
+        res = np.array(res, dtype=np.int64)
+        agents = np.array(agents, dtype=np.int64)
+        print("  mdungeon %dx%d power %d: %d maps, solver ran %d, wins by agent %s, cap hits %d, %.1fs" % (
+            h, w, power, len(maps), int((agents[:, 4] > -2).sum()),
+            [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)],
+            int((agents[:, :4] >= power).any(1).sum()), time.time() - t0))
+        save("stats_mdungeon_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+             solver_power=np.array(power), keys=np.array(STAT_KEYS["mdungeon"]))
+
+
 # ----------------------------------------------------------------------------- range reward
 def gen_range_reward():
     bands = [(1, 1), (np.inf, np.inf), (-np.inf, -np.inf), (2, 5), (4, np.inf), (1, 3), (0, 0), (3, 3), (2, 2), (1, 5)]
@@ -509,7 +613,7 @@ def main():
     a = ap.parse_args()
     jobs = {
         "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
-        "stats_sokoban": gen_stats_sokoban, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
+        "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
         "wrappers": gen_wrappers,
     }
     for k, fn in jobs.items():

@@ -11,29 +11,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 SO = os.path.join(ORACLE_DIR, "libpcgrl_oracle.so")
 
-PROBS = {"binary": 0, "zelda": 1, "sokoban": 2}
+PROBS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3}
 REPS = {"narrow": 0, "wide": 1, "turtle": 2, "narrowcast": 3, "narrowmulti": 4, "turtlecast": 5}
 MAX_ACTION = 9
 ADJ_KEYS = {k: i for i, k in enumerate([
     "change_percentage", "width", "height", "target_path", "random_probs", "max_enemies",
     "target_enemy_dist", "solver_power", "max_crates", "max_targets", "min_solution",
-    "random_start", "random_tile", "warp"])}
+    "random_start", "random_tile", "warp", "max_potions", "max_treasures", "target_col_enemies", "target_solution"])}
 TILES = {
     "binary": ["empty", "solid"],
     "zelda": ["empty", "solid", "player", "key", "door", "bat", "scorpion", "spider"],
     "sokoban": ["empty", "solid", "player", "crate", "target"],
+    "mdungeon": ["empty", "solid", "player", "exit", "potion", "treasure", "goblin", "ogre"],
 }
 REWARD_KEYS = {
     "binary": ["regions", "path-length"],
     "zelda": ["player", "key", "door", "regions", "enemies", "nearest-enemy", "path-length"],
     "sokoban": ["player", "crate", "target", "regions", "ratio", "dist-win", "sol-length"],
+    "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-enemies", "dist-win", "sol-length"],
 }
 INFO_KEYS = {
     "binary": ["regions", "path-length", "path-imp"],
     "zelda": ["player", "key", "door", "enemies", "regions", "nearest-enemy", "path-length"],
     "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
+    "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
+                 "dist-win", "sol-length"],
 }
-NSTATS = {"binary": 2, "zelda": 7, "sokoban": 6}
+NSTATS = {"binary": 2, "zelda": 7, "sokoban": 6, "mdungeon": 11}
 
 _lib = None
 
@@ -94,7 +98,7 @@ def seed_key(seed):
 def get_stats(prob, m, pw=None, ph=None, solver_power=5000, with_iters=False):
     m = np.ascontiguousarray(m, dtype=np.uint8)
     h, w = m.shape
-    out = np.zeros(8, np.int64)
+    out = np.zeros(12, np.int64)
     it = np.zeros(4, np.int32)
     lib().orc_get_stats(PROBS[prob], _p(m), w, h, pw or w, ph or h, solver_power, _p(out), _p(it))
     res = out[:NSTATS[prob]].copy()
@@ -166,7 +170,7 @@ class OracleEnv:
         a[:np.size(action)] = np.asarray(action).ravel()
         r = C.c_double()
         d = C.c_int()
-        info = np.zeros(12, np.int64)
+        info = np.zeros(16, np.int64)
         lib().orc_step(self._h, _p(a), C.byref(r), C.byref(d), _p(info))
         keys = INFO_KEYS[self.prob] + ["iterations", "changes"]
         inf = {k: int(info[i]) for i, k in enumerate(keys)}
