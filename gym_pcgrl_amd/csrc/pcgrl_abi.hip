@@ -36,6 +36,7 @@
 #include "pcgrl_algos.h"
 #include "sokoban_solver.h"
 #include "sokoban_fast.h"
+#include "mdungeon_solver.h"
 
 #include "worklist.h"
 #include "kernels_update.h"
@@ -44,6 +45,7 @@
 #include "kernels_reset.h"
 #include "kernels_step.h"
 #include "kernels_sokoban.h"
+#include "kernels_mdungeon.h"
 #include "kernels_misc.h"
 
 // ------------------------------------------------------------------------------------------
@@ -82,19 +84,21 @@ static thread_local int g_last_hip = 0;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// problems whose statistics need a search kernel after k_stats (the Sokoban solver, the MiniDungeons planner)
+static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGRL_MDUNGEON; }
 static int validate_config(const pcgrl_config* c) {
     if (!c) return PCGRL_EINVAL;
-    if (c->prob < 0 || c->prob > 2 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
+    if (c->prob < 0 || c->prob > 3 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
     if (c->num_envs < 1) return PCGRL_EINVAL;
     if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
     if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
-    if (c->prob == PCGRL_SOKOBAN) {   // limits of the solver kernel (sokoban_solver.h)
+    if (solver_prob(c->prob)) {   // limits of the solver kernels (sokoban_solver.h, mdungeon_solver.h)
         if ((c->width + 2) * (c->height + 2) > 256) return PCGRL_EINVAL;
         if (c->solver_power < 1 || c->solver_power > 16383) return PCGRL_EINVAL;
     }
     return PCGRL_OK;
 }
-static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_ZELDA ? 8 : 5); }
+static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_SOKOBAN ? 5 : 8); }
 
 static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     memset(P, 0, sizeof(*P));
@@ -110,7 +114,8 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     P->random_probs = c->random_probs; P->auto_reset = c->auto_reset;
     P->target_path = c->target_path; P->max_enemies = c->max_enemies; P->target_enemy_dist = c->target_enemy_dist;
     P->max_crates = c->max_crates; P->target_solution = c->target_solution; P->solver_power = c->solver_power;
-    for (int i = 0; i < 8; i++) P->rewards[i] = c->rewards[i];
+    P->max_potions = c->max_potions; P->max_treasures = c->max_treasures; P->target_col_enemies = c->target_col_enemies;
+    for (int i = 0; i < PCGRL_MAX_REWARDS; i++) P->rewards[i] = c->rewards[i];
     pcgrl_build_cdf(c->tile_probs, P->ntiles, P->cdf);
 }
 
@@ -140,7 +145,7 @@ static size_t scratch_bytes_base(const pcgrl_config* c);
 static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c); }
 static size_t scratch_bytes_base(const pcgrl_config* c) {
     size_t b = wl_bytes(c);
-    if (c->prob == PCGRL_SOKOBAN) {
+    if (solver_prob(c->prob)) {           // (an MdNode is as large as a SokNode)
         const size_t nodes = 4 * (size_t)c->solver_power + 4;
         b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
         b += sok_sched_bytes(c->num_envs);
@@ -245,9 +250,9 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     }
     {   // PCGRL_INLINE_RESET=0 routes resets through the reset list + k_reset instead (A/B measurements)
         const char* ir = getenv("PCGRL_INLINE_RESET");
-        B.inline_reset = (h->cfg.prob != PCGRL_SOKOBAN && !(ir && ir[0] == '0')) ? 1 : 0;
+        B.inline_reset = (!solver_prob(h->cfg.prob) && !(ir && ir[0] == '0')) ? 1 : 0;
     }
-    if (h->cfg.prob == PCGRL_SOKOBAN) {
+    if (solver_prob(h->cfg.prob)) {
         // the arena is sized for the solver_power the buffers were allocated with
         const int power = h->alloc_solver_power = h->cfg.solver_power;
         const size_t nodes = 4 * (size_t)power + 4;
@@ -288,7 +293,7 @@ int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
     if (c->prob != h->cfg.prob || c->rep != h->cfg.rep || c->num_envs != h->cfg.num_envs ||
         c->width != h->cfg.width || c->height != h->cfg.height)
         return PCGRL_EINVAL;
-    if (h->bound && c->prob == PCGRL_SOKOBAN && c->solver_power > h->alloc_solver_power) return PCGRL_EINVAL;   // arena too small: re-create
+    if (h->bound && solver_prob(c->prob) && c->solver_power > h->alloc_solver_power) return PCGRL_EINVAL;   // arena too small: re-create
     h->cfg = *c;
     fill_params(c, &h->P);
     return PCGRL_OK;
@@ -387,6 +392,7 @@ static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, i
     switch (h->P.prob) {
         case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, inline_reset, st);
         case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, inline_reset, st);
+        case PCGRL_PROB_MDUNGEON: return launch_stats_p<PCGRL_PROB_MDUNGEON>(h, list, parity, mode, clr, 0, st);
         default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, parity, mode, clr, 0, st);
     }
 }
@@ -457,6 +463,19 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
     }
     int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
     HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
+    if (h->P.prob == PCGRL_PROB_MDUNGEON) {
+        static bool md_attr_set = false;
+        if (!md_attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdungeon), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
+            md_attr_set = true;
+        }
+        const size_t md_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
+        hipLaunchKernelGGL(k_mdungeon, dim3(SOK_BLOCKS), dim3(64), md_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
+                           sync, clr);
+        HIPCHK(hipGetLastError());
+        return PCGRL_OK;
+    }
     hipLaunchKernelGGL(k_sokoban, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
                        sync, sync + SOK_SY_WORDS, clr);
     HIPCHK(hipGetLastError());
@@ -486,6 +505,7 @@ static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int c
     switch (h->P.prob) {
         case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, list, park_list, parity, clr, st);
         case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, list, park_list, parity, clr, st);
+        case PCGRL_PROB_MDUNGEON: return launch_reset_p<PCGRL_PROB_MDUNGEON>(h, list, park_list, parity, clr, st);
         default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, list, park_list, parity, clr, st);
     }
 }
@@ -497,7 +517,7 @@ static int reset_one(pcgrl_env* h, void* stream) {
     const int n = h->P.num_envs, par = h->parity;
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_RST);
     HIPCHK(hipGetLastError());
-    const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN;
+    const bool sok = solver_prob(h->P.prob);
     int rc = launch_reset(h, WL_RST, WL_SOL2, par, sok ? -1 : (par ^ 1), st);
     if (rc) return rc;
     if (sok && (rc = launch_solver(h, 0, WL_SOL2, MODE_START, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
@@ -519,7 +539,7 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
     if ((rc = prof_mark(h, st))) return rc;
     // The last kernel of the step clears the other parity's work-list counters.  Every problem but Sokoban is
     // two launches: k_stats also resets the environments whose episode ended (auto_reset).
-    const bool sok = h->P.prob == PCGRL_PROB_SOKOBAN, ar = h->P.auto_reset != 0;
+    const bool sok = solver_prob(h->P.prob), ar = h->P.auto_reset != 0;
     if (!sok) {
         const bool inl = ar && h->B.inline_reset;
         rc = launch_stats(h, WL_CHG, par, MODE_STEP, (ar && !inl) ? -1 : (par ^ 1), inl ? 1 : 0, st);
@@ -652,7 +672,7 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_CHG);
     HIPCHK(hipGetLastError());
-    const bool sok = P.prob == PCGRL_PROB_SOKOBAN;
+    const bool sok = solver_prob(P.prob);
     int rc = launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), 0, st);
     if (rc) return rc;
     if (sok && (rc = launch_solver(h, 0, WL_SOL2, MODE_SETMAP, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;

@@ -43,8 +43,9 @@ struct PcgrlParams {
     int32_t random_start, random_tile, warp, random_probs, auto_reset;
     int32_t target_path, max_enemies, target_enemy_dist, max_crates, target_solution, solver_power;
     int32_t prob_width, prob_height;   // the Problem's own width/height (zelda_prob.py:99, sokoban_prob.py:140)
-    int32_t pad_;
-    double rewards[PCGRL_MAX_STATS];
+    int32_t max_potions, max_treasures, pad_;   // mdungeon_prob.py:25-26
+    double target_col_enemies;         // mdungeon_prob.py:28
+    double rewards[PCGRL_MAX_REWARDS];
     double cdf[PCGRL_MAX_TILES];
 };
 
@@ -77,6 +78,24 @@ PCGRL_HD int range_reward_i(int nv, int ov, int lo, int hi) {
     return hi - ov + nv - lo;
 }
 
+// The mdungeon statistics row has eleven values in the reference (mdungeon_prob.py:139-157); the per-environment rows of
+// this library have eight 32-bit slots, so the planner's five results share two of them:
+//   s[0..5] = player, exit, potions, treasures, enemies, regions
+//   s[6]    = sol-length if the planner won, else dist-win
+//   s[7]    = col-potions | col-treasures << 8 | col-enemies << 16 | won << 24    (a solvable level has < 256 things)
+// (dist-win is 0 when the planner won and sol-length is 0 when it did not, mdungeon_prob.py:112-126.)
+PCGRL_HD int md_won(const int32_t* s) { return (s[7] >> 24) & 1; }
+PCGRL_HD int md_dist_win(const int32_t* s) { return md_won(s) ? 0 : s[6]; }
+PCGRL_HD int md_sol_length(const int32_t* s) { return md_won(s) ? s[6] : 0; }
+PCGRL_HD int md_col_potions(const int32_t* s) { return s[7] & 255; }
+PCGRL_HD int md_col_treasures(const int32_t* s) { return (s[7] >> 8) & 255; }
+PCGRL_HD int md_col_enemies(const int32_t* s) { return (s[7] >> 16) & 255; }
+PCGRL_HD void md_pack(int32_t* s, const int* out5) {   // out5 = dist-win, sol-length, col-potions, col-treasures, col-enemies
+    const int won = out5[1] > 0 ? 1 : 0;              // the exit is never under the player at depth 0
+    s[6] = won ? out5[1] : out5[0];
+    s[7] = (out5[2] & 255) | ((out5[3] & 255) << 8) | ((out5[4] & 255) << 16) | (won << 24);
+}
+
 // binary_prob.py:98-106 | zelda_prob.py:124-142 | sokoban_prob.py:157-175 (same summation order; the
 // products and sums are done in fp64 exactly as Python does them with int * weight)
 PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int32_t* o) {
@@ -91,6 +110,18 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
         r = r + (double)range_reward_i(n[4], o[4], 1, 1) * w[3];
         r = r + (double)range_reward_i(n[5], o[5], P.target_enemy_dist, PCGRL_IPOS) * w[5];
         r = r + (double)range_reward_i(n[6], o[6], PCGRL_IPOS, PCGRL_IPOS) * w[6];
+        return r;
+    } else if (P.prob == PCGRL_PROB_MDUNGEON) {
+        // weights in the order of MDungeonProblem._rewards, summed in the order of get_reward (mdungeon_prob.py:183-206)
+        double r = (double)range_reward_i(n[0], o[0], 1, 1) * w[0];
+        r = r + (double)range_reward_i(n[1], o[1], 1, 1) * w[1];
+        r = r + (double)range_reward_i(n[4], o[4], 1, P.max_enemies) * w[4];
+        r = r + (double)range_reward_i(n[3], o[3], PCGRL_INEG, P.max_treasures) * w[3];
+        r = r + (double)range_reward_i(n[2], o[2], PCGRL_INEG, P.max_potions) * w[2];
+        r = r + (double)range_reward_i(n[5], o[5], 1, 1) * w[5];
+        r = r + (double)range_reward_i(md_col_enemies(n), md_col_enemies(o), PCGRL_IPOS, PCGRL_IPOS) * w[6];
+        r = r + (double)range_reward_i(md_dist_win(n), md_dist_win(o), PCGRL_INEG, PCGRL_INEG) * w[7];
+        r = r + (double)range_reward_i(md_sol_length(n), md_sol_length(o), PCGRL_IPOS, PCGRL_IPOS) * w[8];
         return r;
     } else {
         int nr = n[1] - n[2], orr = o[1] - o[2];
@@ -109,9 +140,13 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
 PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t* start) {
     if (P.prob == PCGRL_PROB_BINARY) return n[0] == 1 && n[1] - start[1] >= P.target_path;
     if (P.prob == PCGRL_PROB_ZELDA) return n[5] >= P.target_enemy_dist && n[6] >= P.target_path;
+    if (P.prob == PCGRL_PROB_MDUNGEON) {   // mdungeon_prob.py:219-222 (true division, compared in fp64)
+        const int en = n[4] > 1 ? n[4] : 1;
+        return md_sol_length(n) >= P.target_solution && n[4] > 0 && (double)md_col_enemies(n) / (double)en > P.target_col_enemies;
+    }
     return n[5] >= P.target_solution;
 }
-PCGRL_HD int num_stats(int prob) { return prob == PCGRL_PROB_BINARY ? 2 : (prob == PCGRL_PROB_ZELDA ? 7 : 6); }
+PCGRL_HD int num_stats(int prob) { return prob == PCGRL_PROB_BINARY ? 2 : (prob == PCGRL_PROB_ZELDA ? 7 : (prob == PCGRL_PROB_SOKOBAN ? 6 : 8)); }
 
 // ---------------------------------------------------------------- bitboard programs
 //
@@ -536,4 +571,27 @@ PCGRL_D bool sokoban_stats(B& g, const PcgrlParams& P, typename B::mask_t b0, ty
     out[4] = P.prob_width * P.prob_height * (P.prob_width + P.prob_height);
     out[5] = 0;
     return np_ == 1 && nc == nt && nc > 0 && regions == 1;
+}
+
+// mdungeon_prob.py:139-157 without the planner.  out: the packed row described at md_pack (dist-win default W*H, nothing
+// collected).  Returns true when the planner precondition (mdungeon_prob.py:152) holds.
+template <class B>
+PCGRL_D bool mdungeon_stats(B& g, const PcgrlParams& P, typename B::mask_t b0, typename B::mask_t b1,
+                            typename B::mask_t b2, typename B::mask_t valid, int32_t* out) {
+    typedef typename B::mask_t M;
+    // ids: 0 empty 1 solid 2 player 3 exit 4 potion 5 treasure 6 goblin 7 ogre (mdungeon_prob.py:49-50)
+    M solid = ~b2 & ~b1 & b0 & valid;
+    M player = ~b2 & b1 & ~b0 & valid;
+    M exitm = ~b2 & b1 & b0 & valid;
+    M potion = b2 & ~b1 & ~b0 & valid;
+    M treasure = b2 & ~b1 & b0 & valid;
+    M enemy = b2 & b1 & valid;
+    const int np_ = g.popcount_sum(player), nx = g.popcount_sum(exitm);
+    out[0] = np_; out[1] = nx;
+    out[2] = g.popcount_sum(potion); out[3] = g.popcount_sum(treasure); out[4] = g.popcount_sum(enemy);
+    const int regions = count_regions(g, valid & ~solid);
+    out[5] = regions;
+    out[6] = P.prob_width * P.prob_height;
+    out[7] = 0;
+    return np_ == 1 && nx == 1 && regions == 1;
 }

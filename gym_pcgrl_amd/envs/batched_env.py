@@ -19,11 +19,12 @@ from .representations import REP_IDS, REPRESENTATIONS
 class InfoBatch:
     """Struct-of-tensors view of the per-step info dicts (pcgrl_env.py:144-148)."""
 
-    def __init__(self, keys, table, max_iterations, max_changes):
+    def __init__(self, keys, table, max_iterations, max_changes, decode=None):
         self.keys = list(keys)
         self.table = table            # int32 [N,10]: problem info (8 slots), iterations, changes
         self.max_iterations = max_iterations
         self.max_changes = max_changes
+        self._decode = decode         # Problem.decode_rows for rows that pack several values into a slot (mdungeon)
 
     def __getitem__(self, key):
         if key == "iterations":
@@ -34,13 +35,16 @@ class InfoBatch:
             return self.max_iterations
         if key == "max_changes":
             return self.max_changes
+        if self._decode is not None:
+            return self._decode(self.table)[:, self.keys.index(key)]
         return self.table[:, self.keys.index(key)]
 
     def to_list(self):
         t = self.table.cpu().numpy()
+        vals = self._decode(self.table).cpu().numpy() if self._decode is not None else t
         out = []
-        for row in t:
-            d = {k: int(row[i]) for i, k in enumerate(self.keys)}
+        for row, v in zip(t, vals):
+            d = {k: int(v[i]) for i, k in enumerate(self.keys)}
             d["iterations"] = int(row[8])
             d["changes"] = int(row[9])
             d["max_iterations"] = self.max_iterations
@@ -259,7 +263,8 @@ class BatchedPcgrlEnv:
         self._last_actions = a   # keep the buffer alive until the launches are done
         _lib.check(self._lib.pcgrl_step(self._handle, C.c_void_p(a.data_ptr()), self._stream()), "pcgrl_step")
         b = self._bufs
-        info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes)
+        decode = self._prob.decode_rows if self._prob.name == "mdungeon" else None
+        info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
         return self._obs(), b["reward"], b["done"].view(self._torch.bool), info
 
     # gym.vector-style split call
@@ -333,7 +338,7 @@ class BatchedPcgrlEnv:
 
     @property
     def stats(self):
-        return self._bufs["stats"][:, :len(self._prob.stat_keys)]
+        return self._prob.decode_rows(self._bufs["stats"])
 
     def state_dict(self):
         """Everything a batch of environments carries between steps (checkpoint / resume): maps, first maps,

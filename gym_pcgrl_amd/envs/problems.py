@@ -2,14 +2,14 @@
 
 The statistics, rewards and episode-over tests run on the GPU (csrc/pcgrl_algos.h); these
 classes hold what the reference keeps as Python attributes (probs/problem.py:10-20,
-binary_prob.py:14-27, zelda_prob.py:17-37, sokoban_prob.py:15-36) and reproduce
+binary_prob.py:14-27, zelda_prob.py:17-37, sokoban_prob.py:15-36, mdungeon_prob.py:16-41) and reproduce
 `adjust_param` (problem.py:66-72 and the subclasses) including its quirks: `probs` only
 overrides existing keys, sokoban `max_targets` overwrites `max_crates`, the sokoban kwarg is
 `min_solution`.
 """
 from collections import OrderedDict
 
-PROB_IDS = {"binary": 0, "zelda": 1, "sokoban": 2}
+PROB_IDS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3}
 
 
 class Problem:
@@ -49,6 +49,11 @@ class Problem:
     # scalars shipped to the device config
     def device_params(self):
         return {}
+
+    def decode_rows(self, table):
+        """Device stats / info rows (torch int32 [N, >=8]) -> columns in the order of `stat_keys`.  Identity for the
+        problems whose rows hold one value per slot."""
+        return table[:, :len(self.stat_keys)]
 
 
 class BinaryProblem(Problem):
@@ -136,4 +141,53 @@ class SokobanProblem(Problem):
                     solver_power=int(self._solver_power))
 
 
-PROBLEMS = {"binary": BinaryProblem, "zelda": ZeldaProblem, "sokoban": SokobanProblem}
+class MDungeonProblem(Problem):
+    """probs/mdungeon_prob.py.  The reference's eleven statistics travel in the eight slots of a device row (see
+    include/pcgrl_hip.h, pcgrl_layout.stats); `decode_rows` spreads them out again."""
+    name = "mdungeon"
+    tiles = ("empty", "solid", "player", "exit", "potion", "treasure", "goblin", "ogre")
+    stat_keys = ("player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures",
+                 "col-enemies", "dist-win", "sol-length")
+    info_keys = stat_keys
+    reward_keys = ("player", "exit", "potions", "treasures", "enemies", "regions", "col-enemies", "dist-win", "sol-length")
+
+    def __init__(self):
+        super().__init__()
+        self._width, self._height = 7, 11
+        self._prob = OrderedDict([("empty", 0.4), ("solid", 0.4), ("player", 0.02), ("exit", 0.02), ("potion", 0.03),
+                                  ("treasure", 0.03), ("goblin", 0.05), ("ogre", 0.05)])
+        self._border_tile = "solid"
+        self._solver_power = 5000
+        self._max_enemies = 6
+        self._max_potions = 2
+        self._max_treasures = 3
+        self._target_col_enemies = 0.5
+        self._target_solution = 20
+        self._rewards = OrderedDict([("player", 3), ("exit", 3), ("potions", 1), ("treasures", 1), ("enemies", 2),
+                                     ("regions", 5), ("col-enemies", 2), ("dist-win", 0.1), ("sol-length", 1)])
+
+    def adjust_param(self, **kwargs):
+        super().adjust_param(**kwargs)
+        self._solver_power = kwargs.get("solver_power", self._solver_power)
+        self._max_enemies = kwargs.get("max_enemies", self._max_enemies)
+        self._max_potions = kwargs.get("max_potions", self._max_potions)
+        self._max_treasures = kwargs.get("max_treasures", self._max_treasures)
+        self._target_col_enemies = kwargs.get("target_col_enemies", self._target_col_enemies)
+        self._target_solution = kwargs.get("target_solution", self._target_solution)
+
+    def device_params(self):
+        return dict(solver_power=int(self._solver_power), max_enemies=int(self._max_enemies),
+                    max_potions=int(self._max_potions), max_treasures=int(self._max_treasures),
+                    target_col_enemies=float(self._target_col_enemies), target_solution=int(self._target_solution))
+
+    def decode_rows(self, table):
+        import torch
+        won = (table[:, 7] >> 24) & 1
+        zero = torch.zeros_like(won)
+        cols = [table[:, k] for k in range(6)]
+        cols += [table[:, 7] & 255, (table[:, 7] >> 8) & 255, (table[:, 7] >> 16) & 255]
+        cols += [torch.where(won == 1, zero, table[:, 6]), torch.where(won == 1, table[:, 6], zero)]
+        return torch.stack(cols, 1)
+
+
+PROBLEMS = {"binary": BinaryProblem, "zelda": ZeldaProblem, "sokoban": SokobanProblem, "mdungeon": MDungeonProblem}

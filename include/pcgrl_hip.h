@@ -7,7 +7,7 @@
  *
  *   pcgrl_create / pcgrl_configure   PcgrlEnv.__init__ pcgrl_env.py:27-42, adjust_param :106-115,
  *                                    Problem/Representation.adjust_param (probs/problem.py:66-72,
- *                                    binary_prob.py:49-59, zelda_prob.py:59-71, sokoban_prob.py:60-73,
+ *                                    binary_prob.py:49-59, zelda_prob.py:59-71, sokoban_prob.py:60-73, mdungeon_prob.py:68-84,
  *                                    reps/representation.py:53-54, narrow_rep.py:86-88, turtle_rep.py:42-44)
  *   pcgrl_seed                       PcgrlEnv.seed pcgrl_env.py:54-57 (host passes MT19937 keys)
  *   pcgrl_reset                      PcgrlEnv.reset pcgrl_env.py:66-76 for every environment
@@ -31,14 +31,15 @@
 extern "C" {
 #endif
 
-/* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]); + pcgrl_seed_words. */
-#define PCGRL_ABI_VERSION 3
+/* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]); + pcgrl_seed_words.
+ * 4: + the mdungeon problem: pcgrl_config grew (max_potions, max_treasures, target_col_enemies, rewards[12]). */
+#define PCGRL_ABI_VERSION 4
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
 #define PCGRL_ESTATE (-3)   /* call order violated (e.g. step before bind/reset) */
 
-enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2 };
+enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2, PCGRL_MDUNGEON = 3 };
 enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2, PCGRL_NARROW_CAST = 3, PCGRL_NARROW_MULTI = 4, PCGRL_TURTLE_CAST = 5 };
 
 /* Batch-wide parameters (everything the reference keeps as attributes of PcgrlEnv/Problem/Representation). */
@@ -50,11 +51,12 @@ typedef struct pcgrl_config {
     int32_t random_start, random_tile, warp, random_probs;
     int32_t auto_reset;                    /* 1: a done env is reset inside step (vector-env semantics) */
     int32_t target_path;                   /* binary 20, zelda 16 */
-    int32_t max_enemies, target_enemy_dist;            /* zelda */
-    int32_t max_crates, target_solution, solver_power; /* sokoban */
-    int32_t reserved_;
+    int32_t max_enemies, target_enemy_dist;            /* zelda (max_enemies: mdungeon too) */
+    int32_t max_crates, target_solution, solver_power; /* sokoban (target_solution, solver_power: mdungeon too) */
+    int32_t max_potions, max_treasures;                /* mdungeon */
+    double target_col_enemies;                         /* mdungeon */
     double tile_probs[8];                  /* Problem._prob in tile order (un-normalised) */
-    double rewards[8];                     /* Problem._rewards in the problem's own key order */
+    double rewards[12];                    /* Problem._rewards in the problem's own key order */
 } pcgrl_config;
 
 /* Byte sizes of the caller-provided device buffers for a configuration (N = num_envs). */
@@ -62,14 +64,17 @@ typedef struct pcgrl_layout {
     int32_t group;        /* lanes per map: 16 (height <= 16) or 64 */
     int32_t mask_bytes;   /* bytes per row mask: 4 (width <= 32) or 8 */
     int32_t nplanes;      /* bit planes of the tile id: 1 binary, 3 zelda/sokoban */
-    int32_t nstats;       /* 2 binary, 7 zelda, 6 sokoban */
+    int32_t nstats;       /* used slots of a stats row: 2 binary, 7 zelda, 6 sokoban, 8 mdungeon (packed, see below) */
     size_t map;           /* u8  [N,H,W]   observation "map" */
     size_t old_map;       /* u8  [N,H,W]   Representation._old_map */
     size_t heatmap;       /* i16 [N,H,W]   observation "heatmap" (counts) */
     size_t pos;           /* u8  [N,2]     observation "pos" (x,y); unused for wide */
     size_t planes;        /* mask[N,group,nplanes] row bitboards of the tile-id bits (the planes of a row are adjacent) */
     size_t counters;      /* i32 [N,2]     iteration, changes */
-    size_t stats;         /* i32 [N,8]     current _rep_stats */
+    size_t stats;         /* i32 [N,8]     current _rep_stats.  mdungeon keeps its eleven values in eight slots:
+                                            player, exit, potions, treasures, enemies, regions, then slot 6 = sol-length if
+                                            the planner won else dist-win, slot 7 = col-potions | col-treasures << 8 |
+                                            col-enemies << 16 | won << 24 */
     size_t start_stats;   /* i32 [N,8]     Problem._start_stats */
     size_t info;          /* i32 [N,10]    per-step info: stats[8], iterations, changes */
     size_t reward;        /* f64 [N] */

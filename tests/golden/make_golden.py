@@ -451,6 +451,9 @@ def gen_adjust_param():
         ("sokoban", "narrow", []),
         ("sokoban", "narrow", [dict(width=7, height=6), dict(change_percentage=0.4)]),
         ("sokoban", "turtle", [dict(change_percentage=1.0)]),
+        ("mdungeon", "narrow", []),
+        ("mdungeon", "wide", [dict(width=5, height=6), dict(change_percentage=0.9)]),
+        ("mdungeon", "turtle", [dict(width=14, height=14, change_percentage=0.3)]),
     ]
     for prob, rep, calls in cases:
         env = gym.make("%s-%s-v0" % (prob, rep))
@@ -556,6 +559,18 @@ TRAJS = [
     ("binary_turtlecast", "binary", "turtlecast", 16, 300, ()),
     ("zelda_turtlecast_warp", "zelda", "turtlecast", 8, 300, (dict(warp=True, width=13, height=9), dict(change_percentage=0.5))),
     ("binary_turtlecast_64", "binary", "turtlecast", 3, 200, (dict(width=64, height=64),)),
+    # the mdungeon problem (the open / small variants make the planner run in a large share of the steps)
+    ("mdungeon_narrow", "mdungeon", "narrow", 32, 300, ()),
+    ("mdungeon_wide_open", "mdungeon", "wide", 24, 300, (dict(probs={"empty": 0.82, "solid": 0.04, "player": 0.02, "exit": 0.02,
+                                                                      "potion": 0.02, "treasure": 0.03, "goblin": 0.03, "ogre": 0.02},
+                                                               change_percentage=0.6),)),
+    ("mdungeon_turtle_5x6", "mdungeon", "turtle", 24, 400, (dict(width=5, height=6), dict(
+        change_percentage=0.9, probs={"empty": 0.7, "solid": 0.1, "player": 0.04, "exit": 0.04}, target_solution=4,
+        target_col_enemies=0.3, max_enemies=3, max_potions=1, max_treasures=1, solver_power=600,
+        rewards={"dist-win": 0.3, "col-enemies": 1.5, "regions": 2}),)),
+    ("mdungeon_narrow_monsters", "mdungeon", "narrow", 16, 300, (dict(width=6, height=6), dict(
+        change_percentage=0.8, solver_power=250, target_solution=3, target_col_enemies=0.2,
+        probs={"empty": 0.45, "solid": 0.03, "player": 0.03, "exit": 0.03, "potion": 0.06, "treasure": 0.05, "goblin": 0.1, "ogre": 0.25}),)),
 ]
 
 

@@ -14,6 +14,7 @@ static int g_trace_site[4096], g_trace_rounds[4096], g_trace_n = 0;
 #include "../../gym_pcgrl_amd/csrc/pcgrl_algos.h"
 #include "../../gym_pcgrl_amd/csrc/sokoban_solver.h"
 #include "../../gym_pcgrl_amd/csrc/sokoban_fast.h"
+#include "../../gym_pcgrl_amd/csrc/mdungeon_solver.h"
 #include <vector>
 
 template <class T, int G>
@@ -94,6 +95,8 @@ static void run(int prob, const uint8_t* map, int h, int w, int pw, int ph, int3
         out[0] = regions; out[1] = path;
     } else if (prob == PCGRL_PROB_ZELDA) {
         zelda_stats(g, P, b0, b1, b2, valid, out);
+    } else if (prob == PCGRL_PROB_MDUNGEON) {
+        *need_solver = mdungeon_stats(g, P, b0, b1, b2, valid, out) ? 1 : 0;
     } else {
         *need_solver = sokoban_stats(g, P, b0, b1, b2, valid, out) ? 1 : 0;
     }
@@ -277,6 +280,22 @@ int sim_sokoban_solve2(const uint8_t* map, int h, int w, int power, int shortcut
 }
 int sim_sokoban_solve(const uint8_t* map, int h, int w, int power, int shortcut, int* dist, int* sol, int* iters) {
     return sim_sokoban_solve2(map, h, w, power, shortcut, 0, dist, sol, iters);
+}
+// the device planner of the mdungeon problem (mdungeon_solver.h) run on the host: same pool/heap/table layout as k_mdungeon.
+// out5 = dist-win, sol-length, col-potions, col-treasures, col-enemies
+int sim_mdungeon_solve(const uint8_t* map, int h, int w, int power, int shortcut, int* out5, int* iters) {
+    if ((w + 2) * (h + 2) > 256) return -1;
+    MdLevel L; MdNode root, work;
+    md_build_level(map, w, h, L, root);
+    std::vector<MdNode> pool(4 * (size_t)power + 4);
+    std::vector<uint32_t> heap(4 * (size_t)power + 4);
+    int tsize = 1024; while (tsize < 2 * power) tsize <<= 1;
+    if (power <= SOK_LDS_POWER) tsize = SOK_LDS_TABLE;
+    std::vector<uint32_t> table(tsize);
+    uint32_t* tp = table.data();
+    md_run_game(L, pool.data(), heap.data(), tp, tsize, work, root, power, shortcut != 0,
+                [tp](int n) { for (int i = 0; i < n; i++) tp[i] = 0; }, out5, iters);
+    return 0;
 }
 long sim_iters_reset() { long v = g_sim_iters; g_sim_iters = 0; return v; }
 void sim_set_spurious(int n) { g_spurious = n; }

@@ -13,7 +13,7 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUPPORTED = ("binary", "zelda", "sokoban")
+SUPPORTED = ("binary", "zelda", "sokoban", "mdungeon")
 
 
 def _torch():
@@ -110,6 +110,11 @@ ORACLE_CASES = [
     ("zelda", "turtle", (dict(width=20, height=18), dict(change_percentage=0.5)), 48, 150),
     ("sokoban", "narrow", (), 256, 120),
     ("sokoban", "wide", (dict(width=6, height=6), dict(change_percentage=0.5)), 96, 100),
+    ("mdungeon", "narrow", (), 128, 120),
+    ("mdungeon", "wide", (dict(width=6, height=5), dict(change_percentage=0.7, probs={"empty": 0.7, "solid": 0.08},
+                                                         target_solution=4, target_col_enemies=0.25)), 192, 150),
+    ("mdungeon", "turtle", (dict(width=8, height=8), dict(change_percentage=0.5, solver_power=200,
+                                                           probs={"empty": 0.5, "solid": 0.03, "ogre": 0.2, "goblin": 0.1})), 96, 150),
 ]
 
 

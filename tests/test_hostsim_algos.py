@@ -53,7 +53,13 @@ def test_bitboard_stats_vs_golden(sim, path):
         for variant in ((0,) if i % 7 else (0, 1, 2, 3)):
             out, need = sim_stats(sim, prob, m, variant)
             exp = d["stats"][i]
-            if prob == "sokoban":
+            if prob == "mdungeon":
+                ran = d["agents"][i, 4] > -2
+                assert bool(need) == bool(ran), i
+                assert np.array_equal(out[:6], exp[:6]), (i, out, exp)
+                if not ran:
+                    assert (out[6], out[7]) == (exp[9], 0) and not exp[6:9].any() and exp[10] == 0, (i, out, exp)
+            elif prob == "sokoban":
                 ran = d["agents"][i, 4] > -2
                 assert bool(need) == bool(ran), i
                 assert np.array_equal(out[:4], exp[:4]), (i, out, exp)
@@ -93,6 +99,37 @@ def test_device_sokoban_solver_vs_golden(sim, fast):
                 assert d["agents"][i, 4] == -1 and (d["agents"][i, :4] == d["agents"][i, 0]).all(), (path, i, d["agents"][i])
             n += 1
     assert n > 300 and skipped > 100
+
+
+def test_device_mdungeon_solver_vs_golden(sim):
+    """gym_pcgrl_amd/csrc/mdungeon_solver.h (the code k_mdungeon runs) compiled for the host, against the reference's
+    planner results.  Without the exhausted-search shortcut the per-agent iteration counts must equal the reference's;
+    with it the five results must still be equal, and agents are skipped only after an agent exhausted the state
+    space -- in which case the reference's own counts show that every agent popped the same number of entries."""
+    sim.sim_mdungeon_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = skipped = capped = 0
+    for path in sorted(glob.glob(os.path.join(G, "stats_mdungeon_*.npz"))):
+        d = np.load(path)
+        power = int(d["solver_power"])
+        for i, m in enumerate(d["maps"]):
+            if d["agents"][i, 4] == -2:
+                continue
+            m = np.ascontiguousarray(m)
+            exp = [d["stats"][i, 9], d["stats"][i, 10], d["stats"][i, 6], d["stats"][i, 7], d["stats"][i, 8]]
+            out, it = np.zeros(5, np.int32), np.zeros(4, np.int32)
+            assert sim.sim_mdungeon_solve(_p(m), m.shape[0], m.shape[1], power, 0, _p(out), _p(it)) == 0
+            assert list(out) == exp, (path, i, out, exp)
+            assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
+            out2, it2 = np.zeros(5, np.int32), np.zeros(4, np.int32)
+            assert sim.sim_mdungeon_solve(_p(m), m.shape[0], m.shape[1], power, 1, _p(out2), _p(it2)) == 0
+            assert list(out2) == exp, ("shortcut", path, i, out2, exp)
+            if not np.array_equal(it, it2):
+                skipped += 1
+                a = d["agents"][i]
+                assert a[4] == -1 and a[0] < power and (a[:4] == a[0]).all(), (path, i, a)
+            capped += int((it >= power).any())
+            n += 1
+    assert n > 400 and skipped > 5 and capped > 20
 
 
 def test_bitboard_stats_vs_oracle_random(sim):
