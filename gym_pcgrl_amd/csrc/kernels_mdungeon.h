@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
             const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
             for (int k = 0; k < 8; k++) s[k] = park[k];
             md_pack(s, out5);
-            finalize_item(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+            finalize_item<PCGRL_PROB_MDUNGEON>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
         }
         __threadfence_block();
     }

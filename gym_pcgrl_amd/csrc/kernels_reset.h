@@ -28,7 +28,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_reset(PcgrlParams P, DevBufs B,
         MaskT champ;
         const bool need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, valid, st, champ);
         if (PROB == PCGRL_PROB_BINARY && B.champ && lane < G) reinterpret_cast<MaskT*>(B.champ)[(size_t)e * G + lane] = champ;
-        if (lane == 0) finish_or_park(P, B, e, st, need_solver, MODE_START, parity, item & (WL_NSHARD - 1), true, park_list);
+        if (lane == 0) finish_or_park<PROB>(P, B, e, st, need_solver, MODE_START, parity, item & (WL_NSHARD - 1), true, park_list);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -89,7 +89,7 @@ __device__ __forceinline__ void sok_report(const PcgrlParams& P, const DevBufs& 
     const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
     for (int k = 0; k < 8; k++) s[k] = park[k];
     s[4] = dist; s[5] = sol;
-    finalize_item(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+    finalize_item<PCGRL_PROB_SOKOBAN>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
 }
 
 // One agent on the level in L: the register-resident search (sokoban_fast.h; LDS heap + 64-bit-key table) when the
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
                 const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
                 for (int k = 0; k < 8; k++) s[k] = park[k];
                 s[4] = dist; s[5] = sol;
-                finalize_item(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+                finalize_item<PCGRL_PROB_SOKOBAN>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
             }
             __threadfence();
             atomicAdd(sync + SOK_SY_BFS_DONE, 1);

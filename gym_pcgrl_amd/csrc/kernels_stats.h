@@ -13,23 +13,26 @@ __device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
 // environment is also appended to the reset list (consumed by k_reset), otherwise the caller resets it.
 // `pre` (STEP): iteration/changes read before the environment's counters were reset (k_stats resets an environment that
 // is certain to end its episode *before* it finishes the step).
+// PROB: the problem when the caller is compiled for one (reward and episode-end code of the others drops out), else -1.
+template <int PROB = -1>
 __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
                                               int mode, int parity, int shard, bool push_reset = true, int rst_list = WL_RST,
                                               const int2* pre = nullptr) {
+    const int prob = PROB >= 0 ? PROB : P.prob;
     int32_t* st = B.stats + (size_t)e * 8;
     int32_t* start = B.start_stats + (size_t)e * 8;
     if (mode == MODE_STEP) {
         int32_t old[PCGRL_MAX_STATS], sv[PCGRL_MAX_STATS];
         for (int k = 0; k < 8; k++) { old[k] = st[k]; sv[k] = start[k]; }
         const int2 c = pre ? *pre : reinterpret_cast<const int2*>(B.counters)[e];
-        const double r = compute_reward(P, s, old);
-        const bool d = episode_over(P, s, sv) || c.y >= P.max_changes || c.x >= P.max_iterations;
+        const double r = compute_reward(P, s, old, prob);
+        const bool d = episode_over(P, s, sv, prob) || c.y >= P.max_changes || c.x >= P.max_iterations;
         B.reward[e] = r;
         B.done[e] = d ? 1 : 0;
         episode_account(B, e, r, d);
         int32_t* inf = B.info + (size_t)e * 10;
         for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
-        if (P.prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
+        if (prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
         inf[8] = c.x; inf[9] = c.y;
         if (d && P.auto_reset && push_reset) wl_push(B, parity, rst_list, shard, e);
         return d && P.auto_reset;
@@ -66,6 +69,7 @@ __device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, M
 }
 
 // Lane 0 of the group: hand the item to the solver or finish it.
+template <int PROB = -1>
 __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s, bool need_solver,
                                                int mode, int parity, int shard, bool push_reset = true, int park_list = -1) {
     if (need_solver) {
@@ -77,7 +81,7 @@ __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBu
         wl_push(B, parity, park_list >= 0 ? park_list : (mode == MODE_STEP ? WL_SOL : WL_SOL2), shard, e);
         return false;
     }
-    return finalize_item(P, B, e, s, mode, parity, shard, push_reset);
+    return finalize_item<PROB>(P, B, e, s, mode, parity, shard, push_reset);
 }
 
 // What one wavefront does with its share of the work of a launch (k_stats, and the fused step kernel k_step): `lone` -- a
@@ -127,11 +131,11 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
         MaskT champ_l = 0;
         bool ns = false;
         if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l);
-        if (g.lane == 0 && role == 0 && act) finalize_item(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
+        if (g.lane == 0 && role == 0 && act) finalize_item<PROB>(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
         __builtin_amdgcn_wave_barrier();
         if (role == 1 && have) {
             if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ_l;
-            if (g.lane == 0) finish_or_park(P, B, e, sl, ns, MODE_START, parity, shard);
+            if (g.lane == 0) finish_or_park<PROB>(P, B, e, sl, ns, MODE_START, parity, shard);
         }
         return;
     }
@@ -159,7 +163,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
     int want_reset = 0;
     if (g.lane == 0 && have) {
         if (reset_only) want_reset = 1;
-        else want_reset = finish_or_park(P, B, e, s, need_solver, mode, parity, shard, !inline_reset) ? 1 : 0;
+        else want_reset = finish_or_park<PROB>(P, B, e, s, need_solver, mode, parity, shard, !inline_reset) ? 1 : 0;
     }
     if (inline_reset) {
         const uint64_t want = __ballot(want_reset != 0);     // one bit per group, at its lane 0
@@ -182,7 +186,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
                 int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
                 const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st, champ);
                 if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
-                if (g.lane == 0) finish_or_park(P, B, e, st, ns, MODE_START, parity, shard);
+                if (g.lane == 0) finish_or_park<PROB>(P, B, e, st, ns, MODE_START, parity, shard);
             }
         }
     }
@@ -333,7 +337,7 @@ __device__ __forceinline__ void wave_incremental_item(const PcgrlParams& P, cons
     int want = 0;
     if (lane == 0) {
         int32_t s[PCGRL_MAX_STATS] = {regions, path, 1, 0, 0, 0, 0, 0};
-        want = finalize_item(P, B, e, s, MODE_STEP, parity, e & (WL_NSHARD - 1), !inline_reset) ? 1 : 0;
+        want = finalize_item<PCGRL_PROB_BINARY>(P, B, e, s, MODE_STEP, parity, e & (WL_NSHARD - 1), !inline_reset) ? 1 : 0;
     }
     want = __builtin_amdgcn_readfirstlane(want);
     if (inline_reset && want) {
@@ -343,7 +347,7 @@ __device__ __forceinline__ void wave_incremental_item(const PcgrlParams& P, cons
         int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         compute_item_stats<PCGRL_PROB_BINARY>(g, P, n0, n1, n2, rowmask, st, champ);
         champ_e[lane] = champ;
-        if (lane == 0) finalize_item(P, B, e, st, MODE_START, parity, e & (WL_NSHARD - 1));
+        if (lane == 0) finalize_item<PCGRL_PROB_BINARY>(P, B, e, st, MODE_START, parity, e & (WL_NSHARD - 1));
     }
 }
 
@@ -397,10 +401,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             if (threadIdx.x == 0) {
                 if (!reset_only) {
                     int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], 0, 0, 0, 0, 0, 0};
-                    finalize_item(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &s_pre);
+                    finalize_item<PCGRL_PROB_BINARY>(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &s_pre);
                 }
                 int32_t st[PCGRL_MAX_STATS] = {s_regions[1], s_best[1], s_owner[1] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
-                finalize_item(P, B, e, st, MODE_START, parity, shard);
+                finalize_item<PCGRL_PROB_BINARY>(P, B, e, st, MODE_START, parity, shard);
             }
             __syncthreads();
             continue;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);
             if (threadIdx.x == 0) {
                 int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
-                const bool want = finalize_item(P, B, e, s, mode, parity, shard, !inline_reset);
+                const bool want = finalize_item<PCGRL_PROB_BINARY>(P, B, e, s, mode, parity, shard, !inline_reset);
                 s_flag = (want && inline_reset) ? 1 : 0;
             }
         }
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);
             if (threadIdx.x == 0) {
                 int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
-                finalize_item(P, B, e, s, MODE_START, parity, shard);
+                finalize_item<PCGRL_PROB_BINARY>(P, B, e, s, MODE_START, parity, shard);
             }
         }
         __syncthreads();

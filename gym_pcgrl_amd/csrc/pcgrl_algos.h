@@ -43,7 +43,7 @@ struct PcgrlParams {
     int32_t random_start, random_tile, warp, random_probs, auto_reset;
     int32_t target_path, max_enemies, target_enemy_dist, max_crates, target_solution, solver_power;
     int32_t prob_width, prob_height;   // the Problem's own width/height (zelda_prob.py:99, sokoban_prob.py:140)
-    int32_t max_potions, max_treasures, pad_;   // mdungeon_prob.py:25-26
+    int32_t max_potions, max_treasures;   // mdungeon_prob.py:25-26
     double target_col_enemies;         // mdungeon_prob.py:28
     double rewards[PCGRL_MAX_REWARDS];
     double cdf[PCGRL_MAX_TILES];
@@ -98,11 +98,11 @@ PCGRL_HD void md_pack(int32_t* s, const int* out5) {   // out5 = dist-win, sol-l
 
 // binary_prob.py:98-106 | zelda_prob.py:124-142 | sokoban_prob.py:157-175 (same summation order; the
 // products and sums are done in fp64 exactly as Python does them with int * weight)
-PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int32_t* o) {
+PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int32_t* o, int prob) {
     const double* w = P.rewards;
-    if (P.prob == PCGRL_PROB_BINARY) {
+    if (prob == PCGRL_PROB_BINARY) {
         return (double)range_reward_i(n[0], o[0], 1, 1) * w[0] + (double)range_reward_i(n[1], o[1], PCGRL_IPOS, PCGRL_IPOS) * w[1];
-    } else if (P.prob == PCGRL_PROB_ZELDA) {
+    } else if (prob == PCGRL_PROB_ZELDA) {
         double r = (double)range_reward_i(n[0], o[0], 1, 1) * w[0];
         r = r + (double)range_reward_i(n[1], o[1], 1, 1) * w[1];
         r = r + (double)range_reward_i(n[2], o[2], 1, 1) * w[2];
@@ -111,7 +111,7 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
         r = r + (double)range_reward_i(n[5], o[5], P.target_enemy_dist, PCGRL_IPOS) * w[5];
         r = r + (double)range_reward_i(n[6], o[6], PCGRL_IPOS, PCGRL_IPOS) * w[6];
         return r;
-    } else if (P.prob == PCGRL_PROB_MDUNGEON) {
+    } else if (prob == PCGRL_PROB_MDUNGEON) {
         // weights in the order of MDungeonProblem._rewards, summed in the order of get_reward (mdungeon_prob.py:183-206)
         double r = (double)range_reward_i(n[0], o[0], 1, 1) * w[0];
         r = r + (double)range_reward_i(n[1], o[1], 1, 1) * w[1];
@@ -136,16 +136,18 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
         return r;
     }
 }
+PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int32_t* o) { return compute_reward(P, n, o, P.prob); }
 // binary_prob.py:119-120 | zelda_prob.py:155-156 | sokoban_prob.py:188-189
-PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t* start) {
-    if (P.prob == PCGRL_PROB_BINARY) return n[0] == 1 && n[1] - start[1] >= P.target_path;
-    if (P.prob == PCGRL_PROB_ZELDA) return n[5] >= P.target_enemy_dist && n[6] >= P.target_path;
-    if (P.prob == PCGRL_PROB_MDUNGEON) {   // mdungeon_prob.py:219-222 (true division, compared in fp64)
+PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t* start, int prob) {
+    if (prob == PCGRL_PROB_BINARY) return n[0] == 1 && n[1] - start[1] >= P.target_path;
+    if (prob == PCGRL_PROB_ZELDA) return n[5] >= P.target_enemy_dist && n[6] >= P.target_path;
+    if (prob == PCGRL_PROB_MDUNGEON) {   // mdungeon_prob.py:219-222 (true division, compared in fp64)
         const int en = n[4] > 1 ? n[4] : 1;
         return md_sol_length(n) >= P.target_solution && n[4] > 0 && (double)md_col_enemies(n) / (double)en > P.target_col_enemies;
     }
     return n[5] >= P.target_solution;
 }
+PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t* start) { return episode_over(P, n, start, P.prob); }
 PCGRL_HD int num_stats(int prob) { return prob == PCGRL_PROB_BINARY ? 2 : (prob == PCGRL_PROB_ZELDA ? 7 : (prob == PCGRL_PROB_SOKOBAN ? 6 : 8)); }
 
 // ---------------------------------------------------------------- bitboard programs

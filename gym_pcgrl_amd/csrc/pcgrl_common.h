@@ -17,7 +17,7 @@
 
 #define PCGRL_MAX_TILES 8
 #define PCGRL_MAX_STATS 8
-#define PCGRL_MAX_REWARDS 12
+#define PCGRL_MAX_REWARDS 9
 #define PCGRL_MT_N 624
 #define PCGRL_MT_M 397
 

@@ -58,7 +58,10 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
             double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};
             pcgrl_build_cdf(p, 2, cdf);
         } else {
-            for (int i = 0; i < P.ntiles; i++) cdf[i] = P.cdf[i];
+            // constant indices only: a run-time index into the by-value parameter block makes the compiler keep a
+            // copy of the whole block in scratch memory (entries past ntiles are never looked at)
+#pragma unroll
+            for (int i = 0; i < PCGRL_MAX_TILES; i++) cdf[i] = P.cdf[i];
         }
         for (int c0 = 0; c0 < cells; c0 += 64) {
             // cell c draws ring words 2c, 2c+1 of this episode: 128 new words per round, every
