@@ -31,6 +31,8 @@ WORKLOADS = {
     "C3": ("zelda", "wide", (dict(width=11, height=16),), 65536, "zelda-wide-v0 11x16, 65536 envs/GPU"),
     "C4": ("sokoban", "narrow", (), 131072, "sokoban-narrow-v0 5x5, 131072 envs/GPU"),
     "C5": ("binary", "turtle", (dict(width=64, height=64),), 8192, "binary-turtle-v0 64x64 (adjust_param), 8192 envs/GPU"),
+    # not a BASELINE.json config: the mdungeon problem, reported for completeness
+    "M1": ("mdungeon", "narrow", (), 65536, "mdungeon-narrow-v0 7x11, 65536 envs/GPU"),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
@@ -204,17 +206,18 @@ def main():
         ev_us = min(ph.values()) if ph else 0.0
         # binary maps of <= 16 rows run the whole step as ONE launch (k_step): the "stats" interval is then empty and
         # the kernel's duration is the step time of the timed region itself
-        fused = prob != "sokoban" and ph.get("update", 0.0) > 4 * max(ph.get("stats", 0.0), 1e-3)
-        dom_name = "k_sokoban" if prob == "sokoban" else "k_step" if fused else (
+        solver = prob in ("sokoban", "mdungeon")     # problems with a search kernel after k_stats
+        fused = not solver and ph.get("update", 0.0) > 4 * max(ph.get("stats", 0.0), 1e-3)
+        dom_name = "k_sokoban" if prob == "sokoban" else "k_mdungeon" if prob == "mdungeon" else "k_step" if fused else (
             "k_stats_wide" if (prob == "binary" and H > 16) else "k_stats")
-        dom_us = max((ph.get("solver_or_reset", 0.0) if prob == "sokoban" else ph.get("stats", 0.0)) - ev_us, 0.0)
+        dom_us = max((ph.get("solver_or_reset", 0.0) if solver else ph.get("stats", 0.0)) - ev_us, 0.0)
         if fused:
             dom_us = gpu_ms_per_step * 1e3
-        elif prob != "sokoban":   # the event pass perturbs short steps: never more than the step minus the other kernel
+        elif not solver:          # the event pass perturbs short steps: never more than the step minus the other kernel
             dom_us = min(dom_us, max(gpu_ms_per_step * 1e3 - max(ph.get("update", 0.0) - ev_us, 0.0), 0.0))
         valu, valu_src = measured_valu(a.workload, "k_step" if fused else "k_stats") if n == n_default else (None, None)
         dominant = {"name": dom_name, "avg_us": dom_us, "event_pair_overhead_us": ev_us}
-        if valu and dom_us > 0 and prob != "sokoban":
+        if valu and dom_us > 0 and not solver:
             peak = 256 * 4 * 2.4e9 / 4          # SIMDs x clock / 4 cycles per wave64 VALU instruction
             dominant.update({"valu_wave_instr_per_launch": valu, "valu_source": valu_src,
                              "valu_issue_rate": valu / (dom_us * 1e-6), "valu_issue_peak": peak,

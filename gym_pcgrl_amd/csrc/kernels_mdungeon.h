@@ -1,15 +1,56 @@
 // k_mdungeon: the planner jobs that k_stats / k_reset parked for the mdungeon problem (mdungeon_solver.h), one
-// wavefront per level.  Part of the single translation unit pcgrl_abi.hip.
+// wavefront per search.  Part of the single translation unit pcgrl_abi.hip.
 //
 // MDungeonProblem._run_game (mdungeon_prob.py:110-126) runs A*(1), A*(0.5), A*(0) and BFS one after the other and stops
-// at the first winner.  A level reaches the planner only when it has one player, one exit and is connected
-// (mdungeon_prob.py:152), so the exit is reachable and A*(1) -- manhattan distance to the exit -- wins within a few
-// dozen pops unless monsters that cost more health than the player has stand in the way.  The agents therefore run in
-// sequence inside one wavefront (lane 0 drives the search; every lane helps to clear the visited table), with the exact
-// exhausted-search shortcut of md_run_game.  Jobs are handed out with an atomic ticket on a word the host zeroes
-// before the launch; the node pool, and for a large solver_power the heap and table, are the arena the Sokoban
-// solver uses.
+// at the first winner.  The agents are independent searches from the same root, so only the *selection* is
+// sequential: here the four agents of a level are four tickets (handed out with an atomic counter on a word the host
+// zeroes before the launch) and run concurrently in different workgroups.  Every agent records (win, h, depth, what
+// was collected); the last of the four to finish selects exactly what the sequential loop would have returned -- the
+// first winner in agent order, else the BFS agent's best node -- and finishes the environment's step.  An agent whose
+// result cannot be selected any more is abandoned at its next poll:
+//   * an earlier agent has won (level 3 - a in the low byte of the environment's stop word), or
+//   * some A* agent ran out of states without a win (bit 8): then no agent can win or reach the cap (the exact
+//     shortcut of md_run_game) and only the BFS agent's best node matters, so the other A* agents stop.
+// Nobody waits for anybody: a level with one player, one exit and one region (mdungeon_prob.py:152) is usually won by
+// A*(1) within a few dozen pops, and the other three agents then stop at their first poll.
 #pragma once
+
+#define MD_STOP_EXHAUSTED 256
+struct MdPollHook {
+    const int32_t* stop; int a;
+    __device__ __forceinline__ bool operator()(int it) const {
+        if ((it & SOK_POLL_MASK) != 0) return false;
+        const int v = sok_ld(stop);
+        return (v & 255) >= 4 - a || (a < 3 && (v & MD_STOP_EXHAUSTED));
+    }
+};
+
+// Agent a of environment e is done.  The fourth report selects the result and finishes the item.
+__device__ __forceinline__ void md_report(const PcgrlParams& P, const DevBufs& B, int e, int a, bool win, bool exhausted, const int* out5,
+                                          int mode, int parity, int rst_list) {
+    int32_t* r = B.sok_res + ((size_t)e * 4 + a) * 4;
+    __hip_atomic_store(r + 0, win ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 1, out5[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 2, out5[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 3, (out5[2] & 255) | ((out5[3] & 255) << 8) | ((out5[4] & 255) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (win) atomicMax(B.sok_stop + e, 3 - a);
+    else if (a < 3 && exhausted) atomicOr(B.sok_stop + e, MD_STOP_EXHAUSTED);
+    __threadfence();
+    if (atomicAdd(B.sok_cnt + e, 1) != 3) return;
+    __threadfence();
+    int chosen = 3;
+    for (int k = 2; k >= 0; k--) if (sok_ld(B.sok_res + ((size_t)e * 4 + k) * 4)) chosen = k;
+    const int32_t* q = B.sok_res + ((size_t)e * 4 + chosen) * 4;
+    const int col = sok_ld(q + 3);
+    const int res5[5] = {sok_ld(q + 1), sok_ld(q + 2), col & 255, (col >> 8) & 255, (col >> 16) & 255};
+    B.sok_cnt[e] = 0;      // ready for the next job of this environment (a later launch)
+    B.sok_stop[e] = 0;
+    int32_t s[PCGRL_MAX_STATS];
+    const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+    for (int k = 0; k < 8; k++) s[k] = park[k];
+    md_pack(s, res5);
+    finalize_item<PCGRL_PROB_MDUNGEON>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+}
 
 // Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  Environments that finish their episode here
 // go to `rst_list`.
@@ -19,7 +60,6 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
     __shared__ MdLevel s_L;              // level + node workspace in LDS: they are indexed dynamically
     __shared__ MdNode s_root, s_work;
-    __shared__ int s_go, s_win;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
@@ -35,38 +75,35 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
         int t = 0;
         if (lane == 0) t = atomicAdd(sync + SOK_SY_TICKET_A, 1);
         t = __shfl(t, 0, 64);
-        if (t >= n) break;
+        if (t >= 4 * n) break;
+        const int job = t >> 2, a = t & 3;
         int e, mode;
-        if (t < n_a) { e = wl_get(B, list_a, s_pref_a, t); mode = mode_a; }
-        else { e = wl_get(B, list_b, s_pref_b, t - n_a); mode = mode_b; }
-        if (lane == 0) { md_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root); s_go = 1; s_win = 0; }
-        __threadfence_block();
-        for (int a = 0; a < 4; a++) {
-            if (!s_go) break;                                     // wave-uniform (LDS word written by lane 0 before the fence)
+        if (job < n_a) { e = wl_get(B, list_a, s_pref_a, job); mode = mode_a; }
+        else { e = wl_get(B, list_b, s_pref_b, job - n_a); mode = mode_b; }
+        int skip = 0;
+        if (lane == 0) {
+            const MdPollHook hook = {B.sok_stop + e, a};
+            skip = hook(0) ? 1 : 0;                                  // already decided before this agent started
+            if (!skip) md_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+        }
+        skip = __shfl(skip, 0, 64);
+        if (!skip) {
             if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) md_lds[SOK_LDS_HEAP + i] = 0; }
             else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
-            __threadfence_block();
-            if (lane == 0) {
-                int it = 0;
-                bool exhausted = false, win;
-                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
-                    win = md_search(s_L, pool, md_lds, md_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted);
-                else
-                    win = md_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted);
-                if (win) { s_win = 1; s_go = 0; }
-                else if (a < 3 && exhausted) a = 2;               // exact shortcut (md_run_game): straight to BFS
-            }
-            a = __shfl(a, 0, 64);
-            __threadfence_block();
         }
+        __threadfence_block();
         if (lane == 0) {
-            int out5[5];
-            md_result(s_L, s_root, s_work, s_win != 0, out5);
-            int32_t s[PCGRL_MAX_STATS];
-            const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
-            for (int k = 0; k < 8; k++) s[k] = park[k];
-            md_pack(s, out5);
-            finalize_item<PCGRL_PROB_MDUNGEON>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+            int it = 0, out5[5] = {0, 0, 0, 0, 0};
+            bool exhausted = false, win = false;
+            if (!skip) {
+                const MdPollHook hook = {B.sok_stop + e, a};
+                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
+                    win = md_search(s_L, pool, md_lds, md_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
+                else
+                    win = md_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
+                md_result(s_L, s_root, s_work, win, out5);
+            }
+            md_report(P, B, e, a, win, exhausted, out5, mode, parity, rst_list);
         }
         __threadfence_block();
     }

@@ -93,29 +93,58 @@ PCGRL_D bool md_same(const MdNode& a, const MdNode& b) {
            a.alive[2] == b.alive[2] && a.alive[3] == b.alive[3];
 }
 
+struct MdRaw { uint64_t q[5]; };
+PCGRL_D MdRaw md_load(const MdNode* p) {
+    const uint64_t* s = reinterpret_cast<const uint64_t*>(p);
+    MdRaw r;
+    r.q[0] = s[0]; r.q[1] = s[1]; r.q[2] = s[2]; r.q[3] = s[3]; r.q[4] = s[4];
+    return r;
+}
+PCGRL_D void md_store(MdNode* p, const MdRaw& r) {
+    uint64_t* d = reinterpret_cast<uint64_t*>(p);
+    d[0] = r.q[0]; d[1] = r.q[1]; d[2] = r.q[2]; d[3] = r.q[3]; d[4] = r.q[4];
+}
+
 // One search (one lane).  k < 0: BFSAgent, else AStarAgent with integer weight k in {2,1,0}.  `w` is the node
 // workspace (LDS on the device).  On return `w` holds the returned node (winner, or best node) and the function
 // value is the win flag; out_exhausted: the queue ran empty without a win and without reaching the cap.
-template <class HP, class TP>
+// `hook(iterations)` is called at the top of every iteration; returning true abandons the search (k_mdungeon runs
+// the agents of one level concurrently and knows when a result cannot be selected any more).
+// The node that will be popped next is fetched from the pool one iteration ahead whenever it is already known (BFS:
+// the next queue entry; A*: the heap top after the repair), which takes the global-memory latency of the pop off the
+// serial chain.
+template <class HP, class TP, class Hook>
 PCGRL_D bool md_search(const MdLevel& L, MdNode* pool, HP heap, TP table, int table_mask, MdNode& w, const MdNode& root, int k,
-                       int power, int& out_iters, bool& out_exhausted) {
+                       int power, int& out_iters, bool& out_exhausted, Hook hook) {
     int npool = 0, head = 0, heapn = 0, iterations = 0, best = -1, best_h = 0, best_depth = 0;
     md_copy(pool, &root);
     npool = 1;
     if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth + MD_PRIO_BIAS) << 16) | 0u; heapn = 1; }
-    bool win = false;
+    bool win = false, aborted = false;
     int result = 0;
+    MdRaw ahead = md_load(&root);
+    int ahead_idx = 0;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
         iterations++;
+        if (hook(iterations)) { aborted = true; break; }
         int cur;
         if (k >= 0) {
             const uint32_t last = heap[--heapn];
             cur = (int)((heapn > 0 ? heap[0] : last) & 0xFFFFu);
+            MdRaw fetched = ahead;
+            if (cur != ahead_idx) fetched = md_load(pool + cur);       // global load in flight while the heap is repaired
             if (heapn > 0) { heap[0] = last; sok_siftup(heap, 0, heapn); }
+            md_store(&w, fetched);
+            ahead_idx = -1;
+            if (heapn > 0) { ahead_idx = (int)(heap[0] & 0xFFFFu); ahead = md_load(pool + ahead_idx); }
         } else {
             cur = head++;
+            MdRaw fetched = ahead;
+            if (cur != ahead_idx) fetched = md_load(pool + cur);
+            md_store(&w, fetched);
+            ahead_idx = -1;
+            if (head < npool) { ahead_idx = head; ahead = md_load(pool + head); }
         }
-        md_copy(&w, pool + cur);
         if (w.health == 0) continue;                                   // checkLose
         if (w.player == L.door) { win = true; result = cur; break; }    // checkWin
         const uint32_t hs = md_hash(w);
@@ -157,11 +186,16 @@ PCGRL_D bool md_search(const MdLevel& L, MdNode* pool, HP heap, TP table, int ta
             if (taken >= 0) w.alive[taken >> 6] |= 1ull << (taken & 63);   // undo
         }
     }
-    if (!win) result = best;
+    if (!win) result = best < 0 ? 0 : best;
     md_copy(&w, pool + result);
     out_iters = iterations;
-    out_exhausted = !win && !(k >= 0 ? heapn > 0 : head < npool);
+    out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < npool);
     return win;
+}
+template <class HP, class TP>
+PCGRL_D bool md_search(const MdLevel& L, MdNode* pool, HP heap, TP table, int table_mask, MdNode& w, const MdNode& root, int k,
+                       int power, int& out_iters, bool& out_exhausted) {
+    return md_search(L, pool, heap, table, table_mask, w, root, k, power, out_iters, out_exhausted, SokNoHook());
 }
 
 // The five values _run_game hands to get_stats, from the node a search returned.

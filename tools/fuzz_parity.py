@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz on the GPU box: random (problem, representation, map size, parameters, seed) combinations,
 every step compared with the CPU oracle (done, reward, info; maps at the end).  Not part of the pytest suite (minutes).
-    python tools/fuzz_parity.py [cases] [seed]"""
+    python tools/fuzz_parity.py [cases] [seed] [problem]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -12,13 +12,16 @@ from gym_pcgrl_amd.envs import BatchedPcgrlEnv
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ONLY = sys.argv[3] if len(sys.argv) > 3 else None
 REPS = ["narrow", "wide", "turtle", "narrowcast", "narrowmulti", "turtlecast"]
 t0 = time.time()
 for case in range(cases):
-    prob = ["binary", "binary", "zelda", "zelda", "sokoban"][rs.randint(5)]
+    prob = ONLY or ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon"][rs.randint(7)]
     rep = REPS[rs.randint(6)]
     if prob == "sokoban":
         w, h = int(rs.randint(2, 8)), int(rs.randint(2, 8))
+    elif prob == "mdungeon":
+        w, h = int(rs.randint(1, 13)), int(rs.randint(1, 13))
     else:
         w, h = int(rs.randint(1, 41)), int(rs.randint(1, 41))
         if rs.rand() < 0.4:
@@ -26,6 +29,16 @@ for case in range(cases):
     calls = [dict(width=w, height=h), dict(change_percentage=float(rs.choice([0.05, 0.2, 0.5, 1.0])))]
     if prob == "sokoban":
         calls.append(dict(solver_power=int(rs.choice([50, 300, 1000]))))
+    if prob == "mdungeon":
+        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000, 5000]))))
+        if rs.rand() < 0.7:     # open maps with few players / exits: the planner runs in a good share of the steps
+            mon = float(rs.choice([0.0, 0.03, 0.15]))
+            calls.append(dict(probs={"empty": 0.75, "solid": float(rs.choice([0.02, 0.1])), "player": 0.03, "exit": 0.03,
+                                     "goblin": mon, "ogre": mon}))
+        if rs.rand() < 0.5:
+            calls.append(dict(target_solution=int(rs.randint(1, 8)), target_col_enemies=float(rs.choice([0.0, 0.3, 0.5])),
+                              max_enemies=int(rs.randint(1, 5)), max_potions=int(rs.randint(0, 3)), max_treasures=int(rs.randint(0, 3)),
+                              rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "sol-length": float(rs.choice([1, 0.7]))}))
     if rep in ("narrow", "narrowcast", "narrowmulti") and rs.rand() < 0.3:
         calls.append(dict(random_tile=False))
     if rep in ("turtle", "turtlecast") and rs.rand() < 0.5:
