@@ -25,6 +25,25 @@ struct MdPollHook {
     }
 };
 
+// The four children of a pop, one per lane (lanes 0..3 run the compact search in lockstep; everything else in it is
+// uniform across them).  The results come back through v_readlane, i.e. as scalars.
+struct MdKidsLanes {
+    int lane;
+    template <class TP>
+    __device__ __forceinline__ void operator()(const MdLevel& L, const MdFastLevel& F, TP table, int table_mask, uint64_t key, uint64_t alive,
+                                               int player, int health, MdChild* out) const {
+        const MdChild mine = mdf_child(L, F, table, table_mask, key, alive, player, health, lane & 3);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.key, d);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.key >> 32), d);
+            out[d].key = ((uint64_t)hi << 32) | lo;
+            out[d].h = __builtin_amdgcn_readlane(mine.h, d);
+            out[d].drop = __builtin_amdgcn_readlane(mine.drop, d);
+        }
+    }
+};
+
 // Agent a of environment e is done.  The fourth report selects the result and finishes the item.
 __device__ __forceinline__ void md_report(const PcgrlParams& P, const DevBufs& B, int e, int a, bool win, bool exhausted, const int* out5,
                                           int mode, int parity, int rst_list) {
@@ -60,6 +79,9 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
     __shared__ MdLevel s_L;              // level + node workspace in LDS: they are indexed dynamically
     __shared__ MdNode s_root, s_work;
+    __shared__ MdFastLevel s_F;
+    __shared__ MdFastNode s_cache[4];
+    __shared__ int s_fast;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
@@ -83,27 +105,44 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
         int skip = 0;
         if (lane == 0) {
             const MdPollHook hook = {B.sok_stop + e, a};
-            skip = hook(0) ? 1 : 0;                                  // already decided before this agent started
-            if (!skip) md_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+            skip = (hook(0) || (B.md_only_agent >= 0 && B.md_only_agent != a)) ? 1 : 0;   // already decided before this agent started
+            if (!skip) {
+                md_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+                // the compact search (mdungeon_fast.h) for levels with few things; PCGRL_SOK_GENERIC=1 switches it off (tests)
+                s_fast = (mdf_level(s_L, s_root, s_F) <= MDF_MAXI && B.sok_use_lds && B.sok_fast_maxc >= 0) ? 1 : 0;
+            }
         }
         skip = __shfl(skip, 0, 64);
+        __threadfence_block();
+        const int fast = skip ? 0 : s_fast;
         if (!skip) {
-            if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) md_lds[SOK_LDS_HEAP + i] = 0; }
+            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) md_lds[SOK_LDS_HEAP + i] = 0; }   // 64-bit keys
+            else if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) md_lds[SOK_LDS_HEAP + i] = 0; }
             else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
         }
         __threadfence_block();
-        if (lane == 0) {
+        // the compact search runs on lanes 0..3 (uniform except for the four children of a pop), the generic one on lane 0
+        if (lane < (fast ? 4 : 1)) {
             int it = 0, out5[5] = {0, 0, 0, 0, 0};
             bool exhausted = false, win = false;
             if (!skip) {
                 const MdPollHook hook = {B.sok_stop + e, a};
-                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
+                if (fast) {
+                    uint64_t key = 0;
+                    int hh = 0, dd = 0;
+                    const MdKidsLanes kids = {lane};
+                    win = md_search_fast(s_L, s_F, reinterpret_cast<MdFastNode*>(pool), md_lds, reinterpret_cast<uint64_t*>(md_lds + SOK_LDS_HEAP),
+                                         tsize - 1, s_cache, s_root, KS[a], P.solver_power, key, hh, dd, it, exhausted, hook, kids);
+                    mdf_result(s_F, key, hh, dd, win, out5);
+                } else if (B.sok_use_lds) {   // two instantiations: LDS pointers compile to ds_* instructions
                     win = md_search(s_L, pool, md_lds, md_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
-                else
+                    md_result(s_L, s_root, s_work, win, out5);
+                } else {
                     win = md_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
-                md_result(s_L, s_root, s_work, win, out5);
+                    md_result(s_L, s_root, s_work, win, out5);
+                }
             }
-            md_report(P, B, e, a, win, exhausted, out5, mode, parity, rst_list);
+            if (lane == 0) md_report(P, B, e, a, win, exhausted, out5, mode, parity, rst_list);
         }
         __threadfence_block();
     }

@@ -37,6 +37,7 @@
 #include "sokoban_solver.h"
 #include "sokoban_fast.h"
 #include "mdungeon_solver.h"
+#include "mdungeon_fast.h"
 
 #include "worklist.h"
 #include "kernels_update.h"
@@ -270,6 +271,8 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         {   // PCGRL_SOK_GENERIC=1: every level takes the generic search (tests)
             const char* sg = getenv("PCGRL_SOK_GENERIC");
             B.sok_fast_maxc = (sg && sg[0] == '1') ? -1 : SOKF_MAXC;
+            const char* oa = getenv("PCGRL_MD_ONLY_AGENT");
+            B.md_only_agent = oa ? atoi(oa) : -1;
             const char* hc = getenv("PCGRL_SOK_HARD_CAP");
             B.sok_hard_cap = hc ? atoi(hc) : SOK_HARD_CAP;
             if (B.sok_hard_cap < 0 || B.sok_hard_cap > SOK_HARD_CAP) B.sok_hard_cap = SOK_HARD_CAP;
@@ -467,10 +470,10 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
         static bool md_attr_set = false;
         if (!md_attr_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdungeon), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
+                                       (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4)));
             md_attr_set = true;
         }
-        const size_t md_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
+        const size_t md_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
         hipLaunchKernelGGL(k_mdungeon, dim3(SOK_BLOCKS), dim3(64), md_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
                            sync, clr);
         HIPCHK(hipGetLastError());

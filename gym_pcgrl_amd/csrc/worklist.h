@@ -50,6 +50,7 @@ struct DevBufs {
     SokNode* sok_pool; uint32_t* sok_heap; uint32_t* sok_table; int32_t* status;
     int32_t* sok_res;                // [num_envs][4 agents][win, h, depth, exhausted]
     int32_t* sok_cnt; int32_t* sok_stop;   // [num_envs] agents reported / stop level (kernels_sokoban.h)
+    int32_t md_only_agent;           // >= 0: k_mdungeon runs only this agent (PCGRL_MD_ONLY_AGENT, timing experiments; results are then wrong)
     int32_t* sok_sync;               // [2 launches per step][SOK_SY_WORDS + SOK_HARD_CAP] scheduling words
     int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
     int32_t sok_hard_cap;            // levels k_sokoban may publish per launch (SOK_HARD_CAP; PCGRL_SOK_HARD_CAP lowers it for tests)

@@ -15,6 +15,7 @@ static int g_trace_site[4096], g_trace_rounds[4096], g_trace_n = 0;
 #include "../../gym_pcgrl_amd/csrc/sokoban_solver.h"
 #include "../../gym_pcgrl_amd/csrc/sokoban_fast.h"
 #include "../../gym_pcgrl_amd/csrc/mdungeon_solver.h"
+#include "../../gym_pcgrl_amd/csrc/mdungeon_fast.h"
 #include <vector>
 
 template <class T, int G>
@@ -296,6 +297,32 @@ int sim_mdungeon_solve(const uint8_t* map, int h, int w, int power, int shortcut
     md_run_game(L, pool.data(), heap.data(), tp, tsize, work, root, power, shortcut != 0,
                 [tp](int n) { for (int i = 0; i < n; i++) tp[i] = 0; }, out5, iters);
     return 0;
+}
+// fast = 1: the compact search (mdungeon_fast.h) when the level qualifies, as k_mdungeon does
+int sim_mdungeon_solve2(const uint8_t* map, int h, int w, int power, int shortcut, int fast, int* out5, int* iters) {
+    if ((w + 2) * (h + 2) > 256) return -1;
+    MdLevel L; MdNode root;
+    md_build_level(map, w, h, L, root);
+    MdFastLevel F;
+    const int nitems = mdf_level(L, root, F);
+    if (!(fast && nitems <= MDF_MAXI && power <= SOK_LDS_POWER)) return sim_mdungeon_solve(map, h, w, power, shortcut, out5, iters);
+    std::vector<MdFastNode> pool(4 * (size_t)power + 4);
+    std::vector<uint32_t> heap(4 * (size_t)power + 4);
+    const int tsize = SOK_LDS_TABLE;
+    std::vector<uint64_t> table(tsize);
+    const int KS[4] = {2, 1, 0, -1};
+    bool win = false;
+    uint64_t key = 0; int hh = 0, dd = 0;
+    for (int a = 0; a < 4; a++) iters[a] = 0;
+    for (int a = 0; a < 4 && !win; a++) {
+        for (int i = 0; i < tsize; i++) table[i] = 0;
+        bool exhausted = false;
+        MdFastNode cache[4];
+        win = md_search_fast(L, F, pool.data(), heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, key, hh, dd, iters[a], exhausted, SokNoHook(), MdKidsSerial());
+        if (a < 3 && !win && exhausted && shortcut) a = 2;
+    }
+    mdf_result(F, key, hh, dd, win, out5);
+    return 1;
 }
 long sim_iters_reset() { long v = g_sim_iters; g_sim_iters = 0; return v; }
 void sim_set_spurious(int n) { g_spurious = n; }

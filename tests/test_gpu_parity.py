@@ -464,6 +464,50 @@ def test_sokoban_generic_search_path(path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_mdungeon_*.npz"))), ids=os.path.basename)
+def test_mdungeon_generic_search_path(path, monkeypatch):
+    """k_mdungeon picks the compact search (mdungeon_fast.h) for levels with <= 48 things, which is nearly every
+    fixture level; the generic search must give the same answers: PCGRL_SOK_GENERIC=1 routes every level through it."""
+    _torch()
+    monkeypatch.setenv("PCGRL_SOK_GENERIC", "1")
+    d = np.load(path)
+    maps = d["maps"]
+    n, h, w = maps.shape
+    env = _make("mdungeon", "wide", n, [dict(width=w, height=h), dict(solver_power=int(d["solver_power"]))])
+    env.reset()
+    env.set_maps(maps)
+    got = env.stats.cpu().numpy().astype(np.int64)
+    assert env.check_status() == 0
+    assert np.array_equal(got, d["stats"])
+
+
+@pytest.mark.gpu
+def test_mdungeon_crowded_levels_vs_oracle():
+    """Levels with more than 48 things (beyond the compact search) and a solver_power beyond the LDS heap (global
+    arena) against the oracle."""
+    _torch()
+    rs = np.random.RandomState(23)
+    for (h, w, power, fill) in [(9, 9, 400, 0.8), (8, 10, 6000, 0.25), (7, 11, 6000, 0.75)]:
+        maps = []
+        while len(maps) < 24:
+            m = np.zeros((h, w), np.uint8)
+            cells = rs.permutation(h * w)
+            m.flat[cells[0]] = 2
+            m.flat[cells[1]] = 3
+            k = int(fill * h * w)
+            m.flat[cells[2:2 + k]] = rs.choice([4, 5, 6, 7], size=k, p=[0.3, 0.3, 0.25, 0.15])
+            maps.append(m)
+        maps = np.array(maps)
+        env = _make("mdungeon", "wide", len(maps), [dict(width=w, height=h), dict(solver_power=power)])
+        env.reset()
+        env.set_maps(maps)
+        got = env.stats.cpu().numpy().astype(np.int64)
+        exp = np.array([ol.get_stats("mdungeon", m, solver_power=power) for m in maps])
+        assert np.array_equal(got, exp), np.nonzero((got != exp).any(1))[0]
+        assert (exp[:, 10] > 0).any() and (exp[:, 2:5].sum(1) > (48 if fill > 0.5 else 0)).all()
+
+
+@pytest.mark.gpu
 def test_sokoban_many_crates_vs_oracle():
     """Levels with 8..12 crates (beyond the register-resident search) against the oracle: engineered 8x8 levels,
     crates next to their targets in open space, small solver_power so that every agent runs into the cap or wins."""

@@ -101,13 +101,14 @@ def test_device_sokoban_solver_vs_golden(sim, fast):
     assert n > 300 and skipped > 100
 
 
-def test_device_mdungeon_solver_vs_golden(sim):
+@pytest.mark.parametrize("fast", [0, 1], ids=["generic", "compact"])
+def test_device_mdungeon_solver_vs_golden(sim, fast):
     """gym_pcgrl_amd/csrc/mdungeon_solver.h (the code k_mdungeon runs) compiled for the host, against the reference's
     planner results.  Without the exhausted-search shortcut the per-agent iteration counts must equal the reference's;
     with it the five results must still be equal, and agents are skipped only after an agent exhausted the state
     space -- in which case the reference's own counts show that every agent popped the same number of entries."""
-    sim.sim_mdungeon_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    n = skipped = capped = 0
+    sim.sim_mdungeon_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = skipped = capped = took_fast = 0
     for path in sorted(glob.glob(os.path.join(G, "stats_mdungeon_*.npz"))):
         d = np.load(path)
         power = int(d["solver_power"])
@@ -117,11 +118,13 @@ def test_device_mdungeon_solver_vs_golden(sim):
             m = np.ascontiguousarray(m)
             exp = [d["stats"][i, 9], d["stats"][i, 10], d["stats"][i, 6], d["stats"][i, 7], d["stats"][i, 8]]
             out, it = np.zeros(5, np.int32), np.zeros(4, np.int32)
-            assert sim.sim_mdungeon_solve(_p(m), m.shape[0], m.shape[1], power, 0, _p(out), _p(it)) == 0
+            rc = sim.sim_mdungeon_solve2(_p(m), m.shape[0], m.shape[1], power, 0, fast, _p(out), _p(it))
+            assert rc in (0, 1)
+            took_fast += rc
             assert list(out) == exp, (path, i, out, exp)
             assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
             out2, it2 = np.zeros(5, np.int32), np.zeros(4, np.int32)
-            assert sim.sim_mdungeon_solve(_p(m), m.shape[0], m.shape[1], power, 1, _p(out2), _p(it2)) == 0
+            assert sim.sim_mdungeon_solve2(_p(m), m.shape[0], m.shape[1], power, 1, fast, _p(out2), _p(it2)) in (0, 1)
             assert list(out2) == exp, ("shortcut", path, i, out2, exp)
             if not np.array_equal(it, it2):
                 skipped += 1
@@ -130,6 +133,7 @@ def test_device_mdungeon_solver_vs_golden(sim):
             capped += int((it >= power).any())
             n += 1
     assert n > 400 and skipped > 5 and capped > 20
+    assert (took_fast > 0.9 * n) if fast else took_fast == 0
 
 
 def test_bitboard_stats_vs_oracle_random(sim):
