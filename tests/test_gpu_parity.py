@@ -227,7 +227,8 @@ def test_shard_invariance_and_determinism():
     ("zelda", "wide", (dict(width=11, height=16),), 65536),
     ("binary", "turtle", (dict(width=64, height=64),), 8192),
     ("sokoban", "narrow", (), 131072),
-], ids=["C2", "C3", "C5", "C4"])
+    ("mdungeon", "narrow", (), 65536),
+], ids=["C2", "C3", "C5", "C4", "M1"])
 def test_full_size_properties(prob, rep, calls, N):
     torch = _torch()
     if not _supported(prob):
@@ -299,6 +300,7 @@ def test_wrapper_observations_match_reference(path):
     ("binary", "narrow", 33, 16), ("binary", "turtle", 64, 17), ("binary", "narrowmulti", 16, 17), ("binary", "wide", 64, 64),
     ("zelda", "narrow", 2, 2), ("zelda", "turtlecast", 33, 3), ("zelda", "wide", 64, 5), ("zelda", "narrowcast", 5, 40),
     ("sokoban", "narrow", 1, 3), ("sokoban", "turtle", 14, 14), ("sokoban", "wide", 3, 8),
+    ("mdungeon", "narrow", 1, 2), ("mdungeon", "turtlecast", 14, 14), ("mdungeon", "wide", 3, 9), ("mdungeon", "narrowmulti", 18, 10),
 ], ids=lambda v: str(v))
 def test_edge_shapes_vs_oracle(prob, rep, w, h):
     torch = _torch()
@@ -366,7 +368,7 @@ def test_make_vec_envs_surface():
 
 # ------------------------------------------------------------------ episode statistics + rollout collection
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-wide-v0", "sokoban-turtle-v0"])
+@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-wide-v0", "sokoban-turtle-v0", "mdungeon-narrow-v0"])
 def test_episode_stats_match_oracle_sums(env_id):
     """The in-kernel Monitor (pcgrl_bind_episode_stats): return and length latched when an episode ends must equal
     the sums over the oracle's rewards of that episode, for every environment and every episode."""
@@ -677,7 +679,7 @@ def test_device_seeding_matches_numpy():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-turtle-v0", "sokoban-wide-v0"])
+@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-turtle-v0", "sokoban-wide-v0", "mdungeon-turtle-v0"])
 def test_state_dict_round_trip(env_id):
     """Checkpoint / resume of the environment state: a second batch that loads the state_dict of the
     first continues exactly like it."""
