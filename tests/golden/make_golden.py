@@ -42,6 +42,7 @@ INFO_KEYS = {
     "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
                  "dist-win", "sol-length"],
+    "ddave": ["player", "exit", "diamonds", "key", "spikes", "regions", "col-diamonds", "num-jumps", "dist-win", "sol-length"],
 }
 STAT_KEYS = {
     "binary": ["regions", "path-length"],
@@ -49,6 +50,7 @@ STAT_KEYS = {
     "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
                  "dist-win", "sol-length"],
+    "ddave": ["player", "dist-floor", "exit", "diamonds", "key", "spikes", "regions", "num-jumps", "col-diamonds", "dist-win", "sol-length"],
 }
 
 
@@ -409,6 +411,100 @@ def gen_stats_mdungeon():
              solver_power=np.array(power), keys=np.array(STAT_KEYS["mdungeon"]))
 
 
+# ----------------------------------------------------------------------------- ddave
+def engineer_ddave(rs, h, w, n, solid_max=0.35, spike_max=0.15):
+    """Maps with one player, exit and key (often connected), platforms, diamonds and spikes."""
+    maps = []
+    for _ in range(n):
+        solid = rs.uniform(0.0, solid_max)
+        m = (rs.random_sample((h, w)) < solid).astype(np.uint8)
+        if rs.random_sample() < 0.5 and h > 2:
+            m[:] = 0                                  # platform style: a few horizontal ledges
+            for _k in range(rs.randint(0, 4)):
+                y = rs.randint(1, h); x0 = rs.randint(0, w); x1 = rs.randint(x0, w) + 1
+                m[y, x0:x1] = 1
+        cells = rs.permutation(h * w)
+        c = 0
+        def put(tile, cnt):
+            nonlocal c
+            for _ in range(cnt):
+                if c < len(cells):
+                    m.flat[cells[c]] = tile
+                    c += 1
+        put(2, 1 if rs.random_sample() < 0.92 else rs.randint(0, 3))
+        put(3, 1 if rs.random_sample() < 0.92 else rs.randint(0, 3))
+        put(5, 1 if rs.random_sample() < 0.92 else rs.randint(0, 3))
+        put(4, rs.randint(0, 5))
+        put(6, rs.randint(0, 1 + int(spike_max * h * w)))
+        maps.append(m)
+    return maps
+
+
+def run_agents_ddave(prob, m):
+    """What DDaveProblem._run_game does (ddave_prob.py:92-127), keeping the agents' iteration counts."""
+    from gym_pcgrl.envs.probs.ddave.engine import AStarAgent as DA, BFSAgent as DB, State as DS
+    smap = get_string_map(m, prob.get_tile_types())
+    chars = " #@H$V*"
+    s2c = dict((s, chars[i]) for i, s in enumerate(prob.get_tile_types()))
+    W = prob._width
+    lvl = "#" * (W + 2) + "\n"
+    for row in smap:
+        lvl += "#" + "".join(s2c[c] for c in row) + "#\n"
+    lvl += "#" * (W + 2) + "\n"
+    state = DS()
+    state.stringInitialize(lvl.split("\n"))
+    iters, win = [], -1
+    for k, bal in enumerate((1, 0.5, 0)):
+        sol, st, it = DA().getSolution(state, bal, prob._solver_power)
+        iters.append(it)
+        if st.checkWin():
+            win = k
+            break
+    if win < 0:
+        sol, st, it = DB().getSolution(state, prob._solver_power)
+        iters.append(it)
+        if st.checkWin():
+            win = 3
+    while len(iters) < 4:
+        iters.append(0)
+    return iters, win, (0 if win >= 0 else st.getHeuristic()), (len(sol) if win >= 0 else 0), st.getGameStatus()
+
+
+def gen_stats_ddave():
+    rs = np.random.RandomState(19)
+    prob = PROBLEMS["ddave"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng, power, smax, spk) in [(7, 11, 120, 300, 5000, 0.35, 0.15), (11, 7, 20, 80, 5000, 0.3, 0.1),
+                                                  (5, 5, 40, 120, 5000, 0.3, 0.15), (6, 9, 10, 100, 150, 0.25, 0.1),
+                                                  (7, 11, 0, 80, 600, 0.1, 0.3), (14, 14, 0, 24, 5000, 0.2, 0.1),
+                                                  (2, 6, 0, 40, 5000, 0.1, 0.1), (1, 5, 0, 12, 5000, 0.0, 0.0)]:
+        prob._width, prob._height, prob._solver_power = w, h, power
+        maps = [np.zeros((h, w), np.uint8), np.ones((h, w), np.uint8)]
+        probs7 = np.array(pr + [0.0])
+        maps += [np.minimum(x, 6) for x in random_maps(rs, nrand, h, w, 8, list(probs7))] + engineer_ddave(rs, h, w, neng, smax, spk)
+        t0 = time.time()
+        res, agents = [], []
+        for m in maps:
+            st = stats_of(prob, m)
+            row = [int(st[k]) for k in STAT_KEYS["ddave"]]
+            res.append(row)
+            if st["player"] == 1 and st["exit"] == 1 and st["key"] == 1 and st["regions"] == 1:
+                iters, win, dist, sl, gs = run_agents_ddave(prob, m)
+                assert dist == row[9] and sl == row[10], (dist, sl, row)
+                assert [gs["num_jumps"], gs["col_diamonds"]] == row[7:9]
+                agents.append(iters + [win])
+            else:
+                agents.append([0, 0, 0, 0, -2])
+        res = np.array(res, dtype=np.int64)
+        agents = np.array(agents, dtype=np.int64)
+        print("  ddave %dx%d power %d: %d maps, solver ran %d, wins by agent %s, cap hits %d, %.1fs" % (
+            h, w, power, len(maps), int((agents[:, 4] > -2).sum()),
+            [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)],
+            int((agents[:, :4] >= power).any(1).sum()), time.time() - t0))
+        save("stats_ddave_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+             solver_power=np.array(power), keys=np.array(STAT_KEYS["ddave"]))
+
+
 # ----------------------------------------------------------------------------- range reward
 def gen_range_reward():
     bands = [(1, 1), (np.inf, np.inf), (-np.inf, -np.inf), (2, 5), (4, np.inf), (1, 3), (0, 0), (3, 3), (2, 2), (1, 5)]
@@ -454,6 +550,8 @@ def gen_adjust_param():
         ("mdungeon", "narrow", []),
         ("mdungeon", "wide", [dict(width=5, height=6), dict(change_percentage=0.9)]),
         ("mdungeon", "turtle", [dict(width=14, height=14, change_percentage=0.3)]),
+        ("ddave", "narrow", []),
+        ("ddave", "wide", [dict(width=6, height=5), dict(change_percentage=0.9)]),
     ]
     for prob, rep, calls in cases:
         env = gym.make("%s-%s-v0" % (prob, rep))
@@ -568,6 +666,13 @@ TRAJS = [
         change_percentage=0.9, probs={"empty": 0.7, "solid": 0.1, "player": 0.04, "exit": 0.04}, target_solution=4,
         target_col_enemies=0.3, max_enemies=3, max_potions=1, max_treasures=1, solver_power=600,
         rewards={"dist-win": 0.3, "col-enemies": 1.5, "regions": 2}),)),
+    ("ddave_narrow", "ddave", "narrow", 32, 300, ()),
+    ("ddave_wide_open", "ddave", "wide", 24, 300, (dict(probs={"empty": 0.8, "solid": 0.1, "player": 0.025, "exit": 0.025, "diamond": 0.02,
+                                                                "key": 0.025, "spike": 0.005}, change_percentage=0.6),)),
+    ("ddave_turtle_6x5", "ddave", "turtle", 24, 400, (dict(width=6, height=5), dict(
+        change_percentage=0.9, probs={"empty": 0.7, "solid": 0.12, "player": 0.05, "exit": 0.05, "key": 0.05, "spike": 0.01},
+        target_solution=3, target_jumps=0, max_diamonds=1, min_spikes=2, solver_power=400,
+        rewards={"dist-win": 0.3, "num-jumps": 1.5, "dist-floor": 0.5}),)),
     ("mdungeon_narrow_monsters", "mdungeon", "narrow", 16, 300, (dict(width=6, height=6), dict(
         change_percentage=0.8, solver_power=250, target_solution=3, target_col_enemies=0.2,
         probs={"empty": 0.45, "solid": 0.03, "player": 0.03, "exit": 0.03, "potion": 0.06, "treasure": 0.05, "goblin": 0.1, "ogre": 0.25}),)),
@@ -628,7 +733,7 @@ def main():
     a = ap.parse_args()
     jobs = {
         "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
-        "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
+        "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "stats_ddave": gen_stats_ddave, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
         "wrappers": gen_wrappers,
     }
     for k, fn in jobs.items():

@@ -11,24 +11,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 SO = os.path.join(ORACLE_DIR, "libpcgrl_oracle.so")
 
-PROBS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3}
+PROBS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3, "ddave": 4}
 REPS = {"narrow": 0, "wide": 1, "turtle": 2, "narrowcast": 3, "narrowmulti": 4, "turtlecast": 5}
 MAX_ACTION = 9
 ADJ_KEYS = {k: i for i, k in enumerate([
     "change_percentage", "width", "height", "target_path", "random_probs", "max_enemies",
     "target_enemy_dist", "solver_power", "max_crates", "max_targets", "min_solution",
-    "random_start", "random_tile", "warp", "max_potions", "max_treasures", "target_col_enemies", "target_solution"])}
+    "random_start", "random_tile", "warp", "max_potions", "max_treasures", "target_col_enemies", "target_solution",
+    "max_diamonds", "min_spikes", "target_jumps"])}
 TILES = {
     "binary": ["empty", "solid"],
     "zelda": ["empty", "solid", "player", "key", "door", "bat", "scorpion", "spider"],
     "sokoban": ["empty", "solid", "player", "crate", "target"],
     "mdungeon": ["empty", "solid", "player", "exit", "potion", "treasure", "goblin", "ogre"],
+    "ddave": ["empty", "solid", "player", "exit", "diamond", "key", "spike"],
 }
 REWARD_KEYS = {
     "binary": ["regions", "path-length"],
     "zelda": ["player", "key", "door", "regions", "enemies", "nearest-enemy", "path-length"],
     "sokoban": ["player", "crate", "target", "regions", "ratio", "dist-win", "sol-length"],
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-enemies", "dist-win", "sol-length"],
+    "ddave": ["player", "dist-floor", "exit", "diamonds", "key", "spikes", "regions", "num-jumps", "dist-win", "sol-length"],
 }
 INFO_KEYS = {
     "binary": ["regions", "path-length", "path-imp"],
@@ -36,8 +39,9 @@ INFO_KEYS = {
     "sokoban": ["player", "crate", "target", "regions", "dist-win", "sol-length"],
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
                  "dist-win", "sol-length"],
+    "ddave": ["player", "exit", "diamonds", "key", "spikes", "regions", "col-diamonds", "num-jumps", "dist-win", "sol-length"],
 }
-NSTATS = {"binary": 2, "zelda": 7, "sokoban": 6, "mdungeon": 11}
+NSTATS = {"binary": 2, "zelda": 7, "sokoban": 6, "mdungeon": 11, "ddave": 11}
 
 _lib = None
 

@@ -104,7 +104,7 @@ def test_stats_kat(path):
     for i, m in enumerate(d["maps"]):
         got, it = ol.get_stats(prob, m, solver_power=power, with_iters=True)
         assert np.array_equal(got, d["stats"][i]), (i, got, d["stats"][i], m)
-        if prob in ("sokoban", "mdungeon") and d["agents"][i, 4] > -2:
+        if prob in ("sokoban", "mdungeon", "ddave") and d["agents"][i, 4] > -2:
             assert np.array_equal(it, d["agents"][i, :4]), (i, it, d["agents"][i])
 
 
