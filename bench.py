@@ -33,6 +33,7 @@ WORKLOADS = {
     "C5": ("binary", "turtle", (dict(width=64, height=64),), 8192, "binary-turtle-v0 64x64 (adjust_param), 8192 envs/GPU"),
     # not a BASELINE.json config: the mdungeon problem, reported for completeness
     "M1": ("mdungeon", "narrow", (), 65536, "mdungeon-narrow-v0 7x11, 65536 envs/GPU"),
+    "D1": ("ddave", "narrow", (), 65536, "ddave-narrow-v0 11x7, 65536 envs/GPU"),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
@@ -206,9 +207,9 @@ def main():
         ev_us = min(ph.values()) if ph else 0.0
         # binary maps of <= 16 rows run the whole step as ONE launch (k_step): the "stats" interval is then empty and
         # the kernel's duration is the step time of the timed region itself
-        solver = prob in ("sokoban", "mdungeon")     # problems with a search kernel after k_stats
+        solver = prob in ("sokoban", "mdungeon", "ddave")     # problems with a search kernel after k_stats
         fused = not solver and ph.get("update", 0.0) > 4 * max(ph.get("stats", 0.0), 1e-3)
-        dom_name = "k_sokoban" if prob == "sokoban" else "k_mdungeon" if prob == "mdungeon" else "k_step" if fused else (
+        dom_name = "k_sokoban" if prob == "sokoban" else "k_mdungeon" if prob == "mdungeon" else "k_ddave" if prob == "ddave" else "k_step" if fused else (
             "k_stats_wide" if (prob == "binary" and H > 16) else "k_stats")
         dom_us = max((ph.get("solver_or_reset", 0.0) if solver else ph.get("stats", 0.0)) - ev_us, 0.0)
         if fused:

@@ -1,0 +1,97 @@
+// k_ddave: the planner jobs that k_stats / k_reset parked for the ddave problem (ddave_solver.h), one wavefront per
+// search.  Part of the single translation unit pcgrl_abi.hip.
+//
+// The same scheme as k_mdungeon: the four agents of a level (A*(1), A*(0.5), A*(0), BFS; ddave_prob.py:111-127) are
+// four tickets and run concurrently in different workgroups, every agent records (win, h, depth, jumps, diamonds) and
+// the last of the four to finish selects what the sequential loop would have returned.  An agent stops early only when
+// an earlier agent has won: this engine's visited key ignores the air time, so the states an agent gets to see depend
+// on its own order of exploration and an exhausted agent says nothing about the others (ddave_solver.h).
+#pragma once
+
+struct DdPollHook {
+    const int32_t* stop; int a;
+    __device__ __forceinline__ bool operator()(int it) const { return (it & SOK_POLL_MASK) == 0 && (sok_ld(stop) & 255) >= 4 - a; }
+};
+
+// Agent a of environment e is done.  The fourth report selects the result and finishes the item.
+__device__ __forceinline__ void dd_report(const PcgrlParams& P, const DevBufs& B, int e, int a, bool win, const int* out4, int mode, int parity,
+                                          int rst_list) {
+    int32_t* r = B.sok_res + ((size_t)e * 4 + a) * 4;
+    __hip_atomic_store(r + 0, win ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 1, out4[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 2, out4[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 3, (out4[2] & 0xFFFF) | ((out4[3] & 255) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (win) atomicMax(B.sok_stop + e, 3 - a);
+    __threadfence();
+    if (atomicAdd(B.sok_cnt + e, 1) != 3) return;
+    __threadfence();
+    int chosen = 3;
+    for (int k = 2; k >= 0; k--) if (sok_ld(B.sok_res + ((size_t)e * 4 + k) * 4)) chosen = k;
+    const int32_t* q = B.sok_res + ((size_t)e * 4 + chosen) * 4;
+    const int jd = sok_ld(q + 3);
+    const int res4[4] = {sok_ld(q + 1), sok_ld(q + 2), jd & 0xFFFF, (jd >> 16) & 255};
+    B.sok_cnt[e] = 0;      // ready for the next job of this environment (a later launch)
+    B.sok_stop[e] = 0;
+    int32_t s[PCGRL_MAX_STATS];
+    const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+    for (int k = 0; k < 8; k++) s[k] = park[k];
+    dd_pack(s, res4);
+    finalize_item<PCGRL_PROB_DDAVE>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
+}
+
+// Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  Environments that finish their episode here
+// go to `rst_list`.
+__global__ __launch_bounds__(64) void k_ddave(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
+                                              int rst_list, int32_t* sync, int clear_parity) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t dd_lds[];
+    __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
+    __shared__ DdLevel s_L;              // level + node workspace in LDS: they are indexed dynamically
+    __shared__ DdNode s_root, s_work;
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    const int lane = threadIdx.x;
+    const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
+    const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
+    const int n = n_a + n_b;
+    DdNode* pool = reinterpret_cast<DdNode*>(B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride);
+    uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
+    uint32_t* g_table = B.sok_use_lds ? nullptr : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
+    const int tsize = B.sok_use_lds ? SOK_LDS_TABLE : B.sok_table_size;
+    const int W = P.width, H = P.height;
+    const int KS[4] = {2, 1, 0, -1};
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(sync + SOK_SY_TICKET_A, 1);
+        t = __shfl(t, 0, 64);
+        if (t >= 4 * n) break;
+        const int job = t >> 2, a = t & 3;
+        int e, mode;
+        if (job < n_a) { e = wl_get(B, list_a, s_pref_a, job); mode = mode_a; }
+        else { e = wl_get(B, list_b, s_pref_b, job - n_a); mode = mode_b; }
+        int skip = 0;
+        if (lane == 0) {
+            const DdPollHook hook = {B.sok_stop + e, a};
+            skip = hook(0) ? 1 : 0;                                  // already decided before this agent started
+            if (!skip) dd_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+        }
+        skip = __shfl(skip, 0, 64);
+        if (!skip) {
+            if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) dd_lds[SOK_LDS_HEAP + i] = 0; }
+            else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
+        }
+        __threadfence_block();
+        if (lane == 0) {
+            int it = 0, out4[4] = {0, 0, 0, 0};
+            bool exhausted = false, win = false;
+            if (!skip) {
+                const DdPollHook hook = {B.sok_stop + e, a};
+                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
+                    win = dd_search(s_L, pool, dd_lds, dd_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
+                else
+                    win = dd_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
+                dd_result(s_L, s_work, win, out4);
+            }
+            dd_report(P, B, e, a, win, out4, mode, parity, rst_list);
+        }
+        __threadfence_block();
+    }
+}

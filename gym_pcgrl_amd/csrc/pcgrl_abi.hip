@@ -38,6 +38,7 @@
 #include "sokoban_fast.h"
 #include "mdungeon_solver.h"
 #include "mdungeon_fast.h"
+#include "ddave_solver.h"
 
 #include "worklist.h"
 #include "kernels_update.h"
@@ -47,6 +48,7 @@
 #include "kernels_step.h"
 #include "kernels_sokoban.h"
 #include "kernels_mdungeon.h"
+#include "kernels_ddave.h"
 #include "kernels_misc.h"
 
 // ------------------------------------------------------------------------------------------
@@ -86,10 +88,10 @@ static thread_local int g_last_hip = 0;
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // problems whose statistics need a search kernel after k_stats (the Sokoban solver, the MiniDungeons planner)
-static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGRL_MDUNGEON; }
+static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGRL_MDUNGEON || prob == PCGRL_DDAVE; }
 static int validate_config(const pcgrl_config* c) {
     if (!c) return PCGRL_EINVAL;
-    if (c->prob < 0 || c->prob > 3 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
+    if (c->prob < 0 || c->prob > 4 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
     if (c->num_envs < 1) return PCGRL_EINVAL;
     if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
     if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
@@ -99,7 +101,7 @@ static int validate_config(const pcgrl_config* c) {
     }
     return PCGRL_OK;
 }
-static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_SOKOBAN ? 5 : 8); }
+static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_SOKOBAN ? 5 : (prob == PCGRL_DDAVE ? 7 : 8)); }
 
 static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     memset(P, 0, sizeof(*P));
@@ -116,6 +118,7 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     P->target_path = c->target_path; P->max_enemies = c->max_enemies; P->target_enemy_dist = c->target_enemy_dist;
     P->max_crates = c->max_crates; P->target_solution = c->target_solution; P->solver_power = c->solver_power;
     P->max_potions = c->max_potions; P->max_treasures = c->max_treasures; P->target_col_enemies = c->target_col_enemies;
+    P->max_diamonds = c->max_diamonds; P->min_spikes = c->min_spikes; P->target_jumps = c->target_jumps;
     for (int i = 0; i < PCGRL_MAX_REWARDS; i++) P->rewards[i] = c->rewards[i];
     pcgrl_build_cdf(c->tile_probs, P->ntiles, P->cdf);
 }
@@ -396,6 +399,7 @@ static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, i
         case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, inline_reset, st);
         case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, inline_reset, st);
         case PCGRL_PROB_MDUNGEON: return launch_stats_p<PCGRL_PROB_MDUNGEON>(h, list, parity, mode, clr, 0, st);
+        case PCGRL_PROB_DDAVE: return launch_stats_p<PCGRL_PROB_DDAVE>(h, list, parity, mode, clr, 0, st);
         default: return launch_stats_p<PCGRL_PROB_SOKOBAN>(h, list, parity, mode, clr, 0, st);
     }
 }
@@ -466,6 +470,18 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
     }
     int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
     HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
+    if (h->P.prob == PCGRL_PROB_DDAVE) {
+        static bool dd_attr_set = false;
+        if (!dd_attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ddave), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
+            dd_attr_set = true;
+        }
+        const size_t dd_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
+        hipLaunchKernelGGL(k_ddave, dim3(SOK_BLOCKS), dim3(64), dd_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
+        HIPCHK(hipGetLastError());
+        return PCGRL_OK;
+    }
     if (h->P.prob == PCGRL_PROB_MDUNGEON) {
         static bool md_attr_set = false;
         if (!md_attr_set) {
@@ -509,6 +525,7 @@ static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int c
         case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, list, park_list, parity, clr, st);
         case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, list, park_list, parity, clr, st);
         case PCGRL_PROB_MDUNGEON: return launch_reset_p<PCGRL_PROB_MDUNGEON>(h, list, park_list, parity, clr, st);
+        case PCGRL_PROB_DDAVE: return launch_reset_p<PCGRL_PROB_DDAVE>(h, list, park_list, parity, clr, st);
         default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, list, park_list, parity, clr, st);
     }
 }

@@ -44,6 +44,7 @@ struct PcgrlParams {
     int32_t target_path, max_enemies, target_enemy_dist, max_crates, target_solution, solver_power;
     int32_t prob_width, prob_height;   // the Problem's own width/height (zelda_prob.py:99, sokoban_prob.py:140)
     int32_t max_potions, max_treasures;   // mdungeon_prob.py:25-26
+    int32_t max_diamonds, min_spikes, target_jumps, pad_;   // ddave_prob.py:23-27
     double target_col_enemies;         // mdungeon_prob.py:28
     double rewards[PCGRL_MAX_REWARDS];
     double cdf[PCGRL_MAX_TILES];
@@ -96,6 +97,19 @@ PCGRL_HD void md_pack(int32_t* s, const int* out5) {   // out5 = dist-win, sol-l
     s[7] = (out5[2] & 255) | ((out5[3] & 255) << 8) | ((out5[4] & 255) << 16) | (won << 24);
 }
 
+// The ddave row (ddave_prob.py:141-161 has eleven values too; a level the planner accepts has fewer than 256 cells):
+//   s[0] = player | exit << 8 | key << 16, s[1] = dist-floor, s[2] = diamonds, s[3] = spikes, s[4] = regions,
+//   s[5] = num-jumps, s[6] = sol-length if the planner won else dist-win, s[7] = col-diamonds | won << 24
+PCGRL_HD int dd_player(const int32_t* s) { return s[0] & 255; }
+PCGRL_HD int dd_exit(const int32_t* s) { return (s[0] >> 8) & 255; }
+PCGRL_HD int dd_key(const int32_t* s) { return (s[0] >> 16) & 255; }
+PCGRL_HD void dd_pack(int32_t* s, const int* out4) {   // out4 = dist-win, sol-length, num-jumps, col-diamonds
+    const int won = out4[1] > 0 ? 1 : 0;              // the player never starts on the exit holding the key
+    s[5] = out4[2];
+    s[6] = won ? out4[1] : out4[0];
+    s[7] = (out4[3] & 255) | (won << 24);
+}
+
 // binary_prob.py:98-106 | zelda_prob.py:124-142 | sokoban_prob.py:157-175 (same summation order; the
 // products and sums are done in fp64 exactly as Python does them with int * weight)
 PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int32_t* o, int prob) {
@@ -110,6 +124,20 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
         r = r + (double)range_reward_i(n[4], o[4], 1, 1) * w[3];
         r = r + (double)range_reward_i(n[5], o[5], P.target_enemy_dist, PCGRL_IPOS) * w[5];
         r = r + (double)range_reward_i(n[6], o[6], PCGRL_IPOS, PCGRL_IPOS) * w[6];
+        return r;
+    } else if (prob == PCGRL_PROB_DDAVE) {
+        // weights in the order of DDaveProblem._rewards, summed in the order of get_reward (ddave_prob.py:187-209);
+        // dist-win / sol-length / won share slots the way mdungeon's do
+        double r = (double)range_reward_i(dd_player(n), dd_player(o), 1, 1) * w[0];
+        r = r + (double)range_reward_i(n[1], o[1], 0, 0) * w[1];
+        r = r + (double)range_reward_i(dd_exit(n), dd_exit(o), 1, 1) * w[2];
+        r = r + (double)range_reward_i(n[3], o[3], P.min_spikes, PCGRL_IPOS) * w[5];
+        r = r + (double)range_reward_i(n[2], o[2], PCGRL_INEG, P.max_diamonds) * w[3];
+        r = r + (double)range_reward_i(dd_key(n), dd_key(o), 1, 1) * w[4];
+        r = r + (double)range_reward_i(n[4], o[4], 1, 1) * w[6];
+        r = r + (double)range_reward_i(n[5], o[5], PCGRL_IPOS, PCGRL_IPOS) * w[7];
+        r = r + (double)range_reward_i(md_dist_win(n), md_dist_win(o), PCGRL_INEG, PCGRL_INEG) * w[8];
+        r = r + (double)range_reward_i(md_sol_length(n), md_sol_length(o), PCGRL_IPOS, PCGRL_IPOS) * w[9];
         return r;
     } else if (prob == PCGRL_PROB_MDUNGEON) {
         // weights in the order of MDungeonProblem._rewards, summed in the order of get_reward (mdungeon_prob.py:183-206)
@@ -141,6 +169,7 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
 PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t* start, int prob) {
     if (prob == PCGRL_PROB_BINARY) return n[0] == 1 && n[1] - start[1] >= P.target_path;
     if (prob == PCGRL_PROB_ZELDA) return n[5] >= P.target_enemy_dist && n[6] >= P.target_path;
+    if (prob == PCGRL_PROB_DDAVE) return md_sol_length(n) >= P.target_solution && n[5] > P.target_jumps;   // ddave_prob.py:218-220
     if (prob == PCGRL_PROB_MDUNGEON) {   // mdungeon_prob.py:219-222 (true division, compared in fp64)
         const int en = n[4] > 1 ? n[4] : 1;
         return md_sol_length(n) >= P.target_solution && n[4] > 0 && (double)md_col_enemies(n) / (double)en > P.target_col_enemies;
@@ -148,7 +177,7 @@ PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t
     return n[5] >= P.target_solution;
 }
 PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t* start) { return episode_over(P, n, start, P.prob); }
-PCGRL_HD int num_stats(int prob) { return prob == PCGRL_PROB_BINARY ? 2 : (prob == PCGRL_PROB_ZELDA ? 7 : (prob == PCGRL_PROB_SOKOBAN ? 6 : 8)); }
+PCGRL_HD int num_stats(int prob) { return prob == PCGRL_PROB_BINARY ? 2 : (prob == PCGRL_PROB_ZELDA ? 7 : (prob == PCGRL_PROB_SOKOBAN ? 6 : 8)); }   // mdungeon, ddave: packed rows
 
 // ---------------------------------------------------------------- bitboard programs
 //
@@ -596,4 +625,51 @@ PCGRL_D bool mdungeon_stats(B& g, const PcgrlParams& P, typename B::mask_t b0, t
     out[6] = P.prob_width * P.prob_height;
     out[7] = 0;
     return np_ == 1 && nx == 1 && regions == 1;
+}
+
+// helper.py:37-43, 56-62 get_floor_dist(map, ["player"], ["solid"]): for every player tile the number of cells between
+// it and the first solid tile below it in its column, or H - 1 if there is none.  All player bits fall together, one
+// row per round; `valid` has the rows of the map.
+template <class B>
+PCGRL_D int floor_dist(B& g, typename B::mask_t player, typename B::mask_t solid, typename B::mask_t valid, int H) {
+    typedef typename B::mask_t M;
+    M act = player;
+    int n_act = g.popcount_sum(act), result = 0, lost = 0;
+    for (int dy = 1; dy < H && n_act > 0; dy++) {
+        const M moved = g.up(act) & valid;               // row r receives row r - 1
+        const int n_moved = g.popcount_sum(moved);
+        lost += n_act - n_moved;                         // left the map through its last row
+        const M hit = moved & solid;
+        const int n_hit = g.popcount_sum(hit);
+        result += n_hit * (dy - 1);
+        act = moved & ~solid;
+        n_act = n_moved - n_hit;
+    }
+    return result + (lost + n_act) * (H - 1);
+}
+
+// ddave_prob.py:141-161 without the planner.  out: the packed row described at dd_pack (dist-win default W*H, no jumps,
+// nothing collected).  Returns true when the planner precondition (ddave_prob.py:156-157) holds.
+template <class B>
+PCGRL_D bool ddave_stats(B& g, const PcgrlParams& P, typename B::mask_t b0, typename B::mask_t b1,
+                         typename B::mask_t b2, typename B::mask_t valid, int32_t* out) {
+    typedef typename B::mask_t M;
+    // ids: 0 empty 1 solid 2 player 3 exit 4 diamond 5 key 6 spike (ddave_prob.py:48-49)
+    M solid = ~b2 & ~b1 & b0 & valid;
+    M player = ~b2 & b1 & ~b0 & valid;
+    M exitm = ~b2 & b1 & b0 & valid;
+    M diamond = b2 & ~b1 & ~b0 & valid;
+    M key = b2 & ~b1 & b0 & valid;
+    M spike = b2 & b1 & ~b0 & valid;
+    const int np_ = g.popcount_sum(player), nx = g.popcount_sum(exitm), nk = g.popcount_sum(key);
+    out[0] = (np_ & 255) | ((nx & 255) << 8) | ((nk & 255) << 16);
+    out[1] = floor_dist(g, player, solid, valid, P.height);
+    out[2] = g.popcount_sum(diamond);
+    out[3] = g.popcount_sum(spike);
+    const int regions = count_regions(g, valid & ~solid & ~spike);
+    out[4] = regions;
+    out[5] = 0;
+    out[6] = P.prob_width * P.prob_height;
+    out[7] = 0;
+    return np_ == 1 && nx == 1 && nk == 1 && regions == 1;
 }

@@ -36,12 +36,12 @@ class InfoBatch:
         if key == "max_changes":
             return self.max_changes
         if self._decode is not None:
-            return self._decode(self.table)[:, self.keys.index(key)]
+            return self._decode(self.table, [key])[:, 0]
         return self.table[:, self.keys.index(key)]
 
     def to_list(self):
         t = self.table.cpu().numpy()
-        vals = self._decode(self.table).cpu().numpy() if self._decode is not None else t
+        vals = self._decode(self.table, self.keys).cpu().numpy() if self._decode is not None else t
         out = []
         for row, v in zip(t, vals):
             d = {k: int(v[i]) for i, k in enumerate(self.keys)}
@@ -263,7 +263,7 @@ class BatchedPcgrlEnv:
         self._last_actions = a   # keep the buffer alive until the launches are done
         _lib.check(self._lib.pcgrl_step(self._handle, C.c_void_p(a.data_ptr()), self._stream()), "pcgrl_step")
         b = self._bufs
-        decode = self._prob.decode_rows if self._prob.name == "mdungeon" else None
+        decode = self._prob.decode_rows if self._prob.packed_rows else None
         info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
         return self._obs(), b["reward"], b["done"].view(self._torch.bool), info
 

@@ -2,14 +2,14 @@
 
 The statistics, rewards and episode-over tests run on the GPU (csrc/pcgrl_algos.h); these
 classes hold what the reference keeps as Python attributes (probs/problem.py:10-20,
-binary_prob.py:14-27, zelda_prob.py:17-37, sokoban_prob.py:15-36, mdungeon_prob.py:16-41) and reproduce
+binary_prob.py:14-27, zelda_prob.py:17-37, sokoban_prob.py:15-36, mdungeon_prob.py:16-41, ddave_prob.py:15-40) and reproduce
 `adjust_param` (problem.py:66-72 and the subclasses) including its quirks: `probs` only
 overrides existing keys, sokoban `max_targets` overwrites `max_crates`, the sokoban kwarg is
 `min_solution`.
 """
 from collections import OrderedDict
 
-PROB_IDS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3}
+PROB_IDS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3, "ddave": 4}
 
 
 class Problem:
@@ -50,10 +50,16 @@ class Problem:
     def device_params(self):
         return {}
 
-    def decode_rows(self, table):
-        """Device stats / info rows (torch int32 [N, >=8]) -> columns in the order of `stat_keys`.  Identity for the
-        problems whose rows hold one value per slot."""
-        return table[:, :len(self.stat_keys)]
+    packed_rows = False      # True: the device row packs several values into a slot (decode_rows spreads them out)
+
+    def decode_rows(self, table, keys=None):
+        """Device stats / info rows (torch int32 [N, >=8]) -> columns in the order of `keys` (default `stat_keys`).
+        Plain slices for the problems whose rows hold one value per slot."""
+        keys = list(keys or self.stat_keys)
+        idx = [self.stat_keys.index(k) for k in keys]
+        if idx == list(range(len(idx))):
+            return table[:, :len(idx)]
+        return table[:, idx]
 
 
 class BinaryProblem(Problem):
@@ -180,14 +186,66 @@ class MDungeonProblem(Problem):
                     max_potions=int(self._max_potions), max_treasures=int(self._max_treasures),
                     target_col_enemies=float(self._target_col_enemies), target_solution=int(self._target_solution))
 
-    def decode_rows(self, table):
+    packed_rows = True
+
+    def decode_rows(self, table, keys=None):
         import torch
         won = (table[:, 7] >> 24) & 1
         zero = torch.zeros_like(won)
-        cols = [table[:, k] for k in range(6)]
-        cols += [table[:, 7] & 255, (table[:, 7] >> 8) & 255, (table[:, 7] >> 16) & 255]
-        cols += [torch.where(won == 1, zero, table[:, 6]), torch.where(won == 1, table[:, 6], zero)]
-        return torch.stack(cols, 1)
+        cols = {k: table[:, i] for i, k in enumerate(self.stat_keys[:6])}
+        cols.update({"col-potions": table[:, 7] & 255, "col-treasures": (table[:, 7] >> 8) & 255,
+                     "col-enemies": (table[:, 7] >> 16) & 255,
+                     "dist-win": torch.where(won == 1, zero, table[:, 6]), "sol-length": torch.where(won == 1, table[:, 6], zero)})
+        return torch.stack([cols[k] for k in (keys or self.stat_keys)], 1)
 
 
-PROBLEMS = {"binary": BinaryProblem, "zelda": ZeldaProblem, "sokoban": SokobanProblem, "mdungeon": MDungeonProblem}
+class DDaveProblem(Problem):
+    """probs/ddave_prob.py.  Eleven statistics in the eight slots of a device row (include/pcgrl_hip.h,
+    pcgrl_layout.stats); note that get_debug_info leaves `dist-floor` out and swaps two keys (ddave_prob.py:232-245)."""
+    name = "ddave"
+    tiles = ("empty", "solid", "player", "exit", "diamond", "key", "spike")
+    stat_keys = ("player", "dist-floor", "exit", "diamonds", "key", "spikes", "regions", "num-jumps", "col-diamonds",
+                 "dist-win", "sol-length")
+    info_keys = ("player", "exit", "diamonds", "key", "spikes", "regions", "col-diamonds", "num-jumps", "dist-win", "sol-length")
+    reward_keys = ("player", "dist-floor", "exit", "diamonds", "key", "spikes", "regions", "num-jumps", "dist-win", "sol-length")
+    packed_rows = True
+
+    def __init__(self):
+        super().__init__()
+        self._width, self._height = 11, 7
+        self._prob = OrderedDict([("empty", 0.5), ("solid", 0.3), ("player", 0.02), ("exit", 0.02), ("diamond", 0.04),
+                                  ("key", 0.02), ("spike", 0.1)])
+        self._border_tile = "solid"
+        self._solver_power = 5000
+        self._max_diamonds = 3
+        self._min_spikes = 10
+        self._target_jumps = 2
+        self._target_solution = 20
+        self._rewards = OrderedDict([("player", 3), ("dist-floor", 2), ("exit", 3), ("diamonds", 1), ("key", 3), ("spikes", 1),
+                                     ("regions", 5), ("num-jumps", 3), ("dist-win", 0.1), ("sol-length", 1)])
+
+    def adjust_param(self, **kwargs):
+        super().adjust_param(**kwargs)
+        self._solver_power = kwargs.get("solver_power", self._solver_power)
+        self._max_diamonds = kwargs.get("max_diamonds", self._max_diamonds)
+        self._min_spikes = kwargs.get("min_spikes", self._min_spikes)
+        self._target_jumps = kwargs.get("target_jumps", self._target_jumps)
+        self._target_solution = kwargs.get("target_solution", self._target_solution)
+
+    def device_params(self):
+        return dict(solver_power=int(self._solver_power), max_diamonds=int(self._max_diamonds), min_spikes=int(self._min_spikes),
+                    target_jumps=int(self._target_jumps), target_solution=int(self._target_solution))
+
+    def decode_rows(self, table, keys=None):
+        import torch
+        won = (table[:, 7] >> 24) & 1
+        zero = torch.zeros_like(won)
+        cols = {"player": table[:, 0] & 255, "exit": (table[:, 0] >> 8) & 255, "key": (table[:, 0] >> 16) & 255,
+                "dist-floor": table[:, 1], "diamonds": table[:, 2], "spikes": table[:, 3], "regions": table[:, 4],
+                "num-jumps": table[:, 5], "col-diamonds": table[:, 7] & 255,
+                "dist-win": torch.where(won == 1, zero, table[:, 6]), "sol-length": torch.where(won == 1, table[:, 6], zero)}
+        return torch.stack([cols[k] for k in (keys or self.stat_keys)], 1)
+
+
+PROBLEMS = {"binary": BinaryProblem, "zelda": ZeldaProblem, "sokoban": SokobanProblem, "mdungeon": MDungeonProblem,
+            "ddave": DDaveProblem}

@@ -8,6 +8,7 @@
  *   pcgrl_create / pcgrl_configure   PcgrlEnv.__init__ pcgrl_env.py:27-42, adjust_param :106-115,
  *                                    Problem/Representation.adjust_param (probs/problem.py:66-72,
  *                                    binary_prob.py:49-59, zelda_prob.py:59-71, sokoban_prob.py:60-73, mdungeon_prob.py:68-84,
+ *                                    ddave_prob.py:67-82,
  *                                    reps/representation.py:53-54, narrow_rep.py:86-88, turtle_rep.py:42-44)
  *   pcgrl_seed                       PcgrlEnv.seed pcgrl_env.py:54-57 (host passes MT19937 keys)
  *   pcgrl_reset                      PcgrlEnv.reset pcgrl_env.py:66-76 for every environment
@@ -32,14 +33,15 @@ extern "C" {
 #endif
 
 /* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]); + pcgrl_seed_words.
- * 4: + the mdungeon problem: pcgrl_config grew (max_potions, max_treasures, target_col_enemies, rewards[12]). */
-#define PCGRL_ABI_VERSION 4
+ * 4: + the mdungeon problem: pcgrl_config grew (max_potions, max_treasures, target_col_enemies, rewards[12]).
+ * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps). */
+#define PCGRL_ABI_VERSION 5
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
 #define PCGRL_ESTATE (-3)   /* call order violated (e.g. step before bind/reset) */
 
-enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2, PCGRL_MDUNGEON = 3 };
+enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2, PCGRL_MDUNGEON = 3, PCGRL_DDAVE = 4 };
 enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2, PCGRL_NARROW_CAST = 3, PCGRL_NARROW_MULTI = 4, PCGRL_TURTLE_CAST = 5 };
 
 /* Batch-wide parameters (everything the reference keeps as attributes of PcgrlEnv/Problem/Representation). */
@@ -54,6 +56,8 @@ typedef struct pcgrl_config {
     int32_t max_enemies, target_enemy_dist;            /* zelda (max_enemies: mdungeon too) */
     int32_t max_crates, target_solution, solver_power; /* sokoban (target_solution, solver_power: mdungeon too) */
     int32_t max_potions, max_treasures;                /* mdungeon */
+    int32_t max_diamonds, min_spikes, target_jumps;    /* ddave (+ target_solution, solver_power) */
+    int32_t reserved_;
     double target_col_enemies;                         /* mdungeon */
     double tile_probs[8];                  /* Problem._prob in tile order (un-normalised) */
     double rewards[12];                    /* Problem._rewards in the problem's own key order */
@@ -64,7 +68,7 @@ typedef struct pcgrl_layout {
     int32_t group;        /* lanes per map: 16 (height <= 16) or 64 */
     int32_t mask_bytes;   /* bytes per row mask: 4 (width <= 32) or 8 */
     int32_t nplanes;      /* bit planes of the tile id: 1 binary, 3 zelda/sokoban */
-    int32_t nstats;       /* used slots of a stats row: 2 binary, 7 zelda, 6 sokoban, 8 mdungeon (packed, see below) */
+    int32_t nstats;       /* used slots of a stats row: 2 binary, 7 zelda, 6 sokoban, 8 mdungeon / ddave (packed, see below) */
     size_t map;           /* u8  [N,H,W]   observation "map" */
     size_t old_map;       /* u8  [N,H,W]   Representation._old_map */
     size_t heatmap;       /* i16 [N,H,W]   observation "heatmap" (counts) */
@@ -74,7 +78,9 @@ typedef struct pcgrl_layout {
     size_t stats;         /* i32 [N,8]     current _rep_stats.  mdungeon keeps its eleven values in eight slots:
                                             player, exit, potions, treasures, enemies, regions, then slot 6 = sol-length if
                                             the planner won else dist-win, slot 7 = col-potions | col-treasures << 8 |
-                                            col-enemies << 16 | won << 24 */
+                                            col-enemies << 16 | won << 24; ddave likewise: player | exit << 8 | key << 16,
+                                            dist-floor, diamonds, spikes, regions, num-jumps, then slot 6 = sol-length if the
+                                            planner won else dist-win, slot 7 = col-diamonds | won << 24 */
     size_t start_stats;   /* i32 [N,8]     Problem._start_stats */
     size_t info;          /* i32 [N,10]    per-step info: stats[8], iterations, changes */
     size_t reward;        /* f64 [N] */

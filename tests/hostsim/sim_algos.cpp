@@ -16,6 +16,7 @@ static int g_trace_site[4096], g_trace_rounds[4096], g_trace_n = 0;
 #include "../../gym_pcgrl_amd/csrc/sokoban_fast.h"
 #include "../../gym_pcgrl_amd/csrc/mdungeon_solver.h"
 #include "../../gym_pcgrl_amd/csrc/mdungeon_fast.h"
+#include "../../gym_pcgrl_amd/csrc/ddave_solver.h"
 #include <vector>
 
 template <class T, int G>
@@ -96,6 +97,8 @@ static void run(int prob, const uint8_t* map, int h, int w, int pw, int ph, int3
         out[0] = regions; out[1] = path;
     } else if (prob == PCGRL_PROB_ZELDA) {
         zelda_stats(g, P, b0, b1, b2, valid, out);
+    } else if (prob == PCGRL_PROB_DDAVE) {
+        *need_solver = ddave_stats(g, P, b0, b1, b2, valid, out) ? 1 : 0;
     } else if (prob == PCGRL_PROB_MDUNGEON) {
         *need_solver = mdungeon_stats(g, P, b0, b1, b2, valid, out) ? 1 : 0;
     } else {
@@ -323,6 +326,20 @@ int sim_mdungeon_solve2(const uint8_t* map, int h, int w, int power, int shortcu
     }
     mdf_result(F, key, hh, dd, win, out5);
     return 1;
+}
+// the device planner of the ddave problem (ddave_solver.h) run on the host.  out4 = dist-win, sol-length, num-jumps, col-diamonds
+int sim_ddave_solve(const uint8_t* map, int h, int w, int power, int* out4, int* iters) {
+    if ((w + 2) * (h + 2) > 256) return -1;
+    DdLevel L; DdNode root, work;
+    dd_build_level(map, w, h, L, root);
+    std::vector<DdNode> pool(4 * (size_t)power + 4);
+    std::vector<uint32_t> heap(4 * (size_t)power + 4);
+    int tsize = 1024; while (tsize < 2 * power) tsize <<= 1;
+    if (power <= SOK_LDS_POWER) tsize = SOK_LDS_TABLE;
+    std::vector<uint32_t> table(tsize);
+    uint32_t* tp = table.data();
+    dd_run_game(L, pool.data(), heap.data(), tp, tsize, work, root, power, [tp](int n) { for (int i = 0; i < n; i++) tp[i] = 0; }, out4, iters);
+    return 0;
 }
 long sim_iters_reset() { long v = g_sim_iters; g_sim_iters = 0; return v; }
 void sim_set_spurious(int n) { g_spurious = n; }

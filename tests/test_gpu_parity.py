@@ -13,7 +13,7 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUPPORTED = ("binary", "zelda", "sokoban", "mdungeon")
+SUPPORTED = ("binary", "zelda", "sokoban", "mdungeon", "ddave")
 
 
 def _torch():
@@ -113,6 +113,11 @@ ORACLE_CASES = [
     ("mdungeon", "narrow", (), 128, 120),
     ("mdungeon", "wide", (dict(width=6, height=5), dict(change_percentage=0.7, probs={"empty": 0.7, "solid": 0.08},
                                                          target_solution=4, target_col_enemies=0.25)), 192, 150),
+    ("ddave", "narrow", (), 128, 120),
+    ("ddave", "wide", (dict(width=6, height=5), dict(change_percentage=0.7, probs={"empty": 0.7, "solid": 0.1, "spike": 0.02},
+                                                      target_solution=3, target_jumps=0)), 192, 150),
+    ("ddave", "turtle", (dict(width=9, height=7), dict(change_percentage=0.5, solver_power=150,
+                                                        probs={"empty": 0.6, "solid": 0.15, "player": 0.03, "exit": 0.03, "key": 0.03})), 96, 150),
     ("mdungeon", "turtle", (dict(width=8, height=8), dict(change_percentage=0.5, solver_power=200,
                                                            probs={"empty": 0.5, "solid": 0.03, "ogre": 0.2, "goblin": 0.1})), 96, 150),
 ]
@@ -301,6 +306,7 @@ def test_wrapper_observations_match_reference(path):
     ("zelda", "narrow", 2, 2), ("zelda", "turtlecast", 33, 3), ("zelda", "wide", 64, 5), ("zelda", "narrowcast", 5, 40),
     ("sokoban", "narrow", 1, 3), ("sokoban", "turtle", 14, 14), ("sokoban", "wide", 3, 8),
     ("mdungeon", "narrow", 1, 2), ("mdungeon", "turtlecast", 14, 14), ("mdungeon", "wide", 3, 9), ("mdungeon", "narrowmulti", 18, 10),
+    ("ddave", "narrow", 1, 1), ("ddave", "turtle", 14, 14), ("ddave", "wide", 9, 3), ("ddave", "narrowcast", 12, 16),
 ], ids=lambda v: str(v))
 def test_edge_shapes_vs_oracle(prob, rep, w, h):
     torch = _torch()
@@ -368,7 +374,7 @@ def test_make_vec_envs_surface():
 
 # ------------------------------------------------------------------ episode statistics + rollout collection
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-wide-v0", "sokoban-turtle-v0", "mdungeon-narrow-v0"])
+@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-wide-v0", "sokoban-turtle-v0", "mdungeon-narrow-v0", "ddave-wide-v0"])
 def test_episode_stats_match_oracle_sums(env_id):
     """The in-kernel Monitor (pcgrl_bind_episode_stats): return and length latched when an episode ends must equal
     the sums over the oracle's rewards of that episode, for every environment and every episode."""
@@ -481,6 +487,35 @@ def test_mdungeon_generic_search_path(path, monkeypatch):
     got = env.stats.cpu().numpy().astype(np.int64)
     assert env.check_status() == 0
     assert np.array_equal(got, d["stats"])
+
+
+@pytest.mark.gpu
+def test_ddave_large_solver_power_vs_oracle():
+    """ddave levels with a solver_power beyond the LDS heap (heap and visited table in the global arena) against the
+    oracle: open levels with ledges, many diamonds."""
+    _torch()
+    rs = np.random.RandomState(29)
+    h, w, power = 8, 12, 6000
+    maps = []
+    while len(maps) < 32:
+        m = np.zeros((h, w), np.uint8)
+        for _k in range(rs.randint(1, 5)):
+            y = rs.randint(1, h); x0 = rs.randint(0, w); x1 = rs.randint(x0, w) + 1
+            m[y, x0:x1] = 1
+        cells = rs.permutation(h * w)
+        m.flat[cells[0]] = 2; m.flat[cells[1]] = 3; m.flat[cells[2]] = 5
+        k = rs.randint(0, 8)
+        m.flat[cells[3:3 + k]] = 4
+        m.flat[cells[3 + k:3 + k + rs.randint(0, 4)]] = 6
+        maps.append(m)
+    maps = np.array(maps)
+    env = _make("ddave", "wide", len(maps), [dict(width=w, height=h), dict(solver_power=power)])
+    env.reset()
+    env.set_maps(maps)
+    got = env.stats.cpu().numpy().astype(np.int64)
+    exp = np.array([ol.get_stats("ddave", m, solver_power=power) for m in maps])
+    assert np.array_equal(got, exp), np.nonzero((got != exp).any(1))[0]
+    assert (exp[:, 10] > 0).any() and (exp[:, 10] == 0).any()
 
 
 @pytest.mark.gpu
@@ -679,7 +714,7 @@ def test_device_seeding_matches_numpy():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-turtle-v0", "sokoban-wide-v0", "mdungeon-turtle-v0"])
+@pytest.mark.parametrize("env_id", ["binary-narrow-v0", "zelda-turtle-v0", "sokoban-wide-v0", "mdungeon-turtle-v0", "ddave-narrow-v0"])
 def test_state_dict_round_trip(env_id):
     """Checkpoint / resume of the environment state: a second batch that loads the state_dict of the
     first continues exactly like it."""

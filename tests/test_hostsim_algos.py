@@ -53,7 +53,14 @@ def test_bitboard_stats_vs_golden(sim, path):
         for variant in ((0,) if i % 7 else (0, 1, 2, 3)):
             out, need = sim_stats(sim, prob, m, variant)
             exp = d["stats"][i]
-            if prob == "mdungeon":
+            if prob == "ddave":
+                ran = d["agents"][i, 4] > -2
+                assert bool(need) == bool(ran), i
+                # packed row: player | exit << 8 | key << 16, dist-floor, diamonds, spikes, regions
+                assert list(out[:5]) == [exp[0] | exp[2] << 8 | exp[4] << 16, exp[1], exp[3], exp[5], exp[6]], (i, out, exp, m)
+                if not ran:
+                    assert (out[5], out[6], out[7]) == (0, exp[9], 0) and exp[7] == exp[8] == exp[10] == 0, (i, out, exp)
+            elif prob == "mdungeon":
                 ran = d["agents"][i, 4] > -2
                 assert bool(need) == bool(ran), i
                 assert np.array_equal(out[:6], exp[:6]), (i, out, exp)
@@ -134,6 +141,28 @@ def test_device_mdungeon_solver_vs_golden(sim, fast):
             n += 1
     assert n > 400 and skipped > 5 and capped > 20
     assert (took_fast > 0.9 * n) if fast else took_fast == 0
+
+
+def test_device_ddave_solver_vs_golden(sim):
+    """gym_pcgrl_amd/csrc/ddave_solver.h (the code k_ddave runs) compiled for the host, against the reference's planner
+    results and per-agent iteration counts."""
+    sim.sim_ddave_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = capped = 0
+    for path in sorted(glob.glob(os.path.join(G, "stats_ddave_*.npz"))):
+        d = np.load(path)
+        power = int(d["solver_power"])
+        for i, m in enumerate(d["maps"]):
+            if d["agents"][i, 4] == -2:
+                continue
+            m = np.ascontiguousarray(m)
+            exp = [d["stats"][i, 9], d["stats"][i, 10], d["stats"][i, 7], d["stats"][i, 8]]
+            out, it = np.zeros(4, np.int32), np.zeros(4, np.int32)
+            assert sim.sim_ddave_solve(_p(m), m.shape[0], m.shape[1], power, _p(out), _p(it)) == 0
+            assert list(out) == exp, (path, i, out, exp)
+            assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
+            capped += int((it >= power).any())
+            n += 1
+    assert n > 400 and capped > 30
 
 
 def test_bitboard_stats_vs_oracle_random(sim):

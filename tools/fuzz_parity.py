@@ -16,11 +16,11 @@ ONLY = sys.argv[3] if len(sys.argv) > 3 else None
 REPS = ["narrow", "wide", "turtle", "narrowcast", "narrowmulti", "turtlecast"]
 t0 = time.time()
 for case in range(cases):
-    prob = ONLY or ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon"][rs.randint(7)]
+    prob = ONLY or ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon", "ddave", "ddave"][rs.randint(9)]
     rep = REPS[rs.randint(6)]
     if prob == "sokoban":
         w, h = int(rs.randint(2, 8)), int(rs.randint(2, 8))
-    elif prob == "mdungeon":
+    elif prob in ("mdungeon", "ddave"):
         w, h = int(rs.randint(1, 13)), int(rs.randint(1, 13))
     else:
         w, h = int(rs.randint(1, 41)), int(rs.randint(1, 41))
@@ -39,6 +39,14 @@ for case in range(cases):
             calls.append(dict(target_solution=int(rs.randint(1, 8)), target_col_enemies=float(rs.choice([0.0, 0.3, 0.5])),
                               max_enemies=int(rs.randint(1, 5)), max_potions=int(rs.randint(0, 3)), max_treasures=int(rs.randint(0, 3)),
                               rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "sol-length": float(rs.choice([1, 0.7]))}))
+    if prob == "ddave":
+        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000, 5000]))))
+        if rs.rand() < 0.7:     # open maps with few players / exits / keys: the planner runs in a good share of the steps
+            calls.append(dict(probs={"empty": 0.7, "solid": float(rs.choice([0.05, 0.15])), "player": 0.04, "exit": 0.04, "key": 0.04,
+                                     "spike": float(rs.choice([0.0, 0.03]))}))
+        if rs.rand() < 0.5:
+            calls.append(dict(target_solution=int(rs.randint(1, 8)), target_jumps=int(rs.randint(0, 3)), max_diamonds=int(rs.randint(0, 4)),
+                              min_spikes=int(rs.randint(0, 6)), rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "dist-floor": float(rs.choice([2, 0.5]))}))
     if rep in ("narrow", "narrowcast", "narrowmulti") and rs.rand() < 0.3:
         calls.append(dict(random_tile=False))
     if rep in ("turtle", "turtlecast") and rs.rand() < 0.5:
