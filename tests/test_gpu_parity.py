@@ -99,6 +99,23 @@ def test_golden_trajectory(path):
     _compare_traj(env, d, T)
 
 
+_SWITCH_TRAJ = [("PCGRL_NO_FUSED", p) for p in sorted(glob.glob(os.path.join(G, "traj_binary_*.npz")))
+                if "64" not in os.path.basename(p) and "40x33" not in os.path.basename(p) and "cast" not in os.path.basename(p)
+                and "multi" not in os.path.basename(p)] + \
+               [("PCGRL_FUSED_ZELDA", p) for p in sorted(glob.glob(os.path.join(G, "traj_zelda_*.npz")))
+                if "cast" not in os.path.basename(p)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch,path", _SWITCH_TRAJ, ids=lambda v: os.path.basename(v) if v.endswith(".npz") else v)
+def test_golden_trajectory_other_step_pipeline(switch, path, monkeypatch):
+    """Binary maps of at most 16 rows take the fused one-launch step (k_step) by default and zelda the two-launch
+    pipeline (k_update + k_stats); the library switches select the other pipeline for each, and it must reproduce the
+    reference's trajectories just the same."""
+    monkeypatch.setenv(switch, "1")
+    test_golden_trajectory(path)
+
+
 # ------------------------------------------------------------------ seeded rollouts against the oracle
 ORACLE_CASES = [
     ("binary", "narrow", (), 192, 160),
@@ -680,7 +697,18 @@ def test_paired_certain_resets(prob, rep, calls, E, T, monkeypatch):
     """With thousands of certain resets per launch a wavefront of k_stats takes two of them (four statistics side by
     side).  PCGRL_PAIR_MIN=1 forces that mode on small batches; the rollout must still equal the oracle's."""
     monkeypatch.setenv("PCGRL_PAIR_MIN", "1")
+    monkeypatch.setenv("PCGRL_NO_FUSED", "1")      # k_stats is the kernel that pairs (binary would take k_step otherwise)
     test_rollout_vs_oracle(prob, rep, calls, E, T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
+    """The binary soak cases on maps of at most 16 rows through k_update + k_stats (PCGRL_NO_FUSED=1) instead of the fused
+    k_step -- with two certain resets per wavefront forced as well (PCGRL_PAIR_MIN=1), which only that pipeline has."""
+    monkeypatch.setenv("PCGRL_NO_FUSED", "1")
+    monkeypatch.setenv("PCGRL_PAIR_MIN", "1")
+    test_incremental_routes_soak(*SOAK_CASES[idx])
 
 
 @pytest.mark.gpu
