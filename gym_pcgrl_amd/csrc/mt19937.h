@@ -79,6 +79,16 @@ PCGRL_HD void pcgrl_build_cdf(const double* prob, int n, double* cdf) {
     double last = cdf[n - 1];
     for (int i = 0; i < n; i++) cdf[i] /= last;
 }
+// searchsorted(cdf, u, side='right') with the number of tiles known at compile time (cdf stays in registers)
+template <int N>
+PCGRL_HD int pcgrl_pick_tile_c(const double* cdf, double u) {
+    int idx = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < N; i++) idx += (cdf[i] <= u) ? 1 : 0;
+    return idx < N ? idx : N - 1;
+}
 // searchsorted(cdf, u, side='right')
 PCGRL_HD int pcgrl_pick_tile(const double* cdf, int n, double u) {
     int idx = 0;

@@ -53,15 +53,16 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     __builtin_amdgcn_wave_barrier();
     if (gen_map) {
         // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
-        double cdf[PCGRL_MAX_TILES];
+        // the number of tiles is a property of the problem: constant indices only -- a run-time index into the by-value
+        // parameter block makes the compiler keep a copy of the whole block in scratch memory
+        constexpr int NT = PROB == PCGRL_PROB_BINARY ? 2 : PROB == PCGRL_PROB_SOKOBAN ? 5 : PROB == PCGRL_PROB_DDAVE ? 7 : 8;
+        double cdf[NT];
         if (PROB == PCGRL_PROB_BINARY) {
             double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};
             pcgrl_build_cdf(p, 2, cdf);
         } else {
-            // constant indices only: a run-time index into the by-value parameter block makes the compiler keep a
-            // copy of the whole block in scratch memory (entries past ntiles are never looked at)
 #pragma unroll
-            for (int i = 0; i < PCGRL_MAX_TILES; i++) cdf[i] = P.cdf[i];
+            for (int i = 0; i < NT; i++) cdf[i] = P.cdf[i];
         }
         for (int c0 = 0; c0 < cells; c0 += 64) {
             // cell c draws ring words 2c, 2c+1 of this episode: 128 new words per round, every
@@ -76,7 +77,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
                 mt[s] = ya;
                 mt[mt_wrap(s + 1)] = yb;
                 const double u = mt_to_double(mt_temper(ya), mt_temper(yb));
-                const uint8_t t = (uint8_t)pcgrl_pick_tile(cdf, P.ntiles, u);
+                const uint8_t t = (uint8_t)pcgrl_pick_tile_c<NT>(cdf, u);
                 tiles[c] = t;
                 map_g[c] = t;
                 old_g[c] = t;

@@ -112,3 +112,26 @@ def test_graft_entry_build_runs():
     library, checks the ABI version, builds the oracle)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_packed_stats_rows_decode():
+    """mdungeon and ddave keep eleven statistics in the eight slots of a device row (include/pcgrl_hip.h, md_pack / dd_pack
+    in csrc/pcgrl_algos.h); Problem.decode_rows spreads them out again, in stat_keys or in any requested key order."""
+    import torch
+    from gym_pcgrl_amd.envs.problems import PROBLEMS
+    md = PROBLEMS["mdungeon"]()
+    #            player exit pot tre ene reg  s6   s7 (col-potions | col-treasures << 8 | col-enemies << 16 | won << 24)
+    t = torch.tensor([[1, 1, 2, 3, 4, 1, 23, 1 | 2 << 8 | 3 << 16 | 1 << 24, 7, 8],
+                      [1, 1, 0, 0, 9, 1, -12, 0 | 3 << 8 | 0 << 16, 7, 8],
+                      [2, 0, 5, 1, 0, 3, 77, 0, 7, 8]], dtype=torch.int32)
+    assert md.decode_rows(t).tolist() == [[1, 1, 2, 3, 4, 1, 1, 2, 3, 0, 23], [1, 1, 0, 0, 9, 1, 0, 3, 0, -12, 0],
+                                          [2, 0, 5, 1, 0, 3, 0, 0, 0, 77, 0]]
+    assert md.decode_rows(t, ["sol-length", "dist-win"]).tolist() == [[23, 0], [0, -12], [0, 77]]
+    dd = PROBLEMS["ddave"]()
+    t = torch.tensor([[1 | 1 << 8 | 1 << 16, 3, 2, 5, 1, 4, 17, 2 | 1 << 24, 0, 0],
+                      [2 | 0 << 8 | 3 << 16, 6, 0, 1, 2, 0, 77, 0, 0, 0]], dtype=torch.int32)
+    assert dd.decode_rows(t).tolist() == [[1, 3, 1, 2, 1, 5, 1, 4, 2, 0, 17], [2, 6, 0, 0, 3, 1, 2, 0, 0, 77, 0]]
+    assert dd.decode_rows(t, dd.info_keys).tolist() == [[1, 1, 2, 1, 5, 1, 2, 4, 0, 17], [2, 0, 0, 3, 1, 2, 0, 0, 77, 0]]
+    assert len(dd.info_keys) == 10 and "dist-floor" not in dd.info_keys          # ddave_prob.py:232-245
+    b = PROBLEMS["binary"]()
+    assert b.decode_rows(t).tolist() == [[t[0, 0].item(), 3], [t[1, 0].item(), 6]] and not b.packed_rows
