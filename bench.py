@@ -50,15 +50,18 @@ def make_actions(torch, rep, steps, n, W, H, nt, device, seed):
 
 
 def measured_traffic(workload):
-    """HBM bytes per step from the last committed rocprofv3 PMC passes (profiles/*/<W>_traffic.json:
-    FETCH_SIZE + WRITE_SIZE summed over the step's kernels, in bytes, as reported -- see the SUMMARY.md
-    next to it for the calibration caveat).  None when no profile is committed for the workload."""
+    """HBM bytes per step from the last committed rocprofv3 PMC passes (profiles/*/<W>_traffic.json: FETCH_SIZE and
+    WRITE_SIZE summed over the step's kernels), corrected as calibrated on this GPU with tools/traffic_calib.hip
+    (profiles/*/traffic_calibration.md): FETCH_SIZE reports half of the bytes of the 128-byte lines that are read, for
+    wide coalesced and for narrow scattered reads alike, so fetched bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact for
+    coalesced writes and counts a 32-byte sector per scattered narrow write, so it is taken as it is.
+    None when no profile is committed for the workload."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", workload + "_traffic.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    return d["fetch_bytes_per_step"] + d["write_bytes_per_step"], os.path.relpath(files[-1], ROOT)
+    return 2 * d["fetch_bytes_per_step"] + d["write_bytes_per_step"], os.path.relpath(files[-1], ROOT)
 
 
 def measured_valu(workload, kernel="k_stats"):

@@ -42,8 +42,10 @@ for W in workloads:
         out.append("")
         tot_f = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) for k, v in f.items() if k.startswith("void k_") and len(v["FETCH_SIZE"]) > 4)
         tot_w = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in w.items() if k.startswith("void k_") and len(v["WRITE_SIZE"]) > 4)
-        out.append("HBM traffic per step (sum over the step's kernels, as reported: rocprofv3 KB; FETCH_SIZE may under-report wide coalesced reads by 2x on gfx950, "
-                   "these kernels issue mostly narrow scattered accesses, so the figure is uncalibrated): fetch %.1f MB + write %.1f MB.\n" % (tot_f / 1024, tot_w / 1024))
+        out.append("HBM traffic per step (sum over the step's kernels; rocprofv3 KB): FETCH_SIZE %.1f MB + WRITE_SIZE %.1f MB as reported.  Calibrated "
+                   "on this GPU (`traffic_calibration.md`, `tools/traffic_calib.hip`): FETCH_SIZE is half of the bytes of the 128-byte lines read -- for wide "
+                   "coalesced and narrow scattered reads alike -- and WRITE_SIZE is exact for coalesced writes and counts a 32-byte sector per scattered "
+                   "narrow write, so the step moves **%.1f MB** (2 x fetch + write; what `roofline.traffic` reports).\n" % (tot_f / 1024, tot_w / 1024, (2 * tot_f + tot_w) / 1024))
         json.dump({"workload": W, "fetch_bytes_per_step": tot_f * 1024, "write_bytes_per_step": tot_w * 1024}, open(os.path.join(dst, W + "_traffic.json"), "w"))
         # per-kernel counter averages, read back by bench.py for the VALU-issue figure of the dominant kernel
         pm = {}
@@ -65,5 +67,12 @@ for W in workloads:
                 d["value"] / 1e6, d["ms_per_step"] * 1e3, d["roofline"]["achieved"], d["roofline"]["frac"],
                 (", cpu_baseline %.2f M/s on %d threads (%.0f k/s single)" % (d["cpu_baseline"]["value"] / 1e6, d["cpu_baseline"]["cores"], d["cpu_baseline"]["single_core"] / 1e3)) if "cpu_baseline" in d else ""))
             break
+cal = os.path.join(G, "traffic_calib.txt")
+if os.path.exists(cal):
+    open(os.path.join(dst, "traffic_calibration.md"), "w").write(
+        "# FETCH_SIZE / WRITE_SIZE calibration (MI355X, rocprofv3, `tools/calibrate_traffic.sh`)\n\n"
+        "Known access patterns over a 1 GiB buffer (beyond the 256 MiB Infinity Cache), third repetition:\n\n" + open(cal).read() +
+        "\nReading: FETCH_SIZE = half of the bytes of the 128-byte lines touched, whatever the access width or order; WRITE_SIZE = bytes "
+        "written for full-line coalesced stores, 32 bytes per store for isolated narrow stores.\n")
 open(os.path.join(dst, "SUMMARY.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out)[:3000])
