@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the secondary pcgrl_rollout measurement")
     a = ap.parse_args()
 
     import torch
@@ -202,6 +203,22 @@ def main():
         phase_ms, prof_steps = env.profile_read()
         env.profile(False)
 
+    # secondary figure: the same K steps as ONE pcgrl_rollout call on the action tape (a single launch where the fused
+    # step kernel applies; per-step reward / done / info still written for every step).  Not the headline `value`.
+    rollout = None
+    if rank == 0 and not a.no_rollout:
+        tape = acts[a.warmup:a.warmup + a.steps]
+        env.rollout(tape[:min(20, a.steps)])
+        torch.cuda.synchronize(device)
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        env.rollout(tape)
+        r1.record()
+        torch.cuda.synchronize(device)
+        rms = r0.elapsed_time(r1) / a.steps
+        rollout = {"value": float(n) / (rms * 1e-3), "unit": "env-steps/s (this rank)", "ms_per_step": rms, "steps": a.steps,
+                   "what": "pcgrl_rollout on the same action tape: K steps in one call, per-step reward/done/info kept"}
+
     if rank == 0:
         # dominant kernel (k_stats; for sokoban the solver): its share of the step from the event pass -- the idle
         # intervals of that pass measure the cost of an event pair, which is subtracted -- and, from the committed
@@ -248,6 +265,8 @@ def main():
                          "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
                          "phase_us_per_step_with_event_overhead": ph},
         }
+        if rollout is not None:
+            out["rollout"] = rollout
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, rep, calls)
         print(json.dumps(out))

@@ -8,26 +8,37 @@
 // full recomputations ordered by difficulty bucket, incremental updates -- and after one barrier the four wavefronts work
 // through those tasks (stats_wave_task, the body of k_stats: same statistics, same in-kernel resets).  A block sees ~20
 // changed environments of 64, i.e. five or six wavefront tasks: one or two rounds.
+// pcgrl_rollout runs a whole tape of actions in ONE launch of this kernel (the loop over `steps`).
 // For the binary and zelda problems on maps of at most 16 rows with the single-cell representations and auto-reset; every
 // other configuration takes the two-launch pipeline.
 #pragma once
 
 template <int PROB, int REP, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_step(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity, int gen_map) {
+__global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_step(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity, int gen_map,
+                                                                                                           int steps, size_t action_stride, double* reward_out, uint8_t* done_out, int32_t* info_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // per wave MT ring + tile bytes (in-kernel resets)
     __shared__ int s_items[3][64];      // 0: certain resets, 1: full recomputations (by bucket), 2: incremental updates
     __shared__ int s_n[3];
     __shared__ int s_hist[64];
     constexpr int G = 16, GPW = 4;
-    DevGroup<G, MaskT> g;
-    const int lane64 = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = lane64 / G;
     const int W = P.width, H = P.height;
+    // steps > 1 (pcgrl_rollout): the environments of a block do not depend on any other block, so the block simply goes on
+    // with the next row of the action tape -- no launch, no grid-wide barrier between steps, blocks run ahead of each other
+#pragma clang loop unroll(disable)
+  for (int t = 0; t < steps; t++) {
+    // the thread index goes through an opaque move so that nothing per-lane is hoisted out of the loop and kept in
+    // registers across steps (the single-step kernel needs 97 VGPRs; with hoisting the loop form spilled)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane64 = tid & 63, wv = tid >> 6, gw = lane64 / G;
+    DevGroup<G, MaskT> g(lane64);
+    const int32_t* actions_t = actions + (size_t)t * action_stride;
     if (wv == 1) s_hist[lane64] = 0;
-    __syncthreads();
+    __syncthreads();                        // also: everything the previous step wrote is visible to the whole block
     if (wv == 0) {
         const int e = blockIdx.x * 64 + lane64;
         UpdateOut u = {false, false, false, false, 0, 0};
-        if (e < P.num_envs) u = update_env<REP, MaskT>(P, B, actions, e);
+        if (e < P.num_envs) u = update_env<REP, MaskT>(P, B, actions_t, e);
         const bool first = u.rst || u.sure_done;               // reset-only, or certain to end: k_stats' "lone" items
         const bool packed_full = PROB == PCGRL_PROB_ZELDA && B.zelda_inc;
         int dest = -1, v = e;
@@ -44,8 +55,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
         __builtin_amdgcn_wave_barrier();
         int incl = s_hist[lane64];
         for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane64 >= o) incl += t;
+            const int up = __shfl_up(incl, o, 64);
+            if (lane64 >= o) incl += up;
         }
         const int excl = incl - s_hist[lane64];
         __builtin_amdgcn_wave_barrier();
@@ -70,4 +81,13 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
         const int raw = have ? s_items[lone ? 0 : (inc ? 2 : 1)][item] : 0;
         stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, false, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask);
     }
+    if (reward_out || done_out || info_out) {   // kernel-uniform: the per-step outputs of the block's environments, row t
+        __syncthreads();
+        const int e0 = blockIdx.x * 64, ne = (P.num_envs - e0) < 64 ? (P.num_envs - e0) : 64;
+        const size_t row = (size_t)t * P.num_envs + e0;
+        if (reward_out && tid < ne) reward_out[row + tid] = B.reward[e0 + tid];
+        if (done_out && tid >= 64 && tid - 64 < ne) done_out[row + tid - 64] = B.done[e0 + tid - 64];
+        if (info_out) for (int i = tid; i < ne * 10; i += PCGRL_BLOCK) info_out[row * 10 + i] = B.info[(size_t)e0 * 10 + i];
+    }
+  }
 }

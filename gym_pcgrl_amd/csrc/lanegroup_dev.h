@@ -61,6 +61,7 @@ struct DevGroup<16, MaskT> : DevLaneOps<MaskT> {
         lane = l & 15;
         shift = l & 48;
     }
+    __device__ __forceinline__ explicit DevGroup(int lane64) { lane = lane64 & 15; shift = lane64 & 48; }
     __device__ __forceinline__ mask_t up(mask_t m) const { return dpp_mov0<0x111>(m); }    // row_shr:1
     __device__ __forceinline__ mask_t down(mask_t m) const { return dpp_mov0<0x101>(m); }  // row_shl:1
     __device__ __forceinline__ uint32_t ballot(bool p) const {

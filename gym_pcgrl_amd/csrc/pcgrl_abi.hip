@@ -431,32 +431,40 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
 // One fused launch per step (kernels_step.h) where it applies: binary, maps of at most 16 rows, single-cell
 // representations, auto-reset with the in-kernel reset.  PCGRL_NO_FUSED=1 keeps the two-launch pipeline (A/B, tests).
 static bool env_is_one(const char* name) { const char* v = getenv(name); return v && v[0] == '1'; }
-static bool fused_step_applies(const pcgrl_env* h) {
+static bool fused_step_applies(const pcgrl_env* h, bool rollout = false) {
     const PcgrlParams& P = h->P;
     // (zelda changes 7 of 8 environments per step: a block then has ~18 wavefront tasks for its four wavefronts and the global
     //  work lists balance better -- measured 48 vs 42.6 us/step on C3; PCGRL_FUSED_ZELDA=1 takes the fused kernel anyway)
-    const bool prob_ok = P.prob == PCGRL_PROB_BINARY || (P.prob == PCGRL_PROB_ZELDA && env_is_one("PCGRL_FUSED_ZELDA"));
+    // A rollout has no barrier between steps, so the imbalance between blocks averages out over the tape: zelda takes k_step there.
+    const bool prob_ok = P.prob == PCGRL_PROB_BINARY || (P.prob == PCGRL_PROB_ZELDA && (rollout || env_is_one("PCGRL_FUSED_ZELDA")));
     return prob_ok && P.group == 16 && P.rep <= PCGRL_REP_TURTLE && P.auto_reset &&
            h->B.inline_reset && !env_is_one("PCGRL_NO_FUSED");
 }
+struct RolloutArgs { int steps; size_t action_stride; double* reward_out; uint8_t* done_out; int32_t* info_out; };
 template <int PROB, class MaskT>
-static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
+static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
     const PcgrlParams& P = h->P;
     const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
     const int grid = (P.num_envs + 63) / 64;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
     switch (P.rep) {
-        case PCGRL_REP_NARROW: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen); break;
-        case PCGRL_REP_WIDE: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_WIDE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen); break;
-        default: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_TURTLE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen); break;
+        case PCGRL_REP_NARROW: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen,
+                                                         R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); break;
+        case PCGRL_REP_WIDE: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_WIDE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen,
+                                                         R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); break;
+        default: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_TURTLE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen,
+                                                         R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); break;
     }
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
-static int launch_step(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
+static int launch_step(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R = RolloutArgs{1, 0, nullptr, nullptr, nullptr}) {
     const bool m4 = h->P.mask_bytes == 4;
-    if (h->P.prob == PCGRL_PROB_BINARY) return m4 ? launch_step_pm<PCGRL_PROB_BINARY, uint32_t>(h, actions, parity, st) : launch_step_pm<PCGRL_PROB_BINARY, uint64_t>(h, actions, parity, st);
-    return m4 ? launch_step_pm<PCGRL_PROB_ZELDA, uint32_t>(h, actions, parity, st) : launch_step_pm<PCGRL_PROB_ZELDA, uint64_t>(h, actions, parity, st);
+    if (h->P.prob == PCGRL_PROB_BINARY) return m4 ? launch_step_pm<PCGRL_PROB_BINARY, uint32_t>(h, actions, parity, st, R) : launch_step_pm<PCGRL_PROB_BINARY, uint64_t>(h, actions, parity, st, R);
+    return m4 ? launch_step_pm<PCGRL_PROB_ZELDA, uint32_t>(h, actions, parity, st, R) : launch_step_pm<PCGRL_PROB_ZELDA, uint64_t>(h, actions, parity, st, R);
+}
+static int action_width(int rep) {   // int32 values per environment and step
+    return rep == PCGRL_REP_WIDE ? 3 : (rep == PCGRL_REP_NARROW_CAST || rep == PCGRL_REP_TURTLE_CAST) ? 2 : rep == PCGRL_REP_NARROW_MULTI ? 9 : 1;
 }
 
 static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
@@ -605,6 +613,30 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (rc) return rc;
     h->parity ^= 1;
     if (h->profiling) h->prof_steps++;
+    return PCGRL_OK;
+}
+
+// `steps` consecutive pcgrl_step calls on a tape of actions.  Where the fused step kernel applies this is ONE launch: a block
+// of k_step owns 64 environments that depend on nothing outside the block, so it walks down the tape on its own.
+int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* reward_out, uint8_t* done_out, int32_t* info_out, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!actions || steps < 1) return PCGRL_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->P.num_envs, stride = n * action_width(h->P.rep);
+    if (fused_step_applies(h, true) && !h->profiling) {
+        const RolloutArgs R = {steps, stride, reward_out, done_out, info_out};
+        int rc = launch_step(h, actions, h->parity, st, R);
+        if (rc) return rc;
+        if (steps & 1) h->parity ^= 1;
+        return PCGRL_OK;
+    }
+    for (int t = 0; t < steps; t++) {
+        int rc = pcgrl_step(h, actions + (size_t)t * stride, stream);
+        if (rc) return rc;
+        if (reward_out) HIPCHK(hipMemcpyAsync(reward_out + (size_t)t * n, h->B.reward, n * 8, hipMemcpyDeviceToDevice, st));
+        if (done_out) HIPCHK(hipMemcpyAsync(done_out + (size_t)t * n, h->B.done, n, hipMemcpyDeviceToDevice, st));
+        if (info_out) HIPCHK(hipMemcpyAsync(info_out + (size_t)t * n * 10, h->B.info, n * 40, hipMemcpyDeviceToDevice, st));
+    }
     return PCGRL_OK;
 }
 

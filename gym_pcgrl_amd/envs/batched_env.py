@@ -267,6 +267,32 @@ class BatchedPcgrlEnv:
         info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
         return self._obs(), b["reward"], b["done"].view(self._torch.bool), info
 
+    def rollout(self, actions, want_info=True):
+        """`T` consecutive steps on a tape of actions: int tensor [T, N] (narrow, turtle), [T, N, 3] (wide), [T, N, 2] /
+        [T, N, 9] (cast / multi).  Returns (reward f64 [T, N], done bool [T, N], info) with `info` an InfoBatch over the
+        [T*N, 10] table (rows in step-major order) or None.  The environments end up exactly where T calls of step()
+        would leave them; where the whole step is one kernel (binary maps of at most 16 rows) the tape is ONE launch."""
+        if self._needs_reset:
+            raise RuntimeError("reset() must be called before rollout() (and again after adjust_param changed width/height)")
+        torch = self._torch
+        a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
+        T = int(a.shape[0])
+        aw = self._rep.action_width()
+        if a.numel() != T * self.num_envs * aw:
+            raise ValueError("actions must have shape [T, %d%s], got %s" % (self.num_envs, "" if aw == 1 else ", %d" % aw, tuple(a.shape)))
+        rew = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
+        done = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+        info = torch.empty((T, self.num_envs, 10), dtype=torch.int32, device=self.device) if want_info else None
+        self._last_actions = a
+        _lib.check(self._lib.pcgrl_rollout(self._handle, C.c_void_p(a.data_ptr()), T, C.c_void_p(rew.data_ptr()),
+                                           C.c_void_p(done.data_ptr()), C.c_void_p(info.data_ptr()) if want_info else None,
+                                           self._stream()), "pcgrl_rollout")
+        ib = None
+        if want_info:
+            decode = self._prob.decode_rows if self._prob.packed_rows else None
+            ib = InfoBatch(self._prob.info_keys, info.view(T * self.num_envs, 10), self._max_iterations, self._max_changes, decode)
+        return rew, done.view(torch.bool), ib
+
     # gym.vector-style split call
     def step_async(self, actions):
         self._pending = self.step(actions)

@@ -34,8 +34,8 @@ extern "C" {
 
 /* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]); + pcgrl_seed_words.
  * 4: + the mdungeon problem: pcgrl_config grew (max_potions, max_treasures, target_col_enemies, rewards[12]).
- * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps). */
-#define PCGRL_ABI_VERSION 5
+ * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps).  6: + pcgrl_rollout. */
+#define PCGRL_ABI_VERSION 6
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -122,6 +122,15 @@ int pcgrl_reset(pcgrl_env* env, void* stream);
 /* actions: DEVICE pointer, i32 [N] (narrow, turtle), [N,3] = (x, y, tile) (wide), [N,2] = (type, tile)
  * (narrowcast, turtlecast) or [N,9] (narrowmulti: tile+1 per cell of the 3x3 block, 0 = keep). */
 int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
+/* `steps` consecutive pcgrl_step calls on a tape of actions (a random-action rollout as in the reference's README
+ * loop `env.step(env.action_space.sample())`, a recorded episode, an evaluation run): actions DEVICE i32
+ * [steps, N(, k)] laid out like `steps` action arrays of pcgrl_step one after the other.  Optional DEVICE outputs, one
+ * row per step: reward_out f64 [steps, N], done_out u8 [steps, N], info_out i32 [steps, N, 10]; NULL = not wanted.
+ * The state buffers end up exactly as after the equivalent sequence of pcgrl_step calls.  Where one kernel does the
+ * whole step (binary maps of at most 16 rows) the rollout is a single launch -- blocks of environments run ahead of
+ * each other, there is nothing to wait for between steps; everywhere else it is the sequence of steps. */
+int pcgrl_rollout(pcgrl_env* env, const int32_t* actions, int32_t steps, double* reward_out, uint8_t* done_out,
+                  int32_t* info_out, void* stream);
 /* maps: DEVICE pointer u8 [N,H,W]; replaces every map, recomputes stats (start stats unchanged). */
 int pcgrl_set_maps(pcgrl_env* env, const uint8_t* maps, void* stream);
 /* Observation formatting of the reference's composite wrappers (gym_pcgrl/wrappers.py): Cropped.transform

@@ -712,6 +712,51 @@ def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env_id,calls,N,T", [
+    ("binary-narrow-v0", (), 1000, 150),                              # one launch for the whole tape (k_step); 1000: a partial last block
+    ("binary-turtle-v0", (dict(change_percentage=0.1),), 300, 120),
+    ("binary-wide-v0", (dict(width=21, height=9),), 257, 100),
+    ("zelda-wide-v0", (), 200, 60),                                    # the sequence-of-steps fallback
+    ("sokoban-narrow-v0", (), 128, 40),
+    ("mdungeon-turtle-v0", (dict(width=6, height=6),), 96, 40),
+], ids=lambda v: v if isinstance(v, str) else "")
+def test_rollout_equals_steps(env_id, calls, N, T):
+    """pcgrl_rollout (a tape of actions, one launch where the fused step kernel applies) against the same tape fed to
+    pcgrl_step one row at a time on a twin batch: per-step reward / done / info and the complete final state."""
+    torch = _torch()
+    import gym_pcgrl_amd as gp
+    prob, rep = env_id.split("-")[:2]
+    a_env = _make(prob, rep, N, list(calls), seed=77)
+    b_env = _make(prob, rep, N, list(calls), seed=77)
+    a_env.enable_episode_stats(); b_env.enable_episode_stats()
+    a_env.reset(); b_env.reset()
+    sp = a_env.single_action_space
+    g = torch.Generator(device="cuda").manual_seed(5)
+    if hasattr(sp, "n"):
+        tape = torch.randint(0, int(sp.n), (T, N), generator=g, device="cuda", dtype=torch.int32)
+    else:
+        tape = torch.stack([torch.randint(0, int(k), (T, N), generator=g, device="cuda", dtype=torch.int32) for k in sp.nvec], -1)
+    # first half as one rollout, second half as another (state carries over), against T single steps
+    h = T // 2
+    r1, d1, i1 = a_env.rollout(tape[:h])
+    r2, d2, i2 = a_env.rollout(tape[h:])
+    rew = torch.cat([r1, r2]); done = torch.cat([d1, d2]); info = torch.cat([i1.table.view(h, N, 10), i2.table.view(T - h, N, 10)])
+    for t in range(T):
+        obs, r, d, inf = b_env.step(tape[t])
+        assert torch.equal(rew[t], r), ("reward", t)
+        assert torch.equal(done[t], d), ("done", t)
+        assert torch.equal(info[t], inf.table), ("info", t)
+    assert int(done.sum().item()) > 0
+    sa, sb = a_env.state_dict(), b_env.state_dict()
+    for k in sa:
+        if sa[k] is not None:
+            assert torch.equal(sa[k], sb[k]), k
+    # decoded info of the tape
+    key = a_env._prob.info_keys[0]
+    assert torch.equal(i2[key], a_env._prob.decode_rows(i2.table, [key])[:, 0] if a_env._prob.packed_rows else i2.table[:, 0])
+
+
+@pytest.mark.gpu
 def test_device_seeding_matches_numpy():
     """pcgrl_seed_words: MT19937 init_by_array on the device against numpy's RandomState.seed(list) -- keys of two words
     (what gym's hash_seed gives) and of one word."""
