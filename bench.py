@@ -207,15 +207,23 @@ def main():
     # step kernel applies; per-step reward / done / info still written for every step).  Not the headline `value`.
     rollout = None
     if rank == 0 and not a.no_rollout:
+        # a second batch brought to the same state as the first one had when its timed loop started: same seeds, same
+        # warm-up actions -- the tape below is then exactly the work of the timed loop above
+        env2 = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, device=device, seed=rank * n)
+        for kw in calls:
+            env2.adjust_param(**kw)
+        env2.reset()
+        if a.warmup > 0:
+            env2.rollout(acts[:a.warmup], want_info=False)
         tape = acts[a.warmup:a.warmup + a.steps]
-        env.rollout(tape[:min(20, a.steps)])
         torch.cuda.synchronize(device)
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r0.record()
-        env.rollout(tape)
+        env2.rollout(tape)
         r1.record()
         torch.cuda.synchronize(device)
         rms = r0.elapsed_time(r1) / a.steps
+        env2.close()
         rollout = {"value": float(n) / (rms * 1e-3), "unit": "env-steps/s (this rank)", "ms_per_step": rms, "steps": a.steps,
                    "what": "pcgrl_rollout on the same action tape: K steps in one call, per-step reward/done/info kept"}
 

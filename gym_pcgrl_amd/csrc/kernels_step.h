@@ -13,7 +13,9 @@
 // other configuration takes the two-launch pipeline.
 #pragma once
 
-template <int PROB, int REP, class MaskT>
+// MULTI: the pcgrl_rollout form (loop over the tape); the single-step form is compiled without the loop so that it pays
+// nothing for it.
+template <int PROB, int REP, class MaskT, bool MULTI>
 __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_step(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity, int gen_map,
                                                                                                            int steps, size_t action_stride, double* reward_out, uint8_t* done_out, int32_t* info_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // per wave MT ring + tile bytes (in-kernel resets)
@@ -25,11 +27,11 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     // steps > 1 (pcgrl_rollout): the environments of a block do not depend on any other block, so the block simply goes on
     // with the next row of the action tape -- no launch, no grid-wide barrier between steps, blocks run ahead of each other
 #pragma clang loop unroll(disable)
-  for (int t = 0; t < steps; t++) {
+  for (int t = 0; t < (MULTI ? steps : 1); t++) {
     // the thread index goes through an opaque move so that nothing per-lane is hoisted out of the loop and kept in
     // registers across steps (the single-step kernel needs 97 VGPRs; with hoisting the loop form spilled)
     int tid = (int)threadIdx.x;
-    asm volatile("" : "+v"(tid));
+    if (MULTI) asm volatile("" : "+v"(tid));
     const int lane64 = tid & 63, wv = tid >> 6, gw = lane64 / G;
     DevGroup<G, MaskT> g(lane64);
     const int32_t* actions_t = actions + (size_t)t * action_stride;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
         const int raw = have ? s_items[lone ? 0 : (inc ? 2 : 1)][item] : 0;
         stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, false, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask);
     }
-    if (reward_out || done_out || info_out) {   // kernel-uniform: the per-step outputs of the block's environments, row t
+    if (MULTI && (reward_out || done_out || info_out)) {   // kernel-uniform: the per-step outputs of the block's environments, row t
         __syncthreads();
         const int e0 = blockIdx.x * 64, ne = (P.num_envs - e0) < 64 ? (P.num_envs - e0) : 64;
         const size_t row = (size_t)t * P.num_envs + e0;

@@ -447,14 +447,15 @@ static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipS
     const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
     const int grid = (P.num_envs + 63) / 64;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
+#define PCGRL_LAUNCH_STEP(REPV, MULTI) hipLaunchKernelGGL((k_step<PROB, REPV, MaskT, MULTI>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, \
+                                                          parity, gen, R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out)
+    const bool multi = R.steps > 1 || R.reward_out || R.done_out || R.info_out;
     switch (P.rep) {
-        case PCGRL_REP_NARROW: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen,
-                                                         R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); break;
-        case PCGRL_REP_WIDE: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_WIDE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen,
-                                                         R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); break;
-        default: hipLaunchKernelGGL((k_step<PROB, PCGRL_REP_TURTLE, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, parity, gen,
-                                                         R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); break;
+        case PCGRL_REP_NARROW: if (multi) PCGRL_LAUNCH_STEP(PCGRL_REP_NARROW, true); else PCGRL_LAUNCH_STEP(PCGRL_REP_NARROW, false); break;
+        case PCGRL_REP_WIDE: if (multi) PCGRL_LAUNCH_STEP(PCGRL_REP_WIDE, true); else PCGRL_LAUNCH_STEP(PCGRL_REP_WIDE, false); break;
+        default: if (multi) PCGRL_LAUNCH_STEP(PCGRL_REP_TURTLE, true); else PCGRL_LAUNCH_STEP(PCGRL_REP_TURTLE, false); break;
     }
+#undef PCGRL_LAUNCH_STEP
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
@@ -633,9 +634,12 @@ int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* r
     for (int t = 0; t < steps; t++) {
         int rc = pcgrl_step(h, actions + (size_t)t * stride, stream);
         if (rc) return rc;
-        if (reward_out) HIPCHK(hipMemcpyAsync(reward_out + (size_t)t * n, h->B.reward, n * 8, hipMemcpyDeviceToDevice, st));
-        if (done_out) HIPCHK(hipMemcpyAsync(done_out + (size_t)t * n, h->B.done, n, hipMemcpyDeviceToDevice, st));
-        if (info_out) HIPCHK(hipMemcpyAsync(info_out + (size_t)t * n * 10, h->B.info, n * 40, hipMemcpyDeviceToDevice, st));
+        if (reward_out || done_out || info_out) {
+            hipLaunchKernelGGL(k_copy_step_outputs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->B, (int)n,
+                               reward_out ? reward_out + (size_t)t * n : nullptr, done_out ? done_out + (size_t)t * n : nullptr,
+                               info_out ? info_out + (size_t)t * n * 10 : nullptr);
+            HIPCHK(hipGetLastError());
+        }
     }
     return PCGRL_OK;
 }

@@ -14,7 +14,7 @@ def agg(path):
             d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
 out = ["# %s (MI355X, rocprofv3)\n" % name,
-       "Commands: `tools/profile_gpu.sh <workload> trace sq mem` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 100 --no-cpu-baseline`,",
+       "Commands: `tools/profile_gpu.sh <workload> trace sq mem` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 100 --no-cpu-baseline --no-rollout`,",
        "then separate `--pmc` passes (SQ_* counters; FETCH_SIZE; WRITE_SIZE).  Bench lines: `bench_<W>.json`.\n"]
 for W in workloads:
     out.append("## %s\n" % W)

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 W=${1:-C2}; shift
 WHAT="${*:-trace sq mem}"
-B="python bench.py --workload $W --no-cpu-baseline"
+B="python bench.py --workload $W --no-cpu-baseline --no-rollout"
 for what in $WHAT; do
   case $what in
     trace) rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$W -o $W -- $B --steps 100 > gpurun_out/prof_$W.log 2>&1 ;;
