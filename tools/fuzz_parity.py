@@ -74,7 +74,19 @@ for case in range(cases):
         o.reset()
         exp.append(o.rollout(acts[:, i], want_heat=False))
     keys = list(env._prob.info_keys) + ["iterations", "changes"]
-    for t in range(T):
+    use_rollout = rs.rand() < 0.4          # the whole tape through pcgrl_rollout (one launch where the fused step kernel applies)
+    if use_rollout:
+        tape = torch.as_tensor(acts if acts.shape[2] > 1 else acts[:, :, 0], device="cuda")
+        rew_t, done_t, info_t = env.rollout(tape)
+        got_info = np.stack([info_t[k].cpu().numpy() for k in keys], 1).astype(np.int64).reshape(T, E, len(keys))
+        ok = np.array_equal(done_t.cpu().numpy(), np.stack([x["done"] for x in exp], 1)) and \
+            np.array_equal(rew_t.cpu().numpy(), np.stack([x["reward"] for x in exp], 1)) and \
+            np.array_equal(got_info, np.stack([x["info"] for x in exp], 1))
+        if not ok:
+            print("ROLLOUT MISMATCH", case, prob, rep, calls, "E", E, "seed", seed0)
+            sys.exit(1)
+        obs = env._obs()
+    for t in range(0 if not use_rollout else T, T):
         obs, rew, done, info = env.step(acts[t] if acts.shape[2] > 1 else acts[t, :, 0])
         ok = np.array_equal(done.cpu().numpy(), np.array([x["done"][t] for x in exp])) and \
             np.array_equal(rew.cpu().numpy(), np.array([x["reward"][t] for x in exp])) and \
@@ -87,5 +99,5 @@ for case in range(cases):
         sys.exit(1)
     env.check_status()
     env.close()
-    print("ok", case, prob, rep, (w, h), [list(c.items())[0] for c in calls[1:]], "E", E, "%.0fs" % (time.time() - t0), flush=True)
+    print("ok", case, "rollout" if use_rollout else "steps", prob, rep, (w, h), [list(c.items())[0] for c in calls[1:]], "E", E, "%.0fs" % (time.time() - t0), flush=True)
 print("fuzz passed:", cases, "cases")
