@@ -1,0 +1,223 @@
+// k_step_solver: pcgrl_rollout for the problems whose statistics need a search (Sokoban, mdungeon, ddave) -- a whole
+// tape of steps by persistent blocks, one block per compute unit.  Part of the single translation unit pcgrl_abi.hip.
+//
+// Stepping these problems one launch sequence at a time makes every step wait for its slowest search: with 131 072
+// Sokoban environments three or four levels per step run into the 5 000-pop cap (6.5 ms) while the other 131 000
+// environments are done after 0.2 ms.  The environments do not depend on each other, so for a tape of actions there is no
+// reason to wait: here a block owns up to 512 environments for the whole tape and goes through the phases of a step
+// (update, statistics, resets, searches, the resets and searches those caused) with block barriers only.  A block that
+// meets a capped search is late by that search; nobody else is.  The work lists live in LDS (LocalLists behind wl_push);
+// the device functions are the ones the step kernels use (update_env, stats_wave_task, wave_reset_env, the searches of
+// sokoban_fast.h / sokoban_solver.h, mdungeon_fast.h / mdungeon_solver.h, ddave_solver.h), so the results are the same by
+// construction -- and by test (tests/test_gpu_parity.py::test_rollout_equals_steps).
+// One search region (heap + visited table, 142 KB of LDS) per block: searches run one at a time on wavefront 0 with the
+// agents in sequence; the median search is a few dozen pops.
+#pragma once
+
+// list ids reuse the global ones: WL_CHG changed, WL_RST reset before the searches, WL_SOL / WL_SOL2 search jobs of changed /
+// regenerated maps, WL_RST2 reset after the searches, WL_SOL3 their jobs
+template <int PROB>
+struct SolverGame;
+
+template <>
+struct SolverGame<PCGRL_PROB_SOKOBAN> {
+    struct Shared { SokLevel L; SokNode root, work; SokFastNode cache[4]; int fast; };
+    // all 64 lanes of the wavefront; returns on lane 0 the two statistics the search fills in
+    static __device__ __forceinline__ void run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* lds, SokNode* pool, int lane, int32_t* s) {
+        const int tsize = SOK_LDS_TABLE;
+        if (lane == 0) {
+            const int ncr = sok_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
+            if (ncr > SOK_MAXC) atomicOr(B.status, 1);
+            sok_init_deadlocks(S.L);
+            S.root.h = (uint16_t)sok_heuristic(S.L, S.root.crate);
+            S.fast = (S.L.nc <= B.sok_fast_maxc) ? 1 : 0;
+        }
+        __threadfence_block();
+        const int fast = S.fast;
+        const int KS[4] = {-1, 2, 1, 0};
+        int hh = 0, dd = 0, win = 0;
+        for (int a = 0; a < 4; a++) {
+            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
+            else { for (int i = lane; i < tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
+            __threadfence_block();
+            int stop = 0;
+            if (lane < (fast ? 4 : 1)) {
+                int it = 0; bool exhausted = false;
+                const bool w = sok_run_agent(B, P.solver_power, S.L, S.work, S.root, pool, lds, S.cache, (uint32_t*)nullptr, (uint32_t*)nullptr, tsize, fast,
+                                             KS[a], hh, dd, it, exhausted, SokNoHook(), lane);
+                win = w ? 1 : 0;
+                stop = (w || (a == 0 && exhausted)) ? 1 : 0;      // sok_run_game: first winner, or the exact exhausted-BFS shortcut
+            }
+            stop = __shfl(stop, 0, 64);
+            __threadfence_block();
+            if (stop) break;
+        }
+        if (lane == 0) { s[4] = win ? 0 : hh; s[5] = win ? dd : 0; }
+    }
+};
+template <>
+struct SolverGame<PCGRL_PROB_MDUNGEON> {
+    struct Shared { MdLevel L; MdNode root, work; MdFastLevel F; MdFastNode cache[4]; int fast; };
+    static __device__ __forceinline__ void run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* lds, SokNode* pool, int lane, int32_t* s) {
+        const int tsize = SOK_LDS_TABLE;
+        if (lane == 0) {
+            md_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
+            S.fast = (mdf_level(S.L, S.root, S.F) <= MDF_MAXI && B.sok_fast_maxc >= 0) ? 1 : 0;
+        }
+        __threadfence_block();
+        const int fast = S.fast;
+        const int KS[4] = {2, 1, 0, -1};
+        int out5[5] = {0, 0, 0, 0, 0};
+        for (int a = 0; a < 4; a++) {
+            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
+            else { for (int i = lane; i < tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
+            __threadfence_block();
+            int next = a + 1;
+            if (lane < (fast ? 4 : 1)) {
+                int it = 0; bool exhausted = false, w;
+                if (fast) {
+                    uint64_t key = 0; int hh = 0, dd = 0;
+                    const MdKidsLanes kids = {lane};
+                    w = md_search_fast(S.L, S.F, reinterpret_cast<MdFastNode*>(pool), lds, reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP), tsize - 1,
+                                       S.cache, S.root, KS[a], P.solver_power, key, hh, dd, it, exhausted, SokNoHook(), kids);
+                    mdf_result(S.F, key, hh, dd, w, out5);
+                } else {
+                    w = md_search(S.L, reinterpret_cast<MdNode*>(pool), lds, lds + SOK_LDS_HEAP, tsize - 1, S.work, S.root, KS[a], P.solver_power, it, exhausted);
+                    md_result(S.L, S.root, S.work, w, out5);
+                }
+                if (w) next = 4;
+                else if (a < 3 && exhausted) next = 3;            // md_run_game: straight to BFS
+            }
+            next = __shfl(next, 0, 64);
+            __threadfence_block();
+            a = next - 1;
+        }
+        if (lane == 0) md_pack(s, out5);
+    }
+};
+template <>
+struct SolverGame<PCGRL_PROB_DDAVE> {
+    struct Shared { DdLevel L; DdNode root, work; };
+    static __device__ __forceinline__ void run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* lds, SokNode* pool, int lane, int32_t* s) {
+        const int tsize = SOK_LDS_TABLE;
+        if (lane == 0) dd_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
+        __threadfence_block();
+        const int KS[4] = {2, 1, 0, -1};
+        int out4[4] = {0, 0, 0, 0};
+        for (int a = 0; a < 4; a++) {
+            for (int i = lane; i < tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0;
+            __threadfence_block();
+            int stop = 0;
+            if (lane == 0) {
+                int it = 0; bool exhausted = false;
+                const bool w = dd_search(S.L, reinterpret_cast<DdNode*>(pool), lds, lds + SOK_LDS_HEAP, tsize - 1, S.work, S.root, KS[a], P.solver_power, it,
+                                         exhausted, SokNoHook());
+                dd_result(S.L, S.work, w, out4);
+                stop = w ? 1 : 0;
+            }
+            stop = __shfl(stop, 0, 64);
+            __threadfence_block();
+            if (stop) break;
+        }
+        if (lane == 0) dd_pack(s, out4);
+    }
+};
+
+template <int PROB, int REP, class MaskT>
+__global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevBufs Bg, const int32_t* __restrict__ actions, int gen_map, int steps,
+                                                             size_t action_stride, int envs_per_block, double* reward_out, uint8_t* done_out,
+                                                             int32_t* info_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t ss_lds[];     // heap + visited table of the block's one search at a time
+    __shared__ LocalLists s_lists;
+    __shared__ typename SolverGame<PROB>::Shared s_game;
+    __shared__ __attribute__((aligned(16))) uint8_t s_mt[2][PCGRL_MT_N * 4 + 272];   // MT ring + tile bytes for two resetting wavefronts
+    constexpr int G = 16, GPW = 4;
+    DevBufs B = Bg;
+    B.local = &s_lists;
+    const int W = P.width, H = P.height;
+    const int e0 = blockIdx.x * envs_per_block;
+    const int ne = (P.num_envs - e0) < envs_per_block ? (P.num_envs - e0) : envs_per_block;
+    SokNode* pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < steps; t++) {
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));                 // see k_step: keeps per-lane values from being hoisted across the steps
+        const int lane64 = tid & 63, wv = tid >> 6, gw = lane64 / G;
+        DevGroup<G, MaskT> g(lane64);
+        const MaskT rowmask = row_valid<MaskT>(g.lane, W, H);
+        const int32_t* actions_t = actions + (size_t)t * action_stride;
+        if (tid < WL_NLIST) s_lists.n[tid] = 0;
+        if (tid == 0) s_lists.e0 = e0;
+        __syncthreads();
+        // ---- Representation.update + bookkeeping; unchanged environments are finished here
+        for (int sub = wv * 64; sub < ne; sub += PCGRL_BLOCK) {
+            const int e = e0 + sub + lane64;
+            UpdateOut u = {false, false, false, false, 0, 0};
+            if (sub + lane64 < ne) u = update_env<REP, MaskT>(P, B, actions_t, e);
+            const uint64_t mc = __ballot(u.chg), mr = __ballot(u.rst);
+            const uint64_t below = (1ull << lane64) - 1ull;
+            int bc = 0, br = 0;
+            if (lane64 == 0) { bc = atomicAdd(&s_lists.n[WL_CHG], __popcll(mc)); br = atomicAdd(&s_lists.n[WL_RST], __popcll(mr)); }
+            bc = __shfl(bc, 0, 64); br = __shfl(br, 0, 64);
+            if (u.chg) s_lists.items[WL_CHG][bc + __popcll(mc & below)] = (uint16_t)(sub + lane64);
+            if (u.rst) s_lists.items[WL_RST][br + __popcll(mr & below)] = (uint16_t)(sub + lane64);
+        }
+        __syncthreads();
+        // ---- statistics of the changed maps: finished, or parked for the search (WL_SOL); finished episodes to WL_RST
+        {
+            const int n = s_lists.n[WL_CHG];
+            for (int w0 = wv; w0 * GPW < n; w0 += PCGRL_BLOCK / 64) {
+                const int item = w0 * GPW + gw;
+                const bool have = item < n;
+                const int raw = have ? e0 + (int)s_lists.items[WL_CHG][item] : 0;
+                stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, false, false, false, false, have, raw, lane64, MODE_STEP, 0, 0, gen_map,
+                                                reinterpret_cast<uint32_t*>(s_mt[0]), s_mt[0] + PCGRL_MT_N * 4, rowmask);
+            }
+        }
+        __syncthreads();
+        // ---- two rounds of (resets, searches): the episodes that ended before the searches, then the ones a search ended
+        for (int round = 0; round < 2; round++) {
+            const int rst_list = round == 0 ? WL_RST : WL_RST2, park_list = round == 0 ? WL_SOL2 : WL_SOL3;
+            const int nr = s_lists.n[rst_list];
+            if (wv < 2) {
+                uint32_t* mt = reinterpret_cast<uint32_t*>(s_mt[wv]);
+                uint8_t* tiles = s_mt[wv] + PCGRL_MT_N * 4;
+                for (int i = wv; i < nr; i += 2) {
+                    const int e = e0 + (int)s_lists.items[rst_list][i];
+                    wave_reset_env<PROB>(P, B, e, gen_map, mt, tiles, lane64);
+                    MaskT b0, b1, b2;
+                    planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * G, lane64 < G ? lane64 : -1, b0, b1, b2);
+                    const MaskT valid = (lane64 < G) ? rowmask : (MaskT)0;
+                    int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    MaskT champ;
+                    const bool need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, valid, st, champ);
+                    if (lane64 == 0) finish_or_park<PROB>(P, B, e, st, need_solver, MODE_START, 0, 0, true, park_list);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+            if (wv == 0) {
+                const int na = round == 0 ? s_lists.n[WL_SOL] : 0, nb = s_lists.n[park_list];
+                for (int j = 0; j < na + nb; j++) {
+                    const int mode = j < na ? MODE_STEP : MODE_START;
+                    const int e = e0 + (int)(j < na ? s_lists.items[WL_SOL][j] : s_lists.items[park_list][j - na]);
+                    int32_t s[PCGRL_MAX_STATS];
+                    const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+                    if (lane64 == 0) for (int k = 0; k < 8; k++) s[k] = park[k];
+                    SolverGame<PROB>::run(P, B, e, s_game, ss_lds, pool, lane64, s);
+                    if (lane64 == 0) finalize_item<PROB>(P, B, e, s, mode, 0, 0, true, WL_RST2);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+        }
+        if (reward_out || done_out || info_out) {   // kernel-uniform: the per-step outputs of the block's environments, row t
+            const size_t row = (size_t)t * P.num_envs + e0;
+            for (int i = tid; i < ne; i += PCGRL_BLOCK) {
+                if (reward_out) reward_out[row + i] = B.reward[e0 + i];
+                if (done_out) done_out[row + i] = B.done[e0 + i];
+            }
+            if (info_out) for (int i = tid; i < ne * 10; i += PCGRL_BLOCK) info_out[row * 10 + i] = B.info[(size_t)e0 * 10 + i];
+        }
+    }
+}

@@ -49,6 +49,7 @@
 #include "kernels_sokoban.h"
 #include "kernels_mdungeon.h"
 #include "kernels_ddave.h"
+#include "kernels_step_solver.h"
 #include "kernels_misc.h"
 
 // ------------------------------------------------------------------------------------------
@@ -224,6 +225,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
     B.heat_end = B.heat + (size_t)h->cfg.num_envs * h->cfg.width * h->cfg.height;
     B.ep_return = nullptr; B.ep_length = nullptr; B.last_return = nullptr; B.last_length = nullptr;
+    B.local = nullptr;
     B.planes = b->planes; B.counters = (int32_t*)b->counters; B.stats = (int32_t*)b->stats;
     B.start_stats = (int32_t*)b->start_stats; B.info = (int32_t*)b->info; B.reward = (double*)b->reward;
     B.done = (uint8_t*)b->done; B.tile_p = (double*)b->tile_p; B.rng_rep = (uint32_t*)b->rng_rep;
@@ -539,6 +541,44 @@ static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int c
     }
 }
 
+// pcgrl_rollout for the search problems: persistent blocks that own their environments for the whole tape (kernels_step_solver.h)
+static bool solver_rollout_applies(const pcgrl_env* h, int* envs_per_block) {
+    const PcgrlParams& P = h->P;
+    if (!solver_prob(P.prob) || P.rep > PCGRL_REP_TURTLE || !P.auto_reset || !h->B.sok_use_lds || P.group != 16 || env_is_one("PCGRL_NO_FUSED")) return false;
+    int epb = 64 * ((P.num_envs + SOK_BLOCKS * 64 - 1) / (SOK_BLOCKS * 64));      // one block per compute unit when the batch is large enough
+    epb = epb < 64 ? 64 : epb;
+    if (epb > WL_LOCAL_CAP) return false;                                            // more than 256 x 512 environments: the sequence of steps
+    *envs_per_block = epb;
+    return true;
+}
+template <int PROB, int REP, class MaskT>
+static int launch_step_solver_t(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb) {
+    const size_t lds = (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_solver<PROB, REP, MaskT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (h->P.num_envs + epb - 1) / epb;
+    const int gen = (h->P.random_start || !h->has_old) ? 1 : 0;
+    hipLaunchKernelGGL((k_step_solver<PROB, REP, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, h->P, h->B, actions, gen, R.steps, R.action_stride, epb,
+                       R.reward_out, R.done_out, R.info_out);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+template <int PROB, class MaskT>
+static int launch_step_solver_p(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb) {
+    switch (h->P.rep) {
+        case PCGRL_REP_NARROW: return launch_step_solver_t<PROB, PCGRL_REP_NARROW, MaskT>(h, actions, st, R, epb);
+        case PCGRL_REP_WIDE: return launch_step_solver_t<PROB, PCGRL_REP_WIDE, MaskT>(h, actions, st, R, epb);
+        default: return launch_step_solver_t<PROB, PCGRL_REP_TURTLE, MaskT>(h, actions, st, R, epb);
+    }
+}
+static int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb) {
+    const bool m4 = h->P.mask_bytes == 4;
+    switch (h->P.prob) {
+        case PCGRL_PROB_SOKOBAN: return m4 ? launch_step_solver_p<PCGRL_PROB_SOKOBAN, uint32_t>(h, actions, st, R, epb) : launch_step_solver_p<PCGRL_PROB_SOKOBAN, uint64_t>(h, actions, st, R, epb);
+        case PCGRL_PROB_MDUNGEON: return m4 ? launch_step_solver_p<PCGRL_PROB_MDUNGEON, uint32_t>(h, actions, st, R, epb) : launch_step_solver_p<PCGRL_PROB_MDUNGEON, uint64_t>(h, actions, st, R, epb);
+        default: return m4 ? launch_step_solver_p<PCGRL_PROB_DDAVE, uint32_t>(h, actions, st, R, epb) : launch_step_solver_p<PCGRL_PROB_DDAVE, uint64_t>(h, actions, st, R, epb);
+    }
+}
+
 extern "C" {
 
 static int reset_one(pcgrl_env* h, void* stream) {
@@ -630,6 +670,11 @@ int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* r
         if (rc) return rc;
         if (steps & 1) h->parity ^= 1;
         return PCGRL_OK;
+    }
+    int epb = 0;
+    if (solver_rollout_applies(h, &epb) && !h->profiling) {
+        const RolloutArgs R = {steps, stride, reward_out, done_out, info_out};
+        return launch_step_solver(h, actions, st, R, epb);       // block-local work lists: the global lists and their parity are not touched
     }
     for (int t = 0; t < steps; t++) {
         int rc = pcgrl_step(h, actions + (size_t)t * stride, stream);

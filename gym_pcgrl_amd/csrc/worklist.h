@@ -34,6 +34,7 @@ template <int G> __device__ __forceinline__ unsigned wl_inc_code(int raw) { retu
 // k_stats resets it without recomputing anything.
 #define WL_RESET_ONLY (1 << 30)
 
+struct LocalLists;
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
@@ -50,6 +51,7 @@ struct DevBufs {
     SokNode* sok_pool; uint32_t* sok_heap; uint32_t* sok_table; int32_t* status;
     int32_t* sok_res;                // [num_envs][4 agents][win, h, depth, exhausted]
     int32_t* sok_cnt; int32_t* sok_stop;   // [num_envs] agents reported / stop level (kernels_sokoban.h)
+    struct LocalLists* local;        // non-null: wl_push goes to these block-local LDS lists (k_step_solver sets it in its own copy)
     int32_t md_only_agent;           // >= 0: k_mdungeon runs only this agent (PCGRL_MD_ONLY_AGENT, timing experiments; results are then wrong)
     int32_t* sok_sync;               // [2 launches per step][SOK_SY_WORDS + SOK_HARD_CAP] scheduling words
     int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
@@ -63,7 +65,16 @@ struct DevBufs {
 __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {
     return B.wl_cnt + (size_t)(parity * WL_NLIST + list) * WL_NSHARD * WL_CSTRIDE;
 }
+// Block-local work lists in LDS (k_step_solver: a block that owns its environments for a whole tape of steps keeps its
+// lists to itself).  Entries are environment indices relative to the block's first environment.
+#define WL_LOCAL_CAP 512
+struct LocalLists { int n[WL_NLIST]; int e0; uint16_t items[WL_NLIST][WL_LOCAL_CAP]; };
 __device__ __forceinline__ void wl_push(const DevBufs& B, int parity, int list, int shard, int value) {
+    if (B.local) {
+        const int i = atomicAdd(&B.local->n[list], 1);
+        B.local->items[list][i] = (uint16_t)(value - B.local->e0);
+        return;
+    }
     const int i = atomicAdd(wl_counters(B, parity, list) + shard * WL_CSTRIDE, 1);
     B.wl_items[list][(size_t)shard * B.wl_cap[list] + i] = value;
 }

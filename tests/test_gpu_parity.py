@@ -719,6 +719,11 @@ def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
     ("zelda-wide-v0", (), 200, 60),                                    # the sequence-of-steps fallback
     ("sokoban-narrow-v0", (), 128, 40),
     ("mdungeon-turtle-v0", (dict(width=6, height=6),), 96, 40),
+    ("sokoban-wide-v0", (dict(change_percentage=0.6),), 1000, 60),     # persistent search-problem kernel, 16 blocks of 64
+    ("sokoban-turtle-v0", (dict(solver_power=300),), 20000, 30),          # 128 environments per block
+    ("ddave-narrow-v0", (dict(width=6, height=5), dict(change_percentage=0.8, probs={"empty": 0.7, "solid": 0.1, "player": 0.05,
+                                                                                      "exit": 0.05, "key": 0.05})), 300, 60),
+    ("mdungeon-wide-v0", (dict(width=6, height=6), dict(change_percentage=0.8, probs={"empty": 0.7, "solid": 0.05, "ogre": 0.08})), 300, 60),
 ], ids=lambda v: v if isinstance(v, str) else "")
 def test_rollout_equals_steps(env_id, calls, N, T):
     """pcgrl_rollout (a tape of actions, one launch where the fused step kernel applies) against the same tape fed to
