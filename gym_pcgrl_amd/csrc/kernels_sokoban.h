@@ -98,17 +98,17 @@ __device__ __forceinline__ void sok_report(const PcgrlParams& P, const DevBufs& 
 template <class Hook>
 __device__ __forceinline__ bool sok_run_agent(const DevBufs& B, int power, const SokLevel& L, SokNode& work, const SokNode& root, SokNode* pool,
                                               uint32_t* lds, SokFastNode* cache, uint32_t* g_heap, uint32_t* g_table, int tsize, int fast, int k,
-                                              int& hh, int& dd, int& it, bool& exhausted, Hook hook, int lane) {
+                                              int& hh, int& dd, int& it, bool& exhausted, Hook hook, int lane, int table_off = SOK_LDS_HEAP) {
     if (fast) {
         const SokKidsLanes kids = {lane};
-        uint64_t* tab = reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP);
+        uint64_t* tab = reinterpret_cast<uint64_t*>(lds + table_off);
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool);
         if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids);
         return sok_search_fast<4>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids);
     }
     if (lane != 0) return false;
     if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
-        return sok_search(L, pool, lds, lds + SOK_LDS_HEAP, tsize - 1, work, root, k, power, hh, dd, it, exhausted, hook);
+        return sok_search(L, pool, lds, lds + table_off, tsize - 1, work, root, k, power, hh, dd, it, exhausted, hook);
     return sok_search(L, pool, g_heap, g_table, tsize - 1, work, root, k, power, hh, dd, it, exhausted, hook);
 }
 

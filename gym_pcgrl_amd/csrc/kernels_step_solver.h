@@ -10,21 +10,32 @@
 // the device functions are the ones the step kernels use (update_env, stats_wave_task, wave_reset_env, the searches of
 // sokoban_fast.h / sokoban_solver.h, mdungeon_fast.h / mdungeon_solver.h, ddave_solver.h), so the results are the same by
 // construction -- and by test (tests/test_gpu_parity.py::test_rollout_equals_steps).
-// One search region (heap + visited table, 142 KB of LDS) per block: searches run one at a time on wavefront 0 with the
-// agents in sequence; the median search is a few dozen pops.
+// One full search region (heap + visited table, 142 KB of LDS) per block; the four wavefronts first try their jobs in small
+// private regions carved out of it (the median search is a few dozen pops), the rest is redone by wavefront 0 in the full one.
 #pragma once
 
 // list ids reuse the global ones: WL_CHG changed, WL_RST reset before the searches, WL_SOL / WL_SOL2 search jobs of changed /
 // regenerated maps, WL_RST2 reset after the searches, WL_SOL3 their jobs
+//
+// SolverGame<PROB>::run: _run_game of one level by one wavefront with the agents in sequence, inside a given search region
+// (`heap`, `table` of `tsize` slots at `heap + table_off` words) and with at most `power` pops per agent.  Returns (on every
+// lane) whether the result is final: with power < solver_power an agent that is stopped by the limit makes the whole job
+// "not final" -- it is then run again with the full region and the full power.  A search that ends by winning or by running
+// out of states before the limit gives what the full search gives (the table size only changes the probe sequences).
+#define SS_SMALL_POPS 256
+#define SS_SMALL_TABLE 1024
+#define SS_SMALL_HEAP 1028                                /* 1 + 4 * SS_SMALL_POPS entries, padded */
+#define SS_SMALL_WORDS (SS_SMALL_HEAP + 2 * SS_SMALL_TABLE) /* per wavefront, 32-bit words */
+#define SS_SMALL_NODES 1040
+
 template <int PROB>
 struct SolverGame;
 
 template <>
 struct SolverGame<PCGRL_PROB_SOKOBAN> {
     struct Shared { SokLevel L; SokNode root, work; SokFastNode cache[4]; int fast; };
-    // all 64 lanes of the wavefront; returns on lane 0 the two statistics the search fills in
-    static __device__ __forceinline__ void run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* lds, SokNode* pool, int lane, int32_t* s) {
-        const int tsize = SOK_LDS_TABLE;
+    static __device__ __forceinline__ bool run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* heap, int table_off, int tsize, int power,
+                                               SokNode* pool, int lane, int32_t* s) {
         if (lane == 0) {
             const int ncr = sok_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
             if (ncr > SOK_MAXC) atomicOr(B.status, 1);
@@ -35,31 +46,32 @@ struct SolverGame<PCGRL_PROB_SOKOBAN> {
         __threadfence_block();
         const int fast = S.fast;
         const int KS[4] = {-1, 2, 1, 0};
-        int hh = 0, dd = 0, win = 0;
+        int hh = 0, dd = 0, win = 0, final = 1;
         for (int a = 0; a < 4; a++) {
-            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
-            else { for (int i = lane; i < tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
+            for (int i = lane; i < (fast ? 2 : 1) * tsize; i += 64) heap[table_off + i] = 0;      // 64-bit keys on the fast path
             __threadfence_block();
             int stop = 0;
             if (lane < (fast ? 4 : 1)) {
                 int it = 0; bool exhausted = false;
-                const bool w = sok_run_agent(B, P.solver_power, S.L, S.work, S.root, pool, lds, S.cache, (uint32_t*)nullptr, (uint32_t*)nullptr, tsize, fast,
-                                             KS[a], hh, dd, it, exhausted, SokNoHook(), lane);
+                const bool w = sok_run_agent(B, power, S.L, S.work, S.root, pool, heap, S.cache, (uint32_t*)nullptr, (uint32_t*)nullptr, tsize, fast,
+                                             KS[a], hh, dd, it, exhausted, SokNoHook(), lane, table_off);
                 win = w ? 1 : 0;
-                stop = (w || (a == 0 && exhausted)) ? 1 : 0;      // sok_run_game: first winner, or the exact exhausted-BFS shortcut
+                if (!w && !exhausted && power < P.solver_power) { final = 0; stop = 1; }        // stopped by the reduced limit
+                else stop = (w || (a == 0 && exhausted)) ? 1 : 0;   // sok_run_game: first winner, or the exact exhausted-BFS shortcut
             }
             stop = __shfl(stop, 0, 64);
             __threadfence_block();
             if (stop) break;
         }
         if (lane == 0) { s[4] = win ? 0 : hh; s[5] = win ? dd : 0; }
+        return __shfl(final, 0, 64) != 0;
     }
 };
 template <>
 struct SolverGame<PCGRL_PROB_MDUNGEON> {
     struct Shared { MdLevel L; MdNode root, work; MdFastLevel F; MdFastNode cache[4]; int fast; };
-    static __device__ __forceinline__ void run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* lds, SokNode* pool, int lane, int32_t* s) {
-        const int tsize = SOK_LDS_TABLE;
+    static __device__ __forceinline__ bool run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* heap, int table_off, int tsize, int power,
+                                               SokNode* pool, int lane, int32_t* s) {
         if (lane == 0) {
             md_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
             S.fast = (mdf_level(S.L, S.root, S.F) <= MDF_MAXI && B.sok_fast_maxc >= 0) ? 1 : 0;
@@ -67,10 +79,9 @@ struct SolverGame<PCGRL_PROB_MDUNGEON> {
         __threadfence_block();
         const int fast = S.fast;
         const int KS[4] = {2, 1, 0, -1};
-        int out5[5] = {0, 0, 0, 0, 0};
+        int out5[5] = {0, 0, 0, 0, 0}, final = 1;
         for (int a = 0; a < 4; a++) {
-            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
-            else { for (int i = lane; i < tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0; }
+            for (int i = lane; i < (fast ? 2 : 1) * tsize; i += 64) heap[table_off + i] = 0;
             __threadfence_block();
             int next = a + 1;
             if (lane < (fast ? 4 : 1)) {
@@ -78,14 +89,15 @@ struct SolverGame<PCGRL_PROB_MDUNGEON> {
                 if (fast) {
                     uint64_t key = 0; int hh = 0, dd = 0;
                     const MdKidsLanes kids = {lane};
-                    w = md_search_fast(S.L, S.F, reinterpret_cast<MdFastNode*>(pool), lds, reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP), tsize - 1,
-                                       S.cache, S.root, KS[a], P.solver_power, key, hh, dd, it, exhausted, SokNoHook(), kids);
+                    w = md_search_fast(S.L, S.F, reinterpret_cast<MdFastNode*>(pool), heap, reinterpret_cast<uint64_t*>(heap + table_off), tsize - 1,
+                                       S.cache, S.root, KS[a], power, key, hh, dd, it, exhausted, SokNoHook(), kids);
                     mdf_result(S.F, key, hh, dd, w, out5);
                 } else {
-                    w = md_search(S.L, reinterpret_cast<MdNode*>(pool), lds, lds + SOK_LDS_HEAP, tsize - 1, S.work, S.root, KS[a], P.solver_power, it, exhausted);
+                    w = md_search(S.L, reinterpret_cast<MdNode*>(pool), heap, heap + table_off, tsize - 1, S.work, S.root, KS[a], power, it, exhausted);
                     md_result(S.L, S.root, S.work, w, out5);
                 }
-                if (w) next = 4;
+                if (!w && !exhausted && power < P.solver_power) { final = 0; next = 4; }
+                else if (w) next = 4;
                 else if (a < 3 && exhausted) next = 3;            // md_run_game: straight to BFS
             }
             next = __shfl(next, 0, 64);
@@ -93,33 +105,36 @@ struct SolverGame<PCGRL_PROB_MDUNGEON> {
             a = next - 1;
         }
         if (lane == 0) md_pack(s, out5);
+        return __shfl(final, 0, 64) != 0;
     }
 };
 template <>
 struct SolverGame<PCGRL_PROB_DDAVE> {
     struct Shared { DdLevel L; DdNode root, work; };
-    static __device__ __forceinline__ void run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* lds, SokNode* pool, int lane, int32_t* s) {
-        const int tsize = SOK_LDS_TABLE;
+    static __device__ __forceinline__ bool run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* heap, int table_off, int tsize, int power,
+                                               SokNode* pool, int lane, int32_t* s) {
         if (lane == 0) dd_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
         __threadfence_block();
         const int KS[4] = {2, 1, 0, -1};
-        int out4[4] = {0, 0, 0, 0};
+        int out4[4] = {0, 0, 0, 0}, final = 1;
         for (int a = 0; a < 4; a++) {
-            for (int i = lane; i < tsize; i += 64) lds[SOK_LDS_HEAP + i] = 0;
+            for (int i = lane; i < tsize; i += 64) heap[table_off + i] = 0;
             __threadfence_block();
             int stop = 0;
             if (lane == 0) {
                 int it = 0; bool exhausted = false;
-                const bool w = dd_search(S.L, reinterpret_cast<DdNode*>(pool), lds, lds + SOK_LDS_HEAP, tsize - 1, S.work, S.root, KS[a], P.solver_power, it,
+                const bool w = dd_search(S.L, reinterpret_cast<DdNode*>(pool), heap, heap + table_off, tsize - 1, S.work, S.root, KS[a], power, it,
                                          exhausted, SokNoHook());
                 dd_result(S.L, S.work, w, out4);
-                stop = w ? 1 : 0;
+                if (!w && !exhausted && power < P.solver_power) { final = 0; stop = 1; }
+                else stop = w ? 1 : 0;
             }
             stop = __shfl(stop, 0, 64);
             __threadfence_block();
             if (stop) break;
         }
         if (lane == 0) dd_pack(s, out4);
+        return __shfl(final, 0, 64) != 0;
     }
 };
 
@@ -129,8 +144,11 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
                                                              int32_t* info_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ss_lds[];     // heap + visited table of the block's one search at a time
     __shared__ LocalLists s_lists;
-    __shared__ typename SolverGame<PROB>::Shared s_game;
-    __shared__ __attribute__((aligned(16))) uint8_t s_mt[2][PCGRL_MT_N * 4 + 272];   // MT ring + tile bytes for two resetting wavefronts
+    __shared__ typename SolverGame<PROB>::Shared s_game[4];
+    __shared__ uint16_t s_big[WL_LOCAL_CAP];        // search jobs that need the full region
+    __shared__ int s_nbig;
+    // the resets (MT ring + tile bytes per wavefront) borrow the search region: resets and searches are separate phases
+    constexpr int kMtBytes = PCGRL_MT_N * 4 + 272;
     constexpr int G = 16, GPW = 4;
     DevBufs B = Bg;
     B.local = &s_lists;
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
                 const bool have = item < n;
                 const int raw = have ? e0 + (int)s_lists.items[WL_CHG][item] : 0;
                 stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, false, false, false, false, have, raw, lane64, MODE_STEP, 0, 0, gen_map,
-                                                reinterpret_cast<uint32_t*>(s_mt[0]), s_mt[0] + PCGRL_MT_N * 4, rowmask);
+                                                ss_lds, reinterpret_cast<uint8_t*>(ss_lds), rowmask);      // (no in-kernel resets on this path: unused)
             }
         }
         __syncthreads();
@@ -179,10 +197,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
         for (int round = 0; round < 2; round++) {
             const int rst_list = round == 0 ? WL_RST : WL_RST2, park_list = round == 0 ? WL_SOL2 : WL_SOL3;
             const int nr = s_lists.n[rst_list];
-            if (wv < 2) {
-                uint32_t* mt = reinterpret_cast<uint32_t*>(s_mt[wv]);
-                uint8_t* tiles = s_mt[wv] + PCGRL_MT_N * 4;
-                for (int i = wv; i < nr; i += 2) {
+            {
+                uint32_t* mt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ss_lds) + wv * kMtBytes);
+                uint8_t* tiles = reinterpret_cast<uint8_t*>(mt) + PCGRL_MT_N * 4;
+                for (int i = wv; i < nr; i += PCGRL_BLOCK / 64) {
                     const int e = e0 + (int)s_lists.items[rst_list][i];
                     wave_reset_env<PROB>(P, B, e, gen_map, mt, tiles, lane64);
                     MaskT b0, b1, b2;
@@ -196,15 +214,38 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
                 }
             }
             __syncthreads();
+            // searches: every wavefront takes jobs and tries them inside a small private region with a small pop limit -- the
+            // median search is a few dozen pops -- and the few that do not finish there are redone by wavefront 0 with the
+            // full region and the full solver_power
+            const int na = round == 0 ? s_lists.n[WL_SOL] : 0, nb = s_lists.n[park_list];
+            if (tid == 0) s_nbig = 0;
+            __syncthreads();
+            const int small_power = P.solver_power < SS_SMALL_POPS ? P.solver_power : SS_SMALL_POPS;
+            for (int j = wv; j < na + nb; j += PCGRL_BLOCK / 64) {
+                const int mode = j < na ? MODE_STEP : MODE_START;
+                const int e = e0 + (int)(j < na ? s_lists.items[WL_SOL][j] : s_lists.items[park_list][j - na]);
+                int32_t s[PCGRL_MAX_STATS];
+                const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
+                if (lane64 == 0) for (int k = 0; k < 8; k++) s[k] = park[k];
+                const bool final = SolverGame<PROB>::run(P, B, e, s_game[wv], ss_lds + wv * SS_SMALL_WORDS, SS_SMALL_HEAP, SS_SMALL_TABLE, small_power,
+                                                         pool + (size_t)wv * SS_SMALL_NODES, lane64, s);
+                if (lane64 == 0) {
+                    if (final) finalize_item<PROB>(P, B, e, s, mode, 0, 0, true, WL_RST2);
+                    else s_big[atomicAdd(&s_nbig, 1)] = (uint16_t)j;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
             if (wv == 0) {
-                const int na = round == 0 ? s_lists.n[WL_SOL] : 0, nb = s_lists.n[park_list];
-                for (int j = 0; j < na + nb; j++) {
+                const int nbig = s_nbig;
+                for (int q = 0; q < nbig; q++) {
+                    const int j = s_big[q];
                     const int mode = j < na ? MODE_STEP : MODE_START;
                     const int e = e0 + (int)(j < na ? s_lists.items[WL_SOL][j] : s_lists.items[park_list][j - na]);
                     int32_t s[PCGRL_MAX_STATS];
                     const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
                     if (lane64 == 0) for (int k = 0; k < 8; k++) s[k] = park[k];
-                    SolverGame<PROB>::run(P, B, e, s_game, ss_lds, pool, lane64, s);
+                    SolverGame<PROB>::run(P, B, e, s_game[0], ss_lds, SOK_LDS_HEAP, SOK_LDS_TABLE, P.solver_power, pool, lane64, s);
                     if (lane64 == 0) finalize_item<PROB>(P, B, e, s, mode, 0, 0, true, WL_RST2);
                     __builtin_amdgcn_wave_barrier();
                 }

@@ -127,8 +127,10 @@ int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
  * [steps, N(, k)] laid out like `steps` action arrays of pcgrl_step one after the other.  Optional DEVICE outputs, one
  * row per step: reward_out f64 [steps, N], done_out u8 [steps, N], info_out i32 [steps, N, 10]; NULL = not wanted.
  * The state buffers end up exactly as after the equivalent sequence of pcgrl_step calls.  Where one kernel does the
- * whole step (binary maps of at most 16 rows) the rollout is a single launch -- blocks of environments run ahead of
- * each other, there is nothing to wait for between steps; everywhere else it is the sequence of steps. */
+ * whole step (binary and zelda maps of at most 16 rows) the rollout is a single launch -- blocks of environments run ahead
+ * of each other, there is nothing to wait for between steps; the search problems (sokoban, mdungeon, ddave; up to 131 072
+ * environments) run on persistent blocks that own their environments for the whole tape, so that only the block that meets
+ * a long search waits for it; everything else is the sequence of steps. */
 int pcgrl_rollout(pcgrl_env* env, const int32_t* actions, int32_t steps, double* reward_out, uint8_t* done_out,
                   int32_t* info_out, void* stream);
 /* maps: DEVICE pointer u8 [N,H,W]; replaces every map, recomputes stats (start stats unchanged). */
