@@ -63,8 +63,9 @@ for W in workloads:
             except ValueError:
                 continue
             open(os.path.join(dst, "bench_%s.json" % W), "w").write(line + "\n")
-            out.append("bench: **%.1f M env-steps/s**, %.1f us/step, roofline achieved %.0f GB/s (frac %.4f)%s\n" % (
+            out.append("bench: **%.1f M env-steps/s**, %.1f us/step, roofline achieved %.0f GB/s (frac %.4f)%s%s\n" % (
                 d["value"] / 1e6, d["ms_per_step"] * 1e3, d["roofline"]["achieved"], d["roofline"]["frac"],
+                (", as one pcgrl_rollout call %.1f M env-steps/s (%.1f us/step)" % (d["rollout"]["value"] / 1e6, d["rollout"]["ms_per_step"] * 1e3)) if "rollout" in d else "",
                 (", cpu_baseline %.2f M/s on %d threads (%.0f k/s single)" % (d["cpu_baseline"]["value"] / 1e6, d["cpu_baseline"]["cores"], d["cpu_baseline"]["single_core"] / 1e3)) if "cpu_baseline" in d else ""))
             break
 cal = os.path.join(G, "traffic_calib.txt")
