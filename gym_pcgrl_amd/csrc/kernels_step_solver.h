@@ -10,7 +10,7 @@
 // the device functions are the ones the step kernels use (update_env, stats_wave_task, wave_reset_env, the searches of
 // sokoban_fast.h / sokoban_solver.h, mdungeon_fast.h / mdungeon_solver.h, ddave_solver.h), so the results are the same by
 // construction -- and by test (tests/test_gpu_parity.py::test_rollout_equals_steps).
-// One full search region (heap + visited table, 142 KB of LDS) per block; the four wavefronts first try their jobs in small
+// One full search region (heap + visited table, 142 KB of LDS) per block; the eight wavefronts first try the jobs in small
 // private regions carved out of it (the median search is a few dozen pops), the rest is redone by wavefront 0 in the full one.
 #pragma once
 
@@ -27,6 +27,8 @@
 #define SS_SMALL_HEAP 1028                                /* 1 + 4 * SS_SMALL_POPS entries, padded */
 #define SS_SMALL_WORDS (SS_SMALL_HEAP + 2 * SS_SMALL_TABLE) /* per wavefront, 32-bit words */
 #define SS_SMALL_NODES 1040
+#define SS_THREADS 512                                   /* one block per compute unit: eight wavefronts share the phases of a step */
+#define SS_SEARCH_WAVES 8                                 /* wavefronts that take search jobs (a small region each) */
 
 template <int PROB>
 struct SolverGame;
@@ -139,12 +141,12 @@ struct SolverGame<PCGRL_PROB_DDAVE> {
 };
 
 template <int PROB, int REP, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevBufs Bg, const int32_t* __restrict__ actions, int gen_map, int steps,
+__global__ __launch_bounds__(SS_THREADS) void k_step_solver(PcgrlParams P, DevBufs Bg, const int32_t* __restrict__ actions, int gen_map, int steps,
                                                              size_t action_stride, int envs_per_block, double* reward_out, uint8_t* done_out,
                                                              int32_t* info_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ss_lds[];     // heap + visited table of the block's one search at a time
     __shared__ LocalLists s_lists;
-    __shared__ typename SolverGame<PROB>::Shared s_game[4];
+    __shared__ typename SolverGame<PROB>::Shared s_game0;      // the full-region search; the small ones keep theirs in the region itself
     __shared__ uint16_t s_big[WL_LOCAL_CAP];        // search jobs that need the full region
     __shared__ int s_nbig;
     // the resets (MT ring + tile bytes per wavefront) borrow the search region: resets and searches are separate phases
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
         if (tid == 0) s_lists.e0 = e0;
         __syncthreads();
         // ---- Representation.update + bookkeeping; unchanged environments are finished here
-        for (int sub = wv * 64; sub < ne; sub += PCGRL_BLOCK) {
+        for (int sub = wv * 64; sub < ne; sub += SS_THREADS) {
             const int e = e0 + sub + lane64;
             UpdateOut u = {false, false, false, false, 0, 0};
             if (sub + lane64 < ne) u = update_env<REP, MaskT>(P, B, actions_t, e);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
         // ---- statistics of the changed maps: finished, or parked for the search (WL_SOL); finished episodes to WL_RST
         {
             const int n = s_lists.n[WL_CHG];
-            for (int w0 = wv; w0 * GPW < n; w0 += PCGRL_BLOCK / 64) {
+            for (int w0 = wv; w0 * GPW < n; w0 += SS_THREADS / 64) {
                 const int item = w0 * GPW + gw;
                 const bool have = item < n;
                 const int raw = have ? e0 + (int)s_lists.items[WL_CHG][item] : 0;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
             {
                 uint32_t* mt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ss_lds) + wv * kMtBytes);
                 uint8_t* tiles = reinterpret_cast<uint8_t*>(mt) + PCGRL_MT_N * 4;
-                for (int i = wv; i < nr; i += PCGRL_BLOCK / 64) {
+                for (int i = wv; i < nr; i += SS_THREADS / 64) {
                     const int e = e0 + (int)s_lists.items[rst_list][i];
                     wave_reset_env<PROB>(P, B, e, gen_map, mt, tiles, lane64);
                     MaskT b0, b1, b2;
@@ -221,13 +223,15 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
             if (tid == 0) s_nbig = 0;
             __syncthreads();
             const int small_power = P.solver_power < SS_SMALL_POPS ? P.solver_power : SS_SMALL_POPS;
-            for (int j = wv; j < na + nb; j += PCGRL_BLOCK / 64) {
+            typedef typename SolverGame<PROB>::Shared GameShared;
+            GameShared* small_games = reinterpret_cast<GameShared*>(ss_lds + SS_SEARCH_WAVES * SS_SMALL_WORDS);
+            for (int j = wv; j < na + nb && wv < SS_SEARCH_WAVES; j += SS_SEARCH_WAVES) {
                 const int mode = j < na ? MODE_STEP : MODE_START;
                 const int e = e0 + (int)(j < na ? s_lists.items[WL_SOL][j] : s_lists.items[park_list][j - na]);
                 int32_t s[PCGRL_MAX_STATS];
                 const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
                 if (lane64 == 0) for (int k = 0; k < 8; k++) s[k] = park[k];
-                const bool final = SolverGame<PROB>::run(P, B, e, s_game[wv], ss_lds + wv * SS_SMALL_WORDS, SS_SMALL_HEAP, SS_SMALL_TABLE, small_power,
+                const bool final = SolverGame<PROB>::run(P, B, e, small_games[wv], ss_lds + wv * SS_SMALL_WORDS, SS_SMALL_HEAP, SS_SMALL_TABLE, small_power,
                                                          pool + (size_t)wv * SS_SMALL_NODES, lane64, s);
                 if (lane64 == 0) {
                     if (final) finalize_item<PROB>(P, B, e, s, mode, 0, 0, true, WL_RST2);
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
                     int32_t s[PCGRL_MAX_STATS];
                     const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
                     if (lane64 == 0) for (int k = 0; k < 8; k++) s[k] = park[k];
-                    SolverGame<PROB>::run(P, B, e, s_game[0], ss_lds, SOK_LDS_HEAP, SOK_LDS_TABLE, P.solver_power, pool, lane64, s);
+                    SolverGame<PROB>::run(P, B, e, s_game0, ss_lds, SOK_LDS_HEAP, SOK_LDS_TABLE, P.solver_power, pool, lane64, s);
                     if (lane64 == 0) finalize_item<PROB>(P, B, e, s, mode, 0, 0, true, WL_RST2);
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -254,11 +258,11 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_step_solver(PcgrlParams P, DevB
         }
         if (reward_out || done_out || info_out) {   // kernel-uniform: the per-step outputs of the block's environments, row t
             const size_t row = (size_t)t * P.num_envs + e0;
-            for (int i = tid; i < ne; i += PCGRL_BLOCK) {
+            for (int i = tid; i < ne; i += SS_THREADS) {
                 if (reward_out) reward_out[row + i] = B.reward[e0 + i];
                 if (done_out) done_out[row + i] = B.done[e0 + i];
             }
-            if (info_out) for (int i = tid; i < ne * 10; i += PCGRL_BLOCK) info_out[row * 10 + i] = B.info[(size_t)e0 * 10 + i];
+            if (info_out) for (int i = tid; i < ne * 10; i += SS_THREADS) info_out[row * 10 + i] = B.info[(size_t)e0 * 10 + i];
         }
     }
 }

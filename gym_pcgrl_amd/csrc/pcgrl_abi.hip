@@ -557,7 +557,7 @@ static int launch_step_solver_t(pcgrl_env* h, const int32_t* actions, hipStream_
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_solver<PROB, REP, MaskT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (h->P.num_envs + epb - 1) / epb;
     const int gen = (h->P.random_start || !h->has_old) ? 1 : 0;
-    hipLaunchKernelGGL((k_step_solver<PROB, REP, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, h->P, h->B, actions, gen, R.steps, R.action_stride, epb,
+    hipLaunchKernelGGL((k_step_solver<PROB, REP, MaskT>), dim3(grid), dim3(SS_THREADS), lds, st, h->P, h->B, actions, gen, R.steps, R.action_stride, epb,
                        R.reward_out, R.done_out, R.info_out);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
