@@ -724,6 +724,8 @@ def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
     ("ddave-narrow-v0", (dict(width=6, height=5), dict(change_percentage=0.8, probs={"empty": 0.7, "solid": 0.1, "player": 0.05,
                                                                                       "exit": 0.05, "key": 0.05})), 300, 60),
     ("mdungeon-wide-v0", (dict(width=6, height=6), dict(change_percentage=0.8, probs={"empty": 0.7, "solid": 0.05, "ogre": 0.08})), 300, 60),
+    ("sokoban-narrow-v0", (dict(solver_power=200),), 131072 + 64, 6),    # more than 256 x 512 environments: the sequence-of-steps fallback
+    ("binary-narrowcast-v0", (), 200, 50),                                # a representation without the fused kernels
 ], ids=lambda v: v if isinstance(v, str) else "")
 def test_rollout_equals_steps(env_id, calls, N, T):
     """pcgrl_rollout (a tape of actions, one launch where the fused step kernel applies) against the same tape fed to
