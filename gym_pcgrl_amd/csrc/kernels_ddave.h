@@ -13,6 +13,25 @@ struct DdPollHook {
     __device__ __forceinline__ bool operator()(int it) const { return (it & SOK_POLL_MASK) == 0 && (sok_ld(stop) & 255) >= 4 - a; }
 };
 
+// The four children of a pop, one per lane (lanes 0..3 run the compact search in lockstep).
+struct DdKidsLanes {
+    int lane;
+    template <class TP>
+    __device__ __forceinline__ void operator()(const DdLevel& L, const DdFastLevel& F, TP table, int table_mask, uint64_t key, int aj, bool ground,
+                                               bool ceiling, DdChild* out) const {
+        const DdChild mine = ddf_child(L, F, table, table_mask, key, aj, ground, ceiling, lane & 3);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.key, d);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.key >> 32), d);
+            out[d].key = ((uint64_t)hi << 32) | lo;
+            out[d].h = __builtin_amdgcn_readlane(mine.h, d);
+            out[d].aj = __builtin_amdgcn_readlane(mine.aj, d);
+            out[d].drop = __builtin_amdgcn_readlane(mine.drop, d);
+        }
+    }
+};
+
 // Agent a of environment e is done.  The fourth report selects the result and finishes the item.
 __device__ __forceinline__ void dd_report(const PcgrlParams& P, const DevBufs& B, int e, int a, bool win, const int* out4, int mode, int parity,
                                           int rst_list) {
@@ -47,6 +66,9 @@ __global__ __launch_bounds__(64) void k_ddave(PcgrlParams P, DevBufs B, int list
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
     __shared__ DdLevel s_L;              // level + node workspace in LDS: they are indexed dynamically
     __shared__ DdNode s_root, s_work;
+    __shared__ DdFastLevel s_F;
+    __shared__ DdFastNode s_cache[4];
+    __shared__ int s_fast;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
@@ -71,26 +93,40 @@ __global__ __launch_bounds__(64) void k_ddave(PcgrlParams P, DevBufs B, int list
         if (lane == 0) {
             const DdPollHook hook = {B.sok_stop + e, a};
             skip = hook(0) ? 1 : 0;                                  // already decided before this agent started
-            if (!skip) dd_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+            if (!skip) {
+                dd_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
+                // the compact search (ddave_fast.h) for levels with few diamonds; PCGRL_SOK_GENERIC=1 switches it off (tests)
+                s_fast = (ddf_level(s_L, s_F) <= DDF_MAXD && B.sok_use_lds && B.sok_fast_maxc >= 0) ? 1 : 0;
+            }
         }
         skip = __shfl(skip, 0, 64);
+        __threadfence_block();
+        const int fast = skip ? 0 : s_fast;
         if (!skip) {
-            if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) dd_lds[SOK_LDS_HEAP + i] = 0; }
+            if (fast) { for (int i = lane; i < 2 * tsize; i += 64) dd_lds[SOK_LDS_HEAP + i] = 0; }   // 64-bit keys
+            else if (B.sok_use_lds) { for (int i = lane; i < tsize; i += 64) dd_lds[SOK_LDS_HEAP + i] = 0; }
             else { for (int i = lane; i < tsize; i += 64) g_table[i] = 0; }
         }
         __threadfence_block();
-        if (lane == 0) {
+        if (lane < (fast ? 4 : 1)) {
             int it = 0, out4[4] = {0, 0, 0, 0};
             bool exhausted = false, win = false;
             if (!skip) {
                 const DdPollHook hook = {B.sok_stop + e, a};
-                if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
+                if (fast) {
+                    uint64_t key = 0;
+                    int hh = 0, dd = 0, jj = 0;
+                    const DdKidsLanes kids = {lane};
+                    win = dd_search_fast(s_L, s_F, reinterpret_cast<DdFastNode*>(pool), dd_lds, reinterpret_cast<uint64_t*>(dd_lds + SOK_LDS_HEAP),
+                                         tsize - 1, s_cache, s_root, KS[a], P.solver_power, key, hh, dd, jj, it, exhausted, hook, kids);
+                    ddf_result(s_F, key, hh, dd, jj, win, out4);
+                } else if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
                     win = dd_search(s_L, pool, dd_lds, dd_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
                 else
                     win = dd_search(s_L, pool, g_heap, g_table, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
-                dd_result(s_L, s_work, win, out4);
+                if (!fast) dd_result(s_L, s_work, win, out4);
             }
-            dd_report(P, B, e, a, win, out4, mode, parity, rst_list);
+            if (lane == 0) dd_report(P, B, e, a, win, out4, mode, parity, rst_list);
         }
         __threadfence_block();
     }

@@ -112,22 +112,34 @@ struct SolverGame<PCGRL_PROB_MDUNGEON> {
 };
 template <>
 struct SolverGame<PCGRL_PROB_DDAVE> {
-    struct Shared { DdLevel L; DdNode root, work; };
+    struct Shared { DdLevel L; DdNode root, work; DdFastLevel F; DdFastNode cache[4]; int fast; };
     static __device__ __forceinline__ bool run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* heap, int table_off, int tsize, int power,
                                                SokNode* pool, int lane, int32_t* s) {
-        if (lane == 0) dd_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
+        if (lane == 0) {
+            dd_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
+            S.fast = (ddf_level(S.L, S.F) <= DDF_MAXD && B.sok_fast_maxc >= 0) ? 1 : 0;
+        }
         __threadfence_block();
+        const int fast = S.fast;
         const int KS[4] = {2, 1, 0, -1};
         int out4[4] = {0, 0, 0, 0}, final = 1;
         for (int a = 0; a < 4; a++) {
-            for (int i = lane; i < tsize; i += 64) heap[table_off + i] = 0;
+            for (int i = lane; i < (fast ? 2 : 1) * tsize; i += 64) heap[table_off + i] = 0;
             __threadfence_block();
             int stop = 0;
-            if (lane == 0) {
-                int it = 0; bool exhausted = false;
-                const bool w = dd_search(S.L, reinterpret_cast<DdNode*>(pool), heap, heap + table_off, tsize - 1, S.work, S.root, KS[a], power, it,
-                                         exhausted, SokNoHook());
-                dd_result(S.L, S.work, w, out4);
+            if (lane < (fast ? 4 : 1)) {
+                int it = 0; bool exhausted = false, w;
+                if (fast) {
+                    uint64_t key = 0; int hh = 0, dd = 0, jj = 0;
+                    const DdKidsLanes kids = {lane};
+                    w = dd_search_fast(S.L, S.F, reinterpret_cast<DdFastNode*>(pool), heap, reinterpret_cast<uint64_t*>(heap + table_off), tsize - 1, S.cache,
+                                       S.root, KS[a], power, key, hh, dd, jj, it, exhausted, SokNoHook(), kids);
+                    ddf_result(S.F, key, hh, dd, jj, w, out4);
+                } else {
+                    w = dd_search(S.L, reinterpret_cast<DdNode*>(pool), heap, heap + table_off, tsize - 1, S.work, S.root, KS[a], power, it, exhausted,
+                                  SokNoHook());
+                    dd_result(S.L, S.work, w, out4);
+                }
                 if (!w && !exhausted && power < P.solver_power) { final = 0; stop = 1; }
                 else stop = w ? 1 : 0;
             }

@@ -39,6 +39,7 @@
 #include "mdungeon_solver.h"
 #include "mdungeon_fast.h"
 #include "ddave_solver.h"
+#include "ddave_fast.h"
 
 #include "worklist.h"
 #include "kernels_update.h"
@@ -485,10 +486,10 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
         static bool dd_attr_set = false;
         if (!dd_attr_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ddave), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((SOK_LDS_HEAP + SOK_LDS_TABLE) * 4)));
+                                       (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4)));
             dd_attr_set = true;
         }
-        const size_t dd_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + SOK_LDS_TABLE) * 4 : 0;
+        const size_t dd_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
         hipLaunchKernelGGL(k_ddave, dim3(SOK_BLOCKS), dim3(64), dd_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
         HIPCHK(hipGetLastError());
         return PCGRL_OK;

@@ -17,6 +17,7 @@ static int g_trace_site[4096], g_trace_rounds[4096], g_trace_n = 0;
 #include "../../gym_pcgrl_amd/csrc/mdungeon_solver.h"
 #include "../../gym_pcgrl_amd/csrc/mdungeon_fast.h"
 #include "../../gym_pcgrl_amd/csrc/ddave_solver.h"
+#include "../../gym_pcgrl_amd/csrc/ddave_fast.h"
 #include <vector>
 
 template <class T, int G>
@@ -340,6 +341,32 @@ int sim_ddave_solve(const uint8_t* map, int h, int w, int power, int* out4, int*
     uint32_t* tp = table.data();
     dd_run_game(L, pool.data(), heap.data(), tp, tsize, work, root, power, [tp](int n) { for (int i = 0; i < n; i++) tp[i] = 0; }, out4, iters);
     return 0;
+}
+// fast = 1: the compact search (ddave_fast.h) when the level qualifies, as k_ddave does
+int sim_ddave_solve2(const uint8_t* map, int h, int w, int power, int fast, int* out4, int* iters) {
+    if ((w + 2) * (h + 2) > 256) return -1;
+    DdLevel L; DdNode root;
+    dd_build_level(map, w, h, L, root);
+    DdFastLevel F;
+    const int nd = ddf_level(L, F);
+    if (!(fast && nd <= DDF_MAXD && power <= SOK_LDS_POWER)) return sim_ddave_solve(map, h, w, power, out4, iters);
+    std::vector<DdFastNode> pool(4 * (size_t)power + 4);
+    std::vector<uint32_t> heap(4 * (size_t)power + 4);
+    const int tsize = SOK_LDS_TABLE;
+    std::vector<uint64_t> table(tsize);
+    const int KS[4] = {2, 1, 0, -1};
+    bool win = false;
+    uint64_t key = 0; int hh = 0, dd = 0, jj = 0;
+    for (int a = 0; a < 4; a++) iters[a] = 0;
+    for (int a = 0; a < 4 && !win; a++) {
+        for (int i = 0; i < tsize; i++) table[i] = 0;
+        bool exhausted = false;
+        DdFastNode cache[4];
+        win = dd_search_fast(L, F, pool.data(), heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, key, hh, dd, jj, iters[a], exhausted,
+                             SokNoHook(), DdKidsSerial());
+    }
+    ddf_result(F, key, hh, dd, jj, win, out4);
+    return 1;
 }
 long sim_iters_reset() { long v = g_sim_iters; g_sim_iters = 0; return v; }
 void sim_set_spurious(int n) { g_spurious = n; }

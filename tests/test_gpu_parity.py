@@ -507,6 +507,24 @@ def test_mdungeon_generic_search_path(path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_ddave_*.npz"))), ids=os.path.basename)
+def test_ddave_generic_search_path(path, monkeypatch):
+    """k_ddave picks the compact search (ddave_fast.h) for levels with <= 48 diamonds, which is every fixture level; the
+    generic search must give the same answers: PCGRL_SOK_GENERIC=1 routes every level through it."""
+    _torch()
+    monkeypatch.setenv("PCGRL_SOK_GENERIC", "1")
+    d = np.load(path)
+    maps = d["maps"]
+    n, h, w = maps.shape
+    env = _make("ddave", "wide", n, [dict(width=w, height=h), dict(solver_power=int(d["solver_power"]))])
+    env.reset()
+    env.set_maps(maps)
+    got = env.stats.cpu().numpy().astype(np.int64)
+    assert env.check_status() == 0
+    assert np.array_equal(got, d["stats"])
+
+
+@pytest.mark.gpu
 def test_ddave_large_solver_power_vs_oracle():
     """ddave levels with a solver_power beyond the LDS heap (heap and visited table in the global arena) against the
     oracle: open levels with ledges, many diamonds."""

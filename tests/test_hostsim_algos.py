@@ -143,11 +143,12 @@ def test_device_mdungeon_solver_vs_golden(sim, fast):
     assert (took_fast > 0.9 * n) if fast else took_fast == 0
 
 
-def test_device_ddave_solver_vs_golden(sim):
+@pytest.mark.parametrize("fast", [0, 1], ids=["generic", "compact"])
+def test_device_ddave_solver_vs_golden(sim, fast):
     """gym_pcgrl_amd/csrc/ddave_solver.h (the code k_ddave runs) compiled for the host, against the reference's planner
     results and per-agent iteration counts."""
-    sim.sim_ddave_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    n = capped = 0
+    sim.sim_ddave_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = capped = took_fast = 0
     for path in sorted(glob.glob(os.path.join(G, "stats_ddave_*.npz"))):
         d = np.load(path)
         power = int(d["solver_power"])
@@ -157,12 +158,15 @@ def test_device_ddave_solver_vs_golden(sim):
             m = np.ascontiguousarray(m)
             exp = [d["stats"][i, 9], d["stats"][i, 10], d["stats"][i, 7], d["stats"][i, 8]]
             out, it = np.zeros(4, np.int32), np.zeros(4, np.int32)
-            assert sim.sim_ddave_solve(_p(m), m.shape[0], m.shape[1], power, _p(out), _p(it)) == 0
+            rc = sim.sim_ddave_solve2(_p(m), m.shape[0], m.shape[1], power, fast, _p(out), _p(it))
+            assert rc in (0, 1)
+            took_fast += rc
             assert list(out) == exp, (path, i, out, exp)
             assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
             capped += int((it >= power).any())
             n += 1
     assert n > 400 and capped > 30
+    assert (took_fast > 0.9 * n) if fast else took_fast == 0
 
 
 def test_bitboard_stats_vs_oracle_random(sim):
