@@ -18,6 +18,9 @@ out = ["# %s (MI355X, rocprofv3)\n" % name,
        "then separate `--pmc` passes (SQ_* counters; FETCH_SIZE; WRITE_SIZE).  Bench lines: `bench_<W>.json`.\n"]
 for W in workloads:
     out.append("## %s\n" % W)
+    if W.endswith("R"):
+        out.append("`bench.py --workload %s --steps 200` *with* its pcgrl_rollout leg: the two calls of `k_step<..., true>` / `k_step_solver` are the 20-step "
+                   "warm-up tape and the timed 200-step tape (max us / 200 = the `rollout.ms_per_step` of the bench line).\n" % W[:-1])
     ks = os.path.join(G, "prof_" + W, W + "_kernel_stats.csv")
     if os.path.exists(ks):
         shutil.copy(ks, os.path.join(dst, W + "_kernel_stats.csv"))

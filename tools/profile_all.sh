@@ -1,6 +1,6 @@
 #!/bin/bash
 # Full profiling session of a round on the GPU box (one gpurun call); results land in gpurun_out/.
-#   tools/profile_all.sh ; then: python tools/make_profile_summary.py <name> C2 C3 C4 C5
+#   tools/profile_all.sh ; then: python tools/make_profile_summary.py <name> C2 C3 C4 C5 C2R C4R
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -8,6 +8,8 @@ timeout 600 tools/profile_gpu.sh C2 trace sq mem
 timeout 400 tools/profile_gpu.sh C3 trace sq mem
 timeout 400 tools/profile_gpu.sh C5 trace sq mem
 timeout 600 tools/profile_gpu.sh C4 trace sq mem
+timeout 300 tools/profile_gpu.sh C2 rtrace
+timeout 400 tools/profile_gpu.sh C4 rtrace
 for w in C2 C3 C4 C5; do
   timeout 400 python bench.py --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
   tail -c 400 gpurun_out/bench_$w.json
