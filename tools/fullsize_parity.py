@@ -11,8 +11,12 @@ import oracle_lib as ol
 from gym_pcgrl_amd.envs import BatchedPcgrlEnv
 
 CASES = [("binary", "narrow", (), 65536, 160), ("zelda", "wide", (dict(width=11, height=16),), 65536, 80),
-         ("binary", "turtle", (dict(width=64, height=64),), 8192, 100), ("sokoban", "narrow", (), 131072, 40)]
-for prob, rep, calls, N, T in CASES:
+         ("binary", "turtle", (dict(width=64, height=64),), 8192, 100), ("sokoban", "narrow", (), 131072, 40),
+         ("mdungeon", "narrow", (), 65536, 40), ("ddave", "narrow", (), 65536, 40)]
+# every case twice: stepping, and the same tape as one pcgrl_rollout call (the fused / persistent kernels at full size)
+for prob, rep, calls, N, T in [c for c in CASES for _ in (0, 1)]:
+    use_rollout = getattr(sys.modules[__name__], "_flip", False)
+    _flip = not use_rollout
     env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=N, seed=0)
     for kw in calls:
         env.adjust_param(**kw)
@@ -34,7 +38,15 @@ for prob, rep, calls, N, T in CASES:
         exp.append(o.rollout(a_host[:, j], want_heat=False))
     keys = list(env._prob.info_keys) + ["iterations", "changes"]
     ti = torch.as_tensor(idx, device="cuda")
-    for t in range(T):
+    if use_rollout:
+        rew_t, done_t, info_t = env.rollout(acts if acts.shape[2] > 1 else acts[:, :, 0])
+        got = np.stack([info_t[k].view(T, N)[:, ti].cpu().numpy() for k in keys], 2).astype(np.int64)
+        ok = np.array_equal(done_t[:, ti].cpu().numpy(), np.stack([x["done"] for x in exp], 1)) and \
+            np.array_equal(rew_t[:, ti].cpu().numpy(), np.stack([x["reward"] for x in exp], 1)) and \
+            np.array_equal(got, np.stack([x["info"] for x in exp], 1))
+        assert ok, ("ROLLOUT MISMATCH", prob, rep)
+        obs = env._obs()
+    for t in range(0 if not use_rollout else T, T):
         obs, rew, done, info = env.step(acts[t] if acts.shape[2] > 1 else acts[t, :, 0])
         ok = np.array_equal(done[ti].cpu().numpy(), np.array([x["done"][t] for x in exp])) and \
             np.array_equal(rew[ti].cpu().numpy(), np.array([x["reward"][t] for x in exp])) and \
@@ -42,6 +54,6 @@ for prob, rep, calls, N, T in CASES:
         assert ok, ("MISMATCH", prob, rep, "step", t)
     assert np.array_equal(obs["map"][ti].cpu().numpy(), np.stack([x["maps"][-1] for x in exp]))
     env.check_status()
-    print("ok", prob, rep, "N", N, "steps", T, "sampled envs", len(idx), flush=True)
+    print("ok", "rollout" if use_rollout else "steps", prob, rep, "N", N, "steps", T, "sampled envs", len(idx), flush=True)
     env.close()
 print("full-size parity passed")
