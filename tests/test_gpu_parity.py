@@ -217,6 +217,29 @@ def test_facade_matches_golden():
         assert np.array_equal(o["heatmap"], d["heatmap"][t, 0].astype(np.float64))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,env_id", [("traj_mdungeon_narrow", "mdungeon-narrow-v0"), ("traj_ddave_narrow", "ddave-narrow-v0")])
+def test_facade_packed_problems(name, env_id):
+    """The single-environment facade on the two problems whose device rows pack several statistics into a slot: the info dict
+    has the reference's keys and values (ddave: get_debug_info's own key order, without dist-floor)."""
+    _torch()
+    import gym_pcgrl_amd
+    d = np.load(os.path.join(G, name + ".npz"))
+    env = gym_pcgrl_amd.make(env_id)
+    env.seed(int(d["cfg"][4]))
+    o = env.reset()
+    assert np.array_equal(o["map"], d["map0"][0])
+    keys = [str(k) for k in d["info_keys"]]
+    for t in range(80):
+        o, r, dn, info = env.step(int(d["actions"][t, 0, 0]))
+        assert r == d["reward"][t, 0] and dn == bool(d["done"][t, 0])
+        assert [info[k] for k in keys] == list(d["info"][t, 0])
+        assert set(info) == set(keys) | {"max_iterations", "max_changes"}
+        if dn:
+            o = env.reset()
+        assert np.array_equal(o["map"], d["maps"][t, 0])
+
+
 # ------------------------------------------------------------------ shard invariance / determinism
 def test_shard_invariance_and_determinism():
     torch = _torch()
