@@ -692,7 +692,13 @@ def gen_wrappers():
         ("actionmap_zelda_wide", "zelda-wide-v0", "actionmap", 0, 8, 150),
         ("actionmap_binary_wide", "binary-wide-v0", "actionmap", 0, 8, 150),
         ("actionmap_sokoban_wide", "sokoban-wide-v0", "actionmap", 0, 8, 150),
+        ("cropped_mdungeon_turtle", "mdungeon-turtle-v0", "cropped", 22, 8, 150),
+        ("cropped_ddave_narrow", "ddave-narrow-v0", "cropped", 22, 8, 150),
+        ("actionmap_ddave_wide", "ddave-wide-v0", "actionmap", 0, 8, 150),
     ]
+    only = os.environ.get("PCGRL_GOLDEN_WRAP_ONLY")
+    if only:
+        cases = [c for c in cases if c[0] in only.split(",")]
     for name, game, kind, size, E, T in cases:
         envs = []
         for i in range(E):
