@@ -159,7 +159,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_step_solver(PcgrlParams P, DevBu
     extern __shared__ __attribute__((aligned(16))) uint32_t ss_lds[];     // heap + visited table of the block's one search at a time
     __shared__ LocalLists s_lists;
     __shared__ typename SolverGame<PROB>::Shared s_game0;      // the full-region search; the small ones keep theirs in the region itself
-    __shared__ uint16_t s_big[WL_LOCAL_CAP];        // search jobs that need the full region
+    __shared__ uint16_t s_big[2 * WL_LOCAL_CAP];    // search jobs that need the full region (at most every WL_SOL + park-list entry)
     __shared__ int s_nbig;
     // the resets (MT ring + tile bytes per wavefront) borrow the search region: resets and searches are separate phases
     constexpr int kMtBytes = PCGRL_MT_N * 4 + 272;

@@ -805,6 +805,37 @@ def test_rollout_equals_steps(env_id, calls, N, T):
 
 
 @pytest.mark.gpu
+def test_rollout_many_long_searches_per_block():
+    """The persistent search-problem kernel when most environments of a block need a long search in the same step: every
+    environment starts from an open Sokoban level whose searches run beyond the small tier (the deferred-job list of a
+    block then holds most of its environments), against single steps on a twin batch."""
+    torch = _torch()
+    N, T = 400, 6
+    m = np.zeros((6, 6), np.uint8)
+    m[0, 0] = 2; m[2, 2] = 3; m[3, 3] = 3; m[2, 4] = 3; m[5, 5] = 4; m[0, 5] = 4; m[5, 0] = 4
+    maps = np.repeat(m[None], N, 0)
+    envs = []
+    for _ in range(2):
+        e = _make("sokoban", "wide", N, [dict(width=6, height=6), dict(solver_power=1500, change_percentage=1.0)], seed=5)
+        e.reset()
+        e.set_maps(maps)
+        envs.append(e)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    # writes of empty tiles into the empty area: the level changes little, the searches stay long
+    tape = torch.stack([torch.randint(3, 6, (T, N), generator=g, device="cuda", dtype=torch.int32),
+                        torch.randint(4, 6, (T, N), generator=g, device="cuda", dtype=torch.int32),
+                        torch.randint(0, 2, (T, N), generator=g, device="cuda", dtype=torch.int32)], -1)
+    rew, done, info = envs[0].rollout(tape)
+    for t in range(T):
+        obs, r, d, inf = envs[1].step(tape[t])
+        assert torch.equal(rew[t], r) and torch.equal(done[t], d) and torch.equal(info.table.view(T, N, 10)[t], inf.table), t
+    sa, sb = envs[0].state_dict(), envs[1].state_dict()
+    for k in sa:
+        if sa[k] is not None:
+            assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.gpu
 def test_device_seeding_matches_numpy():
     """pcgrl_seed_words: MT19937 init_by_array on the device against numpy's RandomState.seed(list) -- keys of two words
     (what gym's hash_seed gives) and of one word."""
