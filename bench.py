@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the batched PCGRL hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--envs E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C3d|C4|C5|C5b|M1|D1] [--envs E]
+
+With --gpus N > 1 and no RANK in the environment the script launches itself under torch.distributed.run with one rank per
+GPU (127.0.0.1 rendezvous, RCCL barrier, max-over-ranks time) and prints the one JSON line of rank 0 with n_gpus = N; it
+exits non-zero rather than print a line for fewer GPUs than were asked for.  Started by torch.distributed.run itself (the
+driver's way) it behaves the same from the second step on.
 
 A "step" is one BatchedPcgrlEnv.step() over the whole batch (E environments per GPU, weak scaling):
 Representation.update + Problem.get_stats/get_reward + in-kernel auto-reset, random actions that
@@ -31,6 +36,11 @@ WORKLOADS = {
     "C3": ("zelda", "wide", (dict(width=11, height=16),), 65536, "zelda-wide-v0 11x16, 65536 envs/GPU"),
     "C4": ("sokoban", "narrow", (), 131072, "sokoban-narrow-v0 5x5, 131072 envs/GPU"),
     "C5": ("binary", "turtle", (dict(width=64, height=64),), 8192, "binary-turtle-v0 64x64 (adjust_param), 8192 envs/GPU"),
+    # SURVEY 8d secondary variants: zelda at its default size; C5 after a second adjust_param call (Q9: only then does
+    # max_changes follow the 64x64 map: 819 changes per episode instead of 39, so full recomputations dominate)
+    "C3d": ("zelda", "wide", (), 65536, "zelda-wide-v0 11x7 (default size), 65536 envs/GPU"),
+    "C5b": ("binary", "turtle", (dict(width=64, height=64), dict(change_percentage=0.2)), 8192,
+            "binary-turtle-v0 64x64, adjust_param(width,height) then adjust_param(change_percentage=0.2): max_changes 819, 8192 envs/GPU"),
     # not a BASELINE.json config: the mdungeon problem, reported for completeness
     "M1": ("mdungeon", "narrow", (), 65536, "mdungeon-narrow-v0 7x11, 65536 envs/GPU"),
     "D1": ("ddave", "narrow", (), 65536, "ddave-narrow-v0 11x7, 65536 envs/GPU"),
@@ -128,6 +138,40 @@ def cpu_baseline(prob, rep, calls, budget_s=12.0):
             "single_core": rate1}
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(a):
+    """python bench.py --gpus N (N > 1) without a launcher: run N ranks of this script under torch.distributed.run."""
+    import subprocess
+    same_gpu = os.environ.get("PCGRL_BENCH_SAME_GPU") == "1"
+    if not same_gpu and not a.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            sys.stderr.write("bench.py: --gpus %d asked for but %d visible; refusing to print a line for fewer GPUs\n" % (a.gpus, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or len(lines) != 1:
+        sys.stderr.write("bench.py: the %d-rank run failed (rc %d, %d result lines)\n%s\n" % (a.gpus, out.returncode, len(lines), out.stdout[-2000:]))
+        return out.returncode or 3
+    if json.loads(lines[0]).get("n_gpus") != a.gpus:
+        sys.stderr.write("bench.py: the result line does not carry n_gpus = %d\n" % a.gpus)
+        return 4
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,7 +181,14 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary pcgrl_rollout measurement")
+    ap.add_argument("--dry-run", action="store_true", help="process plumbing only (launcher, rendezvous, barrier, max-over-ranks reduction over gloo); "
+                                                          "no GPU, no environment: the line carries value null and dry_run true")
+    ap.add_argument("--steady-warmup", type=int, default=800, help="steps before the steady_state measurement (0: skip it)")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "RANK" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
 
     import torch
     import torch.distributed as dist
@@ -146,7 +197,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
-    assert world == a.gpus or not use_dist, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if world != a.gpus:                      # never report a line for another number of GPUs than was asked for
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d; launch with torch.distributed.run --nproc-per-node %d "
+                         "(or without a launcher: the script starts its own ranks)\n" % (a.gpus, world, a.gpus))
+        sys.exit(2)
+    if a.dry_run:
+        # the multi-process skeleton of the measurement without a GPU (CPU tests): same launcher, same barrier / max-over-ranks
+        # reduction, over gloo; nothing is measured and the line says so
+        if use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        if use_dist:
+            dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "env-steps/sec (whole node)", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "dry_run": True, "max_over_ranks_s": float(tt[0]), "scaling": "weak"}))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # PCGRL_BENCH_SAME_GPU=1 (tests on a one-GPU box): every rank uses cuda:0 and the ranks meet over gloo
     same_gpu = os.environ.get("PCGRL_BENCH_SAME_GPU") == "1"
     if same_gpu:
@@ -202,6 +277,29 @@ def main():
             env.step(acts[t])
         phase_ms, prof_steps = env.profile_read()
         env.profile(False)
+
+    # steady state: the driver's short window right after a reset sees almost no episode end and every map at 50 % density.
+    # The same K steps again once the batch has run for >= --steady-warmup steps (tape rows reused cyclically).
+    steady = None
+    if rank == 0 and a.steady_warmup > 0:
+        L = acts.shape[0]
+        t_now = a.warmup + a.steps + prof_steps
+        for t in range(t_now, max(t_now, a.steady_warmup)):
+            env.step(acts[t % L])
+        t_now = max(t_now, a.steady_warmup)
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        w0 = time.perf_counter()
+        s0.record()
+        for t in range(t_now, t_now + a.steps):
+            env.step(acts[t % L])
+        s1.record()
+        torch.cuda.synchronize(device)
+        w1 = time.perf_counter()
+        sms = s0.elapsed_time(s1) / a.steps
+        steady = {"value": float(n) / ((w1 - w0) / a.steps), "unit": "env-steps/s (this rank)", "ms_per_step": (w1 - w0) / a.steps * 1e3,
+                  "gpu_ms_per_step": sms, "after_steps": t_now, "steps": a.steps,
+                  "what": "the same stepping loop once the batch has run for after_steps steps (episode ends, resets and the whole range of map densities in the mix)"}
 
     # secondary figure: the same K steps as ONE pcgrl_rollout call on the action tape (a single launch where the fused
     # step kernel applies; per-step reward / done / info still written for every step).  Not the headline `value`.
@@ -259,7 +357,7 @@ def main():
         achieved = n * b_alg / (gpu_ms_per_step * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(a.workload) if n == n_default else (None, None)
         out = {
-            "metric": "env-steps/sec (whole node), binary-narrow 14x14 @ 65536 envs" if a.workload == "C2" else "env-steps/sec (whole node)",
+            "metric": "env-steps/sec (whole node), binary-narrow 14x14 @ 65536 envs" if (a.workload == "C2" and n == n_default) else "env-steps/sec (whole node)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
@@ -275,6 +373,9 @@ def main():
                          "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
                          "phase_us_per_step_with_event_overhead": ph},
         }
+        if steady is not None:
+            steady["roofline_frac"] = n * b_alg / (steady["gpu_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            out["steady_state"] = steady
         if rollout is not None:
             out["rollout"] = rollout
         if world == 1 and not a.no_cpu_baseline:

@@ -27,6 +27,17 @@ def registered_ids():
     return sorted(_ENV_IDS)
 
 
+def register_with_gym():
+    """Register every id with gym / gymnasium when one of them is importable (gym_pcgrl/__init__.py:6-12 does this on
+    import; so does this package, below).  Returns the ids registered by this call."""
+    from . import gym_compat
+    if gym_compat.find_gym() is None:
+        return []
+    if not _ENV_IDS:
+        _register_all()
+    return gym_compat.register_all(_ENV_IDS)
+
+
 def _lookup(env_id):
     if not _ENV_IDS:
         _register_all()
@@ -46,3 +57,7 @@ def make_batched(env_id, num_envs, **kwargs):
     from .envs import BatchedPcgrlEnv
     prob, rep = _lookup(env_id)
     return BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=num_envs, **kwargs)
+
+
+
+register_with_gym()      # no-op without gym / gymnasium (neither is on the MI355X image)

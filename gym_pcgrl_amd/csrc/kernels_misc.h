@@ -32,10 +32,11 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_obs_window(PcgrlParams P, DevBu
     }
 }
 // ActionMap.step for the wide representation (wrappers.py:139-154): flat index into (h, w, tiles) -> (x, y, tile)
-__global__ void k_action_map(const int32_t* __restrict__ flat, int32_t* __restrict__ xyv, int n, int w, int h, int dim) {
+__global__ void k_action_map(const int32_t* __restrict__ flat, int32_t* __restrict__ xyv, int n, int w, int h, int dim, int32_t* status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         int a = flat[i];
+        if (a < 0 || a >= w * h * dim) atomicOr(status, PCGRL_STATUS_BAD_ACTION);     // clamped and reported
         a = a < 0 ? 0 : (a >= w * h * dim ? w * h * dim - 1 : a);
         const int v = a % dim, x = (a / dim) % w, y = a / (dim * w);
         xyv[3 * i] = x; xyv[3 * i + 1] = y; xyv[3 * i + 2] = v;

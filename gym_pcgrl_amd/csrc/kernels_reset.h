@@ -43,7 +43,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_planes_from_map(PcgrlParams P, 
     for (int e = blockIdx.x * 4 + wv; e < P.num_envs; e += gridDim.x * 4) {
         for (int c = lane; c < cells; c += 64) {
             uint8_t t = src[(size_t)e * cells + c];
-            t = t < P.ntiles ? t : (uint8_t)(P.ntiles - 1);
+            if (t >= P.ntiles) { atomicOr(B.status, PCGRL_STATUS_BAD_TILE); t = (uint8_t)(P.ntiles - 1); }   // clamped and reported
             tiles[c] = t;
             B.map[(size_t)e * cells + c] = t;
         }

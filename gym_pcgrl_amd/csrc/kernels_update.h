@@ -43,17 +43,23 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         int changes = c.y;
         int x = p0.x, y = p0.y;
         int tile = -1, wx = 0, wy = 0, hx = 0, hy = 0;
+        // An action outside the action space is clamped into it (the reference raises IndexError or writes the bad value)
+        // and reported through the sticky status word: PCGRL_STATUS_BAD_ACTION, BatchedPcgrlEnv.check_status().
+        bool bad = false;
         if (REP == PCGRL_REP_NARROW) {
             const int a = clampi(a0_, 0, P.ntiles);
+            bad = a != a0_;
             if (a > 0) tile = a - 1;
             wx = x; wy = y;
         } else if (REP == PCGRL_REP_WIDE) {
             wx = clampi(a0_, 0, W - 1);
             wy = clampi(a1_, 0, H - 1);
             tile = clampi(a2_, 0, P.ntiles - 1);
+            bad = wx != a0_ || wy != a1_ || tile != a2_;
             hx = wx; hy = wy;
         } else {
             const int a = clampi(a0_, 0, P.ntiles + 3);
+            bad = a != a0_;
             if (a < 4) {   // turtle_rep.py:18,103-125: L,R,U,D with clamp or warp on both axes
                 const int dx = (a == 0) ? -1 : (a == 1 ? 1 : 0), dy = (a == 2) ? -1 : (a == 3 ? 1 : 0);
                 x += dx;
@@ -164,7 +170,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
             heat_increment(B, B.heat + ((size_t)e * H + hy) * W + hx);
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
-        sure_done = chg && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
+        if (bad) atomicOr(B.status, PCGRL_STATUS_BAD_ACTION);
         if (REP != PCGRL_REP_WIDE) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
         // the episode ends whatever the new statistics are (pcgrl_env.py:143): the reset is certain
         sure_done = chg && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
@@ -245,11 +251,13 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
         int vals[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) vals[i] = -1;
+        bool bad = false;     // out-of-range actions are clamped and reported (see update_env)
         if (REP == PCGRL_REP_NARROW_MULTI) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) { const int a = clampi(actions[9 * e + i], 0, NT); vals[i] = a - 1; }
+            for (int i = 0; i < 9; i++) { const int raw = actions[9 * e + i], a = clampi(raw, 0, NT); bad = bad || a != raw; vals[i] = a - 1; }
         } else {
             const int type = actions[2 * e], value = clampi(actions[2 * e + 1], 0, NT - 1);
+            bad = value != actions[2 * e + 1] || type < 0 || type > (REP == PCGRL_REP_NARROW_CAST ? 2 : 5);
             if (REP == PCGRL_REP_NARROW_CAST) {
                 const int t = clampi(type, 0, 2);
                 if (t == 1) vals[4] = value;
@@ -315,6 +323,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
         reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        if (bad) atomicOr(B.status, PCGRL_STATUS_BAD_ACTION);
         if (!chg) {
             int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
             int32_t* inf = B.info + (size_t)e * 10;

@@ -67,6 +67,8 @@ struct pcgrl_env {
     int device;
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
     int alloc_solver_power;
+    // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
+    int no_wide, wide_waves, fused_zelda, no_fused;
     int profiling;
     std::vector<hipEvent_t> events;
     size_t ev_used;
@@ -88,6 +90,19 @@ static thread_local int g_last_hip = 0;
 #define HIPCHK(expr) do { hipError_t err_ = (expr); if (err_ != hipSuccess) { g_last_hip = (int)err_; return PCGRL_EHIP; } } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static bool env_is_one(const char* name) { const char* v = getenv(name); return v && v[0] == '1'; }
+
+// A handle belongs to the device its buffers live on (found at pcgrl_bind).  Every entry point that launches makes that
+// device current for the duration of the call and puts the caller's device back: one host thread may drive several
+// GPUs, each through its own handle.
+struct DeviceGuard {
+    int prev, dev;
+    explicit DeviceGuard(int d) : prev(-1), dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 
 // problems whose statistics need a search kernel after k_stats (the Sokoban solver, the MiniDungeons planner)
 static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGRL_MDUNGEON || prob == PCGRL_DDAVE; }
@@ -141,6 +156,14 @@ static size_t wl_bytes(const pcgrl_config* c) {
 static size_t sok_sync_bytes() { return align_up(2 * (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, 256); }
 static size_t sok_sched_bytes(int num_envs) { return align_up((size_t)num_envs * 18 * 4, 256) + sok_sync_bytes(); }
 static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<= 1; return t; }
+// Node pool of one resident solver block: 4 children per pop of the full search -- and never less than the private
+// small-tier pools of k_step_solver (SS_SEARCH_WAVES wavefronts x SS_SMALL_NODES at pool + wv * SS_SMALL_NODES), so that a
+// small solver_power cannot make them spill into the next block's pool.
+static size_t sok_pool_nodes(int power) {
+    const size_t full = 4 * (size_t)power + 4, small = (size_t)SS_SEARCH_WAVES * SS_SMALL_NODES;
+    return full > small ? full : small;
+}
+static_assert(SS_SMALL_NODES >= 4 * SS_SMALL_POPS + 4, "a small-tier search pushes up to four nodes per pop");
 // rows of the champion component per environment (binary, maps of at most 16 x 32): the incremental statistics path
 static size_t champ_bytes(const pcgrl_config* c) {
     if (c->prob != PCGRL_BINARY) return 0;
@@ -152,12 +175,31 @@ static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c
 static size_t scratch_bytes_base(const pcgrl_config* c) {
     size_t b = wl_bytes(c);
     if (solver_prob(c->prob)) {           // (an MdNode is as large as a SokNode)
-        const size_t nodes = 4 * (size_t)c->solver_power + 4;
+        const size_t nodes = sok_pool_nodes(c->solver_power);
         b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
         b += sok_sched_bytes(c->num_envs);
-        if (c->solver_power > SOK_LDS_POWER) b += SOK_BLOCKS * (align_up(nodes * 4, 256) + (size_t)sok_table_size(c->solver_power) * 4);
+        const size_t hnodes = 4 * (size_t)c->solver_power + 4;
+        if (c->solver_power > SOK_LDS_POWER) b += SOK_BLOCKS * (align_up(hnodes * 4, 256) + (size_t)sok_table_size(c->solver_power) * 4);
     }
     return b;
+}
+
+// Per-DEVICE state the kernels need, (re)established at every pcgrl_bind -- never behind a process-wide flag: a process may
+// hold handles on several GPUs, and both a function attribute and a __device__ symbol belong to one device.
+static int device_setup(pcgrl_env* h) {
+    {   // init_genrand(19650218): the table every MT19937 init_by_array starts from (k_init_by_array)
+        uint32_t tab[PCGRL_MT_N];
+        tab[0] = 19650218u;
+        for (int i = 1; i < PCGRL_MT_N; i++) tab[i] = 1812433253u * (tab[i - 1] ^ (tab[i - 1] >> 30)) + (uint32_t)i;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_mt_genrand), tab, sizeof(tab)));
+    }
+    if (solver_prob(h->cfg.prob)) {   // the search kernels use most of a compute unit's LDS (heap + 64-bit-key table)
+        const int lds = (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4);
+        const void* f = h->cfg.prob == PCGRL_SOKOBAN ? reinterpret_cast<const void*>(k_sokoban)
+                      : h->cfg.prob == PCGRL_MDUNGEON ? reinterpret_cast<const void*>(k_mdungeon) : reinterpret_cast<const void*>(k_ddave);
+        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    return PCGRL_OK;
 }
 
 extern "C" {
@@ -222,6 +264,19 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         !b->start_stats || !b->info || !b->reward || !b->done || !b->tile_p || !b->rng_rep || !b->rng_cursor || !b->scratch)
         return PCGRL_EINVAL;
     if (h->cfg.prob == PCGRL_BINARY && !b->rng_prob) return PCGRL_EINVAL;
+    {   // the handle's device is the one that owns the buffers
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, b->map) == hipSuccess) h->device = at.device;
+        else { (void)hipGetLastError(); HIPCHK(hipGetDevice(&h->device)); }
+    }
+    DeviceGuard guard(h->device);
+    int rc0 = device_setup(h);
+    if (rc0) return rc0;
+    // environment switches (A/B measurements, tests) are read here, once: no getenv on the step path
+    h->no_wide = env_is_one("PCGRL_NO_WIDE") ? 1 : 0;
+    { const char* wvs = getenv("PCGRL_WIDE_WAVES"); h->wide_waves = wvs ? atoi(wvs) : 8; }   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
+    h->fused_zelda = env_is_one("PCGRL_FUSED_ZELDA") ? 1 : 0;
+    h->no_fused = env_is_one("PCGRL_NO_FUSED") ? 1 : 0;
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
     B.heat_end = B.heat + (size_t)h->cfg.num_envs * h->cfg.width * h->cfg.height;
@@ -262,7 +317,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     if (solver_prob(h->cfg.prob)) {
         // the arena is sized for the solver_power the buffers were allocated with
         const int power = h->alloc_solver_power = h->cfg.solver_power;
-        const size_t nodes = 4 * (size_t)power + 4;
+        const size_t nodes = sok_pool_nodes(power), hnodes = 4 * (size_t)power + 4;
         uint8_t* a = s + wl_bytes(&h->cfg);
         B.sok_pool = (SokNode*)a;
         B.sok_pool_stride = (int32_t)(align_up(nodes * sizeof(SokNode), 256) / sizeof(SokNode));
@@ -284,10 +339,10 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
             if (B.sok_hard_cap < 0 || B.sok_hard_cap > SOK_HARD_CAP) B.sok_hard_cap = SOK_HARD_CAP;
         }
         B.sok_table_size = sok_table_size(power);
-        B.sok_heap_stride = (int32_t)(align_up(nodes * 4, 256) / 4);
+        B.sok_heap_stride = (int32_t)(align_up(hnodes * 4, 256) / 4);
         if (!B.sok_use_lds) {
             B.sok_heap = (uint32_t*)a;
-            a += SOK_BLOCKS * align_up(nodes * 4, 256);
+            a += SOK_BLOCKS * align_up(hnodes * 4, 256);
             B.sok_table = (uint32_t*)a;
         }
     }
@@ -310,6 +365,7 @@ int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
 
 int pcgrl_set_tile_probs(pcgrl_env* h, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
+    DeviceGuard guard(h->device);
     const int n = h->cfg.num_envs;
     hipLaunchKernelGGL(k_bcast_tile_p, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->B.tile_p, n,
                        h->cfg.tile_probs[0], h->cfg.tile_probs[1]);
@@ -320,6 +376,7 @@ int pcgrl_set_tile_probs(pcgrl_env* h, void* stream) {
 int pcgrl_seed(pcgrl_env* h, const uint32_t* keys, int32_t first, int32_t count, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
     if (!keys || first < 0 || count < 1 || first + count > h->cfg.num_envs) return PCGRL_EINVAL;
+    DeviceGuard guard(h->device);
     const size_t bytes = (size_t)count * PCGRL_MT_N * 4, off = (size_t)first * PCGRL_MT_N;
     HIPCHK(hipMemcpyAsync(h->B.rng_rep + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     if (h->B.rng_prob) HIPCHK(hipMemcpyAsync(h->B.rng_prob + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -335,14 +392,7 @@ int pcgrl_seed(pcgrl_env* h, const uint32_t* keys, int32_t first, int32_t count,
 int pcgrl_seed_words(pcgrl_env* h, const uint32_t* words, int32_t first, int32_t count, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
     if (!words || first < 0 || count < 1 || first + count > h->cfg.num_envs) return PCGRL_EINVAL;
-    static bool table_ready = false;
-    if (!table_ready) {
-        uint32_t tab[PCGRL_MT_N];
-        tab[0] = 19650218u;
-        for (int i = 1; i < PCGRL_MT_N; i++) tab[i] = 1812433253u * (tab[i - 1] ^ (tab[i - 1] >> 30)) + (uint32_t)i;
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_mt_genrand), tab, sizeof(tab)));
-        table_ready = true;
-    }
+    DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpy2DAsync(h->B.rng_rep + (size_t)first * PCGRL_MT_N, PCGRL_MT_N * 4, words, 12, 12, (size_t)count, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_init_by_array, dim3((count + 63) / 64), dim3(64), 0, st, h->B.rng_rep, h->B.rng_prob, h->B.rng_cur, first, count);
@@ -372,9 +422,8 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     // (1: shard 0 of the bucketed changed list -- single-cell representations of the binary problem on 16-row maps;
     //  2: the list WL_RST -- everything else that resets in k_stats)
     const int lone0 = !(mode == MODE_STEP && inline_reset) ? 0 : ((PROB == PCGRL_PROB_BINARY && P.group == 16 && P.rep <= PCGRL_REP_TURTLE) ? 1 : 2);
-    if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !getenv("PCGRL_NO_WIDE")) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
-        const char* wvs = getenv("PCGRL_WIDE_WAVES");
-        const int nw = wvs ? atoi(wvs) : 8;   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
+    if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !h->no_wide) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
+        const int nw = h->wide_waves;
         const size_t lds1 = inline_reset ? (size_t)(nw == 8 ? 8 : 4) * (PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
         const int gridw = P.num_envs < 16384 ? P.num_envs : 16384;
         // wavefronts per map: with the incremental route only ~10 % of the changes (and the resets) come here, so the launch
@@ -433,15 +482,14 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
 // scheduling words (two launches per step), zeroed here.  Episodes the solver ends go to rst_list.
 // One fused launch per step (kernels_step.h) where it applies: binary, maps of at most 16 rows, single-cell
 // representations, auto-reset with the in-kernel reset.  PCGRL_NO_FUSED=1 keeps the two-launch pipeline (A/B, tests).
-static bool env_is_one(const char* name) { const char* v = getenv(name); return v && v[0] == '1'; }
 static bool fused_step_applies(const pcgrl_env* h, bool rollout = false) {
     const PcgrlParams& P = h->P;
     // (zelda changes 7 of 8 environments per step: a block then has ~18 wavefront tasks for its four wavefronts and the global
     //  work lists balance better -- measured 48 vs 42.6 us/step on C3; PCGRL_FUSED_ZELDA=1 takes the fused kernel anyway)
     // A rollout has no barrier between steps, so the imbalance between blocks averages out over the tape: zelda takes k_step there.
-    const bool prob_ok = P.prob == PCGRL_PROB_BINARY || (P.prob == PCGRL_PROB_ZELDA && (rollout || env_is_one("PCGRL_FUSED_ZELDA")));
+    const bool prob_ok = P.prob == PCGRL_PROB_BINARY || (P.prob == PCGRL_PROB_ZELDA && (rollout || h->fused_zelda));
     return prob_ok && P.group == 16 && P.rep <= PCGRL_REP_TURTLE && P.auto_reset &&
-           h->B.inline_reset && !env_is_one("PCGRL_NO_FUSED");
+           h->B.inline_reset && !h->no_fused;
 }
 struct RolloutArgs { int steps; size_t action_stride; double* reward_out; uint8_t* done_out; int32_t* info_out; };
 template <int PROB, class MaskT>
@@ -474,33 +522,15 @@ static int action_width(int rep) {   // int32 values per environment and step
 static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
                          hipStream_t st) {
     const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sokoban), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4)));
-        attr_set = true;
-    }
     int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
     HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
     if (h->P.prob == PCGRL_PROB_DDAVE) {
-        static bool dd_attr_set = false;
-        if (!dd_attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ddave), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4)));
-            dd_attr_set = true;
-        }
         const size_t dd_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
         hipLaunchKernelGGL(k_ddave, dim3(SOK_BLOCKS), dim3(64), dd_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
         HIPCHK(hipGetLastError());
         return PCGRL_OK;
     }
     if (h->P.prob == PCGRL_PROB_MDUNGEON) {
-        static bool md_attr_set = false;
-        if (!md_attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdungeon), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4)));
-            md_attr_set = true;
-        }
         const size_t md_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
         hipLaunchKernelGGL(k_mdungeon, dim3(SOK_BLOCKS), dim3(64), md_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
                            sync, clr);
@@ -545,7 +575,7 @@ static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int c
 // pcgrl_rollout for the search problems: persistent blocks that own their environments for the whole tape (kernels_step_solver.h)
 static bool solver_rollout_applies(const pcgrl_env* h, int* envs_per_block) {
     const PcgrlParams& P = h->P;
-    if (!solver_prob(P.prob) || P.rep > PCGRL_REP_TURTLE || !P.auto_reset || !h->B.sok_use_lds || P.group != 16 || env_is_one("PCGRL_NO_FUSED")) return false;
+    if (!solver_prob(P.prob) || P.rep > PCGRL_REP_TURTLE || !P.auto_reset || !h->B.sok_use_lds || P.group != 16 || h->no_fused) return false;
     int epb = 64 * ((P.num_envs + SOK_BLOCKS * 64 - 1) / (SOK_BLOCKS * 64));      // one block per compute unit when the batch is large enough
     epb = epb < 64 ? 64 : epb;
     if (epb > WL_LOCAL_CAP) return false;                                            // more than 256 x 512 environments: the sequence of steps
@@ -594,12 +624,18 @@ static int reset_one(pcgrl_env* h, void* stream) {
     return PCGRL_OK;
 }
 
-static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
+// *used_lists: the step went through the global work lists (every path but the fused kernel).  Invariant of the handle:
+// at the start of every call the counters of h->parity are zero.  A pass through the lists leaves them dirty and has its last
+// kernel zero the other parity's, so the caller flips h->parity after it; the fused kernels never touch the lists and
+// must NOT flip it (an odd number of fused steps followed by a list step would otherwise land on uncleared counters).
+static int step_one(pcgrl_env* h, const int32_t* actions, void* stream, bool* used_lists) {
     hipStream_t st = (hipStream_t)stream;
     const int par = h->parity;
     int rc;
+    *used_lists = true;
     if ((rc = prof_mark(h, st))) return rc;
     if (fused_step_applies(h)) {      // the whole step in one launch
+        *used_lists = false;
         if ((rc = launch_step(h, actions, par, st))) return rc;
         for (int k = 0; k < 6; k++) if ((rc = prof_mark(h, st))) return rc;
         return PCGRL_OK;
@@ -640,6 +676,7 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream) {
 
 int pcgrl_reset(pcgrl_env* h, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
+    DeviceGuard guard(h->device);
     int rc = reset_one(h, stream);
     if (rc) return rc;
     h->parity ^= 1;
@@ -651,9 +688,11 @@ int pcgrl_reset(pcgrl_env* h, void* stream) {
 int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!actions) return PCGRL_EINVAL;
-    int rc = step_one(h, actions, stream);
+    DeviceGuard guard(h->device);
+    bool used_lists = true;
+    int rc = step_one(h, actions, stream, &used_lists);
     if (rc) return rc;
-    h->parity ^= 1;
+    if (used_lists) h->parity ^= 1;
     if (h->profiling) h->prof_steps++;
     return PCGRL_OK;
 }
@@ -663,14 +702,12 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
 int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* reward_out, uint8_t* done_out, int32_t* info_out, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!actions || steps < 1) return PCGRL_EINVAL;
+    DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->P.num_envs, stride = n * action_width(h->P.rep);
     if (fused_step_applies(h, true) && !h->profiling) {
         const RolloutArgs R = {steps, stride, reward_out, done_out, info_out};
-        int rc = launch_step(h, actions, h->parity, st, R);
-        if (rc) return rc;
-        if (steps & 1) h->parity ^= 1;
-        return PCGRL_OK;
+        return launch_step(h, actions, h->parity, st, R);     // no work lists, no parity flip (see step_one)
     }
     int epb = 0;
     if (solver_rollout_applies(h, &epb) && !h->profiling) {
@@ -697,6 +734,7 @@ int pcgrl_bind_episode_stats(pcgrl_env* h, double* ep_return, int32_t* ep_length
     if (!h || !h->bound) return PCGRL_ESTATE;
     const int any = (ep_return != nullptr) + (ep_length != nullptr) + (last_return != nullptr) + (last_length != nullptr);
     if (any != 0 && any != 4) return PCGRL_EINVAL;
+    DeviceGuard guard(h->device);
     const size_t n = (size_t)h->cfg.num_envs;
     if (any) {
         HIPCHK(hipMemsetAsync(ep_return, 0, n * 8, (hipStream_t)stream));
@@ -722,6 +760,7 @@ int pcgrl_profile_read(pcgrl_env* h, double* phase_ms, int32_t* steps) {
     for (int k = 0; k < PCGRL_NPHASE; k++) phase_ms[k] = 0.0;
     *steps = h->prof_steps;
     if (h->ev_used == 0) return PCGRL_OK;
+    DeviceGuard guard(h->device);
     HIPCHK(hipEventSynchronize(h->events[h->ev_used - 1]));
     const size_t per = PCGRL_NPHASE + 1;
     for (size_t s0 = 0; s0 + per <= h->ev_used; s0 += per)
@@ -737,6 +776,7 @@ int pcgrl_observe(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int3
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!out || out_h < 1 || out_w < 1) return PCGRL_EINVAL;
     if (centered && h->P.rep == PCGRL_REP_WIDE) return PCGRL_EINVAL;   // Cropped needs a cursor (wrappers.py:170)
+    DeviceGuard guard(h->device);
     const int depth = onehot ? h->P.ntiles : 1;
     const size_t total = (size_t)h->P.num_envs * out_h * out_w;
     const int grid = (int)((total + PCGRL_BLOCK - 1) / PCGRL_BLOCK < 16384 ? (total + PCGRL_BLOCK - 1) / PCGRL_BLOCK : 16384);
@@ -748,14 +788,16 @@ int pcgrl_observe(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int3
 int pcgrl_action_map(pcgrl_env* h, const int32_t* flat, int32_t* xyv, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
     if (!flat || !xyv) return PCGRL_EINVAL;
+    DeviceGuard guard(h->device);
     const int n = h->P.num_envs;
-    hipLaunchKernelGGL(k_action_map, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, xyv, n, h->P.width, h->P.height, h->P.ntiles);
+    hipLaunchKernelGGL(k_action_map, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, xyv, n, h->P.width, h->P.height, h->P.ntiles, h->B.status);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
 
 int pcgrl_status(pcgrl_env* h, void* stream, int32_t* status) {
     if (!h || !h->bound || !status) return PCGRL_ESTATE;
+    DeviceGuard guard(h->device);
     HIPCHK(hipMemcpyAsync(status, h->B.status, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return PCGRL_OK;
@@ -784,6 +826,7 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
 int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!maps) return PCGRL_EINVAL;
+    DeviceGuard guard(h->device);
     int rc = set_maps_one(h, maps, stream);
     if (rc) return rc;
     h->parity ^= 1;

@@ -2,6 +2,10 @@
 // Part of the single translation unit pcgrl_abi.hip (see its header comment for the overall picture).
 #pragma once
 #define PCGRL_BLOCK 256
+// bits of the sticky status word (pcgrl_status; include/pcgrl_hip.h)
+#define PCGRL_STATUS_TOO_MANY_CRATES 1
+#define PCGRL_STATUS_BAD_ACTION 2
+#define PCGRL_STATUS_BAD_TILE 4
 enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
 
 // Work lists (changed environments, environments to reset, sokoban solver jobs).  A list is 64 shards,

@@ -358,6 +358,11 @@ class BatchedPcgrlEnv:
         _lib.check(self._lib.pcgrl_status(self._handle, self._stream(), C.byref(st)), "pcgrl_status")
         if st.value & 1:
             raise RuntimeError("sokoban level with more than 32 crates: outside the solver kernel's limits")
+        if st.value & 2:
+            raise IndexError("an action outside the action space was passed to step()/rollout() (it was clamped into range; "
+                             "the reference raises IndexError or writes the bad value)")
+        if st.value & 4:
+            raise ValueError("set_maps() was given a tile id >= get_num_tiles() (it was clamped)")
         return st.value
 
     def profile(self, enable=True):

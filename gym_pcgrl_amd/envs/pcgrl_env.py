@@ -10,10 +10,12 @@ from collections import OrderedDict
 
 import numpy as np
 
+from .. import gym_compat
 from .batched_env import BatchedPcgrlEnv
 
 
-class PcgrlEnv:
+class PcgrlEnv(gym_compat.env_base()):
+    """A gym.Env when gym / gymnasium is importable (pcgrl_env.py:14), a plain class otherwise."""
     metadata = {"render.modes": ["human", "rgb_array"]}
 
     def __init__(self, prob="binary", rep="narrow", device=None):
@@ -24,8 +26,8 @@ class PcgrlEnv:
         self._sync_spaces()
 
     def _sync_spaces(self):
-        self.action_space = self._batched.action_space
-        self.observation_space = self._batched.observation_space
+        self.action_space = gym_compat.convert_space(self._batched.action_space)
+        self.observation_space = gym_compat.convert_space(self._batched.observation_space)
 
     # attributes the reference exposes and scripts poke at
     _max_changes = property(lambda s: s._batched._max_changes)

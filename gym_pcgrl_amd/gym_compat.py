@@ -1,0 +1,85 @@
+"""gym / gymnasium integration, active only when one of them is importable (neither is on the MI355X image).
+
+The reference registers '{prob}-{rep}-v0' for every problem x representation when it is imported
+(gym_pcgrl/__init__.py:6-12), its PcgrlEnv is a gym.Env (envs/pcgrl_env.py:14), and its wrappers start from
+`gym.make(game)` (wrappers.py:21-24).  With gym present `import gym_pcgrl_amd` does the same: the ids are registered with
+entry point `gym_pcgrl_amd.envs:PcgrlEnv` (a gym.Env subclass then, spaces converted to the library's own classes), so the
+reference's wrappers.py and scripts run on this package by importing it in place of `gym_pcgrl`.  `PcgrlVectorEnv` is the
+batched environment behind the gym.vector.VectorEnv surface.
+"""
+import importlib
+import sys
+
+
+def find_gym():
+    """The gym module to integrate with: an already imported `gym` / `gymnasium` (this is how a test shim is found too),
+    else whichever of the two imports; None when neither does."""
+    for name in ("gym", "gymnasium"):
+        if name in sys.modules:
+            return sys.modules[name]
+    for name in ("gym", "gymnasium"):
+        try:
+            return importlib.import_module(name)
+        except ImportError:
+            continue
+    return None
+
+
+def env_base():
+    g = find_gym()
+    return g.Env if g is not None and hasattr(g, "Env") else object
+
+
+def vector_env_base():
+    g = find_gym()
+    vec = getattr(g, "vector", None) if g is not None else None
+    return getattr(vec, "VectorEnv", object) if vec is not None else object
+
+
+def convert_space(space):
+    """Descriptor of gym_pcgrl_amd.spaces -> the gym library's own space class (identity without gym, and under a gym
+    whose `spaces` module IS gym_pcgrl_amd.spaces, as in the test shim)."""
+    from collections import OrderedDict
+
+    from . import spaces as S
+    g = find_gym()
+    gs = getattr(g, "spaces", None) if g is not None else None
+    if gs is None or gs is S:
+        return space
+    if isinstance(space, S.Discrete):
+        return gs.Discrete(space.n)
+    if isinstance(space, S.MultiDiscrete):
+        return gs.MultiDiscrete(space.nvec)
+    if isinstance(space, S.Box):
+        return gs.Box(low=space.low, high=space.high, dtype=space.dtype.type)
+    if isinstance(space, S.Dict):
+        return gs.Dict(OrderedDict((k, convert_space(s)) for k, s in space.spaces.items()))
+    return space
+
+
+_registered = []
+
+
+def register_all(ids):
+    """gym_pcgrl/__init__.py:6-12 for this package.  `ids`: {env id: (prob, rep)}.  Ids that something else registered
+    already (the reference itself, or an earlier import) are left alone.  Returns the ids registered by this call."""
+    g = find_gym()
+    if g is None:
+        return []
+    try:
+        register = importlib.import_module(g.__name__ + ".envs.registration").register
+    except (ImportError, AttributeError):
+        register = getattr(g, "register", None)
+    if register is None:
+        return []
+    done = []
+    for env_id, (prob, rep) in sorted(ids.items()):
+        if env_id in _registered:
+            continue
+        try:
+            register(id=env_id, entry_point="gym_pcgrl_amd.envs:PcgrlEnv", kwargs={"prob": prob, "rep": rep})
+        except Exception:      # gym.error.Error "Cannot re-register id": keep the existing registration
+            continue
+        _registered.append(env_id)
+        done.append(env_id)
+    return done

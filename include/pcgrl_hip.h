@@ -152,8 +152,10 @@ int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* st
  * default).  Call after pcgrl_bind. */
 int pcgrl_bind_episode_stats(pcgrl_env* env, double* ep_return, int32_t* ep_length, double* last_return,
                              int32_t* last_length, void* stream);
-/* Sticky device status word (0 = fine; bit 0: a sokoban level had more crates than the solver supports).
- * Synchronises the stream. */
+/* Sticky device status word, 0 = fine.  Bit 0 (1): a sokoban level had more crates than the solver supports.
+ * Bit 1 (2): an action outside the action space was clamped into it (the reference raises IndexError or writes the
+ * bad value: narrow_rep.py:101-103, wide_rep.py:68-69, turtle_rep.py:101-129, wrappers.py:139-154).  Bit 2 (4):
+ * pcgrl_set_maps was handed a tile id >= the number of tiles (clamped).  Synchronises the stream. */
 int pcgrl_status(pcgrl_env* env, void* stream, int32_t* status);
 
 

@@ -1,0 +1,185 @@
+"""Step-by-step GPU-vs-oracle comparisons shared by the `-m gpu` tests and the command-line tools (tools/fuzz_parity.py,
+tools/fullsize_parity.py).  Test infrastructure: the oracle is the checker here, never the thing measured.
+
+fuzz_case(rs, ...)      one random (problem, representation, map size, parameters, seed) configuration; every step of the
+                        HIP path -- stepping, or the whole tape as one pcgrl_rollout call -- against the CPU oracle
+fullsize_case(...)      a benchmark configuration at its real batch size (the paths only large batches take: paired certain
+                        resets, every bucket in use, 512 environments per persistent block); a sample of environments
+                        compared with the oracle at every step
+"""
+import numpy as np
+
+import oracle_lib as ol
+
+REPS = ["narrow", "wide", "turtle", "narrowcast", "narrowmulti", "turtlecast"]
+PROB_MIX = ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon", "ddave", "ddave"]
+
+
+def draw_config(rs, only=None):
+    """-> (prob, rep, (w, h), calls, E, T, seed0, use_rollout): everything random about one fuzz configuration."""
+    prob = only or PROB_MIX[rs.randint(len(PROB_MIX))]
+    rep = REPS[rs.randint(6)]
+    if prob == "sokoban":
+        w, h = int(rs.randint(2, 8)), int(rs.randint(2, 8))
+    elif prob in ("mdungeon", "ddave"):
+        w, h = int(rs.randint(1, 13)), int(rs.randint(1, 13))
+    else:
+        w, h = int(rs.randint(1, 41)), int(rs.randint(1, 41))
+        if rs.rand() < 0.4:
+            h = int(rs.randint(1, 17)); w = int(rs.randint(1, 33))
+    calls = [dict(width=w, height=h), dict(change_percentage=float(rs.choice([0.05, 0.2, 0.5, 1.0])))]
+    if prob == "sokoban":
+        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000]))))
+    if prob == "mdungeon":
+        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000, 5000]))))
+        if rs.rand() < 0.7:     # open maps with few players / exits: the planner runs in a good share of the steps
+            mon = float(rs.choice([0.0, 0.03, 0.15]))
+            calls.append(dict(probs={"empty": 0.75, "solid": float(rs.choice([0.02, 0.1])), "player": 0.03, "exit": 0.03,
+                                     "goblin": mon, "ogre": mon}))
+        if rs.rand() < 0.5:
+            calls.append(dict(target_solution=int(rs.randint(1, 8)), target_col_enemies=float(rs.choice([0.0, 0.3, 0.5])),
+                              max_enemies=int(rs.randint(1, 5)), max_potions=int(rs.randint(0, 3)), max_treasures=int(rs.randint(0, 3)),
+                              rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "sol-length": float(rs.choice([1, 0.7]))}))
+    if prob == "ddave":
+        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000, 5000]))))
+        if rs.rand() < 0.7:     # open maps with few players / exits / keys: the planner runs in a good share of the steps
+            calls.append(dict(probs={"empty": 0.7, "solid": float(rs.choice([0.05, 0.15])), "player": 0.04, "exit": 0.04, "key": 0.04,
+                                     "spike": float(rs.choice([0.0, 0.03]))}))
+        if rs.rand() < 0.5:
+            calls.append(dict(target_solution=int(rs.randint(1, 8)), target_jumps=int(rs.randint(0, 3)), max_diamonds=int(rs.randint(0, 4)),
+                              min_spikes=int(rs.randint(0, 6)), rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "dist-floor": float(rs.choice([2, 0.5]))}))
+    if rep in ("narrow", "narrowcast", "narrowmulti") and rs.rand() < 0.3:
+        calls.append(dict(random_tile=False))
+    if rep in ("turtle", "turtlecast") and rs.rand() < 0.5:
+        calls.append(dict(warp=True))
+    if rs.rand() < 0.2:
+        calls.append(dict(random_start=False))
+    E = int(rs.choice([8, 33, 96])) if w * h > 400 else int(rs.choice([33, 96, 200]))
+    T = 120 if w * h > 400 else 200
+    seed0 = int(rs.randint(1, 10 ** 6))
+    return prob, rep, (w, h), calls, E, T, seed0
+
+
+def _oracle_rollouts(prob, rep, calls, seeds, acts_by_env):
+    out = []
+    for seed, a in zip(seeds, acts_by_env):
+        o = ol.OracleEnv(prob, rep)
+        for kw in calls:
+            o.adjust_param(**kw)
+        o.seed(int(seed))
+        o.reset()
+        out.append(o.rollout(a, want_heat=False))
+    return out
+
+
+def run_config(prob, rep, calls, E, T, seed0, rs, use_rollout, mixed=False, steps_scale=1.0):
+    """One configuration on the GPU against the oracle.  `mixed`: the first part of the tape as one rollout of ODD length,
+    the rest as single steps on the same handle (switching between the fused and the work-list pipelines).  Returns None
+    or a string describing the first mismatch."""
+    import torch
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    T = max(4, int(T * steps_scale))
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=E, seed=seed0)
+    try:
+        for kw in calls:
+            env.adjust_param(**kw)
+        env.reset()
+        sp = env.single_action_space
+        if hasattr(sp, "n"):
+            acts = rs.randint(0, sp.n, size=(T, E, 1)).astype(np.int32)
+        else:
+            acts = np.stack([rs.randint(0, int(k), size=(T, E)) for k in sp.nvec], -1).astype(np.int32)
+        exp = _oracle_rollouts(prob, rep, calls, [seed0 + i for i in range(E)], [acts[:, i] for i in range(E)])
+        keys = list(env._prob.info_keys) + ["iterations", "changes"]
+        t_roll = 0
+        obs = env._obs()
+        if use_rollout or mixed:
+            t_roll = T if not mixed else (T // 3) | 1
+            tape = torch.as_tensor(acts[:t_roll] if acts.shape[2] > 1 else acts[:t_roll, :, 0], device="cuda")
+            rew_t, done_t, info_t = env.rollout(tape)
+            got_info = np.stack([info_t[k].cpu().numpy() for k in keys], 1).astype(np.int64).reshape(t_roll, E, len(keys))
+            ok = np.array_equal(done_t.cpu().numpy(), np.stack([x["done"][:t_roll] for x in exp], 1)) and \
+                np.array_equal(rew_t.cpu().numpy(), np.stack([x["reward"][:t_roll] for x in exp], 1)) and \
+                np.array_equal(got_info, np.stack([x["info"][:t_roll] for x in exp], 1))
+            if not ok:
+                return "ROLLOUT MISMATCH %s %s %s E %d seed %d" % (prob, rep, calls, E, seed0)
+        for t in range(t_roll, T):
+            obs, rew, done, info = env.step(acts[t] if acts.shape[2] > 1 else acts[t, :, 0])
+            ok = np.array_equal(done.cpu().numpy(), np.array([x["done"][t] for x in exp])) and \
+                np.array_equal(rew.cpu().numpy(), np.array([x["reward"][t] for x in exp])) and \
+                np.array_equal(np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64), np.stack([x["info"][t] for x in exp]))
+            if not ok:
+                return "MISMATCH %s %s %s E %d seed %d step %d" % (prob, rep, calls, E, seed0, t)
+        if not np.array_equal(obs["map"].cpu().numpy(), np.stack([x["maps"][-1] for x in exp])):
+            return "MAP MISMATCH %s %s %s E %d seed %d" % (prob, rep, calls, E, seed0)
+        env.check_status()
+    finally:
+        env.close()
+    return None
+
+
+def fuzz_case(rs, only=None, rollout_share=0.4, mixed_share=0.0, steps_scale=1.0):
+    """Draw one configuration from `rs` and run it.  -> (description, error or None)."""
+    prob, rep, wh, calls, E, T, seed0 = draw_config(rs, only)
+    u = rs.rand()
+    use_rollout = u < rollout_share
+    mixed = (not use_rollout) and u < rollout_share + mixed_share
+    err = run_config(prob, rep, calls, E, T, seed0, rs, use_rollout, mixed, steps_scale)
+    how = "rollout" if use_rollout else ("rollout+steps" if mixed else "steps")
+    return "%s %s %s %s %s E %d" % (how, prob, rep, wh, [list(c.items())[0] for c in calls[1:]], E), err
+
+
+FULLSIZE_CASES = {
+    "C2": ("binary", "narrow", (), 65536, 160),
+    "C3": ("zelda", "wide", (dict(width=11, height=16),), 65536, 80),
+    "C5": ("binary", "turtle", (dict(width=64, height=64),), 8192, 100),
+    "C4": ("sokoban", "narrow", (), 131072, 40),
+    "M1": ("mdungeon", "narrow", (), 65536, 40),
+    "D1": ("ddave", "narrow", (), 65536, 40),
+}
+
+
+def fullsize_case(name, use_rollout, max_steps=None):
+    """A benchmark configuration at its real batch size; 294 sampled environments (the first 64, the last 32, 200 spread
+    over the batch) compared with the oracle at every step.  Raises AssertionError on a mismatch; returns the number of
+    sampled environments."""
+    import torch
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    prob, rep, calls, N, T = FULLSIZE_CASES[name]
+    if max_steps:
+        T = min(T, max_steps)
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=N, seed=0)
+    try:
+        for kw in calls:
+            env.adjust_param(**kw)
+        env.reset()
+        sp = env.single_action_space
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        if hasattr(sp, "n"):
+            acts = torch.randint(0, sp.n, (T, N, 1), device="cuda", dtype=torch.int32, generator=g)
+        else:
+            acts = torch.stack([torch.randint(0, int(k), (T, N), device="cuda", dtype=torch.int32, generator=g) for k in sp.nvec], -1).contiguous()
+        idx = np.unique(np.concatenate([np.arange(0, 64), np.linspace(0, N - 1, 200).astype(int), np.arange(N - 32, N)]))
+        a_host = acts[:, torch.as_tensor(idx, device="cuda")].cpu().numpy()
+        exp = _oracle_rollouts(prob, rep, calls, idx, [a_host[:, j] for j in range(len(idx))])
+        keys = list(env._prob.info_keys) + ["iterations", "changes"]
+        ti = torch.as_tensor(idx, device="cuda")
+        obs = env._obs()
+        if use_rollout:
+            rew_t, done_t, info_t = env.rollout(acts if acts.shape[2] > 1 else acts[:, :, 0])
+            got = np.stack([info_t[k].view(T, N)[:, ti].cpu().numpy() for k in keys], 2).astype(np.int64)
+            assert np.array_equal(done_t[:, ti].cpu().numpy(), np.stack([x["done"] for x in exp], 1)), ("rollout done", name)
+            assert np.array_equal(rew_t[:, ti].cpu().numpy(), np.stack([x["reward"] for x in exp], 1)), ("rollout reward", name)
+            assert np.array_equal(got, np.stack([x["info"] for x in exp], 1)), ("rollout info", name)
+        else:
+            for t in range(T):
+                obs, rew, done, info = env.step(acts[t] if acts.shape[2] > 1 else acts[t, :, 0])
+                assert np.array_equal(done[ti].cpu().numpy(), np.array([x["done"][t] for x in exp])), ("done", name, t)
+                assert np.array_equal(rew[ti].cpu().numpy(), np.array([x["reward"][t] for x in exp])), ("reward", name, t)
+                assert np.array_equal(np.stack([info[k][ti].cpu().numpy() for k in keys], 1).astype(np.int64),
+                                      np.stack([x["info"][t] for x in exp])), ("info", name, t)
+        assert np.array_equal(obs["map"][ti].cpu().numpy(), np.stack([x["maps"][-1] for x in exp])), ("map", name)
+        env.check_status()
+    finally:
+        env.close()
+    return len(idx)

@@ -273,7 +273,8 @@ def test_shard_invariance_and_determinism():
     ("binary", "turtle", (dict(width=64, height=64),), 8192),
     ("sokoban", "narrow", (), 131072),
     ("mdungeon", "narrow", (), 65536),
-], ids=["C2", "C3", "C5", "C4", "M1"])
+    ("ddave", "narrow", (), 65536),
+], ids=["C2", "C3", "C5", "C4", "M1", "D1"])
 def test_full_size_properties(prob, rep, calls, N):
     torch = _torch()
     if not _supported(prob):
@@ -757,7 +758,7 @@ def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
     ("binary-narrow-v0", (), 1000, 150),                              # one launch for the whole tape (k_step); 1000: a partial last block
     ("binary-turtle-v0", (dict(change_percentage=0.1),), 300, 120),
     ("binary-wide-v0", (dict(width=21, height=9),), 257, 100),
-    ("zelda-wide-v0", (), 200, 60),                                    # the sequence-of-steps fallback
+    ("zelda-wide-v0", (), 200, 60),                                    # rollout: one launch of k_step; the twin steps through k_update + k_stats
     ("sokoban-narrow-v0", (), 128, 40),
     ("mdungeon-turtle-v0", (dict(width=6, height=6),), 96, 40),
     ("sokoban-wide-v0", (dict(change_percentage=0.6),), 1000, 60),     # persistent search-problem kernel, 16 blocks of 64
@@ -910,3 +911,188 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 4096 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-6
+
+
+# ------------------------------------------------------------------ switching between the fused and the work-list pipelines
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,calls,T1", [
+    ("zelda-wide-v0", (), 1), ("zelda-wide-v0", (), 3), ("zelda-narrow-v0", (dict(change_percentage=0.5),), 7),
+    ("binary-narrow-v0", (), 5), ("zelda-turtle-v0", (), 2),
+], ids=lambda v: str(v) if isinstance(v, (str, int)) else "")
+def test_rollout_then_step_same_handle(env_id, calls, T1):
+    """reset(); rollout(T1 steps, T1 odd: the fused kernel for zelda) ; step() x 20 (zelda: k_update -> work lists -> k_stats);
+    set_maps(); rollout(); step() ... on ONE handle, against a twin that only ever calls step().  A fused launch must leave
+    the work-list parity alone: the lists of the parity a later step uses have to be the cleared ones."""
+    torch = _torch()
+    prob, rep = env_id.split("-")[:2]
+    N = 700
+    a_env = _make(prob, rep, N, list(calls), seed=31)
+    b_env = _make(prob, rep, N, list(calls), seed=31)
+    a_env.enable_episode_stats(); b_env.enable_episode_stats()
+    a_env.reset(); b_env.reset()
+    sp = a_env.single_action_space
+    g = torch.Generator(device="cuda").manual_seed(8)
+
+    def tape(T):
+        if hasattr(sp, "n"):
+            return torch.randint(0, int(sp.n), (T, N), generator=g, device="cuda", dtype=torch.int32)
+        return torch.stack([torch.randint(0, int(k), (T, N), generator=g, device="cuda", dtype=torch.int32) for k in sp.nvec], -1)
+
+    def same_state(tag):
+        sa, sb = a_env.state_dict(), b_env.state_dict()
+        for k in sa:
+            if sa[k] is not None:
+                assert torch.equal(sa[k], sb[k]), (tag, k)
+
+    for phase, T in enumerate((T1, 1, T1 + 2)):
+        tp = tape(T)
+        rew, done, info = a_env.rollout(tp)
+        for t in range(T):
+            _, r, d, inf = b_env.step(tp[t])
+            assert torch.equal(rew[t], r) and torch.equal(done[t], d) and torch.equal(info.table.view(T, N, 10)[t], inf.table), (phase, t)
+        same_state("after rollout %d" % phase)
+        tp = tape(20)
+        for t in range(20):
+            _, ra, da, ia = a_env.step(tp[t])
+            ra, da, ia = ra.clone(), da.clone(), ia.table.clone()
+            _, rb, db, ib = b_env.step(tp[t])
+            assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ia, ib.table), (phase, "step", t)
+        same_state("after steps %d" % phase)
+        if phase == 1:
+            m = b_env._bufs["map"].clone()
+            a_env.set_maps(m); b_env.set_maps(m)
+    a_env.check_status()
+
+
+def test_out_of_range_actions_are_reported():
+    """Actions outside the action space are clamped into it and flagged in the sticky status word (the reference raises
+    IndexError or writes the bad value: narrow_rep.py:101-103, wide_rep.py:68-69)."""
+    torch = _torch()
+    env = _make("binary", "narrow", 64)
+    env.reset()
+    env.step(torch.full((64,), 2, dtype=torch.int32, device="cuda"))
+    assert env.check_status() == 0
+    a = torch.zeros(64, dtype=torch.int32, device="cuda"); a[5] = 3
+    env.step(a)
+    with pytest.raises(IndexError):
+        env.check_status()
+    env.close()
+    env = _make("zelda", "wide", 64)
+    env.reset()
+    a = torch.zeros((64, 3), dtype=torch.int32, device="cuda"); a[7, 0] = 11
+    env.step(a)
+    with pytest.raises(IndexError):
+        env.check_status()
+
+
+# ------------------------------------------------------------------ random configurations and full batch sizes vs the oracle
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(6))
+def test_fuzz_slice(chunk):
+    """A seeded 60-configuration slice of tools/fuzz_parity.py (six chunks of ten): random problem (all five),
+    representation (all six), map size, parameters, seeds; 40 % of the cases as one pcgrl_rollout tape, 15 % as an
+    odd-length rollout followed by single steps; every step against the CPU oracle."""
+    _torch()
+    import parity_harness as ph
+    rs = np.random.RandomState(9000 + chunk)
+    seen = set()
+    for _ in range(10):
+        desc, err = ph.fuzz_case(rs, None, rollout_share=0.4, mixed_share=0.15, steps_scale=0.6)
+        assert err is None, err
+        seen.add(desc.split()[1])
+    assert len(seen) >= 3, seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_rollout", [False, True], ids=["steps", "rollout"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "M1", "D1"])
+def test_full_size_vs_oracle(name, use_rollout):
+    """tools/fullsize_parity.py under the driver: the benchmark configurations at their real batch sizes (paired certain
+    resets, every difficulty bucket in use, 512 environments per persistent block), 294 sampled environments compared with
+    the oracle at every step (at most 60), stepping and as one pcgrl_rollout tape."""
+    _torch()
+    import parity_harness as ph
+    assert ph.fullsize_case(name, use_rollout, max_steps=60) >= 290
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (torch.distributed.run inside) and
+    prints ONE line with n_gpus == 2 -- both ranks on cuda:0 over gloo here (PCGRL_BENCH_SAME_GPU=1: a one-GPU box)."""
+    import json, subprocess, sys
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCGRL_BENCH_SAME_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3", "--envs", "4096",
+                          "--steady-warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 4096 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-6
+    # one rank, same workload: the per-GPU rate of the two-rank line is in the same ballpark (they share one GPU here)
+    out1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3", "--envs", "4096",
+                           "--steady-warmup", "0", "--no-cpu-baseline", "--no-rollout"], env=env, capture_output=True, text=True, timeout=600)
+    d1 = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["config"]["envs_per_gpu"] == 4096
+
+
+@pytest.mark.gpu
+def test_gym_make_and_vector_env_under_a_gym_module():
+    """With a gym module present (the test shim; gym itself is not on the image): `gym.make('zelda-narrow-v0')` gives a
+    gym.Env that a gym.Wrapper built the way the reference's wrappers are (wrappers.py:11,21-24: gym.make(game), find the
+    PcgrlEnv by class name, adjust_param) drives through the reference trajectory; PcgrlVectorEnv steps like the batch."""
+    import subprocess, sys
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gym_shim
+gym = gym_shim.install(reference_root=os.path.join(%r, "_no_reference_here"))
+import gym_pcgrl_amd                         # in place of `import gym_pcgrl`: registers the ids
+gym_pcgrl_amd.register_with_gym()
+get_pcgrl_env = lambda env: env if "PcgrlEnv" in str(type(env)) else get_pcgrl_env(env.env)
+class Plain(gym.Wrapper):
+    def __init__(self, game, **kwargs):
+        self.env = gym.make(game)
+        get_pcgrl_env(self.env).adjust_param(**kwargs)
+        gym.Wrapper.__init__(self, self.env)
+d = np.load(os.path.join(%r, "traj_zelda_narrow.npz"))
+env = Plain("zelda-narrow-v0")
+assert isinstance(env.unwrapped, gym.Env)
+get_pcgrl_env(env).seed(int(d["cfg"][4]))
+o = env.reset()
+assert np.array_equal(o["map"], d["map0"][0])
+keys = [str(k) for k in d["info_keys"]]
+for t in range(120):
+    o, r, dn, info = env.step(int(d["actions"][t, 0, 0]))
+    assert r == d["reward"][t, 0] and dn == bool(d["done"][t, 0]), t
+    assert [info[k] for k in keys] == list(d["info"][t, 0]), t
+    if dn:
+        o = env.reset()
+    assert np.array_equal(o["map"], d["maps"][t, 0]), t
+import torch
+from gym_pcgrl_amd.vector import PcgrlVectorEnv
+N = 64
+v = PcgrlVectorEnv("binary-narrow-v0", num_envs=N, seed=5)
+b = gym_pcgrl_amd.make_batched("binary-narrow-v0", num_envs=N, seed=5)
+assert v.num_envs == N and v.single_action_space.n == 3 and v.observation_space["map"].shape == (N, 14, 14)
+o = v.reset(); ob = b.reset()
+assert o["heatmap"].dtype == np.float64 and np.array_equal(o["map"], ob["map"].cpu().numpy())
+rs = np.random.RandomState(0)
+for t in range(60):
+    a = rs.randint(0, 3, N)
+    v.step_async(a)
+    o, r, dn, infos = v.step_wait()
+    ob, rb, db, ib = b.step(a)
+    assert np.array_equal(o["map"], ob["map"].cpu().numpy()) and np.array_equal(r, rb.cpu().numpy()) and np.array_equal(dn, db.cpu().numpy())
+    assert len(infos) == N and infos[3] == ib.to_list()[3]
+v.close()
+print("ok")
+''' % (root, G, G, G)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]

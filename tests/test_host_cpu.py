@@ -4,6 +4,7 @@ import ast
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -135,3 +136,53 @@ def test_packed_stats_rows_decode():
     assert len(dd.info_keys) == 10 and "dist-floor" not in dd.info_keys          # ddave_prob.py:232-245
     b = PROBLEMS["binary"]()
     assert b.decode_rows(t).tolist() == [[t[0, 0].item(), 3], [t[1, 0].item(), 6]] and not b.packed_rows
+
+
+def test_gym_integration_host_logic():
+    """With a gym module present (here: the test shim that also serves fixture generation; neither gym nor gymnasium is on
+    the image) the package registers its 30 ids with entry point gym_pcgrl_amd.envs:PcgrlEnv (gym_pcgrl/__init__.py:6-12),
+    PcgrlEnv is a gym.Env subclass (pcgrl_env.py:14) whose name still contains 'PcgrlEnv' (wrappers.py:11), and gym.make
+    reaches the class -- which, without a GPU, fails loudly instead of falling back to anything."""
+    import importlib
+    import subprocess
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gym_shim
+gym = gym_shim.install(reference_root=%r)
+import gym_pcgrl_amd
+ids = gym_pcgrl_amd.register_with_gym()
+assert len(ids) >= 30 and "binary-narrow-v0" in ids and "ddave-turtlecast-v0" in ids, len(ids)
+assert gym_pcgrl_amd.register_with_gym() == []            # idempotent
+from gym_pcgrl_amd.envs import PcgrlEnv
+from gym_pcgrl_amd.vector import PcgrlVectorEnv
+assert issubclass(PcgrlEnv, gym.Env) and "PcgrlEnv" in str(PcgrlEnv)
+ep, kw = gym_shim._REGISTRY["zelda-turtle-v0"]
+assert ep == "gym_pcgrl_amd.envs:PcgrlEnv" and kw == {"prob": "zelda", "rep": "turtle"}
+env = gym.make("binary-narrow-v0")             # buffers are allocated by reset(): the constructor needs no GPU
+assert isinstance(env, gym.Env) and env.action_space.n == 3 and env.observation_space["map"].shape == (14, 14)
+wrapped = gym.Wrapper(env)
+find = lambda e: e if "PcgrlEnv" in str(type(e)) else find(e.env)       # wrappers.py:11
+assert find(wrapped) is env
+find(wrapped).adjust_param(width=10, height=8)
+assert env.observation_space["map"].shape == (8, 10)
+try:
+    env.reset()
+except Exception as e:      # no GPU here: the product path fails loudly, it does not fall back to anything
+    assert type(e).__name__ in ("RuntimeError", "AssertionError"), e
+else:
+    raise SystemExit("reset() produced an observation without a GPU")
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests", "golden", "_no_reference_here"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_vector_env_spaces_are_batched():
+    from gym_pcgrl_amd import spaces
+    from gym_pcgrl_amd.vector import _batch_space
+    single = spaces.Dict({"map": spaces.Box(low=0, high=1, shape=(14, 14), dtype=np.uint8), "pos": spaces.Box(low=0, high=13, shape=(2,), dtype=np.uint8)})
+    b = _batch_space(single, 5)
+    assert b["map"].shape == (5, 14, 14) and b["pos"].shape == (5, 2) and b["map"].dtype == np.uint8
+    assert _batch_space(spaces.Discrete(3), 4) == spaces.MultiDiscrete([3, 3, 3, 3])
+    assert _batch_space(spaces.MultiDiscrete([14, 14, 2]), 2).nvec.shape == (2, 3)

@@ -2,6 +2,7 @@
 N>1 path uses: partition, global seeding, and the host-side gather / scatter of per-rank tensors."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -10,6 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from gym_pcgrl_amd import seeding, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_range_partitions_exactly():
@@ -87,3 +90,36 @@ def test_gather_scatter_world2_gloo(total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------ bench.py: its own launcher (no GPU needed)
+def _run_bench(args, extra_env=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    return out.returncode, lines, out.stderr
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run around it: the script launches two ranks itself, they meet
+    over 127.0.0.1 (gloo here: --dry-run is the GPU-less skeleton of the measurement), and exactly one line with
+    n_gpus == 2 comes out."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "7", "--warmup", "2", "--dry-run"])
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 2 and d["dry_run"] is True and d["value"] is None
+    assert d["max_over_ranks_s"] >= 0.02          # rank 1 sleeps 20 ms: the reduction is a max over the ranks
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked():
+    """No GPU here: --gpus 2 must fail (non-zero, no result line) instead of printing an n_gpus = 1 line; so must a rank
+    started under a launcher with another world size than --gpus."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "1"])
+    assert rc != 0 and not lines and "refusing" in err
+    rc, lines, err = _run_bench(["--gpus", "4", "--steps", "5", "--warmup", "1", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert rc != 0 and not lines and "WORLD_SIZE" in err

@@ -1,103 +1,23 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz on the GPU box: random (problem, representation, map size, parameters, seed) combinations,
-every step compared with the CPU oracle (done, reward, info; maps at the end).  Not part of the pytest suite (minutes).
+every step compared with the CPU oracle (done, reward, info; maps at the end); 40 % of the cases as one pcgrl_rollout
+tape, 15 % as an odd-length rollout followed by single steps on the same handle.  A seeded 60-configuration slice of this
+runs under `pytest -m gpu` (tests/test_gpu_parity.py::test_fuzz_slice); this script is for long sessions.
     python tools/fuzz_parity.py [cases] [seed] [problem]"""
 import os, sys, time
 import numpy as np
-import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle_lib as ol
-from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+import parity_harness as ph
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ONLY = sys.argv[3] if len(sys.argv) > 3 else None
-REPS = ["narrow", "wide", "turtle", "narrowcast", "narrowmulti", "turtlecast"]
 t0 = time.time()
 for case in range(cases):
-    prob = ONLY or ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon", "ddave", "ddave"][rs.randint(9)]
-    rep = REPS[rs.randint(6)]
-    if prob == "sokoban":
-        w, h = int(rs.randint(2, 8)), int(rs.randint(2, 8))
-    elif prob in ("mdungeon", "ddave"):
-        w, h = int(rs.randint(1, 13)), int(rs.randint(1, 13))
-    else:
-        w, h = int(rs.randint(1, 41)), int(rs.randint(1, 41))
-        if rs.rand() < 0.4:
-            h = int(rs.randint(1, 17)); w = int(rs.randint(1, 33))
-    calls = [dict(width=w, height=h), dict(change_percentage=float(rs.choice([0.05, 0.2, 0.5, 1.0])))]
-    if prob == "sokoban":
-        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000]))))
-    if prob == "mdungeon":
-        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000, 5000]))))
-        if rs.rand() < 0.7:     # open maps with few players / exits: the planner runs in a good share of the steps
-            mon = float(rs.choice([0.0, 0.03, 0.15]))
-            calls.append(dict(probs={"empty": 0.75, "solid": float(rs.choice([0.02, 0.1])), "player": 0.03, "exit": 0.03,
-                                     "goblin": mon, "ogre": mon}))
-        if rs.rand() < 0.5:
-            calls.append(dict(target_solution=int(rs.randint(1, 8)), target_col_enemies=float(rs.choice([0.0, 0.3, 0.5])),
-                              max_enemies=int(rs.randint(1, 5)), max_potions=int(rs.randint(0, 3)), max_treasures=int(rs.randint(0, 3)),
-                              rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "sol-length": float(rs.choice([1, 0.7]))}))
-    if prob == "ddave":
-        calls.append(dict(solver_power=int(rs.choice([50, 300, 1000, 5000]))))
-        if rs.rand() < 0.7:     # open maps with few players / exits / keys: the planner runs in a good share of the steps
-            calls.append(dict(probs={"empty": 0.7, "solid": float(rs.choice([0.05, 0.15])), "player": 0.04, "exit": 0.04, "key": 0.04,
-                                     "spike": float(rs.choice([0.0, 0.03]))}))
-        if rs.rand() < 0.5:
-            calls.append(dict(target_solution=int(rs.randint(1, 8)), target_jumps=int(rs.randint(0, 3)), max_diamonds=int(rs.randint(0, 4)),
-                              min_spikes=int(rs.randint(0, 6)), rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "dist-floor": float(rs.choice([2, 0.5]))}))
-    if rep in ("narrow", "narrowcast", "narrowmulti") and rs.rand() < 0.3:
-        calls.append(dict(random_tile=False))
-    if rep in ("turtle", "turtlecast") and rs.rand() < 0.5:
-        calls.append(dict(warp=True))
-    if rs.rand() < 0.2:
-        calls.append(dict(random_start=False))
-    E = int(rs.choice([8, 33, 96])) if w * h > 400 else int(rs.choice([33, 96, 200]))
-    T = 120 if w * h > 400 else 200
-    seed0 = int(rs.randint(1, 10 ** 6))
-    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=E, seed=seed0)
-    for kw in calls:
-        env.adjust_param(**kw)
-    env.reset()
-    sp = env.single_action_space
-    if hasattr(sp, "n"):
-        acts = rs.randint(0, sp.n, size=(T, E, 1)).astype(np.int32)
-    else:
-        acts = np.stack([rs.randint(0, int(k), size=(T, E)) for k in sp.nvec], -1).astype(np.int32)
-    exp = []
-    for i in range(E):
-        o = ol.OracleEnv(prob, rep)
-        for kw in calls:
-            o.adjust_param(**kw)
-        o.seed(seed0 + i)
-        o.reset()
-        exp.append(o.rollout(acts[:, i], want_heat=False))
-    keys = list(env._prob.info_keys) + ["iterations", "changes"]
-    use_rollout = rs.rand() < 0.4          # the whole tape through pcgrl_rollout (one launch where the fused step kernel applies)
-    if use_rollout:
-        tape = torch.as_tensor(acts if acts.shape[2] > 1 else acts[:, :, 0], device="cuda")
-        rew_t, done_t, info_t = env.rollout(tape)
-        got_info = np.stack([info_t[k].cpu().numpy() for k in keys], 1).astype(np.int64).reshape(T, E, len(keys))
-        ok = np.array_equal(done_t.cpu().numpy(), np.stack([x["done"] for x in exp], 1)) and \
-            np.array_equal(rew_t.cpu().numpy(), np.stack([x["reward"] for x in exp], 1)) and \
-            np.array_equal(got_info, np.stack([x["info"] for x in exp], 1))
-        if not ok:
-            print("ROLLOUT MISMATCH", case, prob, rep, calls, "E", E, "seed", seed0)
-            sys.exit(1)
-        obs = env._obs()
-    for t in range(0 if not use_rollout else T, T):
-        obs, rew, done, info = env.step(acts[t] if acts.shape[2] > 1 else acts[t, :, 0])
-        ok = np.array_equal(done.cpu().numpy(), np.array([x["done"][t] for x in exp])) and \
-            np.array_equal(rew.cpu().numpy(), np.array([x["reward"][t] for x in exp])) and \
-            np.array_equal(np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64), np.stack([x["info"][t] for x in exp]))
-        if not ok:
-            print("MISMATCH", case, prob, rep, calls, "E", E, "seed", seed0, "step", t)
-            sys.exit(1)
-    if not np.array_equal(obs["map"].cpu().numpy(), np.stack([x["maps"][-1] for x in exp])):
-        print("MAP MISMATCH", case, prob, rep, calls, E, seed0)
+    desc, err = ph.fuzz_case(rs, ONLY, rollout_share=0.4, mixed_share=0.15)
+    if err:
+        print(err, "(case %d)" % case)
         sys.exit(1)
-    env.check_status()
-    env.close()
-    print("ok", case, "rollout" if use_rollout else "steps", prob, rep, (w, h), [list(c.items())[0] for c in calls[1:]], "E", E, "%.0fs" % (time.time() - t0), flush=True)
+    print("ok", case, desc, "%.0fs" % (time.time() - t0), flush=True)
 print("fuzz passed:", cases, "cases")
