@@ -91,7 +91,8 @@ __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBu
 template <int PROB, int G, class MaskT>
 __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevBufs& B, DevGroup<G, MaskT>& g, int lane64, int gw, bool lone,
                                                 bool inc, bool pair, bool zinc, bool have, int raw, int shard, int mode, int parity,
-                                                int inline_reset, int gen_map, uint32_t* mt, uint8_t* tiles, MaskT rowmask) {
+                                                int inline_reset, int gen_map, uint32_t* mt, uint8_t* tiles, MaskT rowmask,
+                                                StepLocal* SL = nullptr) {
     constexpr int GPW = 64 / G;
     constexpr bool kInc = PROB == PCGRL_PROB_BINARY;
     constexpr bool kZinc = PROB == PCGRL_PROB_ZELDA && G == 16 && sizeof(MaskT) == 4;
@@ -121,17 +122,22 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
             if (k > 0 && !pair) break;                        // wave-uniform
             if (!__builtin_amdgcn_readlane((int)have, 2 * k * G)) continue;
             const int ek = __builtin_amdgcn_readlane(e, 2 * k * G);
-            wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
+            // k_step: the draws of this step are still in the draw cache of the environment, not in its ring
+            const int pend = SL ? (int)SL->k[ek - SL->e0] : 0;
+            if (SL && lane64 == 0) SL->dirty[ek - SL->e0] = 1;
+            wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64, pend);
             MaskT t0, t1, t2;
             planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == 2 * k + 1 ? g.lane : -1, t0, t1, t2);
             if (gw == 2 * k + 1) { b0 = t0; b1 = t1; b2 = t2; }
             __builtin_amdgcn_wave_barrier();
         }
+        TL(9);
         const bool act = have && (role == 1 || !reset_only);
         int32_t sl[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         MaskT champ_l = 0;
         bool ns = false;
         if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l);
+        TL(10);
         if (g.lane == 0 && role == 0 && act) finalize_item<PROB>(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
         __builtin_amdgcn_wave_barrier();
         if (role == 1 && have) {
@@ -161,6 +167,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
         need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ);
     }
     if (kInc && compute && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
+    TL(10);
     int want_reset = 0;
     if (g.lane == 0 && have) {
         if (reset_only) want_reset = 1;
@@ -168,12 +175,18 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
     }
     if (inline_reset) {
         const uint64_t want = __ballot(want_reset != 0);     // one bit per group, at its lane 0
+        TL(11);
         if (want) {
+            TL(12);
+            // k_step: wavefront 0 writes the draws of this step into the rings (and its byte-map / heatmap writes land) behind
+            // the barrier; a reset that nobody saw coming waits for that (it has long happened by now)
+            if (SL) { while (__hip_atomic_load(&SL->refill_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2); }
             bool mine = false;
 #pragma unroll
             for (int k = 0; k < GPW; k++) {
                 if ((want >> (k * G)) & 1ull) {               // wave-uniform
                     const int ek = __builtin_amdgcn_readlane(e, k * G);
+                    if (SL && lane64 == 0) SL->dirty[ek - SL->e0] = 1;
                     wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
                     MaskT t0, t1, t2;
                     planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G,

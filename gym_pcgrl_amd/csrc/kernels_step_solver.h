@@ -184,7 +184,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_step_solver(PcgrlParams P, DevBu
         // ---- Representation.update + bookkeeping; unchanged environments are finished here
         for (int sub = wv * 64; sub < ne; sub += SS_THREADS) {
             const int e = e0 + sub + lane64;
-            UpdateOut u = {false, false, false, false, 0, 0};
+            UpdateOut u = {};
             if (sub + lane64 < ne) u = update_env<REP, MaskT>(P, B, actions_t, e);
             const uint64_t mc = __ballot(u.chg), mr = __ballot(u.rst);
             const uint64_t below = (1ull << lane64) - 1ull;

@@ -16,12 +16,20 @@ struct UpdateOut {
     bool sure_done;    // a tile changed and the episode ends whatever the new statistics are
     int bucket;        // difficulty bucket (binary)
     int inc_item;      // packed (environment, cell, passability change) for the incremental routes
+    // FIFO form (fused step kernel): the cursor draws came out of the environment's draw cache; `k` of its words were
+    // consumed (cursor before: cur0) and still have to be written to the ring, and the cache refilled (fifo_refill)
+    int k, cur0;
 };
 // One environment of k_update (thread per environment; also the first phase of the fused step kernel k_step).
-template <int REP, class MaskT>
+// FIFO (k_step only): B's per-environment state pointers lead into the block's LDS copy; cursor draws come from the draw
+// cache; an environment that is certain to be reset writes nothing to the byte map and the heatmap (the reset rewrites both).
+template <int REP, class MaskT, bool FIFO = false>
 __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevBufs& B, const int32_t* __restrict__ actions, int e) {
     bool chg = false, rst = false, cheap = false, sure_done = false;
-    int bucket = 0, inc_item = 0;
+    int bucket = 0, inc_item = 0, k_used = 0, cur0 = 0;
+    uint32_t fw[PCGRL_FIFO_N];
+#pragma unroll
+    for (int i = 0; i < PCGRL_FIFO_N; i++) fw[i] = 0;
     {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
         // ---- round trip 1
@@ -79,7 +87,6 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         // the old tile: from the plane word when there is a single plane (one scattered read less), else from the byte map
         // (nothing of the cell is needed when the action writes no tile: a third of the narrow actions, the moves of turtle)
         const bool writes = tile >= 0;
-        const int old_byte = (NPL > 1 && writes) ? (int)*cell : 0;
         // binary, 16-row maps: the three champion rows around the cell, for the routing decision below
         const bool inc_on = P.prob == PCGRL_PROB_BINARY && B.champ != nullptr;
         MaskT ch0 = 0, chu = 0, chd = 0;
@@ -94,10 +101,24 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
             m0 = pl[0];
             if (NPL > 1) { m1 = pl[1]; m2 = pl[2]; }
         }
-        const int old = (NPL > 1) ? old_byte : (int)((m0 >> wx) & 1);
+        const int old = (int)((m0 >> wx) & 1) | ((NPL > 1) ? (int)(((m1 >> wx) & 1) << 1) | (int)(((m2 >> wx) & 1) << 2) : 0);
         uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
-        if (draws) {
+        cur0 = cur;
+        if (draws && FIFO) {
+            const int tag = B.fifo_tag[e];
+            const uint4* fp = reinterpret_cast<const uint4*>(B.fifo + (size_t)e * PCGRL_FIFO_N);
+            const uint4 fa = fp[0], fb = fp[1];
+            fw[0] = fa.x; fw[1] = fa.y; fw[2] = fa.z; fw[3] = fa.w; fw[4] = fb.x; fw[5] = fb.y; fw[6] = fb.z; fw[7] = fb.w;
+            if (tag != cur) {     // not made for this cursor (right after seeding, or another pipeline drew from the ring): make it now
+#pragma unroll
+                for (int i = 0; i < PCGRL_FIFO_N; i++) {
+                    fw[i] = mt_twist(ring[mt_wrap(cur + i)], ring[mt_wrap(cur + i + 1)], ring[mt_wrap(mt_wrap(cur + PCGRL_MT_M) + i)]);
+                    B.fifo[(size_t)e * PCGRL_FIFO_N + i] = fw[i];
+                }
+            }
+        }
+        if (draws && !FIFO) {
 #pragma unroll
             for (int i = 0; i <= PCGRL_SPEC_DRAWS; i++) xa[i] = ring[mt_wrap(cur + i)];
 #pragma unroll
@@ -120,7 +141,10 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
                 inc_item = wl_inc_pack(16, e, wy, wx, po == pn ? 0u : (pn ? 1u : 2u));
                 cheap = po == pn;
             }
-            *cell = (uint8_t)tile;
+            // (the fused step kernel leaves the byte map and the heatmap of an environment that is certain to be reset to the
+            //  reset, which rewrites both: nothing of wavefront 0 is then in flight for it when the reset starts)
+            const bool dead_writes = FIFO && P.auto_reset && B.inline_reset && (c.y + 1 >= P.max_changes || iter >= P.max_iterations);
+            if (!dead_writes) *cell = (uint8_t)tile;
             const MaskT bit = (MaskT)1 << wx;
             pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
             if (NPL > 1) {
@@ -129,7 +153,45 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
             }
         }
         if (REP == PCGRL_REP_NARROW) {   // the cursor moves on every step (narrow_rep.py:104-113)
-            if (draws) {
+            if (draws && FIFO) {
+                // numpy randint(W) then randint(H) (masked rejection) on the words of the draw cache
+                const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
+                uint32_t mx = rx, my = ry;
+                mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
+                my |= my >> 1; my |= my >> 2; my |= my >> 4; my |= my >> 8; my |= my >> 16;
+                int stage = 0, used = 0;
+                if (rx == 0) { x = 0; stage = 1; }
+                if (stage == 1 && ry == 0) { y = 0; stage = 2; }
+#pragma unroll
+                for (int i = 0; i < PCGRL_FIFO_N; i++) {
+                    if (stage < 2) {
+                        used = i + 1;
+                        const uint32_t v = mt_temper(fw[i]);
+                        if (stage == 0) {
+                            if ((v & mx) <= rx) { x = (int)(v & mx); stage = 1; if (ry == 0) { y = 0; stage = 2; } }
+                        } else {
+                            if ((v & my) <= ry) { y = (int)(v & my); stage = 2; }
+                        }
+                    }
+                }
+                if (stage < 2) {
+                    // every cached word rejected ((1/8)^k tail): put them into the ring and go on there; the cache is rebuilt
+                    // by the next step
+#pragma unroll
+                    for (int i = 0; i < PCGRL_FIFO_N; i++) ring[mt_wrap(cur + i)] = fw[i];
+                    cur = mt_wrap(cur + PCGRL_FIFO_N);
+                    if (stage == 0) { x = mt_randint(ring, cur, W); y = mt_randint(ring, cur, H); }
+                    else y = mt_randint(ring, cur, H);
+                    B.fifo_tag[e] = -1;
+                    __threadfence_block();     // a reset of this environment later in the launch stages the ring from memory
+                    cur0 = cur;
+                } else {
+                    cur = mt_wrap(cur + used);
+                    k_used = used;
+                }
+                B.rng_cur[2 * e] = cur;
+            } else if (draws) {
+                if (B.fifo_tag) B.fifo_tag[e] = -1;     // the draws below bypass the cache
                 // numpy randint(W) then randint(H): masked rejection, consumed in order from the speculative words
                 const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
                 uint32_t mx = rx, my = ry;
@@ -167,7 +229,8 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         // ---- round trip 3
         if (chg) {
             changes += 1;
-            heat_increment(B, B.heat + ((size_t)e * H + hy) * W + hx);
+            const bool dead_writes = FIFO && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
+            if (!dead_writes) heat_increment(B, B.heat + ((size_t)e * H + hy) * W + hx);
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
         if (bad) atomicOr(B.status, PCGRL_STATUS_BAD_ACTION);
@@ -194,6 +257,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
     }
     UpdateOut o;
     o.chg = chg; o.rst = rst; o.cheap = cheap; o.sure_done = sure_done; o.bucket = bucket; o.inc_item = inc_item;
+    o.k = k_used; o.cur0 = cur0;
     return o;
 }
 
@@ -203,7 +267,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     __shared__ int s_base[3];
     __shared__ int s_hist[WL_NSHARD + 1], s_gbase[WL_NSHARD + 1];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
-    UpdateOut u = {false, false, false, false, 0, 0};
+    UpdateOut u = {};
     if (e < P.num_envs) u = update_env<REP, MaskT>(P, B, actions, e);
     const bool chg = u.chg, rst = u.rst, cheap = u.cheap, sure_done = u.sure_done;
     int bucket = u.bucket;

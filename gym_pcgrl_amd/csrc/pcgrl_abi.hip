@@ -170,8 +170,11 @@ static size_t champ_bytes(const pcgrl_config* c) {
     if (c->height <= 16) return (c->width <= 32 && c->num_envs <= WL_INC_ENV_MASK) ? align_up((size_t)c->num_envs * 64, 256) : 0;
     return c->num_envs <= WL_INC64_ENV_MASK ? align_up((size_t)c->num_envs * 64 * (c->width > 32 ? 8 : 4), 256) : 0;
 }
+// draw cache of the narrow representation (DevBufs::fifo, fifo_tag)
+static size_t fifo_words_bytes(const pcgrl_config* c) { return c->rep == PCGRL_NARROW ? align_up((size_t)c->num_envs * PCGRL_FIFO_N * 4, 256) : 0; }
+static size_t fifo_bytes(const pcgrl_config* c) { return c->rep == PCGRL_NARROW ? fifo_words_bytes(c) + align_up((size_t)c->num_envs * 4, 256) : 0; }
 static size_t scratch_bytes_base(const pcgrl_config* c);
-static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c); }
+static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c) + fifo_bytes(c); }
 static size_t scratch_bytes_base(const pcgrl_config* c) {
     size_t b = wl_bytes(c);
     if (solver_prob(c->prob)) {           // (an MdNode is as large as a SokNode)
@@ -310,6 +313,13 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         B.champ = s + scratch_bytes_base(&h->cfg);
         HIPCHK(hipMemsetAsync(B.champ, 0, champ_bytes(&h->cfg), (hipStream_t)stream));
     }
+    B.fifo = nullptr; B.fifo_tag = nullptr;
+    if (fifo_bytes(&h->cfg)) {
+        uint8_t* f = s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg);
+        B.fifo = (uint32_t*)f;
+        B.fifo_tag = (int32_t*)(f + fifo_words_bytes(&h->cfg));
+        HIPCHK(hipMemsetAsync(B.fifo_tag, 0xFF, (size_t)h->cfg.num_envs * 4, (hipStream_t)stream));     // -1: nothing cached yet
+    }
     {   // PCGRL_INLINE_RESET=0 routes resets through the reset list + k_reset instead (A/B measurements)
         const char* ir = getenv("PCGRL_INLINE_RESET");
         B.inline_reset = (!solver_prob(h->cfg.prob) && !(ir && ir[0] == '0')) ? 1 : 0;
@@ -379,6 +389,7 @@ int pcgrl_seed(pcgrl_env* h, const uint32_t* keys, int32_t first, int32_t count,
     DeviceGuard guard(h->device);
     const size_t bytes = (size_t)count * PCGRL_MT_N * 4, off = (size_t)first * PCGRL_MT_N;
     HIPCHK(hipMemcpyAsync(h->B.rng_rep + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (h->B.fifo_tag) HIPCHK(hipMemsetAsync(h->B.fifo_tag + first, 0xFF, (size_t)count * 4, (hipStream_t)stream));
     if (h->B.rng_prob) HIPCHK(hipMemcpyAsync(h->B.rng_prob + off, keys, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     hipLaunchKernelGGL(k_zero_cursors, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->B.rng_cur, first, count);
     HIPCHK(hipGetLastError());
@@ -395,6 +406,7 @@ int pcgrl_seed_words(pcgrl_env* h, const uint32_t* words, int32_t first, int32_t
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpy2DAsync(h->B.rng_rep + (size_t)first * PCGRL_MT_N, PCGRL_MT_N * 4, words, 12, 12, (size_t)count, hipMemcpyHostToDevice, st));
+    if (h->B.fifo_tag) HIPCHK(hipMemsetAsync(h->B.fifo_tag + first, 0xFF, (size_t)count * 4, st));
     hipLaunchKernelGGL(k_init_by_array, dim3((count + 63) / 64), dim3(64), 0, st, h->B.rng_rep, h->B.rng_prob, h->B.rng_cur, first, count);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));   // `words` may be pageable host memory
@@ -495,7 +507,10 @@ struct RolloutArgs { int steps; size_t action_stride; double* reward_out; uint8_
 template <int PROB, class MaskT>
 static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
     const PcgrlParams& P = h->P;
-    const size_t lds = 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
+    // the block's state copy (kernels_step.h) + per wavefront an MT19937 ring and the tile bytes of a map (in-kernel resets)
+    const StepLds SL = step_lds_layout(16 * P.nplanes * (int)sizeof(MaskT), (PROB == PCGRL_PROB_BINARY && h->B.champ) ? 16 * (int)sizeof(MaskT) : 0,
+                                       P.rep == PCGRL_REP_NARROW && h->B.fifo != nullptr);
+    const size_t lds = (size_t)SL.total + 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
     const int grid = (P.num_envs + 63) / 64;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
 #define PCGRL_LAUNCH_STEP(REPV, MULTI) hipLaunchKernelGGL((k_step<PROB, REPV, MaskT, MULTI>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, \
@@ -809,6 +824,8 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     const int n = P.num_envs, par = h->parity, cells = P.width * P.height;
     const size_t lds = 4 * (size_t)((cells + 15) & ~15);
     const int grid = grid_for(n, 4, 4096);
+    // (a caller that restores a checkpoint rewrites the rings and cursors and then comes here: drop the draw cache)
+    if (h->B.fifo_tag) HIPCHK(hipMemsetAsync(h->B.fifo_tag, 0xFF, (size_t)n * 4, st));
     if (P.mask_bytes == 4)
         hipLaunchKernelGGL((k_planes_from_map<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
     else
@@ -822,6 +839,15 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     if (sok && (rc = launch_solver(h, 0, WL_SOL2, MODE_SETMAP, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
     return PCGRL_OK;
 }
+
+#ifdef PCGRL_TIMELINE
+// debug build only (tools/timeline.py): where the kernels write their timeline marks (NULL: off)
+int pcgrl_debug_timeline(void* buf) {
+    unsigned long long* p = (unsigned long long*)buf;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &p, sizeof(p)));
+    return PCGRL_OK;
+}
+#endif
 
 int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;

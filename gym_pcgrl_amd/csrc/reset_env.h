@@ -31,9 +31,12 @@ __device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const ui
 // first map), cursor, both MT19937 rings, heatmap, counters, BinaryProblem.reset.  All 64 lanes call it;
 // `mt` (624 words) and `tiles` (H*W bytes) are this wave's LDS scratch; the tile bytes of the new map are
 // left in `tiles` for the caller to turn into row planes.
+// `pend` > 0 (fused step kernel, an environment that was certain to be reset): the environment's cursor already counts
+// `pend` draws of this step whose words are still in its draw cache and not in its ring; they are patched into the staged
+// ring here.  On return the draw cache of the environment is rebuilt for the new cursor.
 template <int PROB>
 __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt,
-                                               uint8_t* tiles, int lane) {
+                                               uint8_t* tiles, int lane, int pend = 0) {
     const int W = P.width, H = P.height, cells = W * H;
     uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
     uint8_t* map_g = B.map + (size_t)e * cells;
@@ -50,7 +53,15 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         int sl = curs.y + off; sl = sl >= PCGRL_MT_N ? sl - PCGRL_MT_N : sl;
         pw = B.rng_prob[(size_t)e * PCGRL_MT_N + sl];
     }
+    if (pend > 0) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < pend) {
+            int sl = cur - pend + lane; sl = sl < 0 ? sl + PCGRL_MT_N : sl;
+            mt[sl] = B.fifo[(size_t)e * PCGRL_FIFO_N + lane];
+        }
+    }
     __builtin_amdgcn_wave_barrier();
+    TL(13);
     if (gen_map) {
         // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
         // the number of tiles is a property of the problem: constant indices only -- a run-time index into the by-value
@@ -91,6 +102,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         for (int c = lane; c < cells; c += 64) { const uint8_t t = old_g[c]; tiles[c] = t; map_g[c] = t; }
     }
     __builtin_amdgcn_wave_barrier();
+    TL(14);
     if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33
         if (lane == 0) {
             const int x = mt_randint(mt, cur, W);
@@ -100,6 +112,12 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         cur = __shfl(cur, 0, 64);
     }
     __builtin_amdgcn_wave_barrier();
+    TL(15);
+    if (B.fifo && lane < PCGRL_FIFO_N) {     // the words of the next draws, computed ahead (the ring itself stays lazy)
+        const int sl = mt_wrap(cur + lane);
+        B.fifo[(size_t)e * PCGRL_FIFO_N + lane] = mt_twist(mt[sl], mt[mt_wrap(sl + 1)], mt[mt_wrap(sl + PCGRL_MT_M)]);
+        if (lane == 0) B.fifo_tag[e] = cur;
+    }
     for (int i = lane; i < PCGRL_MT_N; i += 64) ring_g[i] = mt[i];
     uint16_t* heat_g = B.heat + (size_t)e * cells;
     for (int c = lane; c < cells; c += 64) heat_g[c] = 0;        // pcgrl_env.py:72
@@ -124,5 +142,6 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         }
     }
     __builtin_amdgcn_wave_barrier();
+    TL(16);
 }
 

@@ -38,6 +38,26 @@ template <int G> __device__ __forceinline__ unsigned wl_inc_code(int raw) { retu
 // k_stats resets it without recomputing anything.
 #define WL_RESET_ONLY (1 << 30)
 
+// Optional in-kernel timeline (tools/timeline.py builds a copy of the library with -DPCGRL_TIMELINE; the product is
+// compiled without it and TL() is nothing): wavefront-private slots, 100 MHz wall clock << 8 | tag.
+#ifdef PCGRL_TIMELINE
+#define TL_SLOTS 48
+__device__ unsigned long long* g_tl_buf;
+__shared__ int s_tl_idx[16];
+__device__ __forceinline__ void tl_mark(int tag) {
+    if ((threadIdx.x & 63) == 0 && g_tl_buf) {
+        const int wv = threadIdx.x >> 6;
+        const int i = s_tl_idx[wv];
+        if (i < TL_SLOTS) { g_tl_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + wv) * TL_SLOTS + i] = ((unsigned long long)wall_clock64() << 8) | (unsigned)tag; s_tl_idx[wv] = i + 1; }
+    }
+}
+#define TL_INIT() do { if ((threadIdx.x & 63) == 0) s_tl_idx[threadIdx.x >> 6] = 0; } while (0)
+#define TL(tag) tl_mark(tag)
+#else
+#define TL_INIT() do {} while (0)
+#define TL(tag) do {} while (0)
+#endif
+
 struct LocalLists;
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
@@ -64,6 +84,21 @@ struct DevBufs {
     int32_t inline_reset;   // k_stats resets finished environments itself (every problem but Sokoban)
     int32_t pair_min;       // from this many certain resets per launch on, a wavefront of k_stats takes two of them (PCGRL_PAIR_MIN)
     int32_t zelda_inc;      // zelda, single-cell representations, maps of at most 16 x 32: changed/incremental items carry (cell, passability change)
+    // Narrow representation: the next PCGRL_FIFO_N words of the representation stream, computed ahead (untempered) -- a derived
+    // cache of (ring, cursor), valid while fifo_tag[e] equals the cursor.  The fused step kernel draws the cursor moves from it
+    // (no ring access on the step's critical path) and refills it behind the barrier; every reset rebuilds it; the other
+    // pipelines draw from the ring and mark it invalid (-1).
+    uint32_t* fifo; int32_t* fifo_tag;
+};
+#define PCGRL_FIFO_N 8
+
+// Block-local state of the fused step kernel (k_step) that the shared device functions have to know about: the block keeps
+// the per-environment state of its 64 environments in LDS (DevBufs pointers rebased into it) for the whole launch.
+struct StepLocal {
+    int e0;
+    int refill_done;            // wavefront 0 has written the consumed draws back to the rings (release / acquire, workgroup scope)
+    uint8_t k[64];              // draws an environment consumed in this step and that are not in its ring yet (certain resets patch them in)
+    uint8_t dirty[64];          // planes / champion / start statistics changed: write them back
 };
 
 __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {

@@ -186,3 +186,29 @@ def test_vector_env_spaces_are_batched():
     assert b["map"].shape == (5, 14, 14) and b["pos"].shape == (5, 2) and b["map"].dtype == np.uint8
     assert _batch_space(spaces.Discrete(3), 4) == spaces.MultiDiscrete([3, 3, 3, 3])
     assert _batch_space(spaces.MultiDiscrete([14, 14, 2]), 2).nvec.shape == (2, 3)
+
+
+def test_fuzz_slice_covers_every_problem_and_representation():
+    """The 60 configurations of test_fuzz_slice, drawn again without running them: all five problems, all six
+    representations, and both tape forms are in the slice."""
+    import parity_harness as ph
+    probs, reps, hows = set(), set(), set()
+    for chunk in range(6):
+        rs = np.random.RandomState(9000 + chunk)
+        for _ in range(10):
+            prob, rep, wh, calls, E, T, seed0 = ph.draw_config(rs)
+            u = rs.rand()
+            hows.add("rollout" if u < 0.4 else ("mixed" if u < 0.55 else "steps"))
+            probs.add(prob); reps.add(rep)
+            sp_n = None   # consume the same draws run_config makes for the action tape, so that the stream stays aligned
+            from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+            env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=E, seed=seed0)
+            for kw in calls:
+                env.adjust_param(**kw)
+            sp = env.single_action_space
+            Ts = max(4, int(T * 0.6))
+            if hasattr(sp, "n"):
+                rs.randint(0, sp.n, size=(Ts, E, 1))
+            else:
+                [rs.randint(0, int(k), size=(Ts, E)) for k in sp.nvec]
+    assert probs == {"binary", "zelda", "sokoban", "mdungeon", "ddave"} and len(reps) == 6 and hows == {"rollout", "mixed", "steps"}, (probs, reps, hows)
