@@ -77,9 +77,11 @@ _lib = None
 
 
 def load():
-    global _lib
+    global _lib, SO
     if _lib is not None:
         return _lib
+    # developer switch (A/B builds of the kernels, tools/): another build of the SAME library; it must exist
+    SO = os.environ.get("PCGRL_HIP_SO", SO)
     if not os.path.exists(SO):
         raise RuntimeError(
             "gym_pcgrl_amd: HIP library %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "

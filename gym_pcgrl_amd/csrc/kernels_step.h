@@ -25,21 +25,27 @@
 // other configuration takes the two-launch pipeline.
 #pragma once
 
-struct StepLds { int planes, champ, stats, start, info, rew, cnt, cur, fifo, tag, pos, done, total; };
-__host__ __device__ __forceinline__ StepLds step_lds_layout(int plane_row_bytes, int champ_row_bytes, bool fifo) {
-    StepLds L;
+// LDS copy of a block: first the segments that are loaded at the start, contiguous and in this order (each a multiple of 16
+// bytes for a full block of 64 environments), then the ones that are only produced.  Sizes depend on the kernel's template
+// parameters only (the champion rows of the binary problem and the draw cache of the narrow representation keep their room
+// even when the feature is off), so that the prefetch can be laid out at compile time.
+struct StepLds { int planes, champ, stats, start, cnt, cur, fifo, tag, pos, act, in_total, info, rew, done, total; };
+__host__ __device__ constexpr StepLds step_lds_layout(int plane_row_bytes, int champ_row_bytes, bool fifo, int action_width) {
+    StepLds L = {};
     int o = 0;
     L.planes = o; o += 64 * plane_row_bytes;
     L.champ = o; o += 64 * champ_row_bytes;
     L.stats = o; o += 64 * 32;
     L.start = o; o += 64 * 32;
-    L.info = o; o += 64 * 40;
-    L.rew = o; o += 64 * 8;
     L.cnt = o; o += 64 * 8;
     L.cur = o; o += 64 * 8;
     L.fifo = o; o += fifo ? 64 * PCGRL_FIFO_N * 4 : 0;
     L.tag = o; o += fifo ? 64 * 4 : 0;
     L.pos = o; o += 64 * 2;
+    L.act = o; o += 64 * 4 * action_width;
+    L.in_total = o;
+    L.info = o; o += 64 * 40;
+    L.rew = o; o += 64 * 8;
     L.done = o; o += 64;
     L.total = (o + 15) & ~15;
     return L;
@@ -56,6 +62,27 @@ __device__ __forceinline__ void blk_copy_rows(uint8_t* dst, const uint8_t* src, 
     const int per = row >> 4;
     for (int i = threadIdx.x; i < rows * per; i += PCGRL_BLOCK)
         if (flag[i / per]) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+}
+
+// One segment of the batched prefetch of a FULL block: the 16-byte slots [SLOT0, SLOT0 + NV) of the LDS copy come from `g`.
+// Thread tid owns the slots tid + 256 c; everything here is resolved at compile time except the predicate and the address, so
+// all loads of all segments are issued back to back and waited for once.
+template <int C, int SLOT0, int NV>
+__device__ __forceinline__ void seg_load_c(uint4& rc, const void* g, bool on, int tid) {
+    if (C * PCGRL_BLOCK + PCGRL_BLOCK - 1 < SLOT0 || C * PCGRL_BLOCK >= SLOT0 + NV) return;     // compile time: no overlap
+    const int slot = C * PCGRL_BLOCK + tid;
+    if (on && slot >= SLOT0 && slot < SLOT0 + NV) rc = reinterpret_cast<const uint4*>(g)[slot - SLOT0];
+}
+// (named registers, not an array: an array indexed through a reference ends up in scratch memory)
+#define PCGRL_SEG_LOAD(SLOT0, NV, G, ON) do { const void* g_ = (G); const bool on_ = (ON); \
+    seg_load_c<0, SLOT0, NV>(r0, g_, on_, tid0); seg_load_c<1, SLOT0, NV>(r1, g_, on_, tid0); seg_load_c<2, SLOT0, NV>(r2, g_, on_, tid0); \
+    seg_load_c<3, SLOT0, NV>(r3, g_, on_, tid0); seg_load_c<4, SLOT0, NV>(r4, g_, on_, tid0); seg_load_c<5, SLOT0, NV>(r5, g_, on_, tid0); \
+    seg_load_c<6, SLOT0, NV>(r6, g_, on_, tid0); seg_load_c<7, SLOT0, NV>(r7, g_, on_, tid0); seg_load_c<8, SLOT0, NV>(r8, g_, on_, tid0); } while (0)
+template <int C, int TOTAL>
+__device__ __forceinline__ void seg_store_c(uint8_t* smem, const uint4& rc, int tid) {
+    if (C * PCGRL_BLOCK >= TOTAL) return;
+    const int slot = C * PCGRL_BLOCK + tid;
+    if (slot < TOTAL) reinterpret_cast<uint4*>(smem)[slot] = rc;
 }
 
 // Wavefront 0, one lane per environment, behind the task barrier: the k words the step drew from the draw cache go into the
@@ -87,7 +114,6 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // the block's state copy, then per wave MT ring + tile bytes (in-kernel resets)
     __shared__ int s_items[3][64];      // 0: certain resets, 1: full recomputations (by bucket), 2: incremental updates
     __shared__ int s_n[3];
-    __shared__ int s_hist[64];
     __shared__ int s_next;              // next wavefront task of the step (the wavefronts take them as they become free)
     __shared__ StepLocal s_loc;
     constexpr int G = 16, GPW = 4;
@@ -99,8 +125,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     const int ne = (P.num_envs - e0) < 64 ? (P.num_envs - e0) : 64;
     const bool has_champ = PROB == PCGRL_PROB_BINARY && Bg.champ != nullptr;
     const bool has_fifo = REP == PCGRL_REP_NARROW && Bg.fifo != nullptr;
-    const int champ_row = has_champ ? G * (int)sizeof(MaskT) : 0;
-    const StepLds L = step_lds_layout(kPlaneRow, champ_row, has_fifo);
+    constexpr int kChampRow = PROB == PCGRL_PROB_BINARY ? G * (int)sizeof(MaskT) : 0;
+    constexpr int AW = REP == PCGRL_REP_WIDE ? 3 : 1;                 // int32 values of an action
+    constexpr StepLds L = step_lds_layout(kPlaneRow, kChampRow, REP == PCGRL_REP_NARROW, AW);
+    const int champ_row = kChampRow;
     // ---- the block's copy of the per-environment state, and a DevBufs for the shared device functions in which index 0 is
     // the block's first environment: the staged arrays point into the LDS copy, the arrays that stay in global memory (byte
     // maps, heatmap, MT19937 rings, tile probabilities, episode statistics) are moved forward to the block's slice.  Inside the
@@ -130,16 +158,43 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     }
     B.pos = smem + L.pos;
     B.done = smem + L.done;
-    blk_copy(smem + L.planes, reinterpret_cast<const uint8_t*>(Bg.planes) + (size_t)e0 * kPlaneRow, ne * kPlaneRow);
-    if (has_champ) blk_copy(smem + L.champ, reinterpret_cast<const uint8_t*>(Bg.champ) + (size_t)e0 * champ_row, ne * champ_row);
-    blk_copy(smem + L.stats, reinterpret_cast<const uint8_t*>(Bg.stats + (size_t)e0 * 8), ne * 32);
-    blk_copy(smem + L.start, reinterpret_cast<const uint8_t*>(Bg.start_stats + (size_t)e0 * 8), ne * 32);
-    blk_copy(smem + L.cnt, reinterpret_cast<const uint8_t*>(Bg.counters + (size_t)e0 * 2), ne * 8);
-    blk_copy(smem + L.cur, reinterpret_cast<const uint8_t*>(Bg.rng_cur + (size_t)e0 * 2), ne * 8);
-    blk_copy(smem + L.pos, Bg.pos + (size_t)e0 * 2, ne * 2);
-    if (has_fifo) {
-        blk_copy(smem + L.fifo, reinterpret_cast<const uint8_t*>(Bg.fifo + (size_t)e0 * PCGRL_FIFO_N), ne * PCGRL_FIFO_N * 4);
-        blk_copy(smem + L.tag, reinterpret_cast<const uint8_t*>(Bg.fifo_tag + e0), ne * 4);
+    const int32_t* act_lds = reinterpret_cast<const int32_t*>(smem + L.act);
+    const uint8_t* g_planes = reinterpret_cast<const uint8_t*>(Bg.planes) + (size_t)e0 * kPlaneRow;
+    const uint8_t* g_champ = has_champ ? reinterpret_cast<const uint8_t*>(Bg.champ) + (size_t)e0 * champ_row : nullptr;
+    if (ne == 64) {
+        // a full block: every load of every segment first, then one wait, then the LDS stores -- one round trip
+        static_assert(L.in_total / 16 <= 9 * PCGRL_BLOCK, "nine 16-byte slots per thread");
+        uint4 r0 = {}, r1 = {}, r2 = {}, r3 = {}, r4 = {}, r5 = {}, r6 = {}, r7 = {}, r8 = {};
+        const int tid0 = (int)threadIdx.x;
+        PCGRL_SEG_LOAD(L.planes / 16, 64 * kPlaneRow / 16, g_planes, true);
+        if (kChampRow) PCGRL_SEG_LOAD(L.champ / 16, (kChampRow ? 64 * kChampRow / 16 : 1), g_champ, has_champ);
+        PCGRL_SEG_LOAD(L.stats / 16, 128, Bg.stats + (size_t)e0 * 8, true);
+        PCGRL_SEG_LOAD(L.start / 16, 128, Bg.start_stats + (size_t)e0 * 8, true);
+        PCGRL_SEG_LOAD(L.cnt / 16, 32, Bg.counters + (size_t)e0 * 2, true);
+        PCGRL_SEG_LOAD(L.cur / 16, 32, Bg.rng_cur + (size_t)e0 * 2, true);
+        if (REP == PCGRL_REP_NARROW) {
+            PCGRL_SEG_LOAD(L.fifo / 16, 64 * PCGRL_FIFO_N * 4 / 16, has_fifo ? Bg.fifo + (size_t)e0 * PCGRL_FIFO_N : nullptr, has_fifo);
+            PCGRL_SEG_LOAD(L.tag / 16, 16, has_fifo ? Bg.fifo_tag + e0 : nullptr, has_fifo);
+        }
+        PCGRL_SEG_LOAD(L.pos / 16, 8, Bg.pos + (size_t)e0 * 2, true);
+        PCGRL_SEG_LOAD(L.act / 16, 16 * AW, actions + (size_t)e0 * AW, true);
+        constexpr int TOT = L.in_total / 16;
+        seg_store_c<0, TOT>(smem, r0, tid0); seg_store_c<1, TOT>(smem, r1, tid0); seg_store_c<2, TOT>(smem, r2, tid0);
+        seg_store_c<3, TOT>(smem, r3, tid0); seg_store_c<4, TOT>(smem, r4, tid0); seg_store_c<5, TOT>(smem, r5, tid0);
+        seg_store_c<6, TOT>(smem, r6, tid0); seg_store_c<7, TOT>(smem, r7, tid0); seg_store_c<8, TOT>(smem, r8, tid0);
+    } else {
+        blk_copy(smem + L.planes, g_planes, ne * kPlaneRow);
+        if (has_champ) blk_copy(smem + L.champ, g_champ, ne * champ_row);
+        blk_copy(smem + L.stats, reinterpret_cast<const uint8_t*>(Bg.stats + (size_t)e0 * 8), ne * 32);
+        blk_copy(smem + L.start, reinterpret_cast<const uint8_t*>(Bg.start_stats + (size_t)e0 * 8), ne * 32);
+        blk_copy(smem + L.cnt, reinterpret_cast<const uint8_t*>(Bg.counters + (size_t)e0 * 2), ne * 8);
+        blk_copy(smem + L.cur, reinterpret_cast<const uint8_t*>(Bg.rng_cur + (size_t)e0 * 2), ne * 8);
+        blk_copy(smem + L.pos, Bg.pos + (size_t)e0 * 2, ne * 2);
+        if (has_fifo) {
+            blk_copy(smem + L.fifo, reinterpret_cast<const uint8_t*>(Bg.fifo + (size_t)e0 * PCGRL_FIFO_N), ne * PCGRL_FIFO_N * 4);
+            blk_copy(smem + L.tag, reinterpret_cast<const uint8_t*>(Bg.fifo_tag + e0), ne * 4);
+        }
+        blk_copy(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)e0 * AW), ne * 4 * AW);
     }
     if (threadIdx.x < 64) s_loc.dirty[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_loc.e0 = 0;
@@ -154,14 +209,14 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     if (MULTI) asm volatile("" : "+v"(tid));
     const int lane64 = tid & 63, wv = tid >> 6, gw = lane64 / G;
     DevGroup<G, MaskT> g(lane64);
-    const int32_t* actions_t = actions + (size_t)t * action_stride + (size_t)e0 * (REP == PCGRL_REP_WIDE ? 3 : 1);
-    if (wv == 1) s_hist[lane64] = 0;
+    if (MULTI && t > 0)     // this step's row of the action tape (the first one came with the state)
+        blk_copy(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)t * action_stride + (size_t)e0 * AW), ne * 4 * AW);
     __syncthreads();                        // the state copy is complete; everything the previous step wrote is visible to the whole block
     TL(17);
     if (wv == 0) {
         const int e = lane64;                                  // block-local index (see B above)
         UpdateOut u = {};
-        if (lane64 < ne) u = update_env<REP, MaskT, true>(P, B, actions_t, e);
+        if (lane64 < ne) u = update_env<REP, MaskT, true>(P, B, act_lds, e);
         TL(2);
         const bool first = u.rst || u.sure_done;               // reset-only, or certain to end: k_stats' "lone" items
         const bool packed_full = PROB == PCGRL_PROB_ZELDA && B.zelda_inc;
@@ -174,21 +229,18 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
         const uint64_t below = (1ull << lane64) - 1ull;
         if (dest == 0) s_items[0][__popcll(m0 & below)] = v;
         if (dest == 2) s_items[2][__popcll(m2 & below)] = v;
-        // full recomputations in bucket order (the four maps that share a wavefront should cost about the same)
-        int rank = 0;
-        const int bucket = u.bucket & 63;
-        if (dest == 1) rank = atomicAdd(&s_hist[bucket], 1);
-        __builtin_amdgcn_wave_barrier();
-        int incl = s_hist[lane64];
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane64 >= o) incl += up;
+        // full recomputations ordered by expected cost (the four maps that share a wavefront should cost about the same):
+        // eight levels of the previous path length, ranked with eight ballots -- no LDS round trips
+        {
+            const int lvl = (u.bucket >> 3) & 7;
+            int pos1 = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const uint64_t mb = __ballot(dest == 1 && lvl == b);
+                pos1 += b < lvl ? __popcll(mb) : (b == lvl ? __popcll(mb & below) : 0);
+            }
+            if (dest == 1) s_items[1][pos1] = v;
         }
-        const int excl = incl - s_hist[lane64];
-        __builtin_amdgcn_wave_barrier();
-        s_hist[lane64] = excl;
-        __builtin_amdgcn_wave_barrier();
-        if (dest == 1) s_items[1][s_hist[bucket] + rank] = v;
         if (lane64 == 0) { s_n[0] = __popcll(m0); s_n[1] = __popcll(m1); s_n[2] = __popcll(m2); s_next = 0; s_loc.refill_done = 0; }
         // LDS-only barrier: what wavefront 0 has in flight to global memory (byte-map cells, heatmap increments) concerns no
         // task that starts now -- environments that are certain to be reset got no such write, the other tasks work on the

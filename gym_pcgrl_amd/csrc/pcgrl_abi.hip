@@ -508,8 +508,8 @@ template <int PROB, class MaskT>
 static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
     const PcgrlParams& P = h->P;
     // the block's state copy (kernels_step.h) + per wavefront an MT19937 ring and the tile bytes of a map (in-kernel resets)
-    const StepLds SL = step_lds_layout(16 * P.nplanes * (int)sizeof(MaskT), (PROB == PCGRL_PROB_BINARY && h->B.champ) ? 16 * (int)sizeof(MaskT) : 0,
-                                       P.rep == PCGRL_REP_NARROW && h->B.fifo != nullptr);
+    const StepLds SL = step_lds_layout(16 * P.nplanes * (int)sizeof(MaskT), PROB == PCGRL_PROB_BINARY ? 16 * (int)sizeof(MaskT) : 0,
+                                       P.rep == PCGRL_REP_NARROW, P.rep == PCGRL_REP_WIDE ? 3 : 1);
     const size_t lds = (size_t)SL.total + 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
     const int grid = (P.num_envs + 63) / 64;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;

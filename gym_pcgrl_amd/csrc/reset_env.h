@@ -43,7 +43,13 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     uint8_t* old_g = B.old_map + (size_t)e * cells;
     const int2 curs = reinterpret_cast<const int2*>(B.rng_cur)[e];
     int cur = curs.x;
-    for (int i = lane; i < PCGRL_MT_N; i += 64) mt[i] = ring_g[i];
+    {   // the ring: every load first, then the LDS stores (one round trip; 624 = 9 x 64 + 48)
+        uint32_t rw[10];
+#pragma unroll
+        for (int j = 0; j < 10; j++) rw[j] = (j < 9 || lane < PCGRL_MT_N - 9 * 64) ? ring_g[j * 64 + lane] : 0u;
+#pragma unroll
+        for (int j = 0; j < 10; j++) if (j < 9 || lane < PCGRL_MT_N - 9 * 64) mt[j * 64 + lane] = rw[j];
+    }
     // BinaryProblem.reset (binary_prob.py:68-72) draws one double = two words from the *problem* stream
     // after the map is made.  Its five operand words are fetched now, by five lanes, off the critical path.
     const bool prob_draw = PROB == PCGRL_PROB_BINARY && P.random_probs;
