@@ -23,7 +23,7 @@ class Config(C.Structure):
         "prob", "rep", "num_envs", "width", "height", "max_changes", "max_iterations",
         "random_start", "random_tile", "warp", "random_probs", "auto_reset", "target_path",
         "max_enemies", "target_enemy_dist", "max_crates", "target_solution", "solver_power", "max_potions",
-        "max_treasures", "max_diamonds", "min_spikes", "target_jumps", "reserved_")] + [
+        "max_treasures", "max_diamonds", "min_spikes", "target_jumps", "min_empty", "min_enemies", "min_jumps")] + [
         ("target_col_enemies", C.c_double), ("tile_probs", C.c_double * 8), ("rewards", C.c_double * 12)]
 
 
@@ -41,7 +41,7 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
 
 
-ABI_VERSION = 6          # include/pcgrl_hip.h PCGRL_ABI_VERSION
+ABI_VERSION = 7          # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",

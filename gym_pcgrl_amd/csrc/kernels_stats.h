@@ -61,6 +61,7 @@ __device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, M
     if (PROB == PCGRL_PROB_ZELDA) { zelda_stats(g, P, b0, b1, b2, valid, s); return false; }
     if (PROB == PCGRL_PROB_MDUNGEON) return mdungeon_stats(g, P, b0, b1, b2, valid, s);
     if (PROB == PCGRL_PROB_DDAVE) return ddave_stats(g, P, b0, b1, b2, valid, s);
+    if (PROB == PCGRL_PROB_SMB) return true;      // no bit planes: everything is computed by k_smb (kernels_smb.h) on the byte map
     return sokoban_stats(g, P, b0, b1, b2, valid, s);
 }
 template <int PROB, class G, class MaskT>

@@ -97,11 +97,15 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
             chd = ch[wy < G - 1 ? wy + 1 : wy];
         }
         MaskT m0 = 0, m1 = 0, m2 = 0;
+        int old_byte = 0;
         if (writes) {
-            m0 = pl[0];
-            if (NPL > 1) { m1 = pl[1]; m2 = pl[2]; }
+            if (NPL == 0) old_byte = (int)*cell;          // smb keeps no bit planes (114 columns): the old tile comes from the byte map
+            else {
+                m0 = pl[0];
+                if (NPL > 1) { m1 = pl[1]; m2 = pl[2]; }
+            }
         }
-        const int old = (int)((m0 >> wx) & 1) | ((NPL > 1) ? (int)(((m1 >> wx) & 1) << 1) | (int)(((m2 >> wx) & 1) << 2) : 0);
+        const int old = NPL == 0 ? old_byte : ((int)((m0 >> wx) & 1) | ((NPL > 1) ? (int)(((m1 >> wx) & 1) << 1) | (int)(((m2 >> wx) & 1) << 2) : 0));
         uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
         cur0 = cur;
@@ -146,7 +150,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
             const bool dead_writes = FIFO && P.auto_reset && B.inline_reset && (c.y + 1 >= P.max_changes || iter >= P.max_iterations);
             if (!dead_writes) *cell = (uint8_t)tile;
             const MaskT bit = (MaskT)1 << wx;
-            pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
+            if (NPL > 0) pl[0] = (tile & 1) ? (m0 | bit) : (m0 & ~bit);
             if (NPL > 1) {
                 pl[1] = (tile & 2) ? (m1 | bit) : (m1 & ~bit);
                 pl[2] = (tile & 4) ? (m2 | bit) : (m2 & ~bit);
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
             const int yy = y + dy;
             if (yy < 0 || yy >= H) continue;
             if (vals[(dy + 1) * 3] < 0 && vals[(dy + 1) * 3 + 1] < 0 && vals[(dy + 1) * 3 + 2] < 0) continue;
-            MaskT m0 = pl_e[yy * NPL], m1 = NPL > 1 ? pl_e[yy * NPL + 1] : (MaskT)0, m2 = NPL > 1 ? pl_e[yy * NPL + 2] : (MaskT)0;
+            MaskT m0 = NPL > 0 ? pl_e[yy * NPL] : (MaskT)0, m1 = NPL > 1 ? pl_e[yy * NPL + 1] : (MaskT)0, m2 = NPL > 1 ? pl_e[yy * NPL + 2] : (MaskT)0;
             bool touched = false;
 #pragma unroll
             for (int dx = -1; dx <= 1; dx++) {
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
                     m2 = (v & 4) ? (m2 | bit) : (m2 & ~bit);
                 }
             }
-            if (touched) { pl_e[yy * NPL] = m0; if (NPL > 1) { pl_e[yy * NPL + 1] = m1; pl_e[yy * NPL + 2] = m2; } }
+            if (touched && NPL > 0) { pl_e[yy * NPL] = m0; if (NPL > 1) { pl_e[yy * NPL + 1] = m1; pl_e[yy * NPL + 2] = m2; } }
         }
         if (REP != PCGRL_REP_TURTLE_CAST) {   // narrow cursor move (narrow_rep.py:104-113), after the write
             if (P.random_tile) {

@@ -50,6 +50,7 @@
 #include "kernels_sokoban.h"
 #include "kernels_mdungeon.h"
 #include "kernels_ddave.h"
+#include "kernels_smb.h"
 #include "kernels_step_solver.h"
 #include "kernels_misc.h"
 
@@ -105,20 +106,22 @@ struct DeviceGuard {
 };
 
 // problems whose statistics need a search kernel after k_stats (the Sokoban solver, the MiniDungeons planner)
-static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGRL_MDUNGEON || prob == PCGRL_DDAVE; }
+static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGRL_MDUNGEON || prob == PCGRL_DDAVE || prob == PCGRL_SMB; }
 static int validate_config(const pcgrl_config* c) {
     if (!c) return PCGRL_EINVAL;
-    if (c->prob < 0 || c->prob > 4 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
+    if (c->prob < 0 || c->prob > 5 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
     if (c->num_envs < 1) return PCGRL_EINVAL;
-    if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
+    if (c->prob == PCGRL_SMB) {   // the platformer's grid is (width + 6) x height cells, a column index fits a byte (kernels_smb.h)
+        if (c->width < 1 || c->width > 250 || c->height < 3 || c->height > SMB_MAX_H) return PCGRL_EINVAL;
+    } else if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
     if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
     if (solver_prob(c->prob)) {   // limits of the solver kernels (sokoban_solver.h, mdungeon_solver.h)
-        if ((c->width + 2) * (c->height + 2) > 256) return PCGRL_EINVAL;
+        if (c->prob != PCGRL_SMB && (c->width + 2) * (c->height + 2) > 256) return PCGRL_EINVAL;
         if (c->solver_power < 1 || c->solver_power > 16383) return PCGRL_EINVAL;
     }
     return PCGRL_OK;
 }
-static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_SOKOBAN ? 5 : (prob == PCGRL_DDAVE ? 7 : 8)); }
+static int ntiles_of(int prob) { return prob == PCGRL_BINARY ? 2 : (prob == PCGRL_SOKOBAN ? 5 : ((prob == PCGRL_DDAVE || prob == PCGRL_SMB) ? 7 : 8)); }
 
 static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     memset(P, 0, sizeof(*P));
@@ -126,7 +129,7 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     P->width = c->width; P->height = c->height;
     P->prob_width = c->width; P->prob_height = c->height;
     P->ntiles = ntiles_of(c->prob);
-    P->nplanes = c->prob == PCGRL_BINARY ? 1 : 3;
+    P->nplanes = c->prob == PCGRL_BINARY ? 1 : (c->prob == PCGRL_SMB ? 0 : 3);      // smb: statistics from the byte map (kernels_smb.h)
     P->group = c->height <= 16 ? 16 : 64;
     P->mask_bytes = c->width <= 32 ? 4 : 8;
     P->max_changes = c->max_changes; P->max_iterations = c->max_iterations;
@@ -136,6 +139,7 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     P->max_crates = c->max_crates; P->target_solution = c->target_solution; P->solver_power = c->solver_power;
     P->max_potions = c->max_potions; P->max_treasures = c->max_treasures; P->target_col_enemies = c->target_col_enemies;
     P->max_diamonds = c->max_diamonds; P->min_spikes = c->min_spikes; P->target_jumps = c->target_jumps;
+    P->min_empty = c->min_empty; P->min_enemies = c->min_enemies; P->min_jumps = c->min_jumps;
     for (int i = 0; i < PCGRL_MAX_REWARDS; i++) P->rewards[i] = c->rewards[i];
     pcgrl_build_cdf(c->tile_probs, P->ntiles, P->cdf);
 }
@@ -199,8 +203,9 @@ static int device_setup(pcgrl_env* h) {
     if (solver_prob(h->cfg.prob)) {   // the search kernels use most of a compute unit's LDS (heap + 64-bit-key table)
         const int lds = (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4);
         const void* f = h->cfg.prob == PCGRL_SOKOBAN ? reinterpret_cast<const void*>(k_sokoban)
-                      : h->cfg.prob == PCGRL_MDUNGEON ? reinterpret_cast<const void*>(k_mdungeon) : reinterpret_cast<const void*>(k_ddave);
-        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                      : h->cfg.prob == PCGRL_MDUNGEON ? reinterpret_cast<const void*>(k_mdungeon)
+                      : h->cfg.prob == PCGRL_SMB ? reinterpret_cast<const void*>(k_smb) : reinterpret_cast<const void*>(k_ddave);
+        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->cfg.prob == PCGRL_SMB ? 150 * 1024 : lds));
     }
     return PCGRL_OK;
 }
@@ -539,6 +544,15 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
     const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
     int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
     HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
+    if (h->P.prob == PCGRL_PROB_SMB) {
+        // heap words in LDS (the first levels; a deeper heap continues in the block's arena) + the visited bitmap
+        const int heap_n = 4 * h->P.solver_power + 4 < SMB_LDS_HEAP ? 4 * h->P.solver_power + 4 : SMB_LDS_HEAP;
+        const size_t vis = (size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 8 + 31) / 32 * 4;
+        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(64), (size_t)heap_n * 4 + vis, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
+                           sync, clr, heap_n);
+        HIPCHK(hipGetLastError());
+        return PCGRL_OK;
+    }
     if (h->P.prob == PCGRL_PROB_DDAVE) {
         const size_t dd_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
         hipLaunchKernelGGL(k_ddave, dim3(SOK_BLOCKS), dim3(64), dd_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
@@ -583,6 +597,7 @@ static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int c
         case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, list, park_list, parity, clr, st);
         case PCGRL_PROB_MDUNGEON: return launch_reset_p<PCGRL_PROB_MDUNGEON>(h, list, park_list, parity, clr, st);
         case PCGRL_PROB_DDAVE: return launch_reset_p<PCGRL_PROB_DDAVE>(h, list, park_list, parity, clr, st);
+        case PCGRL_PROB_SMB: return launch_reset_p<PCGRL_PROB_SMB>(h, list, park_list, parity, clr, st);
         default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, list, park_list, parity, clr, st);
     }
 }
@@ -590,7 +605,7 @@ static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int c
 // pcgrl_rollout for the search problems: persistent blocks that own their environments for the whole tape (kernels_step_solver.h)
 static bool solver_rollout_applies(const pcgrl_env* h, int* envs_per_block) {
     const PcgrlParams& P = h->P;
-    if (!solver_prob(P.prob) || P.rep > PCGRL_REP_TURTLE || !P.auto_reset || !h->B.sok_use_lds || P.group != 16 || h->no_fused) return false;
+    if (!solver_prob(P.prob) || P.prob == PCGRL_PROB_SMB || P.rep > PCGRL_REP_TURTLE || !P.auto_reset || !h->B.sok_use_lds || P.group != 16 || h->no_fused) return false;
     int epb = 64 * ((P.num_envs + SOK_BLOCKS * 64 - 1) / (SOK_BLOCKS * 64));      // one block per compute unit when the batch is large enough
     epb = epb < 64 ? 64 : epb;
     if (epb > WL_LOCAL_CAP) return false;                                            // more than 256 x 512 environments: the sequence of steps
@@ -675,12 +690,13 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream, bool* us
     // regenerates those and parks their solver jobs (SOL2); ONE solver launch then works on SOL and SOL2
     // together, so that the step waits for its slowest search once, not twice.  The few episodes that only the
     // solver could end (RST2) get a second, almost empty reset + solver pass.
-    rc = launch_stats(h, WL_CHG, par, MODE_STEP, -1, 0, st);
-    if (rc) return rc;
+    // (smb has no separate statistics pass: k_smb computes everything from the byte map, so its changed list is the job list)
+    const bool smb = h->P.prob == PCGRL_PROB_SMB;
+    if (!smb && (rc = launch_stats(h, WL_CHG, par, MODE_STEP, -1, 0, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     if (ar && (rc = launch_reset(h, WL_RST, WL_SOL2, par, -1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
-    if ((rc = launch_solver(h, 0, WL_SOL, MODE_STEP, ar ? WL_SOL2 : -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), st))) return rc;
+    if ((rc = launch_solver(h, 0, smb ? WL_CHG : WL_SOL, MODE_STEP, ar ? WL_SOL2 : -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     if (ar && (rc = launch_reset(h, WL_RST2, WL_SOL3, par, -1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
@@ -833,10 +849,10 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_CHG);
     HIPCHK(hipGetLastError());
-    const bool sok = solver_prob(P.prob);
-    int rc = launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), 0, st);
+    const bool sok = solver_prob(P.prob), smb = P.prob == PCGRL_PROB_SMB;
+    int rc = smb ? PCGRL_OK : launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), 0, st);
     if (rc) return rc;
-    if (sok && (rc = launch_solver(h, 0, WL_SOL2, MODE_SETMAP, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
+    if (sok && (rc = launch_solver(h, 0, smb ? WL_CHG : WL_SOL2, MODE_SETMAP, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
     return PCGRL_OK;
 }
 

@@ -44,7 +44,8 @@ struct PcgrlParams {
     int32_t target_path, max_enemies, target_enemy_dist, max_crates, target_solution, solver_power;
     int32_t prob_width, prob_height;   // the Problem's own width/height (zelda_prob.py:99, sokoban_prob.py:140)
     int32_t max_potions, max_treasures;   // mdungeon_prob.py:25-26
-    int32_t max_diamonds, min_spikes, target_jumps, pad_;   // ddave_prob.py:23-27
+    int32_t max_diamonds, min_spikes, target_jumps;   // ddave_prob.py:23-27
+    int32_t min_empty, min_enemies, min_jumps, pad_, pad2_;   // smb_prob.py:21-24
     double target_col_enemies;         // mdungeon_prob.py:28
     double rewards[PCGRL_MAX_REWARDS];
     double cdf[PCGRL_MAX_TILES];
@@ -139,6 +140,17 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
         r = r + (double)range_reward_i(md_dist_win(n), md_dist_win(o), PCGRL_INEG, PCGRL_INEG) * w[8];
         r = r + (double)range_reward_i(md_sol_length(n), md_sol_length(o), PCGRL_IPOS, PCGRL_IPOS) * w[9];
         return r;
+    } else if (prob == PCGRL_PROB_SMB) {
+        // weights and summation in the order of SMBProblem._rewards / get_reward (smb_prob.py:26-35, 169-189)
+        double r = (double)range_reward_i(n[0], o[0], 0, 0) * w[0];
+        r = r + (double)range_reward_i(n[1], o[1], 0, 0) * w[1];
+        r = r + (double)range_reward_i(n[2], o[2], P.min_enemies, P.max_enemies) * w[2];
+        r = r + (double)range_reward_i(n[3], o[3], P.min_empty, PCGRL_IPOS) * w[3];
+        r = r + (double)range_reward_i(n[4], o[4], 0, 0) * w[4];
+        r = r + (double)range_reward_i(n[5], o[5], P.min_jumps, PCGRL_IPOS) * w[5];
+        r = r + (double)range_reward_i(n[6], o[6], 0, 0) * w[6];
+        r = r + (double)range_reward_i(n[7], o[7], 0, 0) * w[7];
+        return r;
     } else if (prob == PCGRL_PROB_MDUNGEON) {
         // weights in the order of MDungeonProblem._rewards, summed in the order of get_reward (mdungeon_prob.py:183-206)
         double r = (double)range_reward_i(n[0], o[0], 1, 1) * w[0];
@@ -170,6 +182,7 @@ PCGRL_HD bool episode_over(const PcgrlParams& P, const int32_t* n, const int32_t
     if (prob == PCGRL_PROB_BINARY) return n[0] == 1 && n[1] - start[1] >= P.target_path;
     if (prob == PCGRL_PROB_ZELDA) return n[5] >= P.target_enemy_dist && n[6] >= P.target_path;
     if (prob == PCGRL_PROB_DDAVE) return md_sol_length(n) >= P.target_solution && n[5] > P.target_jumps;   // ddave_prob.py:218-220
+    if (prob == PCGRL_PROB_SMB) return n[7] <= 0;                                                            // smb_prob.py:191-192
     if (prob == PCGRL_PROB_MDUNGEON) {   // mdungeon_prob.py:219-222 (true division, compared in fp64)
         const int en = n[4] > 1 ? n[4] : 1;
         return md_sol_length(n) >= P.target_solution && n[4] > 0 && (double)md_col_enemies(n) / (double)en > P.target_col_enemies;

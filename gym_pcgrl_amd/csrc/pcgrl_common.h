@@ -21,6 +21,6 @@
 #define PCGRL_MT_N 624
 #define PCGRL_MT_M 397
 
-enum { PCGRL_PROB_BINARY = 0, PCGRL_PROB_ZELDA = 1, PCGRL_PROB_SOKOBAN = 2, PCGRL_PROB_MDUNGEON = 3, PCGRL_PROB_DDAVE = 4 };
+enum { PCGRL_PROB_BINARY = 0, PCGRL_PROB_ZELDA = 1, PCGRL_PROB_SOKOBAN = 2, PCGRL_PROB_MDUNGEON = 3, PCGRL_PROB_DDAVE = 4, PCGRL_PROB_SMB = 5 };
 enum { PCGRL_REP_NARROW = 0, PCGRL_REP_WIDE = 1, PCGRL_REP_TURTLE = 2, PCGRL_REP_NARROW_CAST = 3, PCGRL_REP_NARROW_MULTI = 4,
        PCGRL_REP_TURTLE_CAST = 5 };

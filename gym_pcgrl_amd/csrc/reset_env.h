@@ -9,6 +9,7 @@ __device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const ui
                                                   MaskT& m0, MaskT& m1, MaskT& m2, bool store = true) {
     const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes;
     m0 = 0; m1 = 0; m2 = 0;
+    if (NPL == 0) return;                 // smb keeps no bit planes
     if (row >= 0 && row < G) {
         const int lane = row;
         if (lane < H) {
@@ -72,7 +73,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
         // the number of tiles is a property of the problem: constant indices only -- a run-time index into the by-value
         // parameter block makes the compiler keep a copy of the whole block in scratch memory
-        constexpr int NT = PROB == PCGRL_PROB_BINARY ? 2 : PROB == PCGRL_PROB_SOKOBAN ? 5 : PROB == PCGRL_PROB_DDAVE ? 7 : 8;
+        constexpr int NT = PROB == PCGRL_PROB_BINARY ? 2 : PROB == PCGRL_PROB_SOKOBAN ? 5 : (PROB == PCGRL_PROB_DDAVE || PROB == PCGRL_PROB_SMB) ? 7 : 8;
         double cdf[NT];
         if (PROB == PCGRL_PROB_BINARY) {
             double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};

@@ -138,7 +138,7 @@ class BatchedPcgrlEnv:
         b["old_map"] = z((n, h, w), torch.uint8)
         b["heatmap"] = z((n, h, w), torch.int16)
         b["pos"] = z((n, 2), torch.uint8)
-        b["planes"] = z((n, lay.group, lay.nplanes), mask_dtype)
+        b["planes"] = z((n, lay.group, lay.nplanes), mask_dtype) if lay.nplanes else z((2,), mask_dtype)   # smb keeps no bit planes
         b["counters"] = z((n, 2), torch.int32)
         b["stats"] = z((n, 8), torch.int32)
         b["start_stats"] = z((n, 8), torch.int32)

@@ -9,7 +9,7 @@ overrides existing keys, sokoban `max_targets` overwrites `max_crates`, the soko
 """
 from collections import OrderedDict
 
-PROB_IDS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3, "ddave": 4}
+PROB_IDS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3, "ddave": 4, "smb": 5}
 
 
 class Problem:
@@ -247,5 +247,41 @@ class DDaveProblem(Problem):
         return torch.stack([cols[k] for k in (keys or self.stat_keys)], 1)
 
 
+class SMBProblem(Problem):
+    """probs/smb_prob.py: a 114 x 14 platformer level; every changed map is played by two A* agents (smb/engine.py).
+    `solver_power` is an attribute, not an adjust_param key (smb_prob.py:40-53 does not read it)."""
+    name = "smb"
+    tiles = ("empty", "solid", "enemy", "brick", "question", "coin", "tube")
+    stat_keys = ("dist-floor", "disjoint-tubes", "enemies", "empty", "noise", "jumps", "jumps-dist", "dist-win")
+    info_keys = stat_keys
+    reward_keys = stat_keys
+
+    def __init__(self):
+        super().__init__()
+        self._width, self._height = 114, 14
+        self._prob = OrderedDict([("empty", 0.75), ("solid", 0.1), ("enemy", 0.01), ("brick", 0.04), ("question", 0.01),
+                                  ("coin", 0.02), ("tube", 0.02)])
+        self._border_tile = "solid"
+        self._border_size = (3, 0)
+        self._solver_power = 10000
+        self._min_empty = 900
+        self._min_enemies = 10
+        self._max_enemies = 30
+        self._min_jumps = 20
+        self._rewards = OrderedDict([("dist-floor", 2), ("disjoint-tubes", 1), ("enemies", 1), ("empty", 1), ("noise", 4),
+                                     ("jumps", 2), ("jumps-dist", 2), ("dist-win", 5)])
+
+    def adjust_param(self, **kwargs):
+        super().adjust_param(**kwargs)
+        self._min_empty = kwargs.get("min_empty", self._min_empty)
+        self._min_enemies = kwargs.get("min_enemies", self._min_enemies)
+        self._max_enemies = kwargs.get("max_enemies", self._max_enemies)
+        self._min_jumps = kwargs.get("min_jumps", self._min_jumps)
+
+    def device_params(self):
+        return dict(solver_power=int(self._solver_power), min_empty=int(self._min_empty), min_enemies=int(self._min_enemies),
+                    max_enemies=int(self._max_enemies), min_jumps=int(self._min_jumps))
+
+
 PROBLEMS = {"binary": BinaryProblem, "zelda": ZeldaProblem, "sokoban": SokobanProblem, "mdungeon": MDungeonProblem,
-            "ddave": DDaveProblem}
+            "ddave": DDaveProblem, "smb": SMBProblem}

@@ -8,7 +8,7 @@
  *   pcgrl_create / pcgrl_configure   PcgrlEnv.__init__ pcgrl_env.py:27-42, adjust_param :106-115,
  *                                    Problem/Representation.adjust_param (probs/problem.py:66-72,
  *                                    binary_prob.py:49-59, zelda_prob.py:59-71, sokoban_prob.py:60-73, mdungeon_prob.py:68-84,
- *                                    ddave_prob.py:67-82,
+ *                                    ddave_prob.py:67-82, smb_prob.py:40-53,
  *                                    reps/representation.py:53-54, narrow_rep.py:86-88, turtle_rep.py:42-44)
  *   pcgrl_seed                       PcgrlEnv.seed pcgrl_env.py:54-57 (host passes MT19937 keys)
  *   pcgrl_reset                      PcgrlEnv.reset pcgrl_env.py:66-76 for every environment
@@ -34,30 +34,32 @@ extern "C" {
 
 /* 2: + pcgrl_bind_episode_stats.  3: planes buffer laid out [N,group,nplanes] (was [N,nplanes,group]); + pcgrl_seed_words.
  * 4: + the mdungeon problem: pcgrl_config grew (max_potions, max_treasures, target_col_enemies, rewards[12]).
- * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps).  6: + pcgrl_rollout. */
-#define PCGRL_ABI_VERSION 6
+ * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps).  6: + pcgrl_rollout.
+ * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
+ *    clamped actions. */
+#define PCGRL_ABI_VERSION 7
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
 #define PCGRL_ESTATE (-3)   /* call order violated (e.g. step before bind/reset) */
 
-enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2, PCGRL_MDUNGEON = 3, PCGRL_DDAVE = 4 };
+enum { PCGRL_BINARY = 0, PCGRL_ZELDA = 1, PCGRL_SOKOBAN = 2, PCGRL_MDUNGEON = 3, PCGRL_DDAVE = 4, PCGRL_SMB = 5 };
 enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2, PCGRL_NARROW_CAST = 3, PCGRL_NARROW_MULTI = 4, PCGRL_TURTLE_CAST = 5 };
 
 /* Batch-wide parameters (everything the reference keeps as attributes of PcgrlEnv/Problem/Representation). */
 typedef struct pcgrl_config {
     int32_t prob, rep;
     int32_t num_envs;
-    int32_t width, height;                 /* Problem._width/_height; 1..64 each */
+    int32_t width, height;                 /* Problem._width/_height; 1..64 each (smb: width up to 250, height 3..32) */
     int32_t max_changes, max_iterations;   /* pcgrl_env.py:33-34 / :108-110, computed by the host */
     int32_t random_start, random_tile, warp, random_probs;
     int32_t auto_reset;                    /* 1: a done env is reset inside step (vector-env semantics) */
     int32_t target_path;                   /* binary 20, zelda 16 */
-    int32_t max_enemies, target_enemy_dist;            /* zelda (max_enemies: mdungeon too) */
+    int32_t max_enemies, target_enemy_dist;            /* zelda (max_enemies: mdungeon and smb too) */
     int32_t max_crates, target_solution, solver_power; /* sokoban (target_solution, solver_power: mdungeon too) */
     int32_t max_potions, max_treasures;                /* mdungeon */
     int32_t max_diamonds, min_spikes, target_jumps;    /* ddave (+ target_solution, solver_power) */
-    int32_t reserved_;
+    int32_t min_empty, min_enemies, min_jumps;         /* smb (+ max_enemies, solver_power) */
     double target_col_enemies;                         /* mdungeon */
     double tile_probs[8];                  /* Problem._prob in tile order (un-normalised) */
     double rewards[12];                    /* Problem._rewards in the problem's own key order */
@@ -67,8 +69,8 @@ typedef struct pcgrl_config {
 typedef struct pcgrl_layout {
     int32_t group;        /* lanes per map: 16 (height <= 16) or 64 */
     int32_t mask_bytes;   /* bytes per row mask: 4 (width <= 32) or 8 */
-    int32_t nplanes;      /* bit planes of the tile id: 1 binary, 3 zelda/sokoban */
-    int32_t nstats;       /* used slots of a stats row: 2 binary, 7 zelda, 6 sokoban, 8 mdungeon / ddave (packed, see below) */
+    int32_t nplanes;      /* bit planes of the tile id: 1 binary, 3 zelda/sokoban/mdungeon/ddave, 0 smb (statistics from the byte map) */
+    int32_t nstats;       /* used slots of a stats row: 2 binary, 7 zelda, 6 sokoban, 8 mdungeon / ddave (packed, see below), 8 smb */
     size_t map;           /* u8  [N,H,W]   observation "map" */
     size_t old_map;       /* u8  [N,H,W]   Representation._old_map */
     size_t heatmap;       /* i16 [N,H,W]   observation "heatmap" (counts) */

@@ -43,6 +43,7 @@ INFO_KEYS = {
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
                  "dist-win", "sol-length"],
     "ddave": ["player", "exit", "diamonds", "key", "spikes", "regions", "col-diamonds", "num-jumps", "dist-win", "sol-length"],
+    "smb": ["dist-floor", "disjoint-tubes", "enemies", "empty", "noise", "jumps", "jumps-dist", "dist-win"],
 }
 STAT_KEYS = {
     "binary": ["regions", "path-length"],
@@ -51,6 +52,7 @@ STAT_KEYS = {
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
                  "dist-win", "sol-length"],
     "ddave": ["player", "dist-floor", "exit", "diamonds", "key", "spikes", "regions", "num-jumps", "col-diamonds", "dist-win", "sol-length"],
+    "smb": ["dist-floor", "disjoint-tubes", "enemies", "empty", "noise", "jumps", "jumps-dist", "dist-win"],
 }
 
 
@@ -505,6 +507,102 @@ def gen_stats_ddave():
              solver_power=np.array(power), keys=np.array(STAT_KEYS["ddave"]))
 
 
+
+# ----------------------------------------------------------------------------- smb
+def engineer_smb(rs, h, w, n):
+    """Platformer levels: a floor with gaps, walls of different heights, stairs, ledges, tubes, enemies and coins."""
+    maps = []
+    for k in range(n):
+        m = np.zeros((h, w), np.uint8)
+        style = k % 7
+        if style != 5:
+            m[h - 2:, :] = 1                                        # floor
+            for _ in range(rs.randint(0, 4)):                       # gaps (1-5 wide)
+                x0 = rs.randint(0, w); m[h - 2:, x0:x0 + rs.randint(1, 6)] = 0
+        if style in (1, 2, 4):
+            for _ in range(rs.randint(1, 5)):                       # walls / stairs
+                x0 = rs.randint(0, w); hh = rs.randint(1, min(7, h - 2))
+                if style == 2:
+                    for i in range(hh):
+                        if x0 + i < w:
+                            m[h - 2 - (i + 1):h - 2, x0 + i] = 3
+                else:
+                    m[h - 2 - hh:h - 2, x0] = rs.choice([1, 3, 4, 6])
+        if style in (3, 4):
+            for _ in range(rs.randint(1, 6)):                       # ledges
+                y = rs.randint(1, h - 2); x0 = rs.randint(0, w); m[y, x0:x0 + rs.randint(1, 8)] = rs.choice([3, 4])
+        if style == 5:
+            m = (rs.random_sample((h, w)) < rs.uniform(0.05, 0.3)).astype(np.uint8)
+        if style == 6:                                              # a wall nobody can jump: the searches run long
+            m[:h - 2, rs.randint(w // 2, w)] = 1
+        for _ in range(rs.randint(0, 4)):                           # tubes: pairs and singles
+            x0 = rs.randint(0, w - 1); y0 = rs.randint(max(1, h - 6), h - 1)
+            m[y0:h - 2, x0] = 6
+            if rs.random_sample() < 0.7:
+                m[y0:h - 2, x0 + 1] = 6
+        for _ in range(rs.randint(0, 8)):
+            m[rs.randint(0, h), rs.randint(0, w)] = 2               # enemies
+        for _ in range(rs.randint(0, 8)):
+            m[rs.randint(0, h), rs.randint(0, w)] = 5               # coins
+        maps.append(m)
+    return maps
+
+
+def run_agents_smb(prob, m):
+    """What SMBProblem._run_game does (smb_prob.py:106-145), keeping the agents' iteration counts."""
+    from gym_pcgrl.envs.probs.smb.engine import AStarAgent as SA, State as SS
+    smap = get_string_map(m, prob.get_tile_types())
+    chars = " # ## #"
+    s2c = dict((s, chars[i]) for i, s in enumerate(prob.get_tile_types()))
+    H = prob._height
+    lvl = ""
+    for i, row in enumerate(smap):
+        lvl += "   " if i < H - 3 else (" @ " if i == H - 3 else "###")
+        lvl += "".join(s2c[c] for c in row)
+        lvl += " | " if i < H - 3 else (" # " if i == H - 3 else "###")
+        lvl += "\n"
+    state = SS()
+    state.stringInitialize(lvl.split("\n"))
+    iters = [0, 0, 0, 0]
+    sol, st, it = SA().getSolution(state, 1, prob._solver_power)
+    iters[0] = it
+    win = 0 if st.checkWin() else -1
+    if win < 0:
+        sol, st, it = SA().getSolution(state, 0, prob._solver_power)
+        iters[1] = it
+        win = 1 if st.checkWin() else -1
+    return iters, win, (0 if win >= 0 else st.getHeuristic()), st.getGameStatus()
+
+
+def gen_stats_smb():
+    rs = np.random.RandomState(23)
+    prob = PROBLEMS["smb"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng, power) in [(14, 114, 3, 9, 10000), (14, 114, 4, 20, 1500), (10, 30, 10, 60, 10000), (8, 24, 10, 60, 400),
+                                       (6, 12, 10, 40, 10000), (4, 9, 6, 20, 200), (14, 40, 4, 24, 2500)]:
+        prob._width, prob._height, prob._solver_power = w, h, power
+        maps = [np.zeros((h, w), np.uint8), np.ones((h, w), np.uint8)]
+        flat = np.zeros((h, w), np.uint8); flat[h - 2:, :] = 1
+        maps.append(flat)
+        maps += [np.minimum(x, 6) for x in random_maps(rs, nrand, h, w, 7, pr)] + engineer_smb(rs, h, w, neng)
+        t0 = time.time()
+        res, agents = [], []
+        for m in maps:
+            st = stats_of(prob, m)
+            row = [int(st[k]) for k in STAT_KEYS["smb"]]
+            res.append(row)
+            iters, win, dist, gs = run_agents_smb(prob, m)
+            assert dist == row[7] and gs["jumps"] == row[5], (dist, gs["jumps"], row)
+            agents.append(iters + [win])
+        res = np.array(res, dtype=np.int64)
+        agents = np.array(agents, dtype=np.int64)
+        print("  smb %dx%d power %d: %d maps, wins by agent %s, cap hits %d, %.1fs" % (
+            h, w, power, len(maps), [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1)],
+            int((agents[:, :2] >= power).any(1).sum()), time.time() - t0))
+        save("stats_smb_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+             solver_power=np.array(power), keys=np.array(STAT_KEYS["smb"]))
+
+
 # ----------------------------------------------------------------------------- range reward
 def gen_range_reward():
     bands = [(1, 1), (np.inf, np.inf), (-np.inf, -np.inf), (2, 5), (4, np.inf), (1, 3), (0, 0), (3, 3), (2, 2), (1, 5)]
@@ -673,6 +771,14 @@ TRAJS = [
         change_percentage=0.9, probs={"empty": 0.7, "solid": 0.12, "player": 0.05, "exit": 0.05, "key": 0.05, "spike": 0.01},
         target_solution=3, target_jumps=0, max_diamonds=1, min_spikes=2, solver_power=400,
         rewards={"dist-win": 0.3, "num-jumps": 1.5, "dist-floor": 0.5}),)),
+    # smb (the planner runs on every changed map: small levels keep the reference affordable here)
+    ("smb_narrow_24x8", "smb", "narrow", 8, 200, (dict(width=24, height=8), dict(change_percentage=0.3, probs={"empty": 0.5, "solid": 0.42}))),
+    ("smb_wide_30x10", "smb", "wide", 6, 160, (dict(width=30, height=10), dict(change_percentage=0.2, min_empty=200, min_enemies=1,
+                                                                               max_enemies=4, min_jumps=2, probs={"empty": 0.5, "solid": 0.3, "brick": 0.12},
+                                                                               rewards={"noise": 1, "dist-win": 2.5}))),
+    ("smb_turtle_20x7", "smb", "turtle", 4, 160, (dict(width=20, height=7), dict(change_percentage=0.4, probs={"empty": 0.6, "solid": 0.25}))),
+    ("smb_narrow", "smb", "narrow", 3, 60, ()),
+    ("smb_narrowcast_16x6", "smb", "narrowcast", 4, 120, (dict(width=16, height=6), dict(change_percentage=0.5, probs={"empty": 0.45, "solid": 0.5}))),
     ("mdungeon_narrow_monsters", "mdungeon", "narrow", 16, 300, (dict(width=6, height=6), dict(
         change_percentage=0.8, solver_power=250, target_solution=3, target_col_enemies=0.2,
         probs={"empty": 0.45, "solid": 0.03, "player": 0.03, "exit": 0.03, "potion": 0.06, "treasure": 0.05, "goblin": 0.1, "ogre": 0.25}),)),
@@ -739,7 +845,7 @@ def main():
     a = ap.parse_args()
     jobs = {
         "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
-        "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "stats_ddave": gen_stats_ddave, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
+        "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "stats_ddave": gen_stats_ddave, "stats_smb": gen_stats_smb, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
         "wrappers": gen_wrappers,
     }
     for k, fn in jobs.items():

@@ -11,20 +11,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 SO = os.path.join(ORACLE_DIR, "libpcgrl_oracle.so")
 
-PROBS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3, "ddave": 4}
+PROBS = {"binary": 0, "zelda": 1, "sokoban": 2, "mdungeon": 3, "ddave": 4, "smb": 5}
 REPS = {"narrow": 0, "wide": 1, "turtle": 2, "narrowcast": 3, "narrowmulti": 4, "turtlecast": 5}
 MAX_ACTION = 9
 ADJ_KEYS = {k: i for i, k in enumerate([
     "change_percentage", "width", "height", "target_path", "random_probs", "max_enemies",
     "target_enemy_dist", "solver_power", "max_crates", "max_targets", "min_solution",
     "random_start", "random_tile", "warp", "max_potions", "max_treasures", "target_col_enemies", "target_solution",
-    "max_diamonds", "min_spikes", "target_jumps"])}
+    "max_diamonds", "min_spikes", "target_jumps", "min_empty", "min_enemies", "min_jumps"])}
 TILES = {
     "binary": ["empty", "solid"],
     "zelda": ["empty", "solid", "player", "key", "door", "bat", "scorpion", "spider"],
     "sokoban": ["empty", "solid", "player", "crate", "target"],
     "mdungeon": ["empty", "solid", "player", "exit", "potion", "treasure", "goblin", "ogre"],
     "ddave": ["empty", "solid", "player", "exit", "diamond", "key", "spike"],
+    "smb": ["empty", "solid", "enemy", "brick", "question", "coin", "tube"],
 }
 REWARD_KEYS = {
     "binary": ["regions", "path-length"],
@@ -32,6 +33,7 @@ REWARD_KEYS = {
     "sokoban": ["player", "crate", "target", "regions", "ratio", "dist-win", "sol-length"],
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-enemies", "dist-win", "sol-length"],
     "ddave": ["player", "dist-floor", "exit", "diamonds", "key", "spikes", "regions", "num-jumps", "dist-win", "sol-length"],
+    "smb": ["dist-floor", "disjoint-tubes", "enemies", "empty", "noise", "jumps", "jumps-dist", "dist-win"],
 }
 INFO_KEYS = {
     "binary": ["regions", "path-length", "path-imp"],
@@ -40,8 +42,9 @@ INFO_KEYS = {
     "mdungeon": ["player", "exit", "potions", "treasures", "enemies", "regions", "col-potions", "col-treasures", "col-enemies",
                  "dist-win", "sol-length"],
     "ddave": ["player", "exit", "diamonds", "key", "spikes", "regions", "col-diamonds", "num-jumps", "dist-win", "sol-length"],
+    "smb": ["dist-floor", "disjoint-tubes", "enemies", "empty", "noise", "jumps", "jumps-dist", "dist-win"],
 }
-NSTATS = {"binary": 2, "zelda": 7, "sokoban": 6, "mdungeon": 11, "ddave": 11}
+NSTATS = {"binary": 2, "zelda": 7, "sokoban": 6, "mdungeon": 11, "ddave": 11, "smb": 8}
 
 _lib = None
 

@@ -12,7 +12,7 @@ import numpy as np
 import oracle_lib as ol
 
 REPS = ["narrow", "wide", "turtle", "narrowcast", "narrowmulti", "turtlecast"]
-PROB_MIX = ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon", "ddave", "ddave"]
+PROB_MIX = ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon", "ddave", "ddave", "smb"]
 
 
 def draw_config(rs, only=None):
@@ -23,6 +23,8 @@ def draw_config(rs, only=None):
         w, h = int(rs.randint(2, 8)), int(rs.randint(2, 8))
     elif prob in ("mdungeon", "ddave"):
         w, h = int(rs.randint(1, 13)), int(rs.randint(1, 13))
+    elif prob == "smb":
+        w, h = int(rs.randint(1, 61)), int(rs.randint(3, 17))
     else:
         w, h = int(rs.randint(1, 41)), int(rs.randint(1, 41))
         if rs.rand() < 0.4:
@@ -48,6 +50,8 @@ def draw_config(rs, only=None):
         if rs.rand() < 0.5:
             calls.append(dict(target_solution=int(rs.randint(1, 8)), target_jumps=int(rs.randint(0, 3)), max_diamonds=int(rs.randint(0, 4)),
                               min_spikes=int(rs.randint(0, 6)), rewards={"dist-win": float(rs.choice([0.1, 0.3, 1.0])), "dist-floor": float(rs.choice([2, 0.5]))}))
+    if prob == "smb" and rs.rand() < 0.7:      # mostly blocked levels: episodes do not end at once (smb_prob.py:191-192)
+        calls.append(dict(probs={"empty": 0.5, "solid": float(rs.choice([0.3, 0.45])), "tube": float(rs.choice([0.02, 0.1]))}))
     if rep in ("narrow", "narrowcast", "narrowmulti") and rs.rand() < 0.3:
         calls.append(dict(random_tile=False))
     if rep in ("turtle", "turtlecast") and rs.rand() < 0.5:

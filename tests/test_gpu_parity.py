@@ -13,7 +13,7 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUPPORTED = ("binary", "zelda", "sokoban", "mdungeon", "ddave")
+SUPPORTED = ("binary", "zelda", "sokoban", "mdungeon", "ddave", "smb")
 
 
 def _torch():
@@ -48,6 +48,9 @@ def test_stats_kat(path):
     if "solver_power" in d.files:
         calls.append(dict(solver_power=int(d["solver_power"])))
     env = _make(prob, "wide", n, calls)
+    if prob == "smb":       # smb_prob.py:40-53: solver_power is an attribute there, not an adjust_param key
+        env._prob._solver_power = int(d["solver_power"])
+        env.adjust_param()
     env.reset()
     env.set_maps(maps)
     got = env.stats.cpu().numpy().astype(np.int64)
@@ -137,6 +140,11 @@ ORACLE_CASES = [
                                                         probs={"empty": 0.6, "solid": 0.15, "player": 0.03, "exit": 0.03, "key": 0.03})), 96, 150),
     ("mdungeon", "turtle", (dict(width=8, height=8), dict(change_percentage=0.5, solver_power=200,
                                                            probs={"empty": 0.5, "solid": 0.03, "ogre": 0.2, "goblin": 0.1})), 96, 150),
+    ("smb", "narrow", (), 24, 60),
+    ("smb", "wide", (dict(width=40, height=12), dict(change_percentage=0.1, probs={"empty": 0.5, "solid": 0.35, "brick": 0.08})), 64, 100),
+    ("smb", "turtle", (dict(width=150, height=9), dict(change_percentage=0.05, probs={"empty": 0.55, "solid": 0.3}, min_empty=500, min_jumps=3,
+                                                       rewards={"noise": 1.5, "jumps-dist": 0.5})), 32, 80),
+    ("smb", "narrow", (dict(width=22, height=7), dict(change_percentage=0.5, probs={"empty": 0.5, "solid": 0.45}, random_tile=False)), 48, 100),
 ]
 
 

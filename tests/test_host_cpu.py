@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_lib.EXPORTS) == declared
-    assert L.pcgrl_abi_version() == _lib.ABI_VERSION == 6
+    assert L.pcgrl_abi_version() == _lib.ABI_VERSION == 7
     assert L.pcgrl_error_string(-1).decode().startswith("invalid")
 
 
@@ -82,7 +82,7 @@ def test_adjust_param_table_and_spaces():
                env.get_border_tile()] + adesc + [osp["map"].shape[0], osp["map"].shape[1], int(osp["map"].high.max()),
                                                  int(osp["heatmap"].high.max()), int("pos" in osp)]
         assert got == list(row), (case, got, list(row))
-    assert sorted(gym_pcgrl_amd.registered_ids())[0] == "binary-narrow-v0" and len(gym_pcgrl_amd.registered_ids()) == 30
+    assert sorted(gym_pcgrl_amd.registered_ids())[0] == "binary-narrow-v0" and len(gym_pcgrl_amd.registered_ids()) == 36
     with pytest.raises(KeyError):
         gym_pcgrl_amd.make_batched("nope-narrow-v0", num_envs=1)
 
@@ -211,4 +211,4 @@ def test_fuzz_slice_covers_every_problem_and_representation():
                 rs.randint(0, sp.n, size=(Ts, E, 1))
             else:
                 [rs.randint(0, int(k), size=(Ts, E)) for k in sp.nvec]
-    assert probs == {"binary", "zelda", "sokoban", "mdungeon", "ddave"} and len(reps) == 6 and hows == {"rollout", "mixed", "steps"}, (probs, reps, hows)
+    assert probs == {"binary", "zelda", "sokoban", "mdungeon", "ddave", "smb"} and len(reps) == 6 and hows == {"rollout", "mixed", "steps"}, (probs, reps, hows)
