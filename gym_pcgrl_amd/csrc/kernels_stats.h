@@ -181,7 +181,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
             TL(12);
             // k_step: wavefront 0 writes the draws of this step into the rings (and its byte-map / heatmap writes land) behind
             // the barrier; a reset that nobody saw coming waits for that (it has long happened by now)
-            if (SL) { while (__hip_atomic_load(&SL->refill_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2); }
+            if (SL) { while (__hip_atomic_load(&SL->refill_done[SL->par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < SL->need) __builtin_amdgcn_s_sleep(2); }
             bool mine = false;
 #pragma unroll
             for (int k = 0; k < GPW; k++) {

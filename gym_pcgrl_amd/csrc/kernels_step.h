@@ -30,58 +30,60 @@
 // parameters only (the champion rows of the binary problem and the draw cache of the narrow representation keep their room
 // even when the feature is off), so that the prefetch can be laid out at compile time.
 struct StepLds { int planes, champ, stats, start, cnt, cur, fifo, tag, pos, act, in_total, info, rew, done, total; };
-__host__ __device__ constexpr StepLds step_lds_layout(int plane_row_bytes, int champ_row_bytes, bool fifo, int action_width) {
+__host__ __device__ constexpr StepLds step_lds_layout(int plane_row_bytes, int champ_row_bytes, bool fifo, int action_width, int epb) {
     StepLds L = {};
     int o = 0;
-    L.planes = o; o += 64 * plane_row_bytes;
-    L.champ = o; o += 64 * champ_row_bytes;
-    L.stats = o; o += 64 * 32;
-    L.start = o; o += 64 * 32;
-    L.cnt = o; o += 64 * 8;
-    L.cur = o; o += 64 * 8;
-    L.fifo = o; o += fifo ? 64 * PCGRL_FIFO_N * 4 : 0;
-    L.tag = o; o += fifo ? 64 * 4 : 0;
-    L.pos = o; o += 64 * 2;
-    L.act = o; o += 64 * 4 * action_width;
+    L.planes = o; o += epb * plane_row_bytes;
+    L.champ = o; o += epb * champ_row_bytes;
+    L.stats = o; o += epb * 32;
+    L.start = o; o += epb * 32;
+    L.cnt = o; o += epb * 8;
+    L.cur = o; o += epb * 8;
+    L.fifo = o; o += fifo ? epb * PCGRL_FIFO_N * 4 : 0;
+    L.tag = o; o += fifo ? epb * 4 : 0;
+    L.pos = o; o += epb * 2;
+    L.act = o; o += epb * 4 * action_width;
     L.in_total = o;
-    L.info = o; o += 64 * 40;
-    L.rew = o; o += 64 * 8;
-    L.done = o; o += 64;
+    L.info = o; o += epb * 40;
+    L.rew = o; o += epb * 8;
+    L.done = o; o += epb;
     L.total = (o + 15) & ~15;
     return L;
 }
 
 // Block-wide copy of `bytes` bytes, both sides 16-byte aligned (global <-> LDS; every thread of the block calls it).
+template <int TPB>
 __device__ __forceinline__ void blk_copy(uint8_t* dst, const uint8_t* src, int bytes) {
     const int nv = bytes >> 4;
-    for (int i = threadIdx.x; i < nv; i += PCGRL_BLOCK) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
-    for (int i = (nv << 4) + threadIdx.x; i < bytes; i += PCGRL_BLOCK) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nv; i += TPB) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (int i = (nv << 4) + threadIdx.x; i < bytes; i += TPB) dst[i] = src[i];
 }
 // The same for per-environment rows of `row` bytes (a multiple of 16), only the rows whose flag is set.
+template <int TPB>
 __device__ __forceinline__ void blk_copy_rows(uint8_t* dst, const uint8_t* src, int rows, int row, const uint8_t* flag) {
     const int per = row >> 4;
-    for (int i = threadIdx.x; i < rows * per; i += PCGRL_BLOCK)
+    for (int i = threadIdx.x; i < rows * per; i += TPB)
         if (flag[i / per]) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
 }
 
 // One segment of the batched prefetch of a FULL block: the 16-byte slots [SLOT0, SLOT0 + NV) of the LDS copy come from `g`.
 // Thread tid owns the slots tid + 256 c; everything here is resolved at compile time except the predicate and the address, so
 // all loads of all segments are issued back to back and waited for once.
-template <int C, int SLOT0, int NV>
+template <int TPB, int C, int SLOT0, int NV>
 __device__ __forceinline__ void seg_load_c(uint4& rc, const void* g, bool on, int tid) {
-    if (C * PCGRL_BLOCK + PCGRL_BLOCK - 1 < SLOT0 || C * PCGRL_BLOCK >= SLOT0 + NV) return;     // compile time: no overlap
-    const int slot = C * PCGRL_BLOCK + tid;
+    if (C * TPB + TPB - 1 < SLOT0 || C * TPB >= SLOT0 + NV) return;     // compile time: no overlap
+    const int slot = C * TPB + tid;
     if (on && slot >= SLOT0 && slot < SLOT0 + NV) rc = reinterpret_cast<const uint4*>(g)[slot - SLOT0];
 }
 // (named registers, not an array: an array indexed through a reference ends up in scratch memory)
 #define PCGRL_SEG_LOAD(SLOT0, NV, G, ON) do { const void* g_ = (G); const bool on_ = (ON); \
-    seg_load_c<0, SLOT0, NV>(r0, g_, on_, tid0); seg_load_c<1, SLOT0, NV>(r1, g_, on_, tid0); seg_load_c<2, SLOT0, NV>(r2, g_, on_, tid0); \
-    seg_load_c<3, SLOT0, NV>(r3, g_, on_, tid0); seg_load_c<4, SLOT0, NV>(r4, g_, on_, tid0); seg_load_c<5, SLOT0, NV>(r5, g_, on_, tid0); \
-    seg_load_c<6, SLOT0, NV>(r6, g_, on_, tid0); seg_load_c<7, SLOT0, NV>(r7, g_, on_, tid0); seg_load_c<8, SLOT0, NV>(r8, g_, on_, tid0); } while (0)
-template <int C, int TOTAL>
+    seg_load_c<TPB, 0, SLOT0, NV>(r0, g_, on_, tid0); seg_load_c<TPB, 1, SLOT0, NV>(r1, g_, on_, tid0); seg_load_c<TPB, 2, SLOT0, NV>(r2, g_, on_, tid0); \
+    seg_load_c<TPB, 3, SLOT0, NV>(r3, g_, on_, tid0); seg_load_c<TPB, 4, SLOT0, NV>(r4, g_, on_, tid0); seg_load_c<TPB, 5, SLOT0, NV>(r5, g_, on_, tid0); \
+    seg_load_c<TPB, 6, SLOT0, NV>(r6, g_, on_, tid0); seg_load_c<TPB, 7, SLOT0, NV>(r7, g_, on_, tid0); seg_load_c<TPB, 8, SLOT0, NV>(r8, g_, on_, tid0); } while (0)
+template <int TPB, int C, int TOTAL>
 __device__ __forceinline__ void seg_store_c(uint8_t* smem, const uint4& rc, int tid) {
-    if (C * PCGRL_BLOCK >= TOTAL) return;
-    const int slot = C * PCGRL_BLOCK + tid;
+    if (C * TPB >= TOTAL) return;
+    const int slot = C * TPB + tid;
     if (slot < TOTAL) reinterpret_cast<uint4*>(smem)[slot] = rc;
 }
 
@@ -107,32 +109,35 @@ __device__ __forceinline__ void fifo_refill(const DevBufs& B, int e, int k, int 
 }
 
 // MULTI: the pcgrl_rollout form (loop over the tape); the single-step form is compiled without the loop so that it pays
-// nothing for it.
-template <int PROB, int REP, class MaskT, bool MULTI>
-__global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_step(PcgrlParams P, DevBufs Bg, const int32_t* __restrict__ actions, int parity, int gen_map,
-                                                                                                           int steps, size_t action_stride, double* reward_out, uint8_t* done_out, int32_t* info_out) {
+// nothing for it.  EPB: environments per block, 64 (four wavefronts) or 128 (eight): a block of 128 pools the tasks of twice
+// as many environments over twice as many wavefronts, which evens out the spread between blocks -- a block that happens to
+// hold four certain resets used to end 10 us after the median block, and the launch ends with the last block.
+template <int PROB, int REP, class MaskT, bool MULTI, int EPB>
+__global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_step(PcgrlParams P, DevBufs Bg, const int32_t* __restrict__ actions, int parity, int gen_map,
+                                                                                                     int steps, size_t action_stride, double* reward_out, uint8_t* done_out, int32_t* info_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // the block's state copy, then per wave MT ring + tile bytes (in-kernel resets)
-    __shared__ int s_items[3][64];      // 0: certain resets, 1: full recomputations (by bucket), 2: incremental updates
-    __shared__ int s_n[3];
-    __shared__ int s_next;              // next wavefront task of the step (the wavefronts take them as they become free)
+    constexpr int TPB = EPB * 4, NUPD = EPB / 64;                     // threads; wavefronts that do Representation.update
+    __shared__ int s_items[3][EPB];     // 0: certain resets, 1: full recomputations (by cost level), 2: incremental updates
+    __shared__ int s_n[2][4];           // list lengths and the task ticket of the step, double-buffered by step parity: the
+                                        // set of the NEXT step is zeroed while this one runs (no extra barrier)
     __shared__ StepLocal s_loc;
     constexpr int G = 16, GPW = 4;
     constexpr int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
     constexpr int kPlaneRow = G * NPL * (int)sizeof(MaskT);
     const int W = P.width, H = P.height;
     TL_INIT(); TL(1);
-    const int e0 = blockIdx.x * 64;
-    const int ne = (P.num_envs - e0) < 64 ? (P.num_envs - e0) : 64;
+    const int e0 = blockIdx.x * EPB;
+    const int ne = (P.num_envs - e0) < EPB ? (P.num_envs - e0) : EPB;
     const bool has_champ = PROB == PCGRL_PROB_BINARY && Bg.champ != nullptr;
     const bool has_fifo = REP == PCGRL_REP_NARROW && Bg.fifo != nullptr;
     constexpr int kChampRow = PROB == PCGRL_PROB_BINARY ? G * (int)sizeof(MaskT) : 0;
     constexpr int AW = REP == PCGRL_REP_WIDE ? 3 : 1;                 // int32 values of an action
-    constexpr StepLds L = step_lds_layout(kPlaneRow, kChampRow, REP == PCGRL_REP_NARROW, AW);
+    constexpr StepLds L = step_lds_layout(kPlaneRow, kChampRow, REP == PCGRL_REP_NARROW, AW, EPB);
     const int champ_row = kChampRow;
     // ---- the block's copy of the per-environment state, and a DevBufs for the shared device functions in which index 0 is
     // the block's first environment: the staged arrays point into the LDS copy, the arrays that stay in global memory (byte
     // maps, heatmap, MT19937 rings, tile probabilities, episode statistics) are moved forward to the block's slice.  Inside the
-    // block an environment is known by its index 0..63 only.
+    // block an environment is known by its index 0..EPB-1 only.
     DevBufs B = Bg;
     const size_t cells_ = (size_t)W * H;
     B.map = Bg.map + (size_t)e0 * cells_;
@@ -161,43 +166,45 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     const int32_t* act_lds = reinterpret_cast<const int32_t*>(smem + L.act);
     const uint8_t* g_planes = reinterpret_cast<const uint8_t*>(Bg.planes) + (size_t)e0 * kPlaneRow;
     const uint8_t* g_champ = has_champ ? reinterpret_cast<const uint8_t*>(Bg.champ) + (size_t)e0 * champ_row : nullptr;
-    if (ne == 64) {
+    if (ne == EPB) {
         // a full block: every load of every segment first, then one wait, then the LDS stores -- one round trip
-        static_assert(L.in_total / 16 <= 9 * PCGRL_BLOCK, "nine 16-byte slots per thread");
+        static_assert(L.in_total / 16 <= 9 * TPB, "nine 16-byte slots per thread");
         uint4 r0 = {}, r1 = {}, r2 = {}, r3 = {}, r4 = {}, r5 = {}, r6 = {}, r7 = {}, r8 = {};
         const int tid0 = (int)threadIdx.x;
-        PCGRL_SEG_LOAD(L.planes / 16, 64 * kPlaneRow / 16, g_planes, true);
-        if (kChampRow) PCGRL_SEG_LOAD(L.champ / 16, (kChampRow ? 64 * kChampRow / 16 : 1), g_champ, has_champ);
-        PCGRL_SEG_LOAD(L.stats / 16, 128, Bg.stats + (size_t)e0 * 8, true);
-        PCGRL_SEG_LOAD(L.start / 16, 128, Bg.start_stats + (size_t)e0 * 8, true);
-        PCGRL_SEG_LOAD(L.cnt / 16, 32, Bg.counters + (size_t)e0 * 2, true);
-        PCGRL_SEG_LOAD(L.cur / 16, 32, Bg.rng_cur + (size_t)e0 * 2, true);
+        PCGRL_SEG_LOAD(L.planes / 16, EPB * kPlaneRow / 16, g_planes, true);
+        if (kChampRow) PCGRL_SEG_LOAD(L.champ / 16, (kChampRow ? EPB * kChampRow / 16 : 1), g_champ, has_champ);
+        PCGRL_SEG_LOAD(L.stats / 16, EPB * 2, Bg.stats + (size_t)e0 * 8, true);
+        PCGRL_SEG_LOAD(L.start / 16, EPB * 2, Bg.start_stats + (size_t)e0 * 8, true);
+        PCGRL_SEG_LOAD(L.cnt / 16, EPB / 2, Bg.counters + (size_t)e0 * 2, true);
+        PCGRL_SEG_LOAD(L.cur / 16, EPB / 2, Bg.rng_cur + (size_t)e0 * 2, true);
         if (REP == PCGRL_REP_NARROW) {
-            PCGRL_SEG_LOAD(L.fifo / 16, 64 * PCGRL_FIFO_N * 4 / 16, has_fifo ? Bg.fifo + (size_t)e0 * PCGRL_FIFO_N : nullptr, has_fifo);
-            PCGRL_SEG_LOAD(L.tag / 16, 16, has_fifo ? Bg.fifo_tag + e0 : nullptr, has_fifo);
+            PCGRL_SEG_LOAD(L.fifo / 16, EPB * PCGRL_FIFO_N * 4 / 16, has_fifo ? Bg.fifo + (size_t)e0 * PCGRL_FIFO_N : nullptr, has_fifo);
+            PCGRL_SEG_LOAD(L.tag / 16, EPB / 4, has_fifo ? Bg.fifo_tag + e0 : nullptr, has_fifo);
         }
-        PCGRL_SEG_LOAD(L.pos / 16, 8, Bg.pos + (size_t)e0 * 2, true);
-        PCGRL_SEG_LOAD(L.act / 16, 16 * AW, actions + (size_t)e0 * AW, true);
+        PCGRL_SEG_LOAD(L.pos / 16, EPB / 8, Bg.pos + (size_t)e0 * 2, true);
+        PCGRL_SEG_LOAD(L.act / 16, EPB / 4 * AW, actions + (size_t)e0 * AW, true);
+        asm volatile("" ::: "memory");      // every load above is issued before the first LDS store below waits for its data
         constexpr int TOT = L.in_total / 16;
-        seg_store_c<0, TOT>(smem, r0, tid0); seg_store_c<1, TOT>(smem, r1, tid0); seg_store_c<2, TOT>(smem, r2, tid0);
-        seg_store_c<3, TOT>(smem, r3, tid0); seg_store_c<4, TOT>(smem, r4, tid0); seg_store_c<5, TOT>(smem, r5, tid0);
-        seg_store_c<6, TOT>(smem, r6, tid0); seg_store_c<7, TOT>(smem, r7, tid0); seg_store_c<8, TOT>(smem, r8, tid0);
+        seg_store_c<TPB, 0, TOT>(smem, r0, tid0); seg_store_c<TPB, 1, TOT>(smem, r1, tid0); seg_store_c<TPB, 2, TOT>(smem, r2, tid0);
+        seg_store_c<TPB, 3, TOT>(smem, r3, tid0); seg_store_c<TPB, 4, TOT>(smem, r4, tid0); seg_store_c<TPB, 5, TOT>(smem, r5, tid0);
+        seg_store_c<TPB, 6, TOT>(smem, r6, tid0); seg_store_c<TPB, 7, TOT>(smem, r7, tid0); seg_store_c<TPB, 8, TOT>(smem, r8, tid0);
     } else {
-        blk_copy(smem + L.planes, g_planes, ne * kPlaneRow);
-        if (has_champ) blk_copy(smem + L.champ, g_champ, ne * champ_row);
-        blk_copy(smem + L.stats, reinterpret_cast<const uint8_t*>(Bg.stats + (size_t)e0 * 8), ne * 32);
-        blk_copy(smem + L.start, reinterpret_cast<const uint8_t*>(Bg.start_stats + (size_t)e0 * 8), ne * 32);
-        blk_copy(smem + L.cnt, reinterpret_cast<const uint8_t*>(Bg.counters + (size_t)e0 * 2), ne * 8);
-        blk_copy(smem + L.cur, reinterpret_cast<const uint8_t*>(Bg.rng_cur + (size_t)e0 * 2), ne * 8);
-        blk_copy(smem + L.pos, Bg.pos + (size_t)e0 * 2, ne * 2);
+        blk_copy<TPB>(smem + L.planes, g_planes, ne * kPlaneRow);
+        if (has_champ) blk_copy<TPB>(smem + L.champ, g_champ, ne * champ_row);
+        blk_copy<TPB>(smem + L.stats, reinterpret_cast<const uint8_t*>(Bg.stats + (size_t)e0 * 8), ne * 32);
+        blk_copy<TPB>(smem + L.start, reinterpret_cast<const uint8_t*>(Bg.start_stats + (size_t)e0 * 8), ne * 32);
+        blk_copy<TPB>(smem + L.cnt, reinterpret_cast<const uint8_t*>(Bg.counters + (size_t)e0 * 2), ne * 8);
+        blk_copy<TPB>(smem + L.cur, reinterpret_cast<const uint8_t*>(Bg.rng_cur + (size_t)e0 * 2), ne * 8);
+        blk_copy<TPB>(smem + L.pos, Bg.pos + (size_t)e0 * 2, ne * 2);
         if (has_fifo) {
-            blk_copy(smem + L.fifo, reinterpret_cast<const uint8_t*>(Bg.fifo + (size_t)e0 * PCGRL_FIFO_N), ne * PCGRL_FIFO_N * 4);
-            blk_copy(smem + L.tag, reinterpret_cast<const uint8_t*>(Bg.fifo_tag + e0), ne * 4);
+            blk_copy<TPB>(smem + L.fifo, reinterpret_cast<const uint8_t*>(Bg.fifo + (size_t)e0 * PCGRL_FIFO_N), ne * PCGRL_FIFO_N * 4);
+            blk_copy<TPB>(smem + L.tag, reinterpret_cast<const uint8_t*>(Bg.fifo_tag + e0), ne * 4);
         }
-        blk_copy(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)e0 * AW), ne * 4 * AW);
+        blk_copy<TPB>(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)e0 * AW), ne * 4 * AW);
     }
-    if (threadIdx.x < 64) s_loc.dirty[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_loc.e0 = 0;
+    if (threadIdx.x < EPB) s_loc.dirty[threadIdx.x] = 0;
+    if (threadIdx.x < 8) s_n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+    if (threadIdx.x == 0) { s_loc.e0 = 0; s_loc.need = NUPD; s_loc.refill_done[0] = 0; s_loc.refill_done[1] = 0; }
     uint8_t* reset_scratch = smem + L.total;
     // steps > 1 (pcgrl_rollout): the environments of a block do not depend on any other block, so the block simply goes on
     // with the next row of the action tape -- no launch, no grid-wide barrier between steps, blocks run ahead of each other
@@ -208,27 +215,37 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     int tid = (int)threadIdx.x;
     if (MULTI) asm volatile("" : "+v"(tid));
     const int lane64 = tid & 63, wv = tid >> 6, gw = lane64 / G;
+    const int sp = t & 1;                   // this step's set of list counters
     DevGroup<G, MaskT> g(lane64);
     if (MULTI && t > 0)     // this step's row of the action tape (the first one came with the state)
-        blk_copy(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)t * action_stride + (size_t)e0 * AW), ne * 4 * AW);
+        blk_copy<TPB>(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)t * action_stride + (size_t)e0 * AW), ne * 4 * AW);
     __syncthreads();                        // the state copy is complete; everything the previous step wrote is visible to the whole block
     TL(17);
-    if (wv == 0) {
-        const int e = lane64;                                  // block-local index (see B above)
+    if (wv < NUPD) {
+        const int e = wv * 64 + lane64;                        // block-local index (see B above)
         UpdateOut u = {};
-        if (lane64 < ne) u = update_env<REP, MaskT, true>(P, B, act_lds, e);
+        if (e < ne) u = update_env<REP, MaskT, true>(P, B, act_lds, e);
         TL(2);
         const bool first = u.rst || u.sure_done;               // reset-only, or certain to end: k_stats' "lone" items
         const bool packed_full = PROB == PCGRL_PROB_ZELDA && B.zelda_inc;
         int dest = -1, v = e;
         if (first) { dest = 0; v = u.rst ? (e | WL_RESET_ONLY) : e; }
         else if (u.chg) { dest = u.cheap ? 2 : 1; v = (u.cheap || packed_full) ? u.inc_item : e; }
-        s_loc.k[lane64] = (uint8_t)u.k;
-        if (u.chg) s_loc.dirty[lane64] = 1;
+        s_loc.k[e] = (uint8_t)u.k;
+        if (u.chg) s_loc.dirty[e] = 1;
         const uint64_t m0 = __ballot(dest == 0), m1 = __ballot(dest == 1), m2 = __ballot(dest == 2);
         const uint64_t below = (1ull << lane64) - 1ull;
-        if (dest == 0) s_items[0][__popcll(m0 & below)] = v;
-        if (dest == 2) s_items[2][__popcll(m2 & below)] = v;
+        // this wavefront's stretch of each list (one LDS atomic per list)
+        int b0 = 0, b1 = 0, b2 = 0;
+        if (lane64 == 0) {
+            b0 = m0 ? atomicAdd(&s_n[sp][0], __popcll(m0)) : 0;
+            b1 = m1 ? atomicAdd(&s_n[sp][1], __popcll(m1)) : 0;
+            b2 = m2 ? atomicAdd(&s_n[sp][2], __popcll(m2)) : 0;
+            if (wv == 0) { s_n[sp ^ 1][0] = 0; s_n[sp ^ 1][1] = 0; s_n[sp ^ 1][2] = 0; s_n[sp ^ 1][3] = 0; s_loc.refill_done[sp ^ 1] = 0; s_loc.par = sp; }
+        }
+        b0 = __builtin_amdgcn_readfirstlane(b0); b1 = __builtin_amdgcn_readfirstlane(b1); b2 = __builtin_amdgcn_readfirstlane(b2);
+        if (dest == 0) s_items[0][b0 + __popcll(m0 & below)] = v;
+        if (dest == 2) s_items[2][b2 + __popcll(m2 & below)] = v;
         // full recomputations ordered by expected cost (the four maps that share a wavefront should cost about the same):
         // eight levels of the previous path length, ranked with eight ballots -- no LDS round trips
         {
@@ -239,24 +256,23 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
                 const uint64_t mb = __ballot(dest == 1 && lvl == b);
                 pos1 += b < lvl ? __popcll(mb) : (b == lvl ? __popcll(mb & below) : 0);
             }
-            if (dest == 1) s_items[1][pos1] = v;
+            if (dest == 1) s_items[1][b1 + pos1] = v;
         }
-        if (lane64 == 0) { s_n[0] = __popcll(m0); s_n[1] = __popcll(m1); s_n[2] = __popcll(m2); s_next = 0; s_loc.refill_done = 0; }
-        // LDS-only barrier: what wavefront 0 has in flight to global memory (byte-map cells, heatmap increments) concerns no
-        // task that starts now -- environments that are certain to be reset got no such write, the other tasks work on the
-        // LDS copy -- and is waited for below, before refill_done is published.
+        // LDS-only barrier: what the update wavefronts have in flight to global memory (byte-map cells, heatmap increments)
+        // concerns no task that starts now -- environments that are certain to be reset got no such write, the other tasks work
+        // on the LDS copy -- and is waited for below, before refill_done is published.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (has_fifo && lane64 < ne && u.k > 0 && !first) fifo_refill(B, e, u.k, u.cur0);
+        if (has_fifo && e < ne && u.k > 0 && !first) fifo_refill(B, e, u.k, u.cur0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // ring words, byte-map cells and heatmap increments have landed
-        if (lane64 == 0) __hip_atomic_store(&s_loc.refill_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane64 == 0) __hip_atomic_fetch_add(&s_loc.refill_done[sp], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
     TL(3);
-    const int n0 = s_n[0], n1 = s_n[1], n2 = s_n[2];
+    const int n0 = s_n[sp][0], n1 = s_n[sp][1], n2 = s_n[sp][2];
     const int w_full = (n1 + GPW - 1) / GPW;
     const int w_total = n0 + w_full + (n2 + GPW - 1) / GPW;
     const int tiles_bytes = (W * H + 15) & ~15;
@@ -265,11 +281,11 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
     const MaskT rowmask = row_valid<MaskT>(g.lane, W, H);
     const bool zinc = PROB == PCGRL_PROB_ZELDA && sizeof(MaskT) == 4 && B.zelda_inc;
     // Tasks in the order certain resets (the longest chains), full recomputations, incremental updates; a wavefront takes
-    // the next one whenever it is free, so the block ends when the work is done, not when its unluckiest quarter is
+    // the next one whenever it is free, so the block ends when the work is done, not when its unluckiest wavefront is
     // (a static split left the last wavefront of a block ~10 us behind the others).
     for (;;) {
         int wid = 0;
-        if (lane64 == 0) wid = atomicAdd(&s_next, 1);
+        if (lane64 == 0) wid = atomicAdd(&s_n[sp][3], 1);
         wid = __builtin_amdgcn_readfirstlane(wid);
         if (wid >= w_total) break;
         const bool lone = wid < n0, inc = wid >= n0 + w_full;
@@ -285,24 +301,24 @@ __global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
         __syncthreads();
         const size_t row = (size_t)t * P.num_envs + e0;
         if (reward_out && tid < ne) reward_out[row + tid] = reinterpret_cast<const double*>(smem + L.rew)[tid];
-        if (done_out && tid >= 64 && tid - 64 < ne) done_out[row + tid - 64] = smem[L.done + tid - 64];
-        if (info_out) for (int i = tid; i < ne * 10; i += PCGRL_BLOCK) info_out[row * 10 + i] = reinterpret_cast<const int32_t*>(smem + L.info)[i];
+        if (done_out && tid >= TPB / 2 && tid - TPB / 2 < ne) done_out[row + tid - TPB / 2] = smem[L.done + tid - TPB / 2];
+        if (info_out) for (int i = tid; i < ne * 10; i += TPB) info_out[row * 10 + i] = reinterpret_cast<const int32_t*>(smem + L.info)[i];
     }
   }
     // ---- the block's state goes back, coalesced; plane rows, champion rows and start statistics only where they changed
     __syncthreads();
-    blk_copy(reinterpret_cast<uint8_t*>(Bg.stats + (size_t)e0 * 8), smem + L.stats, ne * 32);
-    blk_copy(reinterpret_cast<uint8_t*>(Bg.info + (size_t)e0 * 10), smem + L.info, ne * 40);
-    blk_copy(reinterpret_cast<uint8_t*>(Bg.reward + e0), smem + L.rew, ne * 8);
-    blk_copy(reinterpret_cast<uint8_t*>(Bg.counters + (size_t)e0 * 2), smem + L.cnt, ne * 8);
-    blk_copy(reinterpret_cast<uint8_t*>(Bg.rng_cur + (size_t)e0 * 2), smem + L.cur, ne * 8);
-    blk_copy(Bg.pos + (size_t)e0 * 2, smem + L.pos, ne * 2);
-    blk_copy(Bg.done + e0, smem + L.done, ne);
+    blk_copy<TPB>(reinterpret_cast<uint8_t*>(Bg.stats + (size_t)e0 * 8), smem + L.stats, ne * 32);
+    blk_copy<TPB>(reinterpret_cast<uint8_t*>(Bg.info + (size_t)e0 * 10), smem + L.info, ne * 40);
+    blk_copy<TPB>(reinterpret_cast<uint8_t*>(Bg.reward + e0), smem + L.rew, ne * 8);
+    blk_copy<TPB>(reinterpret_cast<uint8_t*>(Bg.counters + (size_t)e0 * 2), smem + L.cnt, ne * 8);
+    blk_copy<TPB>(reinterpret_cast<uint8_t*>(Bg.rng_cur + (size_t)e0 * 2), smem + L.cur, ne * 8);
+    blk_copy<TPB>(Bg.pos + (size_t)e0 * 2, smem + L.pos, ne * 2);
+    blk_copy<TPB>(Bg.done + e0, smem + L.done, ne);
     if (has_fifo) {
-        blk_copy(reinterpret_cast<uint8_t*>(Bg.fifo + (size_t)e0 * PCGRL_FIFO_N), smem + L.fifo, ne * PCGRL_FIFO_N * 4);
-        blk_copy(reinterpret_cast<uint8_t*>(Bg.fifo_tag + e0), smem + L.tag, ne * 4);
+        blk_copy<TPB>(reinterpret_cast<uint8_t*>(Bg.fifo + (size_t)e0 * PCGRL_FIFO_N), smem + L.fifo, ne * PCGRL_FIFO_N * 4);
+        blk_copy<TPB>(reinterpret_cast<uint8_t*>(Bg.fifo_tag + e0), smem + L.tag, ne * 4);
     }
-    blk_copy_rows(reinterpret_cast<uint8_t*>(Bg.planes) + (size_t)e0 * kPlaneRow, smem + L.planes, ne, kPlaneRow, s_loc.dirty);
-    if (has_champ) blk_copy_rows(reinterpret_cast<uint8_t*>(Bg.champ) + (size_t)e0 * champ_row, smem + L.champ, ne, champ_row, s_loc.dirty);
-    blk_copy_rows(reinterpret_cast<uint8_t*>(Bg.start_stats + (size_t)e0 * 8), smem + L.start, ne, 32, s_loc.dirty);
+    blk_copy_rows<TPB>(reinterpret_cast<uint8_t*>(Bg.planes) + (size_t)e0 * kPlaneRow, smem + L.planes, ne, kPlaneRow, s_loc.dirty);
+    if (has_champ) blk_copy_rows<TPB>(reinterpret_cast<uint8_t*>(Bg.champ) + (size_t)e0 * champ_row, smem + L.champ, ne, champ_row, s_loc.dirty);
+    blk_copy_rows<TPB>(reinterpret_cast<uint8_t*>(Bg.start_stats + (size_t)e0 * 8), smem + L.start, ne, 32, s_loc.dirty);
 }

@@ -69,7 +69,7 @@ struct pcgrl_env {
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
     int alloc_solver_power;
     // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
-    int no_wide, wide_waves, fused_zelda, no_fused;
+    int no_wide, wide_waves, fused_zelda, no_fused, step_epb;
     int profiling;
     std::vector<hipEvent_t> events;
     size_t ev_used;
@@ -283,8 +283,13 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     // environment switches (A/B measurements, tests) are read here, once: no getenv on the step path
     h->no_wide = env_is_one("PCGRL_NO_WIDE") ? 1 : 0;
     { const char* wvs = getenv("PCGRL_WIDE_WAVES"); h->wide_waves = wvs ? atoi(wvs) : 8; }   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
-    h->fused_zelda = env_is_one("PCGRL_FUSED_ZELDA") ? 1 : 0;
+    { const char* fz = getenv("PCGRL_FUSED_ZELDA"); h->fused_zelda = (fz && fz[0] == '0') ? 0 : 1; }   // =0: zelda steps as k_update + k_stats
     h->no_fused = env_is_one("PCGRL_NO_FUSED") ? 1 : 0;
+    {   // k_step: environments per block (see launch_step_pm)
+        const char* eb = getenv("PCGRL_STEP_EPB");
+        h->step_epb = eb ? atoi(eb) : (h->cfg.num_envs >= 128 * 256 ? 128 : 64);
+        if (h->step_epb != 128) h->step_epb = 64;
+    }
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
     B.heat_end = B.heat + (size_t)h->cfg.num_envs * h->cfg.width * h->cfg.height;
@@ -501,25 +506,29 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
 // representations, auto-reset with the in-kernel reset.  PCGRL_NO_FUSED=1 keeps the two-launch pipeline (A/B, tests).
 static bool fused_step_applies(const pcgrl_env* h, bool rollout = false) {
     const PcgrlParams& P = h->P;
-    // (zelda changes 7 of 8 environments per step: a block then has ~18 wavefront tasks for its four wavefronts and the global
-    //  work lists balance better -- measured 48 vs 42.6 us/step on C3; PCGRL_FUSED_ZELDA=1 takes the fused kernel anyway)
-    // A rollout has no barrier between steps, so the imbalance between blocks averages out over the tape: zelda takes k_step there.
+    // (zelda changes 7 of 8 environments per step -- ~18 wavefront tasks per 64 environments; with the block's state in LDS, the
+    //  tasks handed out dynamically and 128 environments per block the fused kernel is ahead of the two-launch pipeline:
+    //  34.0 vs 38.2 us/step on C3.  PCGRL_FUSED_ZELDA=0 keeps k_update + k_stats (A/B, tests).)
     const bool prob_ok = P.prob == PCGRL_PROB_BINARY || (P.prob == PCGRL_PROB_ZELDA && (rollout || h->fused_zelda));
     return prob_ok && P.group == 16 && P.rep <= PCGRL_REP_TURTLE && P.auto_reset &&
            h->B.inline_reset && !h->no_fused;
 }
 struct RolloutArgs { int steps; size_t action_stride; double* reward_out; uint8_t* done_out; int32_t* info_out; };
-template <int PROB, class MaskT>
-static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
+// Environments per block of k_step: 128 (eight wavefronts, two blocks per compute unit) once the batch fills the chip with
+// them, else 64 (four wavefronts): more, smaller blocks then reach more compute units.  PCGRL_STEP_EPB=64|128 overrides (A/B).
+template <int PROB, class MaskT, int EPB>
+static int launch_step_pme(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
     const PcgrlParams& P = h->P;
     // the block's state copy (kernels_step.h) + per wavefront an MT19937 ring and the tile bytes of a map (in-kernel resets)
     const StepLds SL = step_lds_layout(16 * P.nplanes * (int)sizeof(MaskT), PROB == PCGRL_PROB_BINARY ? 16 * (int)sizeof(MaskT) : 0,
-                                       P.rep == PCGRL_REP_NARROW, P.rep == PCGRL_REP_WIDE ? 3 : 1);
-    const size_t lds = (size_t)SL.total + 4 * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
-    const int grid = (P.num_envs + 63) / 64;
+                                       P.rep == PCGRL_REP_NARROW, P.rep == PCGRL_REP_WIDE ? 3 : 1, EPB);
+    const size_t lds = (size_t)SL.total + (EPB / 16) * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
+    const int grid = (P.num_envs + EPB - 1) / EPB;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
-#define PCGRL_LAUNCH_STEP(REPV, MULTI) hipLaunchKernelGGL((k_step<PROB, REPV, MaskT, MULTI>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, actions, \
-                                                          parity, gen, R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out)
+#define PCGRL_LAUNCH_STEP(REPV, MULTI) do { \
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<PROB, REPV, MaskT, MULTI, EPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_step<PROB, REPV, MaskT, MULTI, EPB>), dim3(grid), dim3(EPB * 4), lds, st, P, h->B, actions, \
+                           parity, gen, R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); } while (0)
     const bool multi = R.steps > 1 || R.reward_out || R.done_out || R.info_out;
     switch (P.rep) {
         case PCGRL_REP_NARROW: if (multi) PCGRL_LAUNCH_STEP(PCGRL_REP_NARROW, true); else PCGRL_LAUNCH_STEP(PCGRL_REP_NARROW, false); break;
@@ -529,6 +538,12 @@ static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipS
 #undef PCGRL_LAUNCH_STEP
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
+}
+template <int PROB, class MaskT>
+static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
+    // (the 128-environment form is built for 32-bit row masks only: the common case)
+    if (sizeof(MaskT) == 4 && h->step_epb == 128) return launch_step_pme<PROB, uint32_t, 128>(h, actions, parity, st, R);
+    return launch_step_pme<PROB, MaskT, 64>(h, actions, parity, st, R);
 }
 static int launch_step(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R = RolloutArgs{1, 0, nullptr, nullptr, nullptr}) {
     const bool m4 = h->P.mask_bytes == 4;

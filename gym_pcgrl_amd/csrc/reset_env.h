@@ -48,6 +48,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         uint32_t rw[10];
 #pragma unroll
         for (int j = 0; j < 10; j++) rw[j] = (j < 9 || lane < PCGRL_MT_N - 9 * 64) ? ring_g[j * 64 + lane] : 0u;
+        asm volatile("" ::: "memory");      // (keeps the compiler from pairing each load with its store)
 #pragma unroll
         for (int j = 0; j < 10; j++) if (j < 9 || lane < PCGRL_MT_N - 9 * 64) mt[j * 64 + lane] = rw[j];
     }

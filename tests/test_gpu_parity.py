@@ -112,10 +112,10 @@ _SWITCH_TRAJ = [("PCGRL_NO_FUSED", p) for p in sorted(glob.glob(os.path.join(G, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch,path", _SWITCH_TRAJ, ids=lambda v: os.path.basename(v) if v.endswith(".npz") else v)
 def test_golden_trajectory_other_step_pipeline(switch, path, monkeypatch):
-    """Binary maps of at most 16 rows take the fused one-launch step (k_step) by default and zelda the two-launch
-    pipeline (k_update + k_stats); the library switches select the other pipeline for each, and it must reproduce the
+    """Binary and zelda maps of at most 16 rows take the fused one-launch step (k_step) by default; the library switches
+    (PCGRL_NO_FUSED=1, PCGRL_FUSED_ZELDA=0) select the two-launch pipeline (k_update + k_stats), which must reproduce the
     reference's trajectories just the same."""
-    monkeypatch.setenv(switch, "1")
+    monkeypatch.setenv(switch, "0" if switch == "PCGRL_FUSED_ZELDA" else "1")
     test_golden_trajectory(path)
 
 

@@ -28,8 +28,9 @@ for t in range(warm):
     env.step(acts[t % 256])
 L = _lib.load()
 L.pcgrl_debug_timeline.argtypes = [C.c_void_p]
-SLOTS, WAVES = 48, 4
-nblk = (n + 63) // 64
+EPB = int(os.environ.get("PCGRL_STEP_EPB", "128" if n >= 128 * 256 else "64"))
+SLOTS, WAVES = 48, EPB // 16
+nblk = (n + EPB - 1) // EPB
 names = {1: "start", 2: "update done", 3: "lists ready", 4: "task: certain reset", 5: "task: full", 6: "task: incremental", 7: "task end", 8: "wave end",
          9: "reset done", 10: "stats done", 11: "finalized", 12: "late reset", 13: "ring staged", 14: "map made", 15: "cursor drawn", 16: "reset stored", 17: "state staged"}
 summ = []
