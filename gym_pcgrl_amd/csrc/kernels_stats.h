@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
     __shared__ MaskT s_rest[2][64];
-    __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag;
+    __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag, s_cur;
     __shared__ int2 s_pre;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     DevGroup<64, MaskT> g;
@@ -404,8 +404,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             if (threadIdx.x == 0) s_pre = reinterpret_cast<const int2*>(B.counters)[e];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (wv == 0) wave_reset_env<PCGRL_PROB_BINARY>(P, B, e, gen_map, mt, tiles, lane);
-            __syncthreads();
+            block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64>(P, B, e, gen_map, mt, tiles, &s_cur);     // (every wavefront helps: reset_env.h)
             MaskT n0, n1, n2;
             planes_from_tiles<MaskT>(P, tiles, planes_e, lane, n0, n1, n2, wv == 0);
             constexpr int TS = NWAVES / 2;
@@ -436,8 +435,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         }
         __syncthreads();
         if (inline_reset && s_flag) {   // block-uniform: PcgrlEnv.reset of this environment, then its start stats
-            if (wv == 0) wave_reset_env<PCGRL_PROB_BINARY>(P, B, e, gen_map, mt, tiles, lane);
-            __syncthreads();
+            block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64>(P, B, e, gen_map, mt, tiles, &s_cur);
             MaskT b0, b1, b2;
             planes_from_tiles<MaskT>(P, tiles, planes_e, lane, b0, b1, b2, wv == 0);
             block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);

@@ -69,7 +69,7 @@ struct pcgrl_env {
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
     int alloc_solver_power;
     // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
-    int no_wide, wide_waves, fused_zelda, no_fused, step_epb;
+    int no_wide, wide_waves, wide_grid, fused_zelda, no_fused, step_epb;
     int profiling;
     std::vector<hipEvent_t> events;
     size_t ev_used;
@@ -282,7 +282,8 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     if (rc0) return rc0;
     // environment switches (A/B measurements, tests) are read here, once: no getenv on the step path
     h->no_wide = env_is_one("PCGRL_NO_WIDE") ? 1 : 0;
-    { const char* wvs = getenv("PCGRL_WIDE_WAVES"); h->wide_waves = wvs ? atoi(wvs) : 8; }   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
+    { const char* wvs = getenv("PCGRL_WIDE_WAVES"); h->wide_waves = wvs ? atoi(wvs) : 8; }
+    { const char* wg = getenv("PCGRL_WIDE_GRID"); h->wide_grid = wg ? atoi(wg) : 16384; if (h->wide_grid < 1) h->wide_grid = 16384; }   // blocks of k_stats_wide   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
     { const char* fz = getenv("PCGRL_FUSED_ZELDA"); h->fused_zelda = (fz && fz[0] == '0') ? 0 : 1; }   // =0: zelda steps as k_update + k_stats
     h->no_fused = env_is_one("PCGRL_NO_FUSED") ? 1 : 0;
     {   // k_step: environments per block (see launch_step_pm)
@@ -447,7 +448,7 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !h->no_wide) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
         const int nw = h->wide_waves;
         const size_t lds1 = inline_reset ? (size_t)(nw == 8 ? 8 : 4) * (PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
-        const int gridw = P.num_envs < 16384 ? P.num_envs : 16384;
+        const int gridw = P.num_envs < h->wide_grid ? P.num_envs : h->wide_grid;
         // wavefronts per map: with the incremental route only ~10 % of the changes (and the resets) come here, so the launch
         // is latency-bound and more wavefronts per map pay (PCGRL_WIDE_WAVES overrides for experiments)
 #define LAUNCH_WIDE(NW) do { if (P.mask_bytes == 4) hipLaunchKernelGGL((k_stats_wide<uint32_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); \

@@ -153,3 +153,101 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     TL(16);
 }
 
+
+
+// The same reset by a whole block (k_stats_wide: maps of up to 64 x 64 cells, 8 192 MT19937 words per map).  One wavefront
+// makes 128 words per round -- 64 rounds for such a map, ~38 us, with the other wavefronts of the block waiting for it: the
+// longest chain of a C5 step.  MT19937's recurrence reaches back 227 words, so 224 threads make 224 words per round (every
+// operand still an old word: all reads, a barrier, all writes), 37 rounds.  Same draws, same order, same results as
+// wave_reset_env; `s_cur`: one shared word.  Every thread of the block calls this; it ends with a block barrier.
+template <int PROB, int NTHREADS>
+__device__ __forceinline__ void block_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt, uint8_t* tiles, int* s_cur) {
+    static_assert(NTHREADS >= 256, "224 generating threads");
+    constexpr int RW = 224;                                  // words per round: even, below 227
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int W = P.width, H = P.height, cells = W * H;
+    uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
+    uint8_t* map_g = B.map + (size_t)e * cells;
+    uint8_t* old_g = B.old_map + (size_t)e * cells;
+    const int2 curs = reinterpret_cast<const int2*>(B.rng_cur)[e];
+    int cur = curs.x;
+    for (int i = tid; i < PCGRL_MT_N; i += NTHREADS) mt[i] = ring_g[i];
+    const bool prob_draw = PROB == PCGRL_PROB_BINARY && P.random_probs;
+    uint32_t pw = 0;
+    if (prob_draw && tid < 5) {                               // BinaryProblem.reset's five operand words (see wave_reset_env)
+        const int off = tid < 3 ? tid : PCGRL_MT_M + (tid - 3);
+        int sl = curs.y + off; sl = sl >= PCGRL_MT_N ? sl - PCGRL_MT_N : sl;
+        pw = B.rng_prob[(size_t)e * PCGRL_MT_N + sl];
+    }
+    __syncthreads();
+    if (gen_map) {
+        constexpr int NT = PROB == PCGRL_PROB_BINARY ? 2 : PROB == PCGRL_PROB_SOKOBAN ? 5 : (PROB == PCGRL_PROB_DDAVE || PROB == PCGRL_PROB_SMB) ? 7 : 8;
+        double cdf[NT];
+        if (PROB == PCGRL_PROB_BINARY) {
+            double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};
+            pcgrl_build_cdf(p, 2, cdf);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; i++) cdf[i] = P.cdf[i];
+        }
+        const int nwords = 2 * cells;
+        for (int w0 = 0; w0 < nwords; w0 += RW) {
+            const bool on = tid < RW && w0 + tid < nwords;
+            const int s = mt_wrap(cur + (tid < RW ? tid : 0));
+            uint32_t y = 0;
+            if (on) y = mt_twist(mt[s], mt[mt_wrap(s + 1)], mt[mt_wrap(s + PCGRL_MT_M)]);
+            __syncthreads();                                  // every operand was read before any slot is rewritten
+            if (on) mt[s] = y;
+            const uint32_t yo = __shfl_down(y, 1, 64);        // the odd word of the pair lives in the next lane of the same wavefront
+            if (on && !(tid & 1)) {
+                const int c = (w0 + tid) >> 1;                // cell c draws words 2c, 2c + 1 (helper.py:310-312, RandomState.choice)
+                const double u = mt_to_double(mt_temper(y), mt_temper(yo));
+                const uint8_t t = (uint8_t)pcgrl_pick_tile_c<NT>(cdf, u);
+                tiles[c] = t; map_g[c] = t; old_g[c] = t;
+            }
+            const int adv = (nwords - w0) < RW ? (nwords - w0) : RW;
+            cur = mt_wrap(cur + adv);
+            __syncthreads();
+        }
+    } else {
+        for (int c = tid; c < cells; c += NTHREADS) { const uint8_t t = old_g[c]; tiles[c] = t; map_g[c] = t; }
+        __syncthreads();
+    }
+    if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33
+        if (tid == 0) {
+            const int x = mt_randint(mt, cur, W);
+            const int y = mt_randint(mt, cur, H);
+            reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+            *s_cur = cur;
+        }
+        __syncthreads();
+        cur = *s_cur;
+    }
+    if (B.fifo && tid < PCGRL_FIFO_N) {
+        const int sl = mt_wrap(cur + tid);
+        B.fifo[(size_t)e * PCGRL_FIFO_N + tid] = mt_twist(mt[sl], mt[mt_wrap(sl + 1)], mt[mt_wrap(sl + PCGRL_MT_M)]);
+        if (tid == 0) B.fifo_tag[e] = cur;
+    }
+    for (int i = tid; i < PCGRL_MT_N; i += NTHREADS) ring_g[i] = mt[i];
+    uint16_t* heat_g = B.heat + (size_t)e * cells;
+    for (int c = tid; c < cells; c += NTHREADS) heat_g[c] = 0;        // pcgrl_env.py:72
+    if (tid == 0) {
+        B.rng_cur[2 * e] = cur;
+        reinterpret_cast<int2*>(B.counters)[e] = make_int2(0, 0);   // pcgrl_env.py:67-68
+    }
+    if (prob_draw && tid < 64) {
+        const uint32_t x0 = __shfl(pw, 0, 64), x1 = __shfl(pw, 1, 64), x2 = __shfl(pw, 2, 64);
+        const uint32_t xm0 = __shfl(pw, 3, 64), xm1 = __shfl(pw, 4, 64);
+        if (lane == 0) {
+            const uint32_t ya = mt_twist(x0, x1, xm0), yb = mt_twist(x1, x2, xm1);
+            uint32_t* ring_p = B.rng_prob + (size_t)e * PCGRL_MT_N;
+            ring_p[curs.y] = ya;
+            ring_p[mt_wrap(curs.y + 1)] = yb;
+            B.rng_cur[2 * e + 1] = mt_wrap(mt_wrap(curs.y + 1) + 1);
+            const double pe = mt_to_double(mt_temper(ya), mt_temper(yb));
+            B.tile_p[2 * e] = pe;
+            B.tile_p[2 * e + 1] = 1 - pe;
+        }
+    }
+    __syncthreads();
+}
