@@ -44,6 +44,7 @@ WORKLOADS = {
     # not a BASELINE.json config: the mdungeon problem, reported for completeness
     "M1": ("mdungeon", "narrow", (), 65536, "mdungeon-narrow-v0 7x11, 65536 envs/GPU"),
     "D1": ("ddave", "narrow", (), 65536, "ddave-narrow-v0 11x7, 65536 envs/GPU"),
+    "S1": ("smb", "narrow", (), 16384, "smb-narrow-v0 114x14, 16384 envs/GPU"),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
@@ -335,9 +336,9 @@ def main():
         ev_us = min(ph.values()) if ph else 0.0
         # binary maps of <= 16 rows run the whole step as ONE launch (k_step): the "stats" interval is then empty and
         # the kernel's duration is the step time of the timed region itself
-        solver = prob in ("sokoban", "mdungeon", "ddave")     # problems with a search kernel after k_stats
+        solver = prob in ("sokoban", "mdungeon", "ddave", "smb")     # problems with a search kernel after k_stats
         fused = not solver and ph.get("update", 0.0) > 4 * max(ph.get("stats", 0.0), 1e-3)
-        dom_name = "k_sokoban" if prob == "sokoban" else "k_mdungeon" if prob == "mdungeon" else "k_ddave" if prob == "ddave" else "k_step" if fused else (
+        dom_name = "k_sokoban" if prob == "sokoban" else "k_mdungeon" if prob == "mdungeon" else "k_ddave" if prob == "ddave" else "k_smb" if prob == "smb" else "k_step" if fused else (
             "k_stats_wide" if (prob == "binary" and H > 16) else "k_stats")
         dom_us = max((ph.get("solver_or_reset", 0.0) if solver else ph.get("stats", 0.0)) - ev_us, 0.0)
         if fused:
@@ -367,8 +368,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": n * b_alg,
-                         "kernel": ("one step = one launch of k_step (update + stats + resets)" if fused else
-                                    "one step = k_update + k_stats (resets inside k_stats); sokoban adds k_reset + k_sokoban"),
+                         "kernel": ("one step = one launch of k_step (state of 64/128 environments per block staged in LDS: update + stats + resets)" if fused else
+                                    "one step = k_update + k_stats (resets inside k_stats); the search problems add k_reset + their search kernel"),
                          "dominant_kernel": dominant,
                          "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
                          "phase_us_per_step_with_event_overhead": ph},

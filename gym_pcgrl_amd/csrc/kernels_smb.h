@@ -15,14 +15,24 @@
 // four moves per state (stay / right / jump / right+jump), always four children; visited on pop by (x, y, airTime); the
 // queue is CPython's heapq on h + balance * depth with h = exit - x.  jump_locs only ever feeds "widest gap between
 // successive jump columns", which is carried in the node (last jump column, widest gap so far).
-// Search state: 8-byte nodes in the block's global arena (the node to be popped next is fetched ahead), heap of packed
-// (priority << 16 | node) words in LDS -- its first 32 768 entries, i.e. levels 0..14; a deeper heap continues in the arena --
-// and the visited set as a bitmap over (x, y, airTime) in LDS.
+// Search state: 8-byte nodes in the wavefront's global arena -- the node to be popped next is either fetched ahead or one of
+// the four children just made, which stay in registers -- a heap of packed (priority << 16 | node) words whose first 8 192
+// entries (levels 0..12; the median search is ~500 pops, nine in ten stay below 2 047) are in LDS and whose deeper levels
+// continue in the arena, and the visited set as a bitmap over (x, y, airTime) in LDS.  Four searches per block (a wavefront
+// each): ~35 KB of LDS per search.
 #pragma once
 
-#define SMB_LDS_HEAP 32768
+#define SMB_LDS_HEAP 8192      /* heap words a search keeps in LDS (levels 0..12: enough for 2 047 pops); deeper levels live in its arena */
+#define SMB_WAVES 4            /* searches a block runs side by side, a wavefront each */
 #define SMB_MAX_H 32
 #define SMB_YOFF 8            /* y ranges over [-5, H): a jump from the top row rises four cells above the screen */
+
+// bytes of one search's arena: node pool + the heap's overflow beyond its LDS part (host: pcgrl_abi.hip sizes the block's share)
+__host__ __device__ __forceinline__ size_t smb_wave_arena_bytes(int power) {
+    const size_t nodes = 4 * (size_t)power + 4;
+    const size_t ovf = nodes > SMB_LDS_HEAP ? nodes - SMB_LDS_HEAP : 0;
+    return (nodes * 8 + ovf * 4 + 255) & ~(size_t)255;
+}
 
 struct SmbHeap {
     uint32_t* lds; uint32_t* glob; int lds_n;
@@ -109,10 +119,12 @@ __device__ __forceinline__ SmbState smb_child(const SmbLevel& L, SmbState s, int
     s.x = nx; s.y = ny;
     return s;
 }
-// AStarAgent.getSolution (engine.py:101-126) by one lane.  `visited` must be all zeros.  Returns whether it won; `out` = the
-// winning node's state, else the best node's (smallest h, then smallest depth, first seen).
+// AStarAgent.getSolution (engine.py:101-126) by lanes 0..3 of a wavefront: everything is uniform across them (they keep the
+// same heap, pool and visited set, writing the same values) except the four children of a pop, which they make side by side
+// -- each child is a handful of dependent LDS lookups in the row masks.  `visited` must be all zeros.  Returns whether it won;
+// `out` = the winning node's state, else the best node's (smallest h, then smallest depth, first seen).
 __device__ __forceinline__ bool smb_search(const SmbLevel& L, const SmbState& root, int balance, int power, uint2* pool, const SmbHeap& H,
-                                           uint32_t* visited, SmbState& out, int& out_iters) {
+                                           uint32_t* visited, SmbState& out, int& out_iters, int lane) {
     const int ky = L.h + SMB_YOFF + 1;
     int npool = 1, heapn = 1, iterations = 0;
     pool[0] = smb_pack(root);
@@ -121,17 +133,26 @@ __device__ __forceinline__ bool smb_search(const SmbLevel& L, const SmbState& ro
     SmbState best = root;
     uint2 ahead = pool[0];
     int ahead_idx = 0;
+    // the four children of the last expansion (pool[kid_base .. kid_base + 3]): the next pop is usually one of them, and a
+    // store to the arena followed by a load of the same node would cost a memory round trip per pop
+    uint2 kid0 = ahead, kid1 = ahead, kid2 = ahead, kid3 = ahead;
+    int kid_base = -8;
     while (iterations < power && heapn > 0) {
         iterations++;
         const uint32_t top = H.get(0), last = H.get(--heapn);
         const int cur = (int)(top & 0xFFFFu);
-        const uint2 raw = cur == ahead_idx ? ahead : pool[cur];
+        uint2 raw;
+        const unsigned kd = (unsigned)(cur - kid_base);
+        if (cur == ahead_idx) raw = ahead;
+        else if (kd < 4u) raw = kd == 0 ? kid0 : (kd == 1 ? kid1 : (kd == 2 ? kid2 : kid3));
+        else raw = pool[cur];
         ahead_idx = -1;
         if (heapn > 0) {
             H.set(0, last);
             smb_siftup_root(H, heapn);
             ahead_idx = (int)(H.get(0) & 0xFFFFu);
-            ahead = pool[ahead_idx];
+            const unsigned ka = (unsigned)(ahead_idx - kid_base);
+            ahead = ka < 4u ? (ka == 0 ? kid0 : (ka == 1 ? kid1 : (ka == 2 ? kid2 : kid3))) : pool[ahead_idx];
         }
         const SmbState s = smb_unpack(raw);
         if (s.y >= L.h) continue;                                     // checkLose
@@ -143,11 +164,17 @@ __device__ __forceinline__ bool smb_search(const SmbLevel& L, const SmbState& ro
         visited[key >> 5] = word | bit;
         const int h = L.exit_x - s.x, bh = L.exit_x - best.x;
         if (!have_best || h < bh || (h == bh && s.depth < best.depth)) { have_best = true; best = s; }
-#pragma unroll 1
+        kid_base = npool;
+        const uint2 mine = smb_pack(smb_child(L, s, lane & 3));       // Node.getChildren: (0,0), (1,0), (0,-1), (1,-1), one per lane
+#pragma unroll
         for (int d = 0; d < 4; d++) {
-            const SmbState c = smb_child(L, s, d);
-            pool[npool] = smb_pack(c);
-            H.set(heapn, ((uint32_t)((L.exit_x - c.x) + balance * c.depth) << 16) | (uint32_t)npool);
+            uint2 pk;
+            pk.x = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, d);
+            pk.y = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, d);
+            if (d == 0) kid0 = pk; else if (d == 1) kid1 = pk; else if (d == 2) kid2 = pk; else kid3 = pk;
+            pool[npool] = pk;
+            const int cx = (int)(pk.x & 255u), cdepth = (int)(pk.x >> 17);
+            H.set(heapn, ((uint32_t)((L.exit_x - cx) + balance * cdepth) << 16) | (uint32_t)npool);
             heapn++;
             smb_siftdown(H, heapn - 1);
             npool++;
@@ -158,25 +185,29 @@ __device__ __forceinline__ bool smb_search(const SmbLevel& L, const SmbState& ro
     return win;
 }
 
-// Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  `sync[0]` (zeroed by the host) hands the jobs out.
-// Environments that finish their episode here go to `rst_list` (auto_reset).
-__global__ __launch_bounds__(64) void k_smb(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list,
-                                            int32_t* sync, int clear_parity, int lds_heap_n) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smb_lds[];       // heap (lds_heap_n words), then the visited bitmap
-    __shared__ uint64_t s_rows[SMB_MAX_H][4];
+// Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  `sync[0]` (zeroed by the host) hands the jobs out, a
+// wavefront at a time.  Environments that finish their episode here go to `rst_list` (auto_reset).
+__global__ __launch_bounds__(SMB_WAVES * 64) void k_smb(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list,
+                                                        int32_t* sync, int clear_parity, int lds_heap_n) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smb_lds[];       // per wavefront: heap (lds_heap_n words), then the visited bitmap
+    __shared__ uint64_t s_rows[SMB_WAVES][SMB_MAX_H][4];
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
-    __shared__ int s_red[8];
+    __shared__ int s_red[SMB_WAVES][8];
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
     const int n = n_a + n_b;
     const int W = P.width, Hh = P.height, cells = W * Hh;
     const int ew = W + 6, ky = Hh + SMB_YOFF + 1;
     const int vis_words = (ew * ky * 8 + 31) / 32;
-    uint32_t* visited = smb_lds + lds_heap_n;
-    uint2* pool = reinterpret_cast<uint2*>(B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride);
-    SmbHeap HP = {smb_lds, B.sok_heap ? B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride : nullptr, lds_heap_n};
+    uint32_t* my_lds = smb_lds + (size_t)wv * (lds_heap_n + ((vis_words + 3) & ~3));
+    uint32_t* visited = my_lds + lds_heap_n;
+    uint8_t* arena = reinterpret_cast<uint8_t*>(B.sok_pool) + (size_t)blockIdx.x * B.sok_pool_stride * sizeof(SokNode) + (size_t)wv * smb_wave_arena_bytes(P.solver_power);
+    uint2* pool = reinterpret_cast<uint2*>(arena);
+    SmbHeap HP = {my_lds, reinterpret_cast<uint32_t*>(arena + (4 * (size_t)P.solver_power + 4) * 8), lds_heap_n};
+    uint64_t (*rows)[4] = s_rows[wv];
+    int* red = s_red[wv];
     for (;;) {
         int t = 0;
         if (lane == 0) t = atomicAdd(sync, 1);
@@ -223,42 +254,34 @@ __global__ __launch_bounds__(64) void k_smb(PcgrlParams P, DevBufs B, int list_a
                     else { const int tl = m[y * W + ex - 3]; sol = tl == 1 || tl == 3 || tl == 4 || tl == 6; }
                 }
                 const uint64_t bal = __ballot(sol);
-                if (lane == 0) s_rows[y][k] = bal;
+                if (lane == 0) rows[y][k] = bal;
             }
         }
-        for (int i = lane; i < vis_words; i += 64) visited[i] = 0;
-        __threadfence_block();
-        // ---- SMBProblem._run_game by one lane
-        int dist_win = 0, jumps = 0, jumps_dist = 0;
-        if (lane == 0) {
-            SmbLevel L = {s_rows, ew, Hh, Hh > 3 ? W + 4 : -1};
-            SmbState root = {1, Hh - 3, 0, 0, 0, 0, 0}, res = root;
-            int it = 0;
-            bool win = smb_search(L, root, 1, P.solver_power, pool, HP, visited, res, it);
-            s_red[0] = win ? 1 : 0;
-            s_red[1] = res.jumps; s_red[2] = res.prev_jump_x; s_red[3] = res.max_gap; s_red[4] = res.x;
-        }
-        __threadfence_block();
-        if (!s_red[0]) {                                               // the second agent, balance 0 (smb_prob.py:139-141)
+        // ---- SMBProblem._run_game by one lane: AStarAgent with balance 1, then -- if it did not win -- balance 0 (smb_prob.py:133-141)
+        int won = 0;
+#pragma clang loop unroll(disable)
+        for (int agent = 0; agent < 2 && !won; agent++) {
             for (int i = lane; i < vis_words; i += 64) visited[i] = 0;
             __threadfence_block();
-            if (lane == 0) {
-                SmbLevel L = {s_rows, ew, Hh, Hh > 3 ? W + 4 : -1};
+            if (lane < 4) {
+                SmbLevel L = {rows, ew, Hh, Hh > 3 ? W + 4 : -1};
                 SmbState root = {1, Hh - 3, 0, 0, 0, 0, 0}, res = root;
                 int it = 0;
-                bool win = smb_search(L, root, 0, P.solver_power, pool, HP, visited, res, it);
-                s_red[0] = win ? 1 : 0;
-                s_red[1] = res.jumps; s_red[2] = res.prev_jump_x; s_red[3] = res.max_gap; s_red[4] = res.x;
+                const bool win = smb_search(L, root, agent == 0 ? 1 : 0, P.solver_power, pool, HP, visited, res, it, lane);
+                if (lane == 0) {
+                    red[0] = win ? 1 : 0;
+                    red[1] = res.jumps; red[2] = res.prev_jump_x; red[3] = res.max_gap; red[4] = res.x;
+                }
             }
             __threadfence_block();
+            won = red[0];
         }
         if (lane == 0) {
             const int exit_x = Hh > 3 ? W + 4 : -1;
-            dist_win = s_red[0] ? 0 : exit_x - s_red[4];
-            jumps = s_red[1];
-            const int tail = P.prob_width - s_red[2];                 // smb_prob.py:166: max(value, self._width - prev_jump)
-            jumps_dist = s_red[3] > tail ? s_red[3] : tail;
-            int32_t s[PCGRL_MAX_STATS] = {c_floor, c_tubes, c_enemy, c_empty, c_noise, jumps, jumps_dist, dist_win};
+            const int dist_win = red[0] ? 0 : exit_x - red[4];
+            const int tail = P.prob_width - red[2];                   // smb_prob.py:166: max(value, self._width - prev_jump)
+            const int jumps_dist = red[3] > tail ? red[3] : tail;
+            int32_t s[PCGRL_MAX_STATS] = {c_floor, c_tubes, c_enemy, c_empty, c_noise, red[1], jumps_dist, dist_win};
             finalize_item<PCGRL_PROB_SMB>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
         }
         __threadfence_block();

@@ -163,7 +163,9 @@ static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<=
 // Node pool of one resident solver block: 4 children per pop of the full search -- and never less than the private
 // small-tier pools of k_step_solver (SS_SEARCH_WAVES wavefronts x SS_SMALL_NODES at pool + wv * SS_SMALL_NODES), so that a
 // small solver_power cannot make them spill into the next block's pool.
-static size_t sok_pool_nodes(int power) {
+static size_t sok_pool_nodes(int power, int prob = -1) {
+    if (prob == PCGRL_SMB)     // k_smb: SMB_WAVES searches per block, each with its own 8-byte-node pool + heap overflow (kernels_smb.h)
+        return (SMB_WAVES * smb_wave_arena_bytes(power) + sizeof(SokNode) - 1) / sizeof(SokNode);
     const size_t full = 4 * (size_t)power + 4, small = (size_t)SS_SEARCH_WAVES * SS_SMALL_NODES;
     return full > small ? full : small;
 }
@@ -182,11 +184,11 @@ static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c
 static size_t scratch_bytes_base(const pcgrl_config* c) {
     size_t b = wl_bytes(c);
     if (solver_prob(c->prob)) {           // (an MdNode is as large as a SokNode)
-        const size_t nodes = sok_pool_nodes(c->solver_power);
+        const size_t nodes = sok_pool_nodes(c->solver_power, c->prob);
         b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
         b += sok_sched_bytes(c->num_envs);
         const size_t hnodes = 4 * (size_t)c->solver_power + 4;
-        if (c->solver_power > SOK_LDS_POWER) b += SOK_BLOCKS * (align_up(hnodes * 4, 256) + (size_t)sok_table_size(c->solver_power) * 4);
+        if (c->solver_power > SOK_LDS_POWER && c->prob != PCGRL_SMB) b += SOK_BLOCKS * (align_up(hnodes * 4, 256) + (size_t)sok_table_size(c->solver_power) * 4);
     }
     return b;
 }
@@ -286,10 +288,12 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     { const char* wg = getenv("PCGRL_WIDE_GRID"); h->wide_grid = wg ? atoi(wg) : 16384; if (h->wide_grid < 1) h->wide_grid = 16384; }   // blocks of k_stats_wide   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
     { const char* fz = getenv("PCGRL_FUSED_ZELDA"); h->fused_zelda = (fz && fz[0] == '0') ? 0 : 1; }   // =0: zelda steps as k_update + k_stats
     h->no_fused = env_is_one("PCGRL_NO_FUSED") ? 1 : 0;
-    {   // k_step: environments per block (see launch_step_pm)
+    {   // k_step: environments per block (see launch_step_pm).  The largest block that still gives (about) every compute unit one and
+        // is resident in one round: 256 environments -> one block per CU (LDS), 128 -> two, 64 -> four.
         const char* eb = getenv("PCGRL_STEP_EPB");
-        h->step_epb = eb ? atoi(eb) : (h->cfg.num_envs >= 128 * 256 ? 128 : 64);
-        if (h->step_epb != 128) h->step_epb = 64;
+        const int n_ = h->cfg.num_envs;
+        h->step_epb = eb ? atoi(eb) : ((n_ >= 192 * 256 && n_ <= 256 * 256) ? 256 : (n_ >= 192 * 128 ? 128 : 64));
+        if (h->step_epb != 128 && h->step_epb != 256) h->step_epb = 64;
     }
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
@@ -338,7 +342,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     if (solver_prob(h->cfg.prob)) {
         // the arena is sized for the solver_power the buffers were allocated with
         const int power = h->alloc_solver_power = h->cfg.solver_power;
-        const size_t nodes = sok_pool_nodes(power), hnodes = 4 * (size_t)power + 4;
+        const size_t nodes = sok_pool_nodes(power, h->cfg.prob), hnodes = 4 * (size_t)power + 4;
         uint8_t* a = s + wl_bytes(&h->cfg);
         B.sok_pool = (SokNode*)a;
         B.sok_pool_stride = (int32_t)(align_up(nodes * sizeof(SokNode), 256) / sizeof(SokNode));
@@ -349,7 +353,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         B.sok_sync = (int32_t*)(a + align_up((size_t)h->cfg.num_envs * 18 * 4, 256));
         HIPCHK(hipMemsetAsync(a, 0, sok_sched_bytes(h->cfg.num_envs), (hipStream_t)stream));
         a += sok_sched_bytes(h->cfg.num_envs);
-        B.sok_use_lds = power <= SOK_LDS_POWER;
+        B.sok_use_lds = power <= SOK_LDS_POWER || h->cfg.prob == PCGRL_SMB;     // (smb has its own heap split, kernels_smb.h)
         {   // PCGRL_SOK_GENERIC=1: every level takes the generic search (tests)
             const char* sg = getenv("PCGRL_SOK_GENERIC");
             B.sok_fast_maxc = (sg && sg[0] == '1') ? -1 : SOKF_MAXC;
@@ -515,8 +519,8 @@ static bool fused_step_applies(const pcgrl_env* h, bool rollout = false) {
            h->B.inline_reset && !h->no_fused;
 }
 struct RolloutArgs { int steps; size_t action_stride; double* reward_out; uint8_t* done_out; int32_t* info_out; };
-// Environments per block of k_step: 128 (eight wavefronts, two blocks per compute unit) once the batch fills the chip with
-// them, else 64 (four wavefronts): more, smaller blocks then reach more compute units.  PCGRL_STEP_EPB=64|128 overrides (A/B).
+// Environments per block of k_step: 64 (four wavefronts), 128 (eight) or 256 (sixteen) -- chosen at pcgrl_bind from the batch
+// size; PCGRL_STEP_EPB=64|128|256 overrides (A/B).
 template <int PROB, class MaskT, int EPB>
 static int launch_step_pme(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
     const PcgrlParams& P = h->P;
@@ -544,6 +548,7 @@ template <int PROB, class MaskT>
 static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
     // (the 128-environment form is built for 32-bit row masks only: the common case)
     if (sizeof(MaskT) == 4 && h->step_epb == 128) return launch_step_pme<PROB, uint32_t, 128>(h, actions, parity, st, R);
+    if (sizeof(MaskT) == 4 && h->step_epb == 256) return launch_step_pme<PROB, uint32_t, 256>(h, actions, parity, st, R);
     return launch_step_pme<PROB, MaskT, 64>(h, actions, parity, st, R);
 }
 static int launch_step(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R = RolloutArgs{1, 0, nullptr, nullptr, nullptr}) {
@@ -561,11 +566,11 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
     int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
     HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
     if (h->P.prob == PCGRL_PROB_SMB) {
-        // heap words in LDS (the first levels; a deeper heap continues in the block's arena) + the visited bitmap
-        const int heap_n = 4 * h->P.solver_power + 4 < SMB_LDS_HEAP ? 4 * h->P.solver_power + 4 : SMB_LDS_HEAP;
-        const size_t vis = (size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 8 + 31) / 32 * 4;
-        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(64), (size_t)heap_n * 4 + vis, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
-                           sync, clr, heap_n);
+        // per wavefront: the heap's LDS part (its first levels; a deeper heap continues in the arena) + the visited bitmap
+        const int heap_n = 4 * h->P.solver_power + 4 < SMB_LDS_HEAP ? ((4 * h->P.solver_power + 4 + 3) & ~3) : SMB_LDS_HEAP;
+        const size_t vis_words = ((size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 8 + 31) / 32 + 3) & ~(size_t)3;
+        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(SMB_WAVES * 64), SMB_WAVES * ((size_t)heap_n + vis_words) * 4, st, h->P, h->B, list_a, mode_a, list_b,
+                           mode_b, parity, rst_list, sync, clr, heap_n);
         HIPCHK(hipGetLastError());
         return PCGRL_OK;
     }

@@ -111,13 +111,39 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     }
     __builtin_amdgcn_wave_barrier();
     TL(14);
-    if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33
-        if (lane == 0) {
-            const int x = mt_randint(mt, cur, W);
-            const int y = mt_randint(mt, cur, H);
-            reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+    if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33: x = randint(W), y = randint(H)
+        // numpy's masked rejection on the next words of the stream.  Eight lanes make the next eight words at once (every operand
+        // is an old word), two ballots pick the first accepted x and the first accepted y after it; only if eight words do not
+        // hold both (probability < 1e-4 for any W, H) lane 0 goes on one word at a time.
+        const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
+        uint32_t mx = rx, my = ry;
+        mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
+        my |= my >> 1; my |= my >> 2; my |= my >> 4; my |= my >> 8; my |= my >> 16;
+        const int sl = mt_wrap(cur + (lane & 7));
+        const uint32_t yw = mt_twist(mt[sl], mt[mt_wrap(sl + 1)], mt[mt_wrap(sl + PCGRL_MT_M)]);
+        const uint32_t v = mt_temper(yw);
+        const uint32_t okx = (uint32_t)__ballot(lane < 8 && (v & mx) <= rx) & 0xFFu;
+        const uint32_t oky = (uint32_t)__ballot(lane < 8 && (v & my) <= ry) & 0xFFu;
+        // index of the word that gives x (-1: randint(1) draws nothing), then of the word that gives y
+        const int ix = rx == 0 ? -1 : (okx ? __ffs((int)okx) - 1 : 8);
+        const uint32_t oky_after = ix >= 7 ? 0u : (ix < 0 ? oky : (oky & ~((2u << ix) - 1u)));       // words after ix (all of them when ix = -1)
+        const int iy = ry == 0 ? ix : (ix >= 8 ? 8 : (oky_after ? __ffs((int)oky_after) - 1 : 8));
+        __builtin_amdgcn_wave_barrier();
+        if (iy < 8) {
+            const int used = iy + 1;                                   // words consumed (0 when neither axis draws)
+            if (lane < used) mt[sl] = yw;
+            const int xv = rx == 0 ? 0 : (int)(__shfl(v, ix < 0 ? 0 : ix, 64) & mx);
+            const int yv = ry == 0 ? 0 : (int)(__shfl(v, iy < 0 ? 0 : iy, 64) & my);
+            if (lane == 0) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)xv, (unsigned char)yv);
+            cur = mt_wrap(cur + used);
+        } else {
+            if (lane == 0) {
+                const int x = mt_randint(mt, cur, W);
+                const int y = mt_randint(mt, cur, H);
+                reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+            }
+            cur = __shfl(cur, 0, 64);
         }
-        cur = __shfl(cur, 0, 64);
     }
     __builtin_amdgcn_wave_barrier();
     TL(15);

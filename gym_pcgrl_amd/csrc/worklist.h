@@ -98,8 +98,8 @@ struct StepLocal {
     int e0;
     int par, need;              // this step's slot of refill_done; how many update wavefronts have to report
     int refill_done[2];         // update wavefronts that have written the consumed draws back to the rings (release / acquire, workgroup scope)
-    uint8_t k[128];             // draws an environment consumed in this step and that are not in its ring yet (certain resets patch them in)
-    uint8_t dirty[128];         // planes / champion / start statistics changed: write them back
+    uint8_t k[256];             // draws an environment consumed in this step and that are not in its ring yet (certain resets patch them in)
+    uint8_t dirty[256];         // planes / champion / start statistics changed: write them back
 };
 
 __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {

@@ -28,7 +28,7 @@ for t in range(warm):
     env.step(acts[t % 256])
 L = _lib.load()
 L.pcgrl_debug_timeline.argtypes = [C.c_void_p]
-EPB = int(os.environ.get("PCGRL_STEP_EPB", "128" if n >= 128 * 256 else "64"))
+EPB = int(os.environ.get("PCGRL_STEP_EPB", "256" if 192 * 256 <= n <= 256 * 256 else ("128" if n >= 192 * 128 else "64")))
 SLOTS, WAVES = 48, EPB // 16
 nblk = (n + EPB - 1) // EPB
 names = {1: "start", 2: "update done", 3: "lists ready", 4: "task: certain reset", 5: "task: full", 6: "task: incremental", 7: "task end", 8: "wave end",
