@@ -254,7 +254,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
 #pragma unroll
             for (int b = 0; b < 8; b++) {
                 const uint64_t mb = __ballot(dest == 1 && lvl == b);
-                pos1 += b < lvl ? __popcll(mb) : (b == lvl ? __popcll(mb & below) : 0);
+                pos1 += b > lvl ? __popcll(mb) : (b == lvl ? __popcll(mb & below) : 0);      // dearest first: the cheap ones fill the gaps at the end
             }
             if (dest == 1) s_items[1][b1 + pos1] = v;
         }
