@@ -14,26 +14,99 @@
 // rows, the player at (1, H-3), a block under the pole at (W+4, H-3), exit column W+4 -- and a player state (x, y, airTime);
 // four moves per state (stay / right / jump / right+jump), always four children; visited on pop by (x, y, airTime); the
 // queue is CPython's heapq on h + balance * depth with h = exit - x.  jump_locs only ever feeds "widest gap between
-// successive jump columns", which is carried in the node (last jump column, widest gap so far).
-// Search state: 8-byte nodes in the wavefront's global arena -- the node to be popped next is either fetched ahead or one of
-// the four children just made, which stay in registers -- a heap of packed (priority << 16 | node) words whose first 8 192
-// entries (levels 0..12; the median search is ~500 pops, nine in ten stay below 2 047) are in LDS and whose deeper levels
-// continue in the arena, and the visited set as a bitmap over (x, y, airTime) in LDS.  Four searches per block (a wavefront
-// each): ~35 KB of LDS per search.
+// successive jump columns".
+//
+// The level lives in registers: lane l holds columns l, 64 + l, 128 + l, 192 + l as bit masks over the rows (bit y + 8 of a
+// column: blocked; rows above the screen free, rows below it blocked), so a move is a 2 x 3 window around the player read with
+// four readlanes and no memory access.  Two searches:
+//  * smb_search_two_label -- balance 1, the whole wavefront, everything in LDS and registers (see there): 24 of 25 searches;
+//  * smb_search -- any balance, lanes 0..3 (the four children of a pop side by side), 8-byte nodes in the wavefront's global
+//    arena and a heap of packed (priority << 16 | node) words whose first levels are in LDS: balance 0 (short searches on the
+//    levels balance 1 did not win) and whatever does not fit the first.
+// LDS per search: 4 096 heap words + the visited bitmap over (x, y, airTime): ~19 KB, eight searches per compute unit.
 #pragma once
 
-#define SMB_LDS_HEAP 8192      /* heap words a search keeps in LDS (levels 0..12: enough for 2 047 pops); deeper levels live in its arena */
-#define SMB_WAVES 4            /* searches a block runs side by side, a wavefront each */
-#define SMB_MAX_H 32
-#define SMB_YOFF 8            /* y ranges over [-5, H): a jump from the top row rises four cells above the screen */
+// developer build only (tools/smb_prof.py: -DPCGRL_SMB_PROF): cycles and pops of the searches, summed into g_tl_buf
+#ifdef PCGRL_SMB_PROF
+#define SP_ADD(i, v) do { if (lane == 0 && g_tl_buf) atomicAdd(&g_tl_buf[i], (unsigned long long)(v)); } while (0)
+#define SP_NOW() clock64()
+#else
+#define SP_ADD(i, v) do {} while (0)
+#define SP_NOW() 0ull
+#endif
 
-// bytes of one search's arena: node pool + the heap's overflow beyond its LDS part (host: pcgrl_abi.hip sizes the block's share)
+#define SMB_LDS_HEAP 4096      /* heap words a search keeps in LDS; smb_search's deeper levels live in its arena */
+#define SMB_MAX_WAVES 8        /* searches a block runs side by side, a wavefront each (the launch takes as many as its LDS allows) */
+#define SMB_MAX_H 32
+#define SMB_YOFF 8             /* y ranges over [-5, H): a jump from the top row rises four cells above the screen */
+#define SMB_ROOT_PAR 0x3FFFu
+
+// bytes of one search's arena: smb_search's node pool + its heap's overflow beyond the LDS part; smb_search_two_label keeps its
+// expansion log (4 bytes per expansion) in the same place (host: pcgrl_abi.hip sizes the block's share)
 __host__ __device__ __forceinline__ size_t smb_wave_arena_bytes(int power) {
     const size_t nodes = 4 * (size_t)power + 4;
-    const size_t ovf = nodes > SMB_LDS_HEAP ? nodes - SMB_LDS_HEAP : 0;
-    return (nodes * 8 + ovf * 4 + 255) & ~(size_t)255;
+    return (nodes * 8 + nodes * 4 + 255) & ~(size_t)255;
 }
 
+struct SmbCols { uint64_t c0, c1, c2, c3; };
+struct SmbState { int x, y, air, depth, jumps, prev_jump_x, max_gap; };
+struct SmbResult { int won, jumps, prev_jump_x, max_gap, x; };
+
+__device__ __forceinline__ uint64_t smb_readlane64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+// the 2 x 3 window around (x, y) -- x, y wavefront-uniform: wx / wx1 = columns x / x + 1, bit 0: row y - 1, bit 1: row y, bit 2: row y + 1
+// (every column register is read with readlane and the choice made on the scalar side: a vector select would only be
+// executed by the active lanes, and smb_search runs with lanes 0..3 active while it reads the columns of all 64)
+template <int NW>
+__device__ __forceinline__ uint64_t smb_column(const SmbCols& C, int x) {
+    const int l = x & 63;
+    const uint64_t v0 = smb_readlane64(C.c0, l), v1 = smb_readlane64(C.c1, l);
+    if (NW == 2) return x < 64 ? v0 : v1;
+    const uint64_t v2 = smb_readlane64(C.c2, l), v3 = smb_readlane64(C.c3, l);
+    return x < 64 ? v0 : (x < 128 ? v1 : (x < 192 ? v2 : v3));
+}
+template <int NW>
+__device__ __forceinline__ void smb_window(const SmbCols& C, int x, int y, uint32_t& wx, uint32_t& wx1) {
+    wx = (uint32_t)(smb_column<NW>(C, x) >> (y + 7)) & 7u;
+    wx1 = (uint32_t)(smb_column<NW>(C, x + 1) >> (y + 7)) & 7u;
+}
+// State.update (engine.py:212-250) for direction d = 0..3: (0,0), (1,0), (0,-1), (1,-1), on the window of the state (which
+// is neither won nor lost: the searches test that before they expand a node)
+__device__ __forceinline__ SmbState smb_child_win(SmbState s, int d, uint32_t wx, uint32_t wx1, int h) {
+    s.depth += 1;
+    const int dx = d & 1, jump = d >> 1;
+    const bool ground = s.y < h - 1 && s.y >= -1 && ((wx >> 2) & 1u);
+    int nx = s.x, ny = s.y;
+    uint32_t wn = wx;
+    if (dx && !((wx1 >> 1) & 1u)) { nx += 1; wn = wx1; }
+    const bool up_free = !(wn & 1u), down_free = !((wn >> 2) & 1u);
+    if (jump) {
+        if (ground && up_free) {
+            s.air = 5; s.jumps += 1;
+            const int gap = s.x - s.prev_jump_x;                     // jump_locs.append((x, y)): the column before the move
+            s.max_gap = gap > s.max_gap ? gap : s.max_gap;
+            s.prev_jump_x = s.x;
+        }
+    } else if (s.air > 0) {
+        s.air = 1;
+    }
+    if (s.air > 1) {
+        s.air -= 1;
+        if (up_free) ny -= 1; else s.air = 1;
+    } else if (s.air == 1) {
+        s.air = 0;
+    } else if (down_free) {
+        ny += 1;
+    }
+    s.x = nx; s.y = ny;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The general search (any balance): lanes 0..3 of a wavefront
+// ---------------------------------------------------------------------------------------------------------------------
 struct SmbHeap {
     uint32_t* lds; uint32_t* glob; int lds_n;
     __device__ __forceinline__ uint32_t get(int i) const { return i < lds_n ? lds[i] : glob[i - lds_n]; }
@@ -68,15 +141,6 @@ __device__ __forceinline__ void smb_siftup_root(const SmbHeap& H, int endpos) {
     H.set(pos, item);
     smb_siftdown(H, pos);
 }
-
-struct SmbLevel { const uint64_t (*rows)[4]; int w, h, exit_x; };
-struct SmbState { int x, y, air, depth, jumps, prev_jump_x, max_gap; };
-__device__ __forceinline__ bool smb_solid(const SmbLevel& L, int x, int y) { return (L.rows[y][x >> 6] >> (x & 63)) & 1ull; }
-__device__ __forceinline__ bool smb_movable(const SmbLevel& L, int x, int y) {          // engine.py:207-210
-    if (y < 0) return true;
-    if (x < 0 || x >= L.w || y >= L.h) return false;
-    return !smb_solid(L, x, y);
-}
 __device__ __forceinline__ uint2 smb_pack(const SmbState& s) {
     uint2 n;
     n.x = (uint32_t)s.x | ((uint32_t)(s.y + SMB_YOFF) << 8) | ((uint32_t)s.air << 14) | ((uint32_t)s.depth << 17);
@@ -89,46 +153,15 @@ __device__ __forceinline__ SmbState smb_unpack(uint2 n) {
     s.jumps = (int)(n.y & 0x3FFFu); s.prev_jump_x = (int)((n.y >> 14) & 255u); s.max_gap = (int)((n.y >> 22) & 255u);
     return s;
 }
-// State.update (engine.py:212-250) for direction d = 0..3: (0,0), (1,0), (0,-1), (1,-1)
-__device__ __forceinline__ SmbState smb_child(const SmbLevel& L, SmbState s, int d) {
-    s.depth += 1;
-    if (s.x >= L.exit_x || s.y >= L.h) return s;                      // checkOver: a finished state does not move
-    const int dx = d & 1, jump = d >> 1;
-    bool ground = false;
-    if (s.y < L.h - 1 && s.y >= -1) ground = smb_solid(L, s.x, s.y + 1);
-    int nx = s.x, ny = s.y;
-    if (dx && smb_movable(L, nx + 1, ny)) nx += 1;
-    if (jump) {
-        if (ground && smb_movable(L, nx, ny - 1)) {
-            s.air = 5; s.jumps += 1;
-            const int gap = s.x - s.prev_jump_x;                     // jump_locs.append((x, y)): the column before the move
-            s.max_gap = gap > s.max_gap ? gap : s.max_gap;
-            s.prev_jump_x = s.x;
-        }
-    } else if (s.air > 0) {
-        s.air = 1;
-    }
-    if (s.air > 1) {
-        s.air -= 1;
-        if (smb_movable(L, nx, ny - 1)) ny -= 1; else s.air = 1;
-    } else if (s.air == 1) {
-        s.air = 0;
-    } else if (smb_movable(L, nx, ny + 1)) {
-        ny += 1;
-    }
-    s.x = nx; s.y = ny;
-    return s;
-}
 // AStarAgent.getSolution (engine.py:101-126) by lanes 0..3 of a wavefront: everything is uniform across them (they keep the
-// same heap, pool and visited set, writing the same values) except the four children of a pop, which they make side by side
-// -- each child is a handful of dependent LDS lookups in the row masks.  `visited` must be all zeros.  Returns whether it won;
-// `out` = the winning node's state, else the best node's (smallest h, then smallest depth, first seen).
-__device__ __forceinline__ bool smb_search(const SmbLevel& L, const SmbState& root, int balance, int power, uint2* pool, const SmbHeap& H,
-                                           uint32_t* visited, SmbState& out, int& out_iters, int lane) {
-    const int ky = L.h + SMB_YOFF + 1;
+// same heap, pool and visited set, writing the same values) except the four children of a pop, which they make side by side.
+// `visited` must be all zeros.  out = the winning node's state, else the best node's (smallest h, then smallest depth, first seen).
+__device__ __forceinline__ void smb_search(const SmbCols& C, int h, int exit_x, const SmbState& root, int balance, int power, uint2* pool, const SmbHeap& H,
+                                           uint32_t* visited, SmbResult& out, int lane) {
+    const int ky = h + SMB_YOFF + 1;
     int npool = 1, heapn = 1, iterations = 0;
     pool[0] = smb_pack(root);
-    H.set(0, ((uint32_t)(L.exit_x - root.x) << 16) | 0u);
+    H.set(0, ((uint32_t)(exit_x - root.x) << 16) | 0u);
     bool have_best = false, win = false;
     SmbState best = root;
     uint2 ahead = pool[0];
@@ -154,18 +187,22 @@ __device__ __forceinline__ bool smb_search(const SmbLevel& L, const SmbState& ro
             const unsigned ka = (unsigned)(ahead_idx - kid_base);
             ahead = ka < 4u ? (ka == 0 ? kid0 : (ka == 1 ? kid1 : (ka == 2 ? kid2 : kid3))) : pool[ahead_idx];
         }
+        raw.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x);
+        raw.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
         const SmbState s = smb_unpack(raw);
-        if (s.y >= L.h) continue;                                     // checkLose
-        if (s.x >= L.exit_x) { win = true; best = s; break; }         // checkWin
+        if (s.y >= h) continue;                                       // checkLose
+        if (s.x >= exit_x) { win = true; best = s; break; }           // checkWin
         const int key = (s.x * ky + (s.y + SMB_YOFF)) * 8 + s.air;
         const uint32_t bit = 1u << (key & 31);
         const uint32_t word = visited[key >> 5];
         if (word & bit) continue;
         visited[key >> 5] = word | bit;
-        const int h = L.exit_x - s.x, bh = L.exit_x - best.x;
-        if (!have_best || h < bh || (h == bh && s.depth < best.depth)) { have_best = true; best = s; }
+        const int hh = exit_x - s.x, bh = exit_x - best.x;
+        if (!have_best || hh < bh || (hh == bh && s.depth < best.depth)) { have_best = true; best = s; }
         kid_base = npool;
-        const uint2 mine = smb_pack(smb_child(L, s, lane & 3));       // Node.getChildren: (0,0), (1,0), (0,-1), (1,-1), one per lane
+        uint32_t wx, wx1;
+        smb_window<4>(C, s.x, s.y, wx, wx1);
+        const uint2 mine = smb_pack(smb_child_win(s, lane & 3, wx, wx1, h));    // Node.getChildren: (0,0), (1,0), (0,-1), (1,-1), one per lane
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             uint2 pk;
@@ -174,40 +211,302 @@ __device__ __forceinline__ bool smb_search(const SmbLevel& L, const SmbState& ro
             if (d == 0) kid0 = pk; else if (d == 1) kid1 = pk; else if (d == 2) kid2 = pk; else kid3 = pk;
             pool[npool] = pk;
             const int cx = (int)(pk.x & 255u), cdepth = (int)(pk.x >> 17);
-            H.set(heapn, ((uint32_t)((L.exit_x - cx) + balance * cdepth) << 16) | (uint32_t)npool);
+            H.set(heapn, ((uint32_t)((exit_x - cx) + balance * cdepth) << 16) | (uint32_t)npool);
             heapn++;
             smb_siftdown(H, heapn - 1);
             npool++;
         }
     }
-    out = best;
-    out_iters = iterations;
-    return win;
+    out.won = win ? 1 : 0;
+    out.jumps = best.jumps; out.prev_jump_x = best.prev_jump_x; out.max_gap = best.max_gap; out.x = best.x;
+    SP_ADD(0, 1); SP_ADD(1, iterations);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AStarAgent with balance 1, by a whole wavefront
+// ---------------------------------------------------------------------------------------------------------------------
+// With balance 1 the priority is f = (exit - x) + depth; a child is one move deeper and at most one column further, so its f
+// is its parent's (it moved right) or one more, pops come in non-decreasing f, and at any time the queue holds only
+// f = fmin (label 0) and f = fmin + 1 (label 1).  heapq on such a queue needs no priority comparisons, only the labels:
+//   heappush: a label-1 item stays where it is appended; a label-0 item climbs past its label-1 ancestors (they move down one
+//             level each) and stops under the first label-0 ancestor;
+//   heappop:  the vacated root is filled along a path that takes the right child unless (left, right) = (0, 1), down to a
+//             leaf -- inside the label-1 part that is "right while there is one, then left", a closed form; the last item goes
+//             to the leaf and, if its label is 0, climbs back to just below the zeros of that path.  Net effect: the first m
+//             path entries move up one level and the last item lands on path position m (m = the leaf's depth for a label-1
+//             last item, the number of zeros on the path below the root otherwise), and at most one label flips.
+// The labels of heap slots 1..4095 (1-based heap index) are bits spread over the wavefront's registers (word w in lane w & 63
+// of a / b), read with readlane: finding a path costs no memory access, and the moves along it are one LDS read and one LDS
+// write with a lane per level.  An item is 32 bits: x | (y + 8) << 8 | airTime << 14 | parent << 17, `parent` = the expansion
+// number of the node it is a child of (the root: SMB_ROOT_PAR).  Depth follows from the label (depth = f - (exit - x)); what
+// the reference carries along in jump_locs is recovered at the end by walking the result's ancestors through the expansion
+// log (log[e] = item of the e-th expanded node, in the wavefront's arena): a node was made by a jump start exactly when its
+// airTime is 4 -- the jump sets 5, the same update takes it to 4, and nothing else produces a 4 -- and the jump's column is its
+// parent's x.  Returns 1 won, 0 not won, 2 the queue outgrew `cap` slots (the caller repeats the search with smb_search).
+struct SmbLab { uint32_t a, b; };
+__device__ __forceinline__ uint32_t smb_lab_word(const SmbLab& Lb, int w) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)(w < 64 ? Lb.a : Lb.b), w & 63);
+}
+__device__ __forceinline__ int smb_lab_get(const SmbLab& Lb, int q) { return (int)((smb_lab_word(Lb, q >> 5) >> (q & 31)) & 1u); }
+__device__ __forceinline__ void smb_lab_set(SmbLab& Lb, int q, int v, int lane) {
+    const int w = q >> 5;
+    const uint32_t m = 1u << (q & 31);
+    if (lane == (w & 63)) {
+        if (w < 64) Lb.a = v ? (Lb.a | m) : (Lb.a & ~m);
+        else Lb.b = v ? (Lb.b | m) : (Lb.b & ~m);
+    }
+}
+// a label-0 item just appended at slot q (its label bit already 0) climbs to its place
+__device__ __forceinline__ void smb_climb(SmbLab& lab, uint32_t* ent, int q, uint32_t item, int lane) {
+    int b = 0;
+    while ((q >> (b + 1)) >= 1 && smb_lab_get(lab, q >> (b + 1))) b++;
+    if (b > 0) {
+        uint32_t mv = item;
+        if (lane < b) mv = ent[q >> (lane + 1)];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < b) ent[q >> lane] = mv;
+        if (lane == 0) ent[q >> b] = item;
+        smb_lab_set(lab, q >> b, 0, lane);
+        smb_lab_set(lab, q, 1, lane);
+    }
+}
+__device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int exit_x, int root_x, int root_y, int power, uint32_t* ent, int cap,
+                                                    uint32_t* visited, uint32_t* log, SmbResult& out, int lane) {
+    const int ky = h + SMB_YOFF + 1;
+    SmbLab lab = {0u, 0u};
+    int n = 1, iterations = 0, nexp = 0, fmin = exit_x - root_x;
+    const uint32_t root = (uint32_t)root_x | ((uint32_t)(root_y + SMB_YOFF) << 8) | (SMB_ROOT_PAR << 17);
+    if (lane == 0) ent[1] = root;
+    bool have_best = false;
+    int status = 0, best_x = root_x, best_depth = 0;
+    uint32_t res = root;
+    while (iterations < power && n > 0) {
+        iterations++;
+        uint32_t rp = ent[1];
+        const uint32_t lastp = ent[n];
+        if (smb_lab_word(lab, 0) & 2u) { lab.a = 0u; lab.b = 0u; fmin++; }      // no label-0 item left: the ones become the zeros
+        const int ll = smb_lab_get(lab, n);
+        n--;
+        if (n > 0) {
+            int q = 1, z = 1;
+            bool ones = false;
+            while (2 * q + 1 <= n) {                                            // both children exist
+                const int c = 2 * q;
+                const uint32_t pr = (smb_lab_word(lab, c >> 5) >> (c & 31)) & 3u;   // label(left) | label(right) << 1
+                q = c + (int)((0xBu >> pr) & 1u);                               // right unless (0, 1)
+                if (pr == 3u) { ones = true; break; }
+                z++;
+            }
+            if (!ones && 2 * q == n) {                                          // a single child: the last slot
+                q = n;
+                if (smb_lab_get(lab, n)) ones = true; else z++;
+            }
+            if (ones) {                                                         // the rest of the path: right while there is one, then left
+                const int a = q + 1, bb = n + 1;
+                int t = (31 - __builtin_clz(bb)) - (31 - __builtin_clz(a));
+                if ((a << t) > bb) t--;
+                q = (a << t) - 1;
+                if (2 * q <= n) q = 2 * q;
+            }
+            const int leaf = q, k = 31 - __builtin_clz(leaf);
+            const int m = ll ? k : z - 1;
+            uint32_t mv = lastp;
+            const bool act = lane < m;
+            if (act) mv = ent[leaf >> (k - lane - 1)];
+            __builtin_amdgcn_wave_barrier();
+            if (act) ent[leaf >> (k - lane)] = mv;
+            if (lane == 0) ent[leaf >> (k - m)] = lastp;
+            if (ll) smb_lab_set(lab, leaf >> (k - z + 1), 1, lane);
+        }
+        rp = (uint32_t)__builtin_amdgcn_readfirstlane((int)rp);
+        const int x = (int)(rp & 255u), y = (int)((rp >> 8) & 63u) - SMB_YOFF, air = (int)((rp >> 14) & 7u);
+        if (y >= h) continue;                                                   // checkLose
+        const int depth = fmin - (exit_x - x);                                  // the popped item's label is 0
+        if (x >= exit_x) { status = 1; res = rp; break; }                       // checkWin
+        const int key = (x * ky + (y + SMB_YOFF)) * 8 + air;
+        const uint32_t bit = 1u << (key & 31);
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)visited[key >> 5]);
+        if (word & bit) continue;
+        if (lane == 0) visited[key >> 5] = word | bit;
+        const int hh = exit_x - x, bh = exit_x - best_x;
+        if (!have_best || hh < bh || (hh == bh && depth < best_depth)) { have_best = true; best_x = x; best_depth = depth; res = rp; }
+        if (n + 4 > cap) { status = 2; break; }
+        if (lane == 0) log[nexp] = rp;
+        uint32_t wx, wx1;
+        smb_window<2>(C, x, y, wx, wx1);
+        SmbState s = {x, y, air, 0, 0, 0, 0};
+        s = smb_child_win(s, lane & 3, wx, wx1, h);                             // Node.getChildren: (0,0), (1,0), (0,-1), (1,-1), one per lane
+        const uint32_t mine = (uint32_t)s.x | ((uint32_t)(s.y + SMB_YOFF) << 8) | ((uint32_t)s.air << 14) | ((uint32_t)nexp << 17);
+        nexp++;
+        if (lane < 4) ent[n + 1 + lane] = mine;
+        // labels of the four: 1 for a child that stayed in its column, 0 for one that moved right (children 1 and 3, both or neither)
+        const bool canr = !((wx1 >> 1) & 1u);
+        {
+            const int q0 = n + 1, sh = q0 & 31, w0 = q0 >> 5;
+            const uint64_t msk = 0xFull << sh, pat = (canr ? 0x5ull : 0xFull) << sh;
+            const uint32_t m_lo = (uint32_t)msk, m_hi = (uint32_t)(msk >> 32), p_lo = (uint32_t)pat, p_hi = (uint32_t)(pat >> 32);
+            if (lane == (w0 & 63)) { if (w0 < 64) lab.a = (lab.a & ~m_lo) | p_lo; else lab.b = (lab.b & ~m_lo) | p_lo; }
+            if (m_hi && lane == ((w0 + 1) & 63)) { if (w0 + 1 < 64) lab.a = (lab.a & ~m_hi) | p_hi; else lab.b = (lab.b & ~m_hi) | p_hi; }
+        }
+        n += 4;
+        if (canr) {
+            smb_climb(lab, ent, n - 2, (uint32_t)__builtin_amdgcn_readlane((int)mine, 1), lane);
+            smb_climb(lab, ent, n, (uint32_t)__builtin_amdgcn_readlane((int)mine, 3), lane);
+        }
+    }
+    // jump_locs of the result, from its ancestors (newest first): jumps, the last jump's column, the widest gap between
+    // successive jump columns counted from column 0 (smb_prob.py:155-166)
+    int jumps = 0, later = -1, max_gap = 0, prev_jump_x = 0;
+    if (status != 2) {
+        __threadfence_block();
+        uint32_t node = res;
+        for (;;) {
+            const uint32_t par = node >> 17;
+            if (par == SMB_ROOT_PAR) break;
+            const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&log[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (((node >> 14) & 7u) == 4u) {
+                const int jx = (int)(pe & 255u);
+                jumps++;
+                if (later < 0) prev_jump_x = jx;
+                else max_gap = later - jx > max_gap ? later - jx : max_gap;
+                later = jx;
+            }
+            node = pe;
+        }
+        if (later > max_gap) max_gap = later;
+    }
+    out.won = status == 1; out.jumps = jumps; out.prev_jump_x = prev_jump_x; out.max_gap = max_gap; out.x = (int)(res & 255u);
+    SP_ADD(2, 1); SP_ADD(3, iterations); SP_ADD(4, status == 2);
+    return status;
+}
+
+// SMBProblem.get_stats of one map (`m`: its tile bytes, in global memory or -- right after an in-kernel reset -- in LDS) by one
+// wavefront, and the end of the step / reset it belongs to (finalize_item).  Returns whether the episode ended (auto_reset).
+struct SmbWave {
+    uint32_t* heap; uint32_t* visited; uint8_t* arena; int lds_heap_n, vis_words;
+};
+__device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, const SmbWave& S, int e, int mode, const uint8_t* m, int parity, int rst_list,
+                                        bool push_reset, int lane) {
+    const int W = P.width, Hh = P.height, cells = W * Hh;
+    const int ew = W + 6;
+    const int exit_x = Hh > 3 ? W + 4 : -1;
+    // ---- the five statistics of the byte map (tiles: 0 empty 1 solid 2 enemy 3 brick 4 question 5 coin 6 tube)
+    int c_floor = 0, c_tubes = 0, c_enemy = 0, c_empty = 0, c_noise = 0;
+    for (int c = lane; c < cells; c += 64) {
+        const int y = c / W, x = c - y * W;
+        const int tl = m[c];
+        c_empty += tl == 0;
+        c_enemy += tl == 2;
+        if (x > 0) c_noise += tl != m[c - 1];
+        if (y > 0) c_noise += tl != m[c - W];
+        if (tl == 6) {
+            const int v = (x > 0 && m[c - 1] == 6) + (x < W - 1 && m[c + 1] == 6);
+            c_tubes += v == 1;
+        }
+        if (tl == 2) {                                            // _calc_dist_floor: the first floor tile at or below the cell
+            int r = Hh - 1;
+            for (int dy = 0; y + dy < Hh; dy++) {
+                const int tb = m[c + dy * W];
+                if (tb == 1 || tb == 3 || tb == 4) { r = dy - 1; break; }
+            }
+            c_floor += r;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_floor += __shfl_xor(c_floor, o, 64); c_tubes += __shfl_xor(c_tubes, o, 64); c_enemy += __shfl_xor(c_enemy, o, 64);
+        c_empty += __shfl_xor(c_empty, o, 64); c_noise += __shfl_xor(c_noise, o, 64);
+    }
+    // ---- the engine's grid (" # ## #": solid, brick, question and tube block) as column masks: lane l holds columns l + 64 k
+    SmbCols C;
+    {
+        uint64_t col[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ex = 64 * k + lane;
+            uint64_t c = ~0ull << (Hh + SMB_YOFF);
+            if (ex < ew) {
+                for (int y = 0; y < Hh; y++) {
+                    bool sol;
+                    if (ex < 3) sol = y > Hh - 3;
+                    else if (ex >= W + 3) sol = y > Hh - 3 || (y == Hh - 3 && ex == W + 4);
+                    else { const int tl = m[y * W + ex - 3]; sol = tl == 1 || tl == 3 || tl == 4 || tl == 6; }
+                    c |= (uint64_t)sol << (y + SMB_YOFF);
+                }
+            } else {
+                c = ~0ull << SMB_YOFF;
+            }
+            col[k] = c;
+        }
+        C.c0 = col[0]; C.c1 = col[1]; C.c2 = col[2]; C.c3 = col[3];
+    }
+    __builtin_amdgcn_wave_barrier();                                  // (m may be in the LDS the searches are about to use)
+    // ---- SMBProblem._run_game: AStarAgent with balance 1, then -- if it did not win -- balance 0 (smb_prob.py:133-141)
+    const bool two_label = ew <= 128 && P.solver_power < (int)SMB_ROOT_PAR;
+    const int cap = S.lds_heap_n - 1 < 4095 ? S.lds_heap_n - 1 : 4095;
+    uint2* pool = reinterpret_cast<uint2*>(S.arena);
+    const SmbHeap HP = {S.heap, reinterpret_cast<uint32_t*>(S.arena + (4 * (size_t)P.solver_power + 4) * 8), S.lds_heap_n};
+    SmbResult res = {0, 0, 0, 0, 1};
+#pragma clang loop unroll(disable)
+    for (int agent = 0; agent < 2 && !res.won; agent++) {
+        for (int i = lane; i < S.vis_words; i += 64) S.visited[i] = 0;
+        __threadfence_block();
+        int status = 2;
+        if (agent == 0 && two_label) {
+            const unsigned long long t0 = SP_NOW();
+            status = smb_search_two_label(C, Hh, exit_x, 1, Hh - 3, P.solver_power, S.heap, cap, S.visited, reinterpret_cast<uint32_t*>(S.arena), res, lane);
+            SP_ADD(5, SP_NOW() - t0);
+            __threadfence_block();
+            if (status == 2) {
+                for (int i = lane; i < S.vis_words; i += 64) S.visited[i] = 0;
+                __threadfence_block();
+            }
+        }
+        if (status == 2) {
+            const unsigned long long t0 = SP_NOW();
+            if (lane < 4) {
+                const SmbState root = {1, Hh - 3, 0, 0, 0, 0, 0};
+                smb_search(C, Hh, exit_x, root, agent == 0 ? 1 : 0, P.solver_power, pool, HP, S.visited, res, lane);
+            }
+            res.won = __shfl(res.won, 0, 64); res.jumps = __shfl(res.jumps, 0, 64); res.prev_jump_x = __shfl(res.prev_jump_x, 0, 64);
+            res.max_gap = __shfl(res.max_gap, 0, 64); res.x = __shfl(res.x, 0, 64);
+            SP_ADD(6, SP_NOW() - t0);
+            __threadfence_block();
+        }
+    }
+    int done = 0;
+    if (lane == 0) {
+        const int dist_win = res.won ? 0 : exit_x - res.x;
+        const int tail = P.prob_width - res.prev_jump_x;              // smb_prob.py:166: max(value, self._width - prev_jump)
+        const int jumps_dist = res.max_gap > tail ? res.max_gap : tail;
+        int32_t s[PCGRL_MAX_STATS] = {c_floor, c_tubes, c_enemy, c_empty, c_noise, res.jumps, jumps_dist, dist_win};
+        done = finalize_item<PCGRL_PROB_SMB>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), push_reset, rst_list) ? 1 : 0;
+    }
+    __threadfence_block();
+    return __shfl(done, 0, 64) != 0;
 }
 
 // Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  `sync[0]` (zeroed by the host) hands the jobs out, a
-// wavefront at a time.  Environments that finish their episode here go to `rst_list` (auto_reset).
-__global__ __launch_bounds__(SMB_WAVES * 64) void k_smb(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list,
-                                                        int32_t* sync, int clear_parity, int lds_heap_n) {
+// wavefront at a time.  An environment that finishes its episode here (a level that can be won ends it: smb_prob.py:191-192) is
+// reset by the same wavefront right away (`inline_reset`: PcgrlEnv.reset, reset_env.h; the new map's statistics and play-through
+// follow as MODE_START) -- one launch and one tail of long searches per step instead of two; without `inline_reset` it goes to
+// `rst_list`.
+__global__ __launch_bounds__(SMB_MAX_WAVES * 64) void k_smb(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list,
+                                                            int32_t* sync, int clear_parity, int lds_heap_n, int inline_reset, int gen_map) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smb_lds[];       // per wavefront: heap (lds_heap_n words), then the visited bitmap
-    __shared__ uint64_t s_rows[SMB_WAVES][SMB_MAX_H][4];
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
-    __shared__ int s_red[SMB_WAVES][8];
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
     const int n = n_a + n_b;
-    const int W = P.width, Hh = P.height, cells = W * Hh;
-    const int ew = W + 6, ky = Hh + SMB_YOFF + 1;
-    const int vis_words = (ew * ky * 8 + 31) / 32;
+    const int cells = P.width * P.height;
+    const int vis_words = ((P.width + 6) * (P.height + SMB_YOFF + 1) * 8 + 31) / 32;
     uint32_t* my_lds = smb_lds + (size_t)wv * (lds_heap_n + ((vis_words + 3) & ~3));
-    uint32_t* visited = my_lds + lds_heap_n;
-    uint8_t* arena = reinterpret_cast<uint8_t*>(B.sok_pool) + (size_t)blockIdx.x * B.sok_pool_stride * sizeof(SokNode) + (size_t)wv * smb_wave_arena_bytes(P.solver_power);
-    uint2* pool = reinterpret_cast<uint2*>(arena);
-    SmbHeap HP = {my_lds, reinterpret_cast<uint32_t*>(arena + (4 * (size_t)P.solver_power + 4) * 8), lds_heap_n};
-    uint64_t (*rows)[4] = s_rows[wv];
-    int* red = s_red[wv];
+    const SmbWave S = {my_lds, my_lds + lds_heap_n,
+                       reinterpret_cast<uint8_t*>(B.sok_pool) + (size_t)blockIdx.x * B.sok_pool_stride * sizeof(SokNode) + (size_t)wv * smb_wave_arena_bytes(P.solver_power),
+                       lds_heap_n, vis_words};
+    uint32_t* mt = my_lds;                                                    // in-kernel reset: MT19937 ring + tile bytes, where the heap is between searches
+    uint8_t* tiles = reinterpret_cast<uint8_t*>(my_lds + PCGRL_MT_N);
     for (;;) {
         int t = 0;
         if (lane == 0) t = atomicAdd(sync, 1);
@@ -216,74 +515,12 @@ __global__ __launch_bounds__(SMB_WAVES * 64) void k_smb(PcgrlParams P, DevBufs B
         int e, mode;
         if (t < n_a) { e = wl_get(B, list_a, s_pref_a, t); mode = mode_a; }
         else { e = wl_get(B, list_b, s_pref_b, t - n_a); mode = mode_b; }
-        const uint8_t* m = B.map + (size_t)e * cells;
-        // ---- the five statistics of the byte map (tiles: 0 empty 1 solid 2 enemy 3 brick 4 question 5 coin 6 tube)
-        int c_floor = 0, c_tubes = 0, c_enemy = 0, c_empty = 0, c_noise = 0;
-        for (int c = lane; c < cells; c += 64) {
-            const int y = c / W, x = c - y * W;
-            const int tl = m[c];
-            c_empty += tl == 0;
-            c_enemy += tl == 2;
-            if (x > 0) c_noise += tl != m[c - 1];
-            if (y > 0) c_noise += tl != m[c - W];
-            if (tl == 6) {
-                const int v = (x > 0 && m[c - 1] == 6) + (x < W - 1 && m[c + 1] == 6);
-                c_tubes += v == 1;
-            }
-            if (tl == 2) {                                            // _calc_dist_floor: the first floor tile at or below the cell
-                int r = Hh - 1;
-                for (int dy = 0; y + dy < Hh; dy++) {
-                    const int tb = m[c + dy * W];
-                    if (tb == 1 || tb == 3 || tb == 4) { r = dy - 1; break; }
-                }
-                c_floor += r;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            c_floor += __shfl_xor(c_floor, o, 64); c_tubes += __shfl_xor(c_tubes, o, 64); c_enemy += __shfl_xor(c_enemy, o, 64);
-            c_empty += __shfl_xor(c_empty, o, 64); c_noise += __shfl_xor(c_noise, o, 64);
-        }
-        // ---- the engine's grid as row bit masks (" # ## #": solid, brick, question and tube block)
-        for (int y = 0; y < Hh; y++) {
-            for (int k = 0; k < 4; k++) {
-                const int ex = 64 * k + lane;
-                bool sol = false;
-                if (ex < ew) {
-                    if (ex < 3) sol = y > Hh - 3;
-                    else if (ex >= W + 3) sol = y > Hh - 3 || (y == Hh - 3 && ex == W + 4);
-                    else { const int tl = m[y * W + ex - 3]; sol = tl == 1 || tl == 3 || tl == 4 || tl == 6; }
-                }
-                const uint64_t bal = __ballot(sol);
-                if (lane == 0) rows[y][k] = bal;
-            }
-        }
-        // ---- SMBProblem._run_game by one lane: AStarAgent with balance 1, then -- if it did not win -- balance 0 (smb_prob.py:133-141)
-        int won = 0;
-#pragma clang loop unroll(disable)
-        for (int agent = 0; agent < 2 && !won; agent++) {
-            for (int i = lane; i < vis_words; i += 64) visited[i] = 0;
+        const bool ended = smb_job(P, B, S, e, mode, B.map + (size_t)e * cells, parity, rst_list, !inline_reset, lane);
+        if (ended && inline_reset) {
+            wave_reset_env<PCGRL_PROB_SMB>(P, B, e, gen_map, mt, tiles, lane);
+            __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            if (lane < 4) {
-                SmbLevel L = {rows, ew, Hh, Hh > 3 ? W + 4 : -1};
-                SmbState root = {1, Hh - 3, 0, 0, 0, 0, 0}, res = root;
-                int it = 0;
-                const bool win = smb_search(L, root, agent == 0 ? 1 : 0, P.solver_power, pool, HP, visited, res, it, lane);
-                if (lane == 0) {
-                    red[0] = win ? 1 : 0;
-                    red[1] = res.jumps; red[2] = res.prev_jump_x; red[3] = res.max_gap; red[4] = res.x;
-                }
-            }
-            __threadfence_block();
-            won = red[0];
+            smb_job(P, B, S, e, MODE_START, tiles, parity, rst_list, false, lane);
         }
-        if (lane == 0) {
-            const int exit_x = Hh > 3 ? W + 4 : -1;
-            const int dist_win = red[0] ? 0 : exit_x - red[4];
-            const int tail = P.prob_width - red[2];                   // smb_prob.py:166: max(value, self._width - prev_jump)
-            const int jumps_dist = red[3] > tail ? red[3] : tail;
-            int32_t s[PCGRL_MAX_STATS] = {c_floor, c_tubes, c_enemy, c_empty, c_noise, red[1], jumps_dist, dist_win};
-            finalize_item<PCGRL_PROB_SMB>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), true, rst_list);
-        }
-        __threadfence_block();
     }
 }

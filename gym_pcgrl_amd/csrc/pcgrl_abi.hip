@@ -69,7 +69,7 @@ struct pcgrl_env {
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
     int alloc_solver_power;
     // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
-    int no_wide, wide_waves, wide_grid, fused_zelda, no_fused, step_epb;
+    int no_wide, wide_waves, wide_grid, fused_zelda, no_fused, step_epb, smb_heap;
     int profiling;
     std::vector<hipEvent_t> events;
     size_t ev_used;
@@ -164,8 +164,8 @@ static int sok_table_size(int power) { int t = 1024; while (t < 2 * power) t <<=
 // small-tier pools of k_step_solver (SS_SEARCH_WAVES wavefronts x SS_SMALL_NODES at pool + wv * SS_SMALL_NODES), so that a
 // small solver_power cannot make them spill into the next block's pool.
 static size_t sok_pool_nodes(int power, int prob = -1) {
-    if (prob == PCGRL_SMB)     // k_smb: SMB_WAVES searches per block, each with its own 8-byte-node pool + heap overflow (kernels_smb.h)
-        return (SMB_WAVES * smb_wave_arena_bytes(power) + sizeof(SokNode) - 1) / sizeof(SokNode);
+    if (prob == PCGRL_SMB)     // k_smb: up to SMB_MAX_WAVES searches per block, each with its own arena (kernels_smb.h)
+        return (SMB_MAX_WAVES * smb_wave_arena_bytes(power) + sizeof(SokNode) - 1) / sizeof(SokNode);
     const size_t full = 4 * (size_t)power + 4, small = (size_t)SS_SEARCH_WAVES * SS_SMALL_NODES;
     return full > small ? full : small;
 }
@@ -294,6 +294,9 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         const int n_ = h->cfg.num_envs;
         h->step_epb = eb ? atoi(eb) : ((n_ >= 192 * 256 && n_ <= 256 * 256) ? 256 : (n_ >= 192 * 128 ? 128 : 64));
         if (h->step_epb != 128 && h->step_epb != 256) h->step_epb = 64;
+        const char* sh_ = getenv("PCGRL_SMB_LDS_HEAP");        // developer switch: heap words a k_smb search keeps in LDS
+        h->smb_heap = sh_ ? atoi(sh_) : SMB_LDS_HEAP;
+        if (h->smb_heap < 256 || h->smb_heap > SMB_LDS_HEAP) h->smb_heap = SMB_LDS_HEAP;
     }
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
@@ -561,16 +564,23 @@ static int action_width(int rep) {   // int32 values per environment and step
 }
 
 static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
-                         hipStream_t st) {
+                         hipStream_t st, int inline_reset = 0) {
     const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
     int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
     HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
     if (h->P.prob == PCGRL_PROB_SMB) {
-        // per wavefront: the heap's LDS part (its first levels; a deeper heap continues in the arena) + the visited bitmap
-        const int heap_n = 4 * h->P.solver_power + 4 < SMB_LDS_HEAP ? ((4 * h->P.solver_power + 4 + 3) & ~3) : SMB_LDS_HEAP;
+        // per wavefront: the heap (smb_search: its first levels; a deeper heap continues in the arena) + the visited bitmap;
+        // as many wavefronts per block (one block per compute unit) as 160 KB of LDS hold, eight at most
+        int heap_n = 4 * h->P.solver_power + 4 < h->smb_heap ? ((4 * h->P.solver_power + 4 + 3) & ~3) : h->smb_heap;
+        const int reset_words = PCGRL_MT_N + ((h->P.width * h->P.height + 15) & ~15) / 4;       // the in-kernel reset stages its ring and tiles there
+        if (heap_n < reset_words) heap_n = (reset_words + 3) & ~3;
         const size_t vis_words = ((size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 8 + 31) / 32 + 3) & ~(size_t)3;
-        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(SMB_WAVES * 64), SMB_WAVES * ((size_t)heap_n + vis_words) * 4, st, h->P, h->B, list_a, mode_a, list_b,
-                           mode_b, parity, rst_list, sync, clr, heap_n);
+        const size_t per_wave = ((size_t)heap_n + vis_words) * 4;
+        int nw = (int)((160 * 1024 - 2048) / per_wave);
+        nw = nw > SMB_MAX_WAVES ? SMB_MAX_WAVES : (nw < 1 ? 1 : nw);
+        const int gen = (h->P.random_start || !h->has_old) ? 1 : 0;
+        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(nw * 64), nw * per_wave, st, h->P, h->B, list_a, mode_a, list_b,
+                           mode_b, parity, rst_list, sync, clr, heap_n, inline_reset, gen);
         HIPCHK(hipGetLastError());
         return PCGRL_OK;
     }
@@ -717,6 +727,13 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream, bool* us
     if ((rc = prof_mark(h, st))) return rc;
     if (ar && (rc = launch_reset(h, WL_RST, WL_SOL2, par, -1, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
+    if (smb && ar) {
+        // k_smb resets the environments whose episode its play-through ends itself (most levels can be won, and winning ends
+        // the episode): one launch, the last of the step
+        if ((rc = launch_solver(h, 0, WL_CHG, MODE_STEP, WL_SOL2, MODE_START, par, WL_RST2, par ^ 1, st, 1))) return rc;
+        for (int k = 0; k < 3; k++) if ((rc = prof_mark(h, st))) return rc;
+        return PCGRL_OK;
+    }
     if ((rc = launch_solver(h, 0, smb ? WL_CHG : WL_SOL, MODE_STEP, ar ? WL_SOL2 : -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     if (ar && (rc = launch_reset(h, WL_RST2, WL_SOL3, par, -1, st))) return rc;
@@ -877,8 +894,8 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     return PCGRL_OK;
 }
 
-#ifdef PCGRL_TIMELINE
-// debug build only (tools/timeline.py): where the kernels write their timeline marks (NULL: off)
+#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF)
+// debug build only (tools/timeline.py, tools/smb_prof.py): where the kernels write their timeline marks (NULL: off)
 int pcgrl_debug_timeline(void* buf) {
     unsigned long long* p = (unsigned long long*)buf;
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &p, sizeof(p)));

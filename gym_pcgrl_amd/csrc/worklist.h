@@ -40,9 +40,11 @@ template <int G> __device__ __forceinline__ unsigned wl_inc_code(int raw) { retu
 
 // Optional in-kernel timeline (tools/timeline.py builds a copy of the library with -DPCGRL_TIMELINE; the product is
 // compiled without it and TL() is nothing): wavefront-private slots, 100 MHz wall clock << 8 | tag.
+#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF)
+__device__ unsigned long long* g_tl_buf;
+#endif
 #ifdef PCGRL_TIMELINE
 #define TL_SLOTS 48
-__device__ unsigned long long* g_tl_buf;
 __shared__ int s_tl_idx[16];
 __device__ __forceinline__ void tl_mark(int tag) {
     if ((threadIdx.x & 63) == 0 && g_tl_buf) {
