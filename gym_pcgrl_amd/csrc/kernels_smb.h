@@ -234,7 +234,8 @@ __device__ __forceinline__ void smb_search(const SmbCols& C, int h, int exit_x, 
 //             leaf -- inside the label-1 part that is "right while there is one, then left", a closed form; the last item goes
 //             to the leaf and, if its label is 0, climbs back to just below the zeros of that path.  Net effect: the first m
 //             path entries move up one level and the last item lands on path position m (m = the leaf's depth for a label-1
-//             last item, the number of zeros on the path below the root otherwise), and at most one label flips.
+//             last item, the number of zeros on the path below the root otherwise), and at most one label flips.  The
+//             label-0 part of that path is the same from one pop to the next except at its end: it is kept, not searched for.
 // The labels of heap slots 1..4095 (1-based heap index) are bits spread over the wavefront's registers (word w in lane w & 63
 // of a / b), read with readlane: finding a path costs no memory access, and the moves along it are one LDS read and one LDS
 // write with a lane per level.  An item is 32 bits: x | (y + 8) << 8 | airTime << 14 | parent << 17, `parent` = the expansion
@@ -256,10 +257,56 @@ __device__ __forceinline__ void smb_lab_set(SmbLab& Lb, int q, int v, int lane) 
         else Lb.b = v ? (Lb.b | m) : (Lb.b & ~m);
     }
 }
-// a label-0 item just appended at slot q (its label bit already 0) climbs to its place
-__device__ __forceinline__ void smb_climb(SmbLab& lab, uint32_t* ent, int q, uint32_t item, int lane) {
-    int b = 0;
-    while ((q >> (b + 1)) >= 1 && smb_lab_get(lab, q >> (b + 1))) b++;
+// "right while there is one, then left" from slot q of a heap of n slots: the leaf the fill path of a pop ends on once it is
+// inside the label-1 part (and the whole path when every label is 0)
+__device__ __forceinline__ int smb_rightmost_leaf(int q, int n) {
+    const int a = q + 1, bb = n + 1;
+    int t = (31 - __builtin_clz(bb)) - (31 - __builtin_clz(a));
+    if ((a << t) > bb) t--;
+    q = (a << t) - 1;
+    return 2 * q <= n ? 2 * q : q;
+}
+// The chain "root, then the right child if its label is 0, else the left child if its label is 0" is the part of a pop's fill
+// path that lies among the label-0 items; `u` is its last slot (0: there is no label-0 item).  It is kept up to date across
+// pushes and pops (a push adds one label-0 slot, a pop takes away at most the chain's end and the last slot), so a pop does not
+// walk down from the root: only when the end of the chain goes away and its left sibling carries a label 0 does the chain
+// continue downwards from there (1.2 steps a pop on average instead of 6.5).
+__device__ __forceinline__ int smb_chain_descend(const SmbLab& lab, int q, int n) {
+    for (;;) {
+        const int c = 2 * q;
+        if (c > n) return q;
+        const uint32_t w = smb_lab_word(lab, c >> 5) >> (c & 31);          // bit 0: label(left), bit 1: label(right)
+        if (c < n && !(w & 2u)) q = c + 1;
+        else if (!(w & 1u)) q = c;
+        else return q;
+    }
+}
+__device__ __forceinline__ int smb_chain_remove_end(const SmbLab& lab, int e, int n) {      // slot e, the chain's end, is no label-0 slot any more
+    if (e == 1) return 0;
+    if ((e & 1) && smb_lab_get(lab, e - 1) == 0) return smb_chain_descend(lab, e - 1, n);   // (e - 1 < e <= n + 1)
+    return e >> 1;
+}
+__device__ __forceinline__ int smb_chain_add(int u, int g) {                                 // slot g (its parent has label 0, or g = 1) got label 0
+    if (g == 1) return 1;
+    if (u == 0) return u;
+    const int p = g >> 1;
+    const int du = 31 - __builtin_clz(u), dp = 31 - __builtin_clz(p);
+    if (du >= dp && (u >> (du - dp)) == p && (p == u || (g & 1))) return g;
+    return u;
+}
+// a label-0 item just appended at slot q (its label bit already 0) climbs to its place; returns the slot it ends on
+__device__ __forceinline__ int smb_climb(SmbLab& lab, uint32_t* ent, int q, uint32_t item, int lane) {
+    // b = how many label-1 ancestors it passes: lane j looks at the j-th ancestor (the label words come over with bpermute),
+    // one ballot (labels along a root path are zeros, then ones)
+    const int sh = lane + 1 < 31 ? lane + 1 : 31;
+    const int anc = q >> sh, w = anc >> 5;
+    uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((w & 63) << 2, (int)lab.a);
+    if (q >= 2048) {                                                            // (wavefront-uniform) slots 2048.. have their labels in b
+        const uint32_t wb = (uint32_t)__builtin_amdgcn_ds_bpermute((w & 63) << 2, (int)lab.b);
+        word = w < 64 ? word : wb;
+    }
+    const bool one = anc >= 1 && ((word >> (anc & 31)) & 1u);
+    const int b = __builtin_ctzll(~__ballot(one));
     if (b > 0) {
         uint32_t mv = item;
         if (lane < b) mv = ent[q >> (lane + 1)];
@@ -269,12 +316,13 @@ __device__ __forceinline__ void smb_climb(SmbLab& lab, uint32_t* ent, int q, uin
         smb_lab_set(lab, q >> b, 0, lane);
         smb_lab_set(lab, q, 1, lane);
     }
+    return q >> b;
 }
 __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int exit_x, int root_x, int root_y, int power, uint32_t* ent, int cap,
                                                     uint32_t* visited, uint32_t* log, SmbResult& out, int lane) {
     const int ky = h + SMB_YOFF + 1;
     SmbLab lab = {0u, 0u};
-    int n = 1, iterations = 0, nexp = 0, fmin = exit_x - root_x;
+    int n = 1, u = 1, iterations = 0, nexp = 0, fmin = exit_x - root_x;
     const uint32_t root = (uint32_t)root_x | ((uint32_t)(root_y + SMB_YOFF) << 8) | (SMB_ROOT_PAR << 17);
     if (lane == 0) ent[1] = root;
     bool have_best = false;
@@ -284,39 +332,29 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
         iterations++;
         uint32_t rp = ent[1];
         const uint32_t lastp = ent[n];
-        if (smb_lab_word(lab, 0) & 2u) { lab.a = 0u; lab.b = 0u; fmin++; }      // no label-0 item left: the ones become the zeros
+        const bool relabel = (smb_lab_word(lab, 0) & 2u) != 0;                  // no label-0 item left: the ones become the zeros
+        if (relabel) { lab.a = 0u; lab.b = 0u; fmin++; }
         const int ll = smb_lab_get(lab, n);
+        const int nold = n;
         n--;
         if (n > 0) {
-            int q = 1, z = 1;
-            bool ones = false;
-            while (2 * q + 1 <= n) {                                            // both children exist
-                const int c = 2 * q;
-                const uint32_t pr = (smb_lab_word(lab, c >> 5) >> (c & 31)) & 3u;   // label(left) | label(right) << 1
-                q = c + (int)((0xBu >> pr) & 1u);                               // right unless (0, 1)
-                if (pr == 3u) { ones = true; break; }
-                z++;
-            }
-            if (!ones && 2 * q == n) {                                          // a single child: the last slot
-                q = n;
-                if (smb_lab_get(lab, n)) ones = true; else z++;
-            }
-            if (ones) {                                                         // the rest of the path: right while there is one, then left
-                const int a = q + 1, bb = n + 1;
-                int t = (31 - __builtin_clz(bb)) - (31 - __builtin_clz(a));
-                if ((a << t) > bb) t--;
-                q = (a << t) - 1;
-                if (2 * q <= n) q = 2 * q;
-            }
-            const int leaf = q, k = 31 - __builtin_clz(leaf);
-            const int m = ll ? k : z - 1;
+            if (relabel) u = smb_rightmost_leaf(1, n);
+            else if (u == nold) u = smb_chain_remove_end(lab, nold, n);
+            // the fill path: the chain, and for a label-1 last item on through the ones to a leaf; every entry on it moves up
+            // one level and the last item takes the end of it
+            const int leaf = ll ? smb_rightmost_leaf(u, n) : u, k = 31 - __builtin_clz(leaf);
             uint32_t mv = lastp;
-            const bool act = lane < m;
+            const bool act = lane < k;
             if (act) mv = ent[leaf >> (k - lane - 1)];
             __builtin_amdgcn_wave_barrier();
             if (act) ent[leaf >> (k - lane)] = mv;
-            if (lane == 0) ent[leaf >> (k - m)] = lastp;
-            if (ll) smb_lab_set(lab, leaf >> (k - z + 1), 1, lane);
+            if (lane == 0) ent[leaf] = lastp;
+            if (ll) {                                                           // the labels on the path move up with the entries: one flip
+                smb_lab_set(lab, u, 1, lane);
+                u = smb_chain_remove_end(lab, u, n);
+            }
+        } else {
+            u = 0;
         }
         rp = (uint32_t)__builtin_amdgcn_readfirstlane((int)rp);
         const int x = (int)(rp & 255u), y = (int)((rp >> 8) & 63u) - SMB_YOFF, air = (int)((rp >> 14) & 7u);
@@ -350,8 +388,8 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
         }
         n += 4;
         if (canr) {
-            smb_climb(lab, ent, n - 2, (uint32_t)__builtin_amdgcn_readlane((int)mine, 1), lane);
-            smb_climb(lab, ent, n, (uint32_t)__builtin_amdgcn_readlane((int)mine, 3), lane);
+            u = smb_chain_add(u, smb_climb(lab, ent, n - 2, (uint32_t)__builtin_amdgcn_readlane((int)mine, 1), lane));
+            u = smb_chain_add(u, smb_climb(lab, ent, n, (uint32_t)__builtin_amdgcn_readlane((int)mine, 3), lane));
         }
     }
     // jump_locs of the result, from its ancestors (newest first): jumps, the last jump's column, the widest gap between
