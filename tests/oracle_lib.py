@@ -58,8 +58,9 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(SO)
+        # PCGRL_ORACLE_SO: another build of the same source (oracle/Makefile `sanitize`: ASan + UBSan, run with LD_PRELOAD=libasan)
+        so = os.environ.get("PCGRL_ORACLE_SO") or build()
+        L = C.CDLL(so)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int]
         L.orc_destroy.argtypes = [C.c_void_p]

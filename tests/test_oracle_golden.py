@@ -147,3 +147,31 @@ def test_trajectory(path):
         assert np.array_equal(out["done"], d["done"][:, i])
         assert np.array_equal(out["info"], d["info"][:, i]), np.nonzero((out["info"] != d["info"][:, i]).any(1))[0][:3]
         assert np.array_equal(out["reward"], d["reward"][:, i])
+
+
+def test_oracle_under_sanitizers():
+    """the oracle built with AddressSanitizer + UndefinedBehaviorSanitizer (oracle/Makefile `sanitize`) replays
+    one statistics file and one trajectory of every problem -- same answers, no sanitizer report."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("PCGRL_ORACLE_SO"):
+        pytest.skip("already running on a substituted oracle build")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip() if shutil.which("gcc") else ""
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan on this host")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "sanitize"])
+    picks = []
+    for prob in ("binary", "zelda", "sokoban", "mdungeon", "ddave", "smb"):
+        picks.append(sorted(glob.glob(os.path.join(G, "stats_%s_*.npz" % prob)))[0])
+        picks.append(sorted(glob.glob(os.path.join(G, "traj_%s_*.npz" % prob)))[0])
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_oracle_golden as t\n"
+            "for p in %r:\n"
+            "    (t.test_stats_kat if '/stats_' in p else t.test_trajectory)(p)\n"
+            "print('replayed', %d)\n") % (os.path.join(root, "tests"), root, picks, len(picks))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", PCGRL_ORACLE_SO=os.path.join(root, "oracle", "_san", "libpcgrl_oracle.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "replayed %d" % len(picks) in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
