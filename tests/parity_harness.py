@@ -140,6 +140,7 @@ FULLSIZE_CASES = {
     "C4": ("sokoban", "narrow", (), 131072, 40),
     "M1": ("mdungeon", "narrow", (), 65536, 40),
     "D1": ("ddave", "narrow", (), 65536, 40),
+    "S1": ("smb", "narrow", (), 16384, 30),
 }
 
 

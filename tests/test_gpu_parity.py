@@ -1010,7 +1010,7 @@ def test_fuzz_slice(chunk):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_rollout", [False, True], ids=["steps", "rollout"])
-@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "M1", "D1"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "M1", "D1", "S1"])
 def test_full_size_vs_oracle(name, use_rollout):
     """tools/fullsize_parity.py under the driver: the benchmark configurations at their real batch sizes (paired certain
     resets, every difficulty bucket in use, 512 environments per persistent block), 294 sampled environments compared with
