@@ -413,6 +413,22 @@ class BatchedPcgrlEnv:
         if not self._torch.equal(self._bufs["stats"][:, :n], stats[:, :n]):   # ... which must be the ones that were saved
             raise ValueError("state_dict is inconsistent: the saved stats are not the stats of the saved maps")
 
+    def set_graphics(self, graphics):
+        """Tile pictures for render(): None = the reference's grey fallback (the default), "drawn" = the package's own
+        pictures (envs/tile_art.py), or a dict {tile name: tile_size x tile_size x 3 image} -- the reference's `_graphics`."""
+        if graphics is None:
+            self._graphics = None
+            return
+        if isinstance(graphics, str):
+            if graphics != "drawn":
+                raise ValueError("unknown graphics %r" % (graphics,))
+            from .tile_art import make_graphics
+            graphics = make_graphics(self._prob.tiles, int(self._prob._tile_size))
+        missing = [t for t in self._prob.tiles if t not in graphics]
+        if missing:
+            raise KeyError("no picture for tiles %r" % (missing,))
+        self._graphics = dict(graphics)
+
     def render(self, mode="rgb_array", index=0):
         """Image of environment `index` with the reference's layout (pcgrl_env.py:161-175): 16-pixel tiles, a one-tile
         border of the border tile (problem.py:142-156), a two-pixel red frame on the cursor cell for narrow/turtle
@@ -428,9 +444,14 @@ class BatchedPcgrlEnv:
         h, w = m.shape
         full = np.full((h + 2 * by, w + 2 * bx), tiles.index(self._prob._border_tile), dtype=np.int64)
         full[by:by + h, bx:bx + w] = m
-        grey = np.array([int(i * 255 / len(tiles)) for i in range(len(tiles))], dtype=np.uint8)
-        img = np.repeat(np.repeat(grey[full], ts, axis=0), ts, axis=1)
-        img = np.stack([img, img, img], -1)
+        gfx = getattr(self, "_graphics", None)
+        if gfx is None:
+            grey = np.array([int(i * 255 / len(tiles)) for i in range(len(tiles))], dtype=np.uint8)
+            img = np.repeat(np.repeat(grey[full], ts, axis=0), ts, axis=1)
+            img = np.stack([img, img, img], -1)
+        else:                                             # Problem.render with a `_graphics` dict (problem.py:128-156)
+            pal = np.stack([np.asarray(gfx[t], dtype=np.uint8)[:ts, :ts, :3] for t in tiles])       # [tile, ts, ts, 3]
+            img = pal[full].transpose(0, 2, 1, 3, 4).reshape(full.shape[0] * ts, full.shape[1] * ts, 3).copy()
         if self._rep.has_pos:
             x, y = [int(v) for v in self._bufs["pos"][index].cpu().numpy()]
             y0, x0 = (y + by) * ts, (x + bx) * ts

@@ -70,5 +70,9 @@ class PcgrlEnv(gym_compat.env_base()):
         viewer is not a dependency) and returns the image as well."""
         return self._batched.render("rgb_array", 0)
 
+    def set_graphics(self, graphics):
+        """None (grey fallback), "drawn" (envs/tile_art.py) or the reference's {tile name: image} dict."""
+        self._batched.set_graphics(graphics)
+
     def close(self):
         self._batched.close()

@@ -662,6 +662,23 @@ def test_render_layout():
     wide = gp.make("binary-wide-v0")
     wide.reset()
     assert (np.asarray(wide.render()) != np.array([255, 0, 0])).any(-1).all()   # no cursor for wide
+    # tile pictures instead of the grey fallback: the package's own drawings, or a caller's dict (the reference's `_graphics`)
+    from gym_pcgrl_amd.envs import tile_art
+    env.set_graphics("drawn")
+    img2 = np.asarray(env.render("rgb_array"))
+    art = tile_art.make_graphics(env._prob.tiles, 16)
+    tiles = env._prob.tiles
+    for yy in range(h):
+        for xx in range(w):
+            if (xx, yy) != (x, y):
+                assert np.array_equal(img2[(yy + 1) * 16:(yy + 2) * 16, (xx + 1) * 16:(xx + 2) * 16], art[tiles[obs["map"][yy, xx]]])
+    assert np.array_equal(img2[:16, :16], art["solid"]) and tuple(img2[(y + 1) * 16, (x + 1) * 16]) == (255, 0, 0)
+    env.set_graphics({t: np.full((16, 16, 3), 10 * i, np.uint8) for i, t in enumerate(tiles)})
+    assert np.asarray(env.render())[8, 8, 0] == 10 * tiles.index("solid")
+    with pytest.raises(KeyError):
+        env.set_graphics({"empty": np.zeros((16, 16, 3), np.uint8)})
+    env.set_graphics(None)
+    assert np.array_equal(np.asarray(env.render("rgb_array")), img)
 
 
 @pytest.mark.gpu

@@ -212,3 +212,18 @@ def test_fuzz_slice_covers_every_problem_and_representation():
             else:
                 [rs.randint(0, int(k), size=(Ts, E)) for k in sp.nvec]
     assert probs == {"binary", "zelda", "sokoban", "mdungeon", "ddave", "smb"} and len(reps) == 6 and hows == {"rollout", "mixed", "steps"}, (probs, reps, hows)
+
+
+def test_tile_art_pictures():
+    """envs/tile_art.py: a picture for every tile of every problem, distinct from each other, deterministic."""
+    from gym_pcgrl_amd.envs import tile_art
+    from gym_pcgrl_amd.envs.problems import PROBLEMS
+    for name, cls in PROBLEMS.items():
+        tiles = cls().tiles
+        g = tile_art.make_graphics(tiles, 16)
+        assert sorted(g) == sorted(tiles)
+        flat = [g[t].tobytes() for t in tiles]
+        assert len(set(flat)) == len(tiles), name                      # no two tiles look the same
+        assert all(v.shape == (16, 16, 3) and v.dtype == np.uint8 for v in g.values())
+        assert g[tiles[0]].tobytes() == tile_art.draw_tile(tiles[0], 16).tobytes()
+    assert tile_art.draw_tile("no-such-tile", 8).shape == (8, 8, 3)
