@@ -557,6 +557,38 @@ def test_ddave_generic_search_path(path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_smb_*.npz"))), ids=os.path.basename)
+def test_smb_search_fallback_path(path, monkeypatch):
+    """k_smb runs the balance-1 play-through on a two-label heap of at most 4 095 slots in LDS and repeats a search whose
+    queue outgrows that with the general search (lanes 0..3, heap continued in global memory) -- which no level of the
+    default size ever needs.  PCGRL_SMB_LDS_HEAP=1024 makes most full-size levels outgrow it: same answers."""
+    _torch()
+    monkeypatch.setenv("PCGRL_SMB_LDS_HEAP", "1024")
+    d = np.load(path)
+    maps = d["maps"]
+    n, h, w = maps.shape
+    env = _make("smb", "wide", n, [dict(width=w, height=h)])
+    env._prob._solver_power = int(d["solver_power"])
+    env.adjust_param()
+    env.reset()
+    env.set_maps(maps)
+    got = env.stats.cpu().numpy().astype(np.int64)
+    assert env.check_status() == 0
+    assert np.array_equal(got, d["stats"])
+
+
+@pytest.mark.gpu
+def test_smb_search_fallback_rollout_vs_oracle(monkeypatch):
+    """The same switch on stepping environments (resets inside k_smb, both searches, the overflow path): 24 environments,
+    40 steps against the oracle."""
+    _torch()
+    import parity_harness as ph
+    monkeypatch.setenv("PCGRL_SMB_LDS_HEAP", "1024")
+    err = ph.run_config("smb", "narrow", [], 24, 40, 77, np.random.RandomState(5), False)
+    assert err is None, err
+
+
+@pytest.mark.gpu
 def test_ddave_large_solver_power_vs_oracle():
     """ddave levels with a solver_power beyond the LDS heap (heap and visited table in the global arena) against the
     oracle: open levels with ledges, many diamonds."""
