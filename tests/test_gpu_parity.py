@@ -578,6 +578,21 @@ def test_smb_search_fallback_path(path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [(130, 14), (250, 8), (60, 32), (122, 20), (123, 5), (7, 3)], ids=lambda s: "%dx%d" % s)
+def test_smb_sizes_vs_oracle(size):
+    """smb beyond the registered 114 x 14: levels wider than 122 (the engine's grid no longer fits two column registers per
+    lane: the general search does the balance-1 play-through too), the widest and the tallest the kernel takes, the
+    boundary between the two searches, and the smallest -- 6 environments, 16 steps against the oracle, blocked and open maps."""
+    _torch()
+    import parity_harness as ph
+    w, h = size
+    for k, calls in enumerate(([dict(width=w, height=h)],
+                               [dict(width=w, height=h), dict(probs={"empty": 0.5, "solid": 0.4, "tube": 0.05})])):
+        err = ph.run_config("smb", "narrow" if k == 0 else "wide", calls, 6, 16, 300 + k, np.random.RandomState(11 + k), False)
+        assert err is None, err
+
+
+@pytest.mark.gpu
 def test_smb_search_fallback_rollout_vs_oracle(monkeypatch):
     """The same switch on stepping environments (resets inside k_smb, both searches, the overflow path): 24 environments,
     40 steps against the oracle."""
