@@ -23,7 +23,8 @@
 //  * smb_search -- any balance, lanes 0..3 (the four children of a pop side by side), 8-byte nodes in the wavefront's global
 //    arena and a heap of packed (priority << 16 | node) words whose first levels are in LDS: balance 0 (short searches on the
 //    levels balance 1 did not win) and whatever does not fit the first.
-// LDS per search: 4 096 heap words + the visited bitmap over (x, y, airTime): ~19 KB, eight searches per compute unit.
+// LDS per search: 2 048 heap words (deeper slots: the wavefront's arena) + the visited bitmap over (x, y, airTime): ~10 KB,
+// sixteen searches per compute unit.
 #pragma once
 
 // developer build only (tools/smb_prof.py: -DPCGRL_SMB_PROF): cycles and pops of the searches, summed into g_tl_buf
@@ -35,8 +36,8 @@
 #define SP_NOW() 0ull
 #endif
 
-#define SMB_LDS_HEAP 4096      /* heap words a search keeps in LDS; smb_search's deeper levels live in its arena */
-#define SMB_MAX_WAVES 8        /* searches a block runs side by side, a wavefront each (the launch takes as many as its LDS allows) */
+#define SMB_LDS_HEAP 2048      /* heap words a search keeps in LDS; deeper levels (slots) live in its arena */
+#define SMB_MAX_WAVES 16       /* searches a block runs side by side, a wavefront each (the launch takes as many as its LDS allows) */
 #define SMB_MAX_H 32
 #define SMB_YOFF 8             /* y ranges over [-5, H): a jump from the top row rises four cells above the screen */
 #define SMB_ROOT_PAR 0x3FFFu
@@ -192,7 +193,7 @@ __device__ __forceinline__ void smb_search(const SmbCols& C, int h, int exit_x, 
         const SmbState s = smb_unpack(raw);
         if (s.y >= h) continue;                                       // checkLose
         if (s.x >= exit_x) { win = true; best = s; break; }           // checkWin
-        const int key = (s.x * ky + (s.y + SMB_YOFF)) * 8 + s.air;
+        const int key = (s.x * ky + (s.y + SMB_YOFF)) * 5 + s.air;          // airTime of a stored state is 0..4
         const uint32_t bit = 1u << (key & 31);
         const uint32_t word = visited[key >> 5];
         if (word & bit) continue;
@@ -294,8 +295,19 @@ __device__ __forceinline__ int smb_chain_add(int u, int g) {                    
     if (du >= dp && (u >> (du - dp)) == p && (p == u || (g & 1))) return g;
     return u;
 }
+// The items of the two-label heap: slots below `lds_n` in LDS, the rest (the deepest level of a large heap: only the searches
+// whose queue grows beyond lds_n slots ever touch it) in the wavefront's arena.  Half the LDS per search buys twice the
+// searches per compute unit; a slot in the arena costs the wavefront that needs it a memory round trip, which the other
+// wavefronts of the SIMD fill.
+struct SmbItems {
+    uint32_t* lds; uint32_t* glob; int lds_n;
+    __device__ __forceinline__ uint32_t get(int q) const {
+        return q < lds_n ? lds[q] : __hip_atomic_load(&glob[q - lds_n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void set(int q, uint32_t v) const { if (q < lds_n) lds[q] = v; else glob[q - lds_n] = v; }
+};
 // a label-0 item just appended at slot q (its label bit already 0) climbs to its place; returns the slot it ends on
-__device__ __forceinline__ int smb_climb(SmbLab& lab, uint32_t* ent, int q, uint32_t item, int lane) {
+__device__ __forceinline__ int smb_climb(SmbLab& lab, const SmbItems& ent, int q, uint32_t item, int lane) {
     // b = how many label-1 ancestors it passes: lane j looks at the j-th ancestor (the label words come over with bpermute),
     // one ballot (labels along a root path are zeros, then ones)
     const int sh = lane + 1 < 31 ? lane + 1 : 31;
@@ -309,29 +321,29 @@ __device__ __forceinline__ int smb_climb(SmbLab& lab, uint32_t* ent, int q, uint
     const int b = __builtin_ctzll(~__ballot(one));
     if (b > 0) {
         uint32_t mv = item;
-        if (lane < b) mv = ent[q >> (lane + 1)];
+        if (lane < b) mv = ent.lds[q >> (lane + 1)];                              // (ancestors: always in LDS)
         __builtin_amdgcn_wave_barrier();
-        if (lane < b) ent[q >> lane] = mv;
-        if (lane == 0) ent[q >> b] = item;
+        if (lane < b) ent.set(q >> lane, mv);
+        if (lane == 0) ent.lds[q >> b] = item;
         smb_lab_set(lab, q >> b, 0, lane);
         smb_lab_set(lab, q, 1, lane);
     }
     return q >> b;
 }
-__device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int exit_x, int root_x, int root_y, int power, uint32_t* ent, int cap,
+__device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int exit_x, int root_x, int root_y, int power, const SmbItems& ent, int cap,
                                                     uint32_t* visited, uint32_t* log, SmbResult& out, int lane) {
     const int ky = h + SMB_YOFF + 1;
     SmbLab lab = {0u, 0u};
     int n = 1, u = 1, iterations = 0, nexp = 0, fmin = exit_x - root_x;
     const uint32_t root = (uint32_t)root_x | ((uint32_t)(root_y + SMB_YOFF) << 8) | (SMB_ROOT_PAR << 17);
-    if (lane == 0) ent[1] = root;
+    if (lane == 0) ent.lds[1] = root;
     bool have_best = false;
     int status = 0, best_x = root_x, best_depth = 0;
     uint32_t res = root;
     while (iterations < power && n > 0) {
         iterations++;
-        uint32_t rp = ent[1];
-        const uint32_t lastp = ent[n];
+        uint32_t rp = ent.lds[1];
+        const uint32_t lastp = ent.get(n);
         const bool relabel = (smb_lab_word(lab, 0) & 2u) != 0;                  // no label-0 item left: the ones become the zeros
         if (relabel) { lab.a = 0u; lab.b = 0u; fmin++; }
         const int ll = smb_lab_get(lab, n);
@@ -345,10 +357,10 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
             const int leaf = ll ? smb_rightmost_leaf(u, n) : u, k = 31 - __builtin_clz(leaf);
             uint32_t mv = lastp;
             const bool act = lane < k;
-            if (act) mv = ent[leaf >> (k - lane - 1)];
+            if (act) mv = ent.get(leaf >> (k - lane - 1));
             __builtin_amdgcn_wave_barrier();
-            if (act) ent[leaf >> (k - lane)] = mv;
-            if (lane == 0) ent[leaf] = lastp;
+            if (act) ent.lds[leaf >> (k - lane)] = mv;                          // (a parent: in LDS)
+            if (lane == 0) ent.set(leaf, lastp);
             if (ll) {                                                           // the labels on the path move up with the entries: one flip
                 smb_lab_set(lab, u, 1, lane);
                 u = smb_chain_remove_end(lab, u, n);
@@ -361,7 +373,7 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
         if (y >= h) continue;                                                   // checkLose
         const int depth = fmin - (exit_x - x);                                  // the popped item's label is 0
         if (x >= exit_x) { status = 1; res = rp; break; }                       // checkWin
-        const int key = (x * ky + (y + SMB_YOFF)) * 8 + air;
+        const int key = (x * ky + (y + SMB_YOFF)) * 5 + air;                // airTime of a stored state is 0..4
         const uint32_t bit = 1u << (key & 31);
         const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)visited[key >> 5]);
         if (word & bit) continue;
@@ -376,7 +388,7 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
         s = smb_child_win(s, lane & 3, wx, wx1, h);                             // Node.getChildren: (0,0), (1,0), (0,-1), (1,-1), one per lane
         const uint32_t mine = (uint32_t)s.x | ((uint32_t)(s.y + SMB_YOFF) << 8) | ((uint32_t)s.air << 14) | ((uint32_t)nexp << 17);
         nexp++;
-        if (lane < 4) ent[n + 1 + lane] = mine;
+        if (lane < 4) ent.set(n + 1 + lane, mine);
         // labels of the four: 1 for a child that stayed in its column, 0 for one that moved right (children 1 and 3, both or neither)
         const bool canr = !((wx1 >> 1) & 1u);
         {
@@ -480,9 +492,11 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
     __builtin_amdgcn_wave_barrier();                                  // (m may be in the LDS the searches are about to use)
     // ---- SMBProblem._run_game: AStarAgent with balance 1, then -- if it did not win -- balance 0 (smb_prob.py:133-141)
     const bool two_label = ew <= 128 && P.solver_power < (int)SMB_ROOT_PAR;
-    const int cap = S.lds_heap_n - 1 < 4095 ? S.lds_heap_n - 1 : 4095;
     uint2* pool = reinterpret_cast<uint2*>(S.arena);
     const SmbHeap HP = {S.heap, reinterpret_cast<uint32_t*>(S.arena + (4 * (size_t)P.solver_power + 4) * 8), S.lds_heap_n};
+    const SmbItems items = {S.heap, HP.glob, S.lds_heap_n};           // (the arena part of smb_search's heap: free while this search runs)
+    // the label bits cover slots 1..4095; the parents of all of them (slots < 2048) must be in LDS for the arena part to be used
+    const int cap = S.lds_heap_n >= 2048 ? 4095 : S.lds_heap_n - 1;
     SmbResult res = {0, 0, 0, 0, 1};
 #pragma clang loop unroll(disable)
     for (int agent = 0; agent < 2 && !res.won; agent++) {
@@ -491,7 +505,7 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
         int status = 2;
         if (agent == 0 && two_label) {
             const unsigned long long t0 = SP_NOW();
-            status = smb_search_two_label(C, Hh, exit_x, 1, Hh - 3, P.solver_power, S.heap, cap, S.visited, reinterpret_cast<uint32_t*>(S.arena), res, lane);
+            status = smb_search_two_label(C, Hh, exit_x, 1, Hh - 3, P.solver_power, items, cap, S.visited, reinterpret_cast<uint32_t*>(S.arena), res, lane);
             SP_ADD(5, SP_NOW() - t0);
             __threadfence_block();
             if (status == 2) {
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(SMB_MAX_WAVES * 64) void k_smb(PcgrlParams P, DevBu
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
     const int n = n_a + n_b;
     const int cells = P.width * P.height;
-    const int vis_words = ((P.width + 6) * (P.height + SMB_YOFF + 1) * 8 + 31) / 32;
+    const int vis_words = ((P.width + 6) * (P.height + SMB_YOFF + 1) * 5 + 31) / 32;
     uint32_t* my_lds = smb_lds + (size_t)wv * (lds_heap_n + ((vis_words + 3) & ~3));
     const SmbWave S = {my_lds, my_lds + lds_heap_n,
                        reinterpret_cast<uint8_t*>(B.sok_pool) + (size_t)blockIdx.x * B.sok_pool_stride * sizeof(SokNode) + (size_t)wv * smb_wave_arena_bytes(P.solver_power),

@@ -296,7 +296,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         if (h->step_epb != 128 && h->step_epb != 256) h->step_epb = 64;
         const char* sh_ = getenv("PCGRL_SMB_LDS_HEAP");        // developer switch: heap words a k_smb search keeps in LDS
         h->smb_heap = sh_ ? atoi(sh_) : SMB_LDS_HEAP;
-        if (h->smb_heap < 256 || h->smb_heap > SMB_LDS_HEAP) h->smb_heap = SMB_LDS_HEAP;
+        if (h->smb_heap < 256 || h->smb_heap > 4096) h->smb_heap = SMB_LDS_HEAP;
     }
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
@@ -574,7 +574,7 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
         int heap_n = 4 * h->P.solver_power + 4 < h->smb_heap ? ((4 * h->P.solver_power + 4 + 3) & ~3) : h->smb_heap;
         const int reset_words = PCGRL_MT_N + ((h->P.width * h->P.height + 15) & ~15) / 4;       // the in-kernel reset stages its ring and tiles there
         if (heap_n < reset_words) heap_n = (reset_words + 3) & ~3;
-        const size_t vis_words = ((size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 8 + 31) / 32 + 3) & ~(size_t)3;
+        const size_t vis_words = ((size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 5 + 31) / 32 + 3) & ~(size_t)3;
         const size_t per_wave = ((size_t)heap_n + vis_words) * 4;
         int nw = (int)((160 * 1024 - 2048) / per_wave);
         nw = nw > SMB_MAX_WAVES ? SMB_MAX_WAVES : (nw < 1 ? 1 : nw);
