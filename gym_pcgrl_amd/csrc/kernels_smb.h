@@ -51,7 +51,7 @@ __host__ __device__ __forceinline__ size_t smb_wave_arena_bytes(int power) {
 
 struct SmbCols { uint64_t c0, c1, c2, c3; };
 struct SmbState { int x, y, air, depth, jumps, prev_jump_x, max_gap; };
-struct SmbResult { int won, jumps, prev_jump_x, max_gap, x; };
+struct SmbResult { int won, jumps, prev_jump_x, max_gap, x, iters; };
 
 __device__ __forceinline__ uint64_t smb_readlane64(uint64_t v, int l) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
@@ -219,7 +219,7 @@ __device__ __forceinline__ void smb_search(const SmbCols& C, int h, int exit_x, 
         }
     }
     out.won = win ? 1 : 0;
-    out.jumps = best.jumps; out.prev_jump_x = best.prev_jump_x; out.max_gap = best.max_gap; out.x = best.x;
+    out.jumps = best.jumps; out.prev_jump_x = best.prev_jump_x; out.max_gap = best.max_gap; out.x = best.x; out.iters = iterations;
     SP_ADD(0, 1); SP_ADD(1, iterations);
 }
 
@@ -425,7 +425,7 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
         }
         if (later > max_gap) max_gap = later;
     }
-    out.won = status == 1; out.jumps = jumps; out.prev_jump_x = prev_jump_x; out.max_gap = max_gap; out.x = (int)(res & 255u);
+    out.won = status == 1; out.jumps = jumps; out.prev_jump_x = prev_jump_x; out.max_gap = max_gap; out.x = (int)(res & 255u); out.iters = iterations;
     SP_ADD(2, 1); SP_ADD(3, iterations); SP_ADD(4, status == 2);
     return status;
 }
@@ -497,7 +497,8 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
     const SmbItems items = {S.heap, HP.glob, S.lds_heap_n};           // (the arena part of smb_search's heap: free while this search runs)
     // the label bits cover slots 1..4095; the parents of all of them (slots < 2048) must be in LDS for the arena part to be used
     const int cap = S.lds_heap_n >= 2048 ? 4095 : S.lds_heap_n - 1;
-    SmbResult res = {0, 0, 0, 0, 1};
+    SmbResult res = {0, 0, 0, 0, 1, 0};
+    int first_iters = 0;
 #pragma clang loop unroll(disable)
     for (int agent = 0; agent < 2 && !res.won; agent++) {
         for (int i = lane; i < S.vis_words; i += 64) S.visited[i] = 0;
@@ -520,13 +521,15 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
                 smb_search(C, Hh, exit_x, root, agent == 0 ? 1 : 0, P.solver_power, pool, HP, S.visited, res, lane);
             }
             res.won = __shfl(res.won, 0, 64); res.jumps = __shfl(res.jumps, 0, 64); res.prev_jump_x = __shfl(res.prev_jump_x, 0, 64);
-            res.max_gap = __shfl(res.max_gap, 0, 64); res.x = __shfl(res.x, 0, 64);
+            res.max_gap = __shfl(res.max_gap, 0, 64); res.x = __shfl(res.x, 0, 64); res.iters = __shfl(res.iters, 0, 64);
             SP_ADD(6, SP_NOW() - t0);
             __threadfence_block();
         }
+        if (agent == 0) first_iters = res.iters;
     }
     int done = 0;
     if (lane == 0) {
+        B.sok_cnt[e] = first_iters;      // how long this level's play-through was: the next step's map differs by a tile (k_update: SMB_LONG_POPS)
         const int dist_win = res.won ? 0 : exit_x - res.x;
         const int tail = P.prob_width - res.prev_jump_x;              // smb_prob.py:166: max(value, self._width - prev_jump)
         const int jumps_dist = res.max_gap > tail ? res.max_gap : tail;
@@ -542,13 +545,16 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
 // reset by the same wavefront right away (`inline_reset`: PcgrlEnv.reset, reset_env.h; the new map's statistics and play-through
 // follow as MODE_START) -- one launch and one tail of long searches per step instead of two; without `inline_reset` it goes to
 // `rst_list`.
-__global__ __launch_bounds__(SMB_MAX_WAVES * 64) void k_smb(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list,
-                                                            int32_t* sync, int clear_parity, int lds_heap_n, int inline_reset, int gen_map) {
+__global__ __launch_bounds__(SMB_MAX_WAVES * 64) void k_smb(PcgrlParams P, DevBufs B, int list_pre, int list_a, int mode_a, int list_b, int mode_b, int parity,
+                                                            int rst_list, int32_t* sync, int clear_parity, int lds_heap_n, int inline_reset, int gen_map) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smb_lds[];       // per wavefront: heap (lds_heap_n words), then the visited bitmap
-    __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
+    __shared__ int s_pref_p[WL_NSHARD + 1], s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
+    // list_pre (mode_a): the levels k_update expects to take long (their last play-through did) -- they go first, so that the
+    // launch does not end on a long search that was started late
+    const int n_p = list_pre >= 0 ? wl_load_prefix(B, parity, list_pre, s_pref_p) : 0;
+    const int n_a = n_p + wl_load_prefix(B, parity, list_a, s_pref_a);
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
     const int n = n_a + n_b;
     const int cells = P.width * P.height;
@@ -565,7 +571,8 @@ __global__ __launch_bounds__(SMB_MAX_WAVES * 64) void k_smb(PcgrlParams P, DevBu
         t = __shfl(t, 0, 64);
         if (t >= n) break;
         int e, mode;
-        if (t < n_a) { e = wl_get(B, list_a, s_pref_a, t); mode = mode_a; }
+        if (t < n_p) { e = wl_get(B, list_pre, s_pref_p, t); mode = mode_a; }
+        else if (t < n_a) { e = wl_get(B, list_a, s_pref_a, t - n_p); mode = mode_a; }
         else { e = wl_get(B, list_b, s_pref_b, t - n_a); mode = mode_b; }
         const bool ended = smb_job(P, B, S, e, mode, B.map + (size_t)e * cells, parity, rst_list, !inline_reset, lane);
         if (ended && inline_reset) {

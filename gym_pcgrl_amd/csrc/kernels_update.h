@@ -295,6 +295,8 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         int dest = -1, v = e;
         if (first) { dest = 2; v = val; }
         else if (chg) { dest = cheap ? 1 : 0; v = (cheap || B.zelda_inc) ? inc_item : e; }
+        // smb: a level whose last play-through was long goes on the list k_smb starts with (WL_INC, which smb has no other use for)
+        if (P.prob == PCGRL_PROB_SMB && dest == 0 && B.sok_cnt[e] >= SMB_LONG_POPS) dest = 1;
         block_append3(dest, v, B, parity, s_cnt, s_base);
     }
 }

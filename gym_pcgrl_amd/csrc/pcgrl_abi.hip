@@ -579,8 +579,9 @@ static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int lis
         int nw = (int)((160 * 1024 - 2048) / per_wave);
         nw = nw > SMB_MAX_WAVES ? SMB_MAX_WAVES : (nw < 1 ? 1 : nw);
         const int gen = (h->P.random_start || !h->has_old) ? 1 : 0;
-        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(nw * 64), nw * per_wave, st, h->P, h->B, list_a, mode_a, list_b,
-                           mode_b, parity, rst_list, sync, clr, heap_n, inline_reset, gen);
+        // (a step's changed levels come on two lists: WL_INC = the ones expected to take long, first; see k_update)
+        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(nw * 64), nw * per_wave, st, h->P, h->B, (list_a == WL_CHG && mode_a == MODE_STEP) ? (int)WL_INC : -1,
+                           list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr, heap_n, inline_reset, gen);
         HIPCHK(hipGetLastError());
         return PCGRL_OK;
     }

@@ -19,6 +19,10 @@ enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
 // environments whose episode the solver kernel ended, SOL3 = solver jobs of *their* resets.
 // INC (binary, 16-row maps): changed environments whose statistics can be updated incrementally (binary_incremental).
 enum { WL_CHG = 0, WL_RST = 1, WL_SOL = 2, WL_SOL2 = 3, WL_RST2 = 4, WL_SOL3 = 5, WL_INC = 6, WL_NLIST = 7 };
+// smb: a level whose last play-through took at least this many pops goes on WL_INC, the list k_smb starts with (kernels_smb.h)
+#ifndef SMB_LONG_POPS
+#define SMB_LONG_POPS 2000
+#endif
 // An INC item (and, for zelda, a CHG item too): environment in bits 0..20, changed cell (row * 32 + column) in bits 21..29,
 // bits 30..31 = what happened to the cell's passability (binary: 1 = became passable, 0 = impassable; zelda: 0 = unchanged,
 // 1 = became passable, 2 = impassable).
