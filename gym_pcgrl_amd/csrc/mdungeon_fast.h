@@ -103,6 +103,16 @@ struct MdKidsSerial {     // one lane makes the four children one after the othe
     }
 };
 
+#if defined(PCGRL_SMB_PROF) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer builds: tools/md_prof.py)
+#define MDP_DECL unsigned long long mdp_t = clock64(), mdp_a[5] = {0, 0, 0, 0, 0}
+#define MDP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = clock64(); mdp_a[i] += n_ - mdp_t; mdp_t = n_; } while (0)
+#define MDP_FLUSH(it) do { if (g_tl_buf && k >= 0) { for (int i_ = 0; i_ < 5; i_++) atomicAdd(&g_tl_buf[16 + i_], mdp_a[i_]); atomicAdd(&g_tl_buf[21], (unsigned long long)(it)); atomicAdd(&g_tl_buf[22], 1ull); } } while (0)
+#else
+#define MDP_DECL do {} while (0)
+#define MDP(i) do {} while (0)
+#define MDP_FLUSH(it) do {} while (0)
+#endif
 // One search.  `table` (64-bit slots) must be all zeros; `cache` is room for four nodes (LDS on the device); `kids` makes
 // the four children of a pop (serially, or one per lane on the device: the search then runs on four lanes in lockstep,
 // uniform except for that step).
@@ -124,8 +134,10 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
     MdFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;   // cache[j] = pool[cache_base + j], j < cache_n
     ret_key = n0.key; ret_h = root.h; ret_depth = 0;
+    MDP_DECL;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < heapn)) {
         iterations++;
+        MDP(4);
         if (hook(iterations)) { aborted = true; break; }
         uint32_t ent;
         MdFastNode nd = ahead;
@@ -154,6 +166,7 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
                 if (!(nxt & MDF_FLAG)) { ahead_idx = (int)(nxt & 0x7FFFu); ahead = pool[ahead_idx]; }
             }
         }
+        MDP(0);
         if (ent & MDF_FLAG) continue;                    // lost, or a key that was visited before it was queued
         const uint64_t key = nd.key;
         const uint64_t alive = key & MDF_ALIVE_MASK;
@@ -167,8 +180,10 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
         if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) {
             have_best = true; best_h = node_h; best_depth = node_depth; best_key = key;
         }
+        MDP(1);
         MdChild kid[4];                         // Node.getChildren: L, R, U, D -- always four
         kids(L, F, table, table_mask, key, alive, node_player, node_health, kid);
+        MDP(2);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -190,7 +205,9 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
                 heap[heapn++] = ent_c;
             }
         }
+        MDP(3);
     }
+    MDP_FLUSH(iterations);
     if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; }
     out_iters = iterations;
     out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < heapn);
