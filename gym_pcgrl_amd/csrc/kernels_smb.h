@@ -250,13 +250,13 @@ __device__ __forceinline__ uint32_t smb_lab_word(const SmbLab& Lb, int w) {
     return (uint32_t)__builtin_amdgcn_readlane((int)(w < 64 ? Lb.a : Lb.b), w & 63);
 }
 __device__ __forceinline__ int smb_lab_get(const SmbLab& Lb, int q) { return (int)((smb_lab_word(Lb, q >> 5) >> (q & 31)) & 1u); }
+// (branch-free: the owner lane's mask is the bit, everybody else's is 0 -- vector selects instead of exec-mask juggling, which is
+// scalar work, and the scalar pipe is the busier one in this kernel)
 __device__ __forceinline__ void smb_lab_set(SmbLab& Lb, int q, int v, int lane) {
     const int w = q >> 5;
-    const uint32_t m = 1u << (q & 31);
-    if (lane == (w & 63)) {
-        if (w < 64) Lb.a = v ? (Lb.a | m) : (Lb.a & ~m);
-        else Lb.b = v ? (Lb.b | m) : (Lb.b & ~m);
-    }
+    const uint32_t m = lane == (w & 63) ? 1u << (q & 31) : 0u;
+    const uint32_t ma = w < 64 ? m : 0u, mb = w < 64 ? 0u : m;
+    if (v) { Lb.a |= ma; Lb.b |= mb; } else { Lb.a &= ~ma; Lb.b &= ~mb; }
 }
 // "right while there is one, then left" from slot q of a heap of n slots: the leaf the fill path of a pop ends on once it is
 // inside the label-1 part (and the whole path when every label is 0)
@@ -395,8 +395,11 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
             const int q0 = n + 1, sh = q0 & 31, w0 = q0 >> 5;
             const uint64_t msk = 0xFull << sh, pat = (canr ? 0x5ull : 0xFull) << sh;
             const uint32_t m_lo = (uint32_t)msk, m_hi = (uint32_t)(msk >> 32), p_lo = (uint32_t)pat, p_hi = (uint32_t)(pat >> 32);
-            if (lane == (w0 & 63)) { if (w0 < 64) lab.a = (lab.a & ~m_lo) | p_lo; else lab.b = (lab.b & ~m_lo) | p_lo; }
-            if (m_hi && lane == ((w0 + 1) & 63)) { if (w0 + 1 < 64) lab.a = (lab.a & ~m_hi) | p_hi; else lab.b = (lab.b & ~m_hi) | p_hi; }
+            const bool own0 = lane == (w0 & 63), own1 = lane == ((w0 + 1) & 63);
+            const uint32_t c0 = own0 ? m_lo : 0u, s0 = own0 ? p_lo : 0u, c1 = own1 ? m_hi : 0u, s1 = own1 ? p_hi : 0u;
+            const bool a0 = w0 < 64, a1 = w0 + 1 < 64;
+            lab.a = (lab.a & ~((a0 ? c0 : 0u) | (a1 ? c1 : 0u))) | (a0 ? s0 : 0u) | (a1 ? s1 : 0u);
+            lab.b = (lab.b & ~((a0 ? 0u : c0) | (a1 ? 0u : c1))) | (a0 ? 0u : s0) | (a1 ? 0u : s1);
         }
         n += 4;
         if (canr) {
