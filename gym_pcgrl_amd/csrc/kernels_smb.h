@@ -410,6 +410,7 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
     // jump_locs of the result, from its ancestors (newest first): jumps, the last jump's column, the widest gap between
     // successive jump columns counted from column 0 (smb_prob.py:155-166)
     int jumps = 0, later = -1, max_gap = 0, prev_jump_x = 0;
+    const unsigned long long t_wb = SP_NOW();
     if (status != 2) {
         __threadfence_block();
         uint32_t node = res;
@@ -429,7 +430,7 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
         if (later > max_gap) max_gap = later;
     }
     out.won = status == 1; out.jumps = jumps; out.prev_jump_x = prev_jump_x; out.max_gap = max_gap; out.x = (int)(res & 255u); out.iters = iterations;
-    SP_ADD(2, 1); SP_ADD(3, iterations); SP_ADD(4, status == 2);
+    SP_ADD(2, 1); SP_ADD(3, iterations); SP_ADD(4, status == 2); SP_ADD(7, SP_NOW() - t_wb);
     return status;
 }
 

@@ -36,5 +36,7 @@ a = buf.cpu().numpy().astype(np.float64)
 print("%d envs, %d steps: %.1f ms/step" % (n, steps, dt / steps * 1e3))
 if a[2]:
     print("wavefront search (balance 1): %d per step, %d of them outgrew the LDS heap; %.0f pops each, %.0f cycles/pop" % (a[2] / steps, a[4] / steps, a[3] / a[2], a[5] / max(a[3], 1)))
+if a[2] and a[7]:
+    print("  of which the walk back through the expansion log: %.0f cycles a search (%.1f %% of its time)" % (a[7] / a[2], 100 * a[7] / max(a[5], 1)))
 if a[0]:
     print("general search (lanes 0..3): %d per step; %.0f pops each, %.0f cycles/pop" % (a[0] / steps, a[1] / a[0], a[6] / max(a[1], 1)))
