@@ -368,7 +368,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": n * b_alg,
-                         "kernel": ("one step = one launch of k_step (state of 64/128 environments per block staged in LDS: update + stats + resets)" if fused else
+                         "kernel": ("one step = one launch of k_step (state of 64 / 128 / 256 environments per block staged in LDS: update + stats + resets)" if fused else
                                     "one step = k_update + k_stats (resets inside k_stats); the search problems add k_reset + their search kernel"),
                          "dominant_kernel": dominant,
                          "algorithmic_bytes_per_env_step": b_alg, "gpu_ms_per_step": gpu_ms_per_step,
