@@ -256,6 +256,7 @@ def main():
         torch.cuda.synchronize(device)
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); ev1.record()   # (the first record of an event creates it: ~60 us of host time that are not part of a step)
     barrier()
     t0 = time.perf_counter()
     ev0.record()                # torch's current stream IS the stream the kernels are launched on
@@ -289,6 +290,7 @@ def main():
             env.step(acts[t % L])
         t_now = max(t_now, a.steady_warmup)
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record(); s1.record()
         torch.cuda.synchronize(device)
         w0 = time.perf_counter()
         s0.record()
