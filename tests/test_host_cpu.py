@@ -227,3 +227,25 @@ def test_tile_art_pictures():
         assert all(v.shape == (16, 16, 3) and v.dtype == np.uint8 for v in g.values())
         assert g[tiles[0]].tobytes() == tile_art.draw_tile(tiles[0], 16).tobytes()
     assert tile_art.draw_tile("no-such-tile", 8).shape == (8, 8, 3)
+
+
+def test_integration_md_binding_matches_the_abi():
+    """The ctypes stub in INTEGRATION.md (what a maintainer of the reference would paste) declares the same structures, in the
+    same order and with the same types, as the binding the package itself uses (gym_pcgrl_amd/_lib.py, which mirrors
+    include/pcgrl_hip.h): the class definitions are executed as they stand in the document and compared field by field."""
+    import ctypes as C
+    import re
+    from gym_pcgrl_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = md[md.index("class Config(C.Structure):"):md.index("def dev(nbytes):")]
+    ns = {"C": C}
+    exec(block, ns)
+    for name in ("Config", "Layout", "Buffers"):
+        doc, lib = ns[name], getattr(_lib, name)
+        assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in lib._fields_], name
+        assert C.sizeof(doc) == C.sizeof(lib)
+    # and every entry point the stub calls is declared in the header
+    hdr = open(os.path.join(root, "include", "pcgrl_hip.h")).read()
+    for fn in set(re.findall(r"L\.(pcgrl_\w+)\(", md)):
+        assert re.search(r"\b%s\s*\(" % fn, hdr), fn
