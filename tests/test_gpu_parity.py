@@ -1165,3 +1165,38 @@ print("ok")
 ''' % (root, G, G, G)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_integration_md_stub_runs_and_matches_the_package():
+    """The ctypes stub of INTEGRATION.md, executed as it stands in the document (library path, N, the seeds' MT19937 states
+    and the actions filled in): after create / bind / seed / reset / step its map, reward and done buffers equal those of a
+    BatchedPcgrlEnv with the same seeds and actions."""
+    torch = _torch()
+    from gym_pcgrl_amd import _lib, seeding
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = md[md.index("import ctypes as C, torch"):]
+    code = code[:code.index("```")]
+    code = code.replace('C.CDLL("libpcgrl_hip.so")', "C.CDLL(%r)" % _lib.build())
+    N, seed0 = 192, 4321
+    keys = np.ascontiguousarray(seeding.mt_states_for_seeds([seed0 + i for i in range(N)]), dtype=np.uint32)
+    assert keys.shape == (N, 624)
+    actions = torch.randint(0, 3, (N,), dtype=torch.int32, device="cuda")
+    ns = {"N": N, "keys": keys, "actions": actions}
+    exec(code, ns)
+    torch.cuda.synchronize()
+    order = ns["BUFS"]
+    buf = dict(zip(order, ns["keep"]))
+    lay = ns["lay"]
+    env = BatchedPcgrlEnv(prob="binary", rep="narrow", num_envs=N, seed=seed0)
+    env.reset()
+    obs, rew, done, info = env.step(actions)
+    got_map = buf["map"][:N * 14 * 14].view(N, 14, 14)
+    assert torch.equal(got_map, obs["map"])
+    assert torch.equal(buf["reward"][:N * 8].view(torch.float64), rew)
+    assert torch.equal(buf["done"][:N], env._bufs["done"])
+    assert torch.equal(buf["pos"][:N * 2].view(N, 2), obs["pos"])
+    assert ns["L"].pcgrl_destroy(ns["h"]) == 0
+    env.close()
