@@ -1200,3 +1200,43 @@ def test_integration_md_stub_runs_and_matches_the_package():
     assert torch.equal(buf["pos"][:N * 2].view(N, 2), obs["pos"])
     assert ns["L"].pcgrl_destroy(ns["h"]) == 0
     env.close()
+
+
+@pytest.mark.gpu
+def test_integration_md_package_surface_runs():
+    """The calls INTEGRATION.md section 1 shows (make / make_batched / adjust_param / step / info access / rollout, the two
+    composite wrappers, the vector-env adapter) run as written, with the shapes and types the document states."""
+    torch = _torch()
+    import gym_pcgrl_amd
+    env = gym_pcgrl_amd.make("binary-narrow-v0")
+    env.seed(42)
+    obs = env.reset()
+    obs, reward, done, info = env.step(env.action_space.sample())
+    assert obs["map"].shape == (14, 14) and isinstance(info, dict) and "path-length" in info
+    N = 256
+    venv = gym_pcgrl_amd.make_batched("binary-narrow-v0", num_envs=N, seed=0)
+    venv.adjust_param(change_percentage=0.2)
+    obs = venv.reset()
+    assert obs["map"].shape == (N, 14, 14) and obs["map"].dtype == torch.uint8 and obs["pos"].shape == (N, 2) and obs["heatmap"].dtype == torch.int16
+    actions = torch.randint(0, 3, (N,), dtype=torch.int32, device="cuda")
+    obs, reward, done, info = venv.step(actions)
+    assert reward.dtype == torch.float64 and done.dtype == torch.bool and info["path-length"].shape == (N,)
+    assert isinstance(info.to_list()[0], dict)
+    tape = torch.randint(0, 3, (7, N), dtype=torch.int32, device="cuda")
+    reward, done, info = venv.rollout(tape)
+    assert reward.shape == (7, N) and done.shape == (7, N)
+    from gym_pcgrl_amd.wrappers import CroppedImagePCGRLWrapper, ActionMapImagePCGRLWrapper
+    w = CroppedImagePCGRLWrapper("zelda-narrow-v0", 22, num_envs=32)
+    img = w.reset()
+    assert img.dtype == torch.uint8 and img.shape[0] == 32 and img.dim() == 4
+    w2 = ActionMapImagePCGRLWrapper("zelda-wide-v0", num_envs=32)
+    img2 = w2.reset()
+    assert img2.dtype == torch.uint8 and img2.shape[0] == 32
+    from gym_pcgrl_amd.vector import PcgrlVectorEnv
+    v = PcgrlVectorEnv("binary-narrow-v0", 16)
+    o = v.reset()
+    v.step_async(np.zeros(16, np.int64))
+    out = v.step_wait()
+    assert len(out) == 4 and np.asarray(out[1]).shape == (16,)
+    for x in (env, venv, w, w2, v):
+        x.close()
