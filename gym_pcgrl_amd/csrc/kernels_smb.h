@@ -19,7 +19,8 @@
 // The level lives in registers: lane l holds columns l, 64 + l, 128 + l, 192 + l as bit masks over the rows (bit y + 8 of a
 // column: blocked; rows above the screen free, rows below it blocked), so a move is a 2 x 3 window around the player read with
 // four readlanes and no memory access.  Two searches:
-//  * smb_search_two_label -- balance 1, the whole wavefront, everything in LDS and registers (see there): 24 of 25 searches;
+//  * smb_search_two_label -- balance 1, the whole wavefront, labels and level in registers, items in LDS (the deepest heap
+//    level in the arena), see there: 24 of 25 searches;
 //  * smb_search -- any balance, lanes 0..3 (the four children of a pop side by side), 8-byte nodes in the wavefront's global
 //    arena and a heap of packed (priority << 16 | node) words whose first levels are in LDS: balance 0 (short searches on the
 //    levels balance 1 did not win) and whatever does not fit the first.
@@ -43,7 +44,7 @@
 #define SMB_ROOT_PAR 0x3FFFu
 
 // bytes of one search's arena: smb_search's node pool + its heap's overflow beyond the LDS part; smb_search_two_label keeps its
-// expansion log (4 bytes per expansion) in the same place (host: pcgrl_abi.hip sizes the block's share)
+// expansion log (4 bytes per expansion) in the first and the deepest level of its heap in the second (host: pcgrl_abi.hip sizes the block's share)
 __host__ __device__ __forceinline__ size_t smb_wave_arena_bytes(int power) {
     const size_t nodes = 4 * (size_t)power + 4;
     return (nodes * 8 + nodes * 4 + 255) & ~(size_t)255;
