@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the batched PCGRL hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C3d|C4|C5|C5b|M1|D1] [--envs E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C3d|C4|C5|C5b|M1|D1|S1|C2w|C3w] [--envs E]
 
 With --gpus N > 1 and no RANK in the environment the script launches itself under torch.distributed.run with one rank per
 GPU (127.0.0.1 rendezvous, RCCL barrier, max-over-ranks time) and prints the one JSON line of rank 0 with n_gpus = N; it
@@ -17,6 +17,9 @@ Extra objects on the JSON line:
   roofline      HBM roofline of the step pipeline: achieved = E * B_alg / (GPU time of the step's
                 kernels, from HIP events recorded around every launch on the launch stream, over
                 the same timed steps), B_alg = 2*H*W + 64 bytes per env-step.
+  configs       (default workload, one GPU) short driver-timed legs of the other BASELINE.json configs (C3, C4, C5), of smb
+                (S1) and of the trainer-shaped wrapped steps (C2w, C3w): first window + steady state, roofline fraction,
+                dominant kernel -- so that every config has a number under the same clock as `value`.
   cpu_baseline  the CPU oracle (oracle/pcgrl_oracle.c, a bit-exact port of the reference) timed on
                 this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -45,12 +48,88 @@ WORKLOADS = {
     "M1": ("mdungeon", "narrow", (), 65536, "mdungeon-narrow-v0 7x11, 65536 envs/GPU"),
     "D1": ("ddave", "narrow", (), 65536, "ddave-narrow-v0 11x7, 65536 envs/GPU"),
     "S1": ("smb", "narrow", (), 16384, "smb-narrow-v0 114x14, 16384 envs/GPU"),
+    # the trainer-shaped step (utils.make_vec_envs :60-71): the same batches behind the reference's composite
+    # wrappers -- the step also leaves the policy's image (crop 28 centred on the cursor / one-hot map) in a device tensor
+    "C2w": ("binary", "narrow", (), 65536, "binary-narrow-v0 14x14 behind CroppedImagePCGRLWrapper(crop 28): step + [N,28,28,1] image, 65536 envs/GPU"),
+    "C3w": ("zelda", "wide", (dict(width=11, height=16),), 65536, "zelda-wide-v0 11x16 behind ActionMapImagePCGRLWrapper: flat actions, step + one-hot [N,16,11,8] image, 65536 envs/GPU"),
 }
+WRAPPED = {"C2w": ("cropped", 28), "C3w": ("actionmap", None)}
+# legs of the default run besides the headline workload: every BASELINE.json config (and smb, and the wrapped steps) gets a
+# driver-timed figure.  (steps, warmup, steady warm-up) are sized so that the whole default run stays well under a minute of GPU time.
+LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 15), "C2w": (20, 5, 800), "C3w": (20, 5, 800)}
+DOMINANT = {"C2": "k_step", "C3": "k_step", "C3d": "k_step", "C4": "k_sokoban", "C5": "k_stats_wide", "C5b": "k_stats_wide", "M1": "k_mdungeon",
+            "D1": "k_ddave", "S1": "k_smb", "C2w": "k_step (writes the image)", "C3w": "k_step (writes the image)"}
+
+
+def make_stepper(torch, workload, n, device, seed):
+    """-> (env, step(actions), reset(), action maker): the bare batched environment, or the same behind the reference's wrapper."""
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    prob, rep, calls, _, _ = WORKLOADS[workload]
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, device=device, seed=seed)
+    for kw in calls:
+        env.adjust_param(**kw)
+    if workload not in WRAPPED:
+        return env, env.step, env.reset, None
+    from gym_pcgrl_amd import wrappers
+    kind, size = WRAPPED[workload]
+    w = wrappers.CroppedImagePCGRLWrapper(env, size) if kind == "cropped" else wrappers.ActionMapImagePCGRLWrapper(env)
+    return env, w.step, w.reset, w
+
+
+def timed_steps(torch, device, step, acts, t0, k):
+    """k steps from tape row t0 (cyclic) between two HIP events on the launch stream -> (wall s, GPU ms per step)."""
+    L = acts.shape[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()          # (the first record of an event creates it: ~60 us of host time that are not part of a step)
+    torch.cuda.synchronize(device)
+    w0 = time.perf_counter()
+    e0.record()
+    for t in range(t0, t0 + k):
+        step(acts[t % L])
+    e1.record()
+    torch.cuda.synchronize(device)
+    return time.perf_counter() - w0, e0.elapsed_time(e1) / k
+
+
+def run_leg(torch, device, workload, steps, warmup, steady_warmup, seed=0):
+    """One short driver-timed measurement of another workload (rank 0, one GPU): first window after a reset + steady state."""
+    prob, rep, calls, n, desc = WORKLOADS[workload]
+    env, step, reset, wrapper = make_stepper(torch, workload, n, device, seed)
+    reset()
+    W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
+    acts = make_actions(torch, rep, steps + warmup + 64, n, W, H, nt, device, 1234, flat=(workload == "C3w"))
+    for t in range(warmup):
+        step(acts[t])
+    wall, gms = timed_steps(torch, device, step, acts, warmup, steps)
+    b_alg = 2 * H * W + 64
+    obs_bytes = 0
+    if wrapper is not None:
+        o = wrapper._obs
+        obs_bytes = int(o.numel() // n)
+    leg = {"workload": desc, "envs": n, "steps": steps, "warmup": warmup, "value": n * steps / wall, "unit": "env-steps/s",
+           "ms_per_step": wall / steps * 1e3, "gpu_ms_per_step": gms, "dominant_kernel": DOMINANT[workload],
+           "algorithmic_bytes_per_env_step": b_alg + obs_bytes,
+           "roofline_frac": n * (b_alg + obs_bytes) / (gms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    if steady_warmup > 0:
+        t_now = warmup + steps
+        for t in range(t_now, steady_warmup):
+            step(acts[t % acts.shape[0]])
+        t_now = max(t_now, steady_warmup)
+        swall, sgms = timed_steps(torch, device, step, acts, t_now, steps)
+        leg["steady_state"] = {"after_steps": t_now, "value": n * steps / swall, "ms_per_step": swall / steps * 1e3, "gpu_ms_per_step": sgms,
+                               "roofline_frac": n * (b_alg + obs_bytes) / (sgms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    if obs_bytes:
+        leg["image_bytes_per_env_step"] = obs_bytes
+    env.close()
+    return leg
+
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def make_actions(torch, rep, steps, n, W, H, nt, device, seed):
+def make_actions(torch, rep, steps, n, W, H, nt, device, seed, flat=False):
     g = torch.Generator(device=device).manual_seed(seed)
+    if flat:        # ActionMap (wrappers.py:139-154): one index into (H, W, tiles)
+        return torch.randint(0, W * H * nt, (steps, n), generator=g, device=device, dtype=torch.int32)
     if rep == "narrow":
         return torch.randint(0, nt + 1, (steps, n), generator=g, device=device, dtype=torch.int32)
     if rep == "turtle":
@@ -184,6 +263,8 @@ def main():
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary pcgrl_rollout measurement")
     ap.add_argument("--dry-run", action="store_true", help="process plumbing only (launcher, rendezvous, barrier, max-over-ranks reduction over gloo); "
                                                           "no GPU, no environment: the line carries value null and dry_run true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the short legs of the other configs (the `configs` object of the default line)")
+    ap.add_argument("--legs", default="C3,C4,C5,S1,C2w,C3w", help="which legs the default line carries")
     ap.add_argument("--steady-warmup", type=int, default=800, help="steps before the steady_state measurement (0: skip it)")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -240,15 +321,14 @@ def main():
     from gym_pcgrl_amd.envs import BatchedPcgrlEnv
     prob, rep, calls, n_default, desc = WORKLOADS[a.workload]
     n = a.envs or n_default
+    wrapped = a.workload in WRAPPED
     # environment axis sharded contiguously: rank r owns global envs [r*n, (r+1)*n), seed = global index
-    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, device=device, seed=rank * n)
-    for kw in calls:
-        env.adjust_param(**kw)
-    env.reset()
+    env, step, reset, wrapper = make_stepper(torch, a.workload, n, device, rank * n)
+    reset()
     W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
-    acts = make_actions(torch, rep, a.steps + a.warmup, n, W, H, nt, device, 1234 + rank)
+    acts = make_actions(torch, rep, a.steps + a.warmup, n, W, H, nt, device, 1234 + rank, flat=(a.workload == "C3w"))
     for t in range(a.warmup):
-        env.step(acts[t])
+        step(acts[t])
 
     def barrier():
         if use_dist:
@@ -261,7 +341,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()                # torch's current stream IS the stream the kernels are launched on
     for t in range(a.warmup, a.warmup + a.steps):
-        env.step(acts[t])
+        step(acts[t])
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
@@ -276,7 +356,7 @@ def main():
     if rank == 0:
         env.profile(True)
         for t in range(a.warmup, a.warmup + min(a.steps, 50)):
-            env.step(acts[t])
+            step(acts[t])
         phase_ms, prof_steps = env.profile_read()
         env.profile(False)
 
@@ -287,7 +367,7 @@ def main():
         L = acts.shape[0]
         t_now = a.warmup + a.steps + prof_steps
         for t in range(t_now, max(t_now, a.steady_warmup)):
-            env.step(acts[t % L])
+            step(acts[t % L])
         t_now = max(t_now, a.steady_warmup)
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record(); s1.record()
@@ -295,7 +375,7 @@ def main():
         w0 = time.perf_counter()
         s0.record()
         for t in range(t_now, t_now + a.steps):
-            env.step(acts[t % L])
+            step(acts[t % L])
         s1.record()
         torch.cuda.synchronize(device)
         w1 = time.perf_counter()
@@ -307,7 +387,7 @@ def main():
     # secondary figure: the same K steps as ONE pcgrl_rollout call on the action tape (a single launch where the fused
     # step kernel applies; per-step reward / done / info still written for every step).  Not the headline `value`.
     rollout = None
-    if rank == 0 and not a.no_rollout:
+    if rank == 0 and not a.no_rollout and not wrapped:
         # a second batch brought to the same state as the first one had when its timed loop started: same seeds, same
         # warm-up actions -- the tape below is then exactly the work of the timed loop above
         env2 = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, device=device, seed=rank * n)
@@ -357,6 +437,8 @@ def main():
         total_steps = float(n) * world * a.steps
         value = total_steps / dt
         b_alg = 2 * H * W + 64
+        if wrapped:        # the trainer-shaped step also writes the policy's image: algorithmic bytes = the step's + the image
+            b_alg += int(wrapper._obs.numel() // n)
         achieved = n * b_alg / (gpu_ms_per_step * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(a.workload) if n == n_default else (None, None)
         out = {
@@ -383,6 +465,19 @@ def main():
             out["rollout"] = rollout
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, rep, calls)
+        if world == 1 and not a.no_legs and a.workload == "C2" and n == n_default:
+            # every other BASELINE.json config (and smb, and the wrapped steps) under the same clock: short legs, rank 0
+            env.close()
+            legs = {}
+            for name in a.legs.split(","):
+                if name in LEGS:
+                    legs[name] = run_leg(torch, device, name, *LEGS[name])
+            for wname, bare in (("C2w", None), ("C3w", "C3")):       # wrapped step against the bare step of the same batch
+                if wname in legs:
+                    base = gpu_ms_per_step if bare is None else legs.get(bare, {}).get("gpu_ms_per_step")
+                    if base:
+                        legs[wname]["gpu_time_vs_bare_step"] = legs[wname]["gpu_ms_per_step"] / base
+            out["configs"] = legs
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

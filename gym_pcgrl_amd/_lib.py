@@ -41,11 +41,11 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
 
 
-ABI_VERSION = 7          # include/pcgrl_hip.h PCGRL_ABI_VERSION
+ABI_VERSION = 8          # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
-           "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout")
+           "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout", "pcgrl_bind_observation")
 NPHASE = 6
 # the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
 # other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
@@ -60,16 +60,38 @@ def sources_newer_than_lib():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+NPARTS = 8               # csrc/pcgrl_abi.hip: PCGRL_PART=0..7 (host ABI; stats; update; step binary; step zelda; search; smb; step_solver)
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): the one source is compiled NPARTS times
+    side by side (-DPCGRL_PART=k, see the head of csrc/pcgrl_abi.hip) and the objects are linked."""
     if not force and not sources_newer_than_lib():
         return SO
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + SOURCES + ["-o", SO]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = jobs or int(os.environ.get("PCGRL_BUILD_JOBS", "0")) or min(NPARTS, os.cpu_count() or 1)
+    objs = [os.path.join(objdir, "part%d.o" % k) for k in range(NPARTS)]
+    cmds = [[hipcc] + flags + ["-DPCGRL_PART=%d" % k, "-c", SOURCES[0], "-o", objs[k]] for k in range(NPARTS)]
+    running, todo, failed = [], list(range(NPARTS)), []
+    while todo or running:
+        while todo and len(running) < jobs:
+            k = todo.pop(0)
+            if verbose:
+                print(" ".join(cmds[k]), flush=True)
+            running.append((k, subprocess.Popen(cmds[k])))
+        k, p = running.pop(0)
+        if p.wait() != 0:
+            failed.append(k)
+    if failed:
+        raise subprocess.CalledProcessError(1, cmds[failed[0]])
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return SO
 
 
@@ -113,6 +135,7 @@ def load():
     L.pcgrl_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_set_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.pcgrl_bind_observation.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.pcgrl_action_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     L.pcgrl_profile.argtypes = [C.c_void_p, C.c_int]

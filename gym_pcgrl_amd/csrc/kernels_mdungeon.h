@@ -73,6 +73,8 @@ __device__ __forceinline__ void md_report(const PcgrlParams& P, const DevBufs& B
 
 // Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  Environments that finish their episode here
 // go to `rst_list`.
+// (a template only so that every part of the library can include this header: instantiated where it is launched)
+template <int PART_TAG>
 __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
                                                  int rst_list, int32_t* sync, int clear_parity) {
     extern __shared__ __attribute__((aligned(16))) uint32_t md_lds[];

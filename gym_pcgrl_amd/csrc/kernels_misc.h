@@ -1,36 +1,6 @@
-// Observation formatting (wrappers), action-map decode and small utility kernels.
+// Action-map decode (wrappers) and small utility kernels; the observation image is kernels_obs.h.
 // Part of the single translation unit pcgrl_abi.hip (see its header comment for the overall picture).
 #pragma once
-// ------------------------------------------------------------------------------------------
-// Observation formatting of the reference's composite wrappers (wrappers.py): Cropped.transform :197-206
-// (pad with the border tile, window of `size` centred on the cursor), OneHotEncoding.transform :101-104,
-// ToImage.transform :53-60 ([h, w, depth] image).  One thread per output cell; depth 1 = raw tile ids,
-// depth T = one-hot.  Writes are coalesced along (cell, depth).
-__global__ __launch_bounds__(PCGRL_BLOCK) void k_obs_window(PcgrlParams P, DevBufs B, uint8_t* __restrict__ out, int oh, int ow,
-                                                             int centered, int pad_value, int depth) {
-    const size_t per_env = (size_t)oh * ow;
-    const size_t total = (size_t)P.num_envs * per_env;
-    for (size_t i = (size_t)blockIdx.x * PCGRL_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * PCGRL_BLOCK) {
-        const int e = (int)(i / per_env);
-        const int rc = (int)(i - (size_t)e * per_env);
-        const int r = rc / ow, c = rc - r * ow;
-        int y = r, x = c;
-        if (centered) {
-            const uchar2 p = reinterpret_cast<const uchar2*>(B.pos)[e];
-            y = (int)p.y + r - oh / 2;     // np.pad(map, size // 2) then padded[y : y + size, x : x + size]
-            x = (int)p.x + c - ow / 2;
-        }
-        int t = pad_value;
-        if (x >= 0 && y >= 0 && x < P.width && y < P.height) t = B.map[((size_t)e * P.height + y) * P.width + x];
-        uint8_t* o = out + i * depth;
-        if (depth == 1) o[0] = (uint8_t)t;
-        else if (depth == 8) {
-            *reinterpret_cast<uint64_t*>(o) = 1ull << (8 * t);
-        } else {
-            for (int d = 0; d < depth; d++) o[d] = (uint8_t)(d == t);
-        }
-    }
-}
 // ActionMap.step for the wide representation (wrappers.py:139-154): flat index into (h, w, tiles) -> (x, y, tile)
 __global__ void k_action_map(const int32_t* __restrict__ flat, int32_t* __restrict__ xyv, int n, int w, int h, int dim, int32_t* status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -550,6 +550,8 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
 // reset by the same wavefront right away (`inline_reset`: PcgrlEnv.reset, reset_env.h; the new map's statistics and play-through
 // follow as MODE_START) -- one launch and one tail of long searches per step instead of two; without `inline_reset` it goes to
 // `rst_list`.
+// (a template only so that every part of the library can include this header: instantiated where it is launched)
+template <int PART_TAG>
 __global__ __launch_bounds__(SMB_MAX_WAVES * 64) void k_smb(PcgrlParams P, DevBufs B, int list_pre, int list_a, int mode_a, int list_b, int mode_b, int parity,
                                                             int rst_list, int32_t* sync, int clear_parity, int lds_heap_n, int inline_reset, int gen_map) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smb_lds[];       // per wavefront: heap (lds_heap_n words), then the visited bitmap

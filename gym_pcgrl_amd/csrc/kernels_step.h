@@ -217,8 +217,11 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     const int lane64 = tid & 63, wv = tid >> 6, gw = lane64 / G;
     const int sp = t & 1;                   // this step's set of list counters
     DevGroup<G, MaskT> g(lane64);
-    if (MULTI && t > 0)     // this step's row of the action tape (the first one came with the state)
-        blk_copy<TPB>(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)t * action_stride + (size_t)e0 * AW), ne * 4 * AW);
+    if (MULTI && t > 0) {   // this step's row of the action tape (the first one came with the state).  A row starts at a multiple
+                            // of num_envs * AW ints -- 4-byte aligned only (65 environments, narrow) -- so it is copied word by word.
+        const int32_t* row = actions + (size_t)t * action_stride + (size_t)e0 * AW;
+        for (int i = tid; i < ne * AW; i += TPB) reinterpret_cast<int32_t*>(smem + L.act)[i] = row[i];
+    }
     __syncthreads();                        // the state copy is complete; everything the previous step wrote is visible to the whole block
     TL(17);
     if (wv < NUPD) {
@@ -321,4 +324,11 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     blk_copy_rows<TPB>(reinterpret_cast<uint8_t*>(Bg.planes) + (size_t)e0 * kPlaneRow, smem + L.planes, ne, kPlaneRow, s_loc.dirty);
     if (has_champ) blk_copy_rows<TPB>(reinterpret_cast<uint8_t*>(Bg.champ) + (size_t)e0 * champ_row, smem + L.champ, ne, champ_row, s_loc.dirty);
     blk_copy_rows<TPB>(reinterpret_cast<uint8_t*>(Bg.start_stats + (size_t)e0 * 8), smem + L.start, ne, 32, s_loc.dirty);
+    // ---- the wrapped observation of the block's environments (pcgrl_bind_observation), straight from the LDS copy: the row
+    // planes are the map, the cursors are there too -- no byte map is read.  A store stream that overlaps with the blocks that
+    // are still computing (the step is latency-bound, the memory system nearly idle).
+    if (Bg.obs.out) {
+        const ObsPlanes<MaskT, NPL> src = {reinterpret_cast<const MaskT*>(smem + L.planes), G};
+        obs_write_block(src, obs_view(P, Bg.obs, e0), smem + L.pos, ne, (int)threadIdx.x, TPB);
+    }
 }

@@ -187,7 +187,11 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
                     if (stage == 0) { x = mt_randint(ring, cur, W); y = mt_randint(ring, cur, H); }
                     else y = mt_randint(ring, cur, H);
                     B.fifo_tag[e] = -1;
-                    __threadfence_block();     // a reset of this environment later in the launch stages the ring from memory
+                    // a reset of this environment later in the launch stages the ring from memory, possibly on another wavefront
+                    // behind an LDS-only barrier: the ring words have to have left this wavefront before it gets there (a
+                    // workgroup-scope fence alone omits the vmcnt wait outside threadgroup-split mode)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __threadfence_block();
                     cur0 = cur;
                 } else {
                     cur = mt_wrap(cur + used);

@@ -31,6 +31,26 @@
 #include <vector>
 
 #include "../../include/pcgrl_hip.h"
+
+// Build: this one source is compiled eight times side by side with -DPCGRL_PART=0..7 -- part 0 is the host side of the ABI and the
+// small utility kernels, each other part holds the launchers (and with them the instantiations) of one kernel family -- and the
+// objects are linked into the library (gym_pcgrl_amd/_lib.py: 2 min 20 s as one unit, ~45 s in parts on eight cores).  Without
+// PCGRL_PART it is one translation unit: the developer builds of tools/ (timeline, search profiles) use that form.
+#ifdef PCGRL_PART
+#define PCGRL_IN_PART(k) (PCGRL_PART == (k))
+#else
+#define PCGRL_IN_PART(k) 1
+#endif
+#define PCGRL_LOCAL __attribute__((visibility("hidden")))
+#define PART_CORE 0          /* (macros, not an enum: they are compared in #if) */
+#define PART_STATS 1
+#define PART_UPDATE 2
+#define PART_STEP_BINARY 3
+#define PART_STEP_ZELDA 4
+#define PART_SEARCH 5
+#define PART_SMB 6
+#define PART_STEP_SOLVER 7
+
 #include "lanegroup_dev.h"
 #include "mt19937.h"
 #include "pcgrl_algos.h"
@@ -43,6 +63,7 @@
 
 #include "worklist.h"
 #include "kernels_update.h"
+#include "kernels_obs.h"
 #include "reset_env.h"
 #include "kernels_stats.h"
 #include "kernels_reset.h"
@@ -52,7 +73,9 @@
 #include "kernels_ddave.h"
 #include "kernels_smb.h"
 #include "kernels_step_solver.h"
+#if PCGRL_IN_PART(PART_CORE)
 #include "kernels_misc.h"
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Host side of the ABI
@@ -71,6 +94,7 @@ struct pcgrl_env {
     // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
     int no_wide, wide_waves, wide_grid, fused_zelda, no_fused, step_epb, smb_heap;
     int profiling;
+    int obs_hold;     // inside pcgrl_rollout's loop of steps: the bound observation is written once, at the end
     std::vector<hipEvent_t> events;
     size_t ev_used;
     int prof_steps;
@@ -87,7 +111,11 @@ static int prof_mark(pcgrl_env* h, hipStream_t st) {
     return PCGRL_OK;
 }
 
-static thread_local int g_last_hip = 0;
+#if PCGRL_IN_PART(PART_CORE)
+PCGRL_LOCAL thread_local int g_last_hip = 0;
+#else
+extern PCGRL_LOCAL thread_local int g_last_hip;
+#endif
 #define HIPCHK(expr) do { hipError_t err_ = (expr); if (err_ != hipSuccess) { g_last_hip = (int)err_; return PCGRL_EHIP; } } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -195,6 +223,9 @@ static size_t scratch_bytes_base(const pcgrl_config* c) {
 
 // Per-DEVICE state the kernels need, (re)established at every pcgrl_bind -- never behind a process-wide flag: a process may
 // hold handles on several GPUs, and both a function attribute and a __device__ symbol belong to one device.
+PCGRL_LOCAL int search_device_setup(pcgrl_env* h);      // PART_SEARCH: dynamic-LDS attribute of k_sokoban / k_mdungeon / k_ddave
+PCGRL_LOCAL int smb_device_setup(pcgrl_env* h);         // PART_SMB: of k_smb
+#if PCGRL_IN_PART(PART_CORE)
 static int device_setup(pcgrl_env* h) {
     {   // init_genrand(19650218): the table every MT19937 init_by_array starts from (k_init_by_array)
         uint32_t tab[PCGRL_MT_N];
@@ -202,13 +233,8 @@ static int device_setup(pcgrl_env* h) {
         for (int i = 1; i < PCGRL_MT_N; i++) tab[i] = 1812433253u * (tab[i - 1] ^ (tab[i - 1] >> 30)) + (uint32_t)i;
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_mt_genrand), tab, sizeof(tab)));
     }
-    if (solver_prob(h->cfg.prob)) {   // the search kernels use most of a compute unit's LDS (heap + 64-bit-key table)
-        const int lds = (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4);
-        const void* f = h->cfg.prob == PCGRL_SOKOBAN ? reinterpret_cast<const void*>(k_sokoban)
-                      : h->cfg.prob == PCGRL_MDUNGEON ? reinterpret_cast<const void*>(k_mdungeon)
-                      : h->cfg.prob == PCGRL_SMB ? reinterpret_cast<const void*>(k_smb) : reinterpret_cast<const void*>(k_ddave);
-        HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->cfg.prob == PCGRL_SMB ? 150 * 1024 : lds));
-    }
+    if (h->cfg.prob == PCGRL_SMB) return smb_device_setup(h);
+    if (solver_prob(h->cfg.prob)) return search_device_setup(h);
     return PCGRL_OK;
 }
 
@@ -251,7 +277,7 @@ int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
     if (!out) return PCGRL_EINVAL;
     pcgrl_env* h = new pcgrl_env();
     h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
-    h->profiling = 0; h->ev_used = 0; h->prof_steps = 0;
+    h->profiling = 0; h->ev_used = 0; h->prof_steps = 0; h->obs_hold = 0;
     memset(&h->B, 0, sizeof(h->B));
     h->cfg = *c;
     fill_params(c, &h->P);
@@ -331,6 +357,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         B.champ = s + scratch_bytes_base(&h->cfg);
         HIPCHK(hipMemsetAsync(B.champ, 0, champ_bytes(&h->cfg), (hipStream_t)stream));
     }
+    B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0};
     B.fifo = nullptr; B.fifo_tag = nullptr;
     if (fifo_bytes(&h->cfg)) {
         uint8_t* f = s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg);
@@ -432,14 +459,26 @@ int pcgrl_seed_words(pcgrl_env* h, const uint32_t* words, int32_t first, int32_t
 }
 
 }  // extern "C"
+#endif  // PART_CORE
 
 // ---- launch helpers ------------------------------------------------------------------------
+struct RolloutArgs { int steps; size_t action_stride; double* reward_out; uint8_t* done_out; int32_t* info_out; };
+PCGRL_LOCAL int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, hipStream_t st);
+PCGRL_LOCAL int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int clr, hipStream_t st);
+PCGRL_LOCAL int launch_planes_from_map(pcgrl_env* h, const uint8_t* maps, hipStream_t st);
+PCGRL_LOCAL int launch_update(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st);
+PCGRL_LOCAL int launch_step_binary(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R);
+PCGRL_LOCAL int launch_step_zelda(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R);
+PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st);
+PCGRL_LOCAL int launch_smb(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st, int inline_reset);
+PCGRL_LOCAL int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb);
 static int grid_for(int items, int per_block, int cap) {
     int g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
     return g < cap ? g : cap;
 }
 
+#if PCGRL_IN_PART(PART_STATS)
 template <int PROB>
 static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, hipStream_t st) {
     const PcgrlParams& P = h->P;
@@ -476,7 +515,7 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
-static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, hipStream_t st) {
+PCGRL_LOCAL int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, hipStream_t st) {
     switch (h->P.prob) {
         case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, inline_reset, st);
         case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, inline_reset, st);
@@ -486,6 +525,9 @@ static int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, i
     }
 }
 
+#endif  // PART_STATS (continued below: launch_reset, launch_planes_from_map)
+
+#if PCGRL_IN_PART(PART_UPDATE)
 template <class MaskT>
 static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
     const PcgrlParams& P = h->P;
@@ -508,8 +550,11 @@ static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hip
     return PCGRL_OK;
 }
 
-// One solver launch: the jobs of list_a (mode_a) and, if list_b >= 0, of list_b (mode_b).  `slot` selects the
-// scheduling words (two launches per step), zeroed here.  Episodes the solver ends go to rst_list.
+PCGRL_LOCAL int launch_update(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
+    return h->P.mask_bytes == 4 ? launch_update_m<uint32_t>(h, actions, parity, st) : launch_update_m<uint64_t>(h, actions, parity, st);
+}
+#endif  // PART_UPDATE
+
 // One fused launch per step (kernels_step.h) where it applies: binary, maps of at most 16 rows, single-cell
 // representations, auto-reset with the in-kernel reset.  PCGRL_NO_FUSED=1 keeps the two-launch pipeline (A/B, tests).
 static bool fused_step_applies(const pcgrl_env* h, bool rollout = false) {
@@ -521,9 +566,9 @@ static bool fused_step_applies(const pcgrl_env* h, bool rollout = false) {
     return prob_ok && P.group == 16 && P.rep <= PCGRL_REP_TURTLE && P.auto_reset &&
            h->B.inline_reset && !h->no_fused;
 }
-struct RolloutArgs { int steps; size_t action_stride; double* reward_out; uint8_t* done_out; int32_t* info_out; };
 // Environments per block of k_step: 64 (four wavefronts), 128 (eight) or 256 (sixteen) -- chosen at pcgrl_bind from the batch
 // size; PCGRL_STEP_EPB=64|128|256 overrides (A/B).
+#if PCGRL_IN_PART(PART_STEP_BINARY) || PCGRL_IN_PART(PART_STEP_ZELDA)
 template <int PROB, class MaskT, int EPB>
 static int launch_step_pme(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
     const PcgrlParams& P = h->P;
@@ -554,56 +599,81 @@ static int launch_step_pm(pcgrl_env* h, const int32_t* actions, int parity, hipS
     if (sizeof(MaskT) == 4 && h->step_epb == 256) return launch_step_pme<PROB, uint32_t, 256>(h, actions, parity, st, R);
     return launch_step_pme<PROB, MaskT, 64>(h, actions, parity, st, R);
 }
+#endif
+#if PCGRL_IN_PART(PART_STEP_BINARY)
+PCGRL_LOCAL int launch_step_binary(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
+    return h->P.mask_bytes == 4 ? launch_step_pm<PCGRL_PROB_BINARY, uint32_t>(h, actions, parity, st, R) : launch_step_pm<PCGRL_PROB_BINARY, uint64_t>(h, actions, parity, st, R);
+}
+#endif
+#if PCGRL_IN_PART(PART_STEP_ZELDA)
+PCGRL_LOCAL int launch_step_zelda(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R) {
+    return h->P.mask_bytes == 4 ? launch_step_pm<PCGRL_PROB_ZELDA, uint32_t>(h, actions, parity, st, R) : launch_step_pm<PCGRL_PROB_ZELDA, uint64_t>(h, actions, parity, st, R);
+}
+#endif
 static int launch_step(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st, const RolloutArgs& R = RolloutArgs{1, 0, nullptr, nullptr, nullptr}) {
-    const bool m4 = h->P.mask_bytes == 4;
-    if (h->P.prob == PCGRL_PROB_BINARY) return m4 ? launch_step_pm<PCGRL_PROB_BINARY, uint32_t>(h, actions, parity, st, R) : launch_step_pm<PCGRL_PROB_BINARY, uint64_t>(h, actions, parity, st, R);
-    return m4 ? launch_step_pm<PCGRL_PROB_ZELDA, uint32_t>(h, actions, parity, st, R) : launch_step_pm<PCGRL_PROB_ZELDA, uint64_t>(h, actions, parity, st, R);
+    return h->P.prob == PCGRL_PROB_BINARY ? launch_step_binary(h, actions, parity, st, R) : launch_step_zelda(h, actions, parity, st, R);
 }
 static int action_width(int rep) {   // int32 values per environment and step
     return rep == PCGRL_REP_WIDE ? 3 : (rep == PCGRL_REP_NARROW_CAST || rep == PCGRL_REP_TURTLE_CAST) ? 2 : rep == PCGRL_REP_NARROW_MULTI ? 9 : 1;
 }
 
-static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
-                         hipStream_t st, int inline_reset = 0) {
-    const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
-    int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
-    HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
-    if (h->P.prob == PCGRL_PROB_SMB) {
-        // per wavefront: the heap (smb_search: its first levels; a deeper heap continues in the arena) + the visited bitmap;
-        // as many wavefronts per block (one block per compute unit) as 160 KB of LDS hold, eight at most
-        int heap_n = 4 * h->P.solver_power + 4 < h->smb_heap ? ((4 * h->P.solver_power + 4 + 3) & ~3) : h->smb_heap;
-        const int reset_words = PCGRL_MT_N + ((h->P.width * h->P.height + 15) & ~15) / 4;       // the in-kernel reset stages its ring and tiles there
-        if (heap_n < reset_words) heap_n = (reset_words + 3) & ~3;
-        const size_t vis_words = ((size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 5 + 31) / 32 + 3) & ~(size_t)3;
-        const size_t per_wave = ((size_t)heap_n + vis_words) * 4;
-        int nw = (int)((160 * 1024 - 2048) / per_wave);
-        nw = nw > SMB_MAX_WAVES ? SMB_MAX_WAVES : (nw < 1 ? 1 : nw);
-        const int gen = (h->P.random_start || !h->has_old) ? 1 : 0;
-        // (a step's changed levels come on two lists: WL_INC = the ones expected to take long, first; see k_update)
-        hipLaunchKernelGGL(k_smb, dim3(SOK_BLOCKS), dim3(nw * 64), nw * per_wave, st, h->P, h->B, (list_a == WL_CHG && mode_a == MODE_STEP) ? (int)WL_INC : -1,
-                           list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr, heap_n, inline_reset, gen);
-        HIPCHK(hipGetLastError());
-        return PCGRL_OK;
-    }
-    if (h->P.prob == PCGRL_PROB_DDAVE) {
-        const size_t dd_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
-        hipLaunchKernelGGL(k_ddave, dim3(SOK_BLOCKS), dim3(64), dd_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
-        HIPCHK(hipGetLastError());
-        return PCGRL_OK;
-    }
-    if (h->P.prob == PCGRL_PROB_MDUNGEON) {
-        const size_t md_lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
-        hipLaunchKernelGGL(k_mdungeon, dim3(SOK_BLOCKS), dim3(64), md_lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
-                           sync, clr);
-        HIPCHK(hipGetLastError());
-        return PCGRL_OK;
-    }
-    hipLaunchKernelGGL(k_sokoban, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
-                       sync, sync + SOK_SY_WORDS, clr);
+// One solver launch: the jobs of list_a (mode_a) and, if list_b >= 0, of list_b (mode_b).  `slot` selects the
+// scheduling words (two launches per step), zeroed here.  Episodes the solver ends go to rst_list.
+#define SMB_LDS_BUDGET (160 * 1024 - 2048)   /* dynamic LDS of a k_smb block: the attribute set at pcgrl_bind and the launch size both come from here */
+#if PCGRL_IN_PART(PART_SMB)
+PCGRL_LOCAL int smb_device_setup(pcgrl_env*) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_smb<0>), hipFuncAttributeMaxDynamicSharedMemorySize, SMB_LDS_BUDGET));
+    return PCGRL_OK;
+}
+PCGRL_LOCAL int launch_smb(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st, int inline_reset) {
+    // per wavefront: the heap (smb_search: its first levels; a deeper heap continues in the arena) + the visited bitmap;
+    // as many wavefronts per block (one block per compute unit) as the LDS budget holds, SMB_MAX_WAVES at most
+    int heap_n = 4 * h->P.solver_power + 4 < h->smb_heap ? ((4 * h->P.solver_power + 4 + 3) & ~3) : h->smb_heap;
+    const int reset_words = PCGRL_MT_N + ((h->P.width * h->P.height + 15) & ~15) / 4;       // the in-kernel reset stages its ring and tiles there
+    if (heap_n < reset_words) heap_n = (reset_words + 3) & ~3;
+    const size_t vis_words = ((size_t)((h->P.width + 6) * (h->P.height + SMB_YOFF + 1) * 5 + 31) / 32 + 3) & ~(size_t)3;
+    const size_t per_wave = ((size_t)heap_n + vis_words) * 4;
+    int nw = (int)(SMB_LDS_BUDGET / per_wave);
+    nw = nw > SMB_MAX_WAVES ? SMB_MAX_WAVES : (nw < 1 ? 1 : nw);
+    if ((size_t)nw * per_wave > SMB_LDS_BUDGET) return PCGRL_EINVAL;      // one search does not fit a compute unit's LDS
+    const int gen = (h->P.random_start || !h->has_old) ? 1 : 0;
+    // (a step's changed levels come on two lists: WL_INC = the ones expected to take long, first; see k_update)
+    hipLaunchKernelGGL(k_smb<0>, dim3(SOK_BLOCKS), dim3(nw * 64), nw * per_wave, st, h->P, h->B, (list_a == WL_CHG && mode_a == MODE_STEP) ? (int)WL_INC : -1,
+                       list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr, heap_n, inline_reset, gen);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
+#endif  // PART_SMB
+#if PCGRL_IN_PART(PART_SEARCH)
+PCGRL_LOCAL int search_device_setup(pcgrl_env* h) {   // the search kernels use most of a compute unit's LDS (heap + 64-bit-key table)
+    const int lds = (int)((SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4);
+    const void* f = h->cfg.prob == PCGRL_SOKOBAN ? reinterpret_cast<const void*>(k_sokoban<0>)
+                  : h->cfg.prob == PCGRL_MDUNGEON ? reinterpret_cast<const void*>(k_mdungeon<0>) : reinterpret_cast<const void*>(k_ddave<0>);
+    HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    return PCGRL_OK;
+}
+PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st) {
+    const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
+    if (h->P.prob == PCGRL_PROB_DDAVE)
+        hipLaunchKernelGGL(k_ddave<0>, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
+    else if (h->P.prob == PCGRL_PROB_MDUNGEON)
+        hipLaunchKernelGGL(k_mdungeon<0>, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
+    else
+        hipLaunchKernelGGL(k_sokoban<0>, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
+                           sync, sync + SOK_SY_WORDS, clr);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+#endif  // PART_SEARCH
+static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
+                         hipStream_t st, int inline_reset = 0) {
+    int32_t* sync = h->B.sok_sync + (size_t)slot * (SOK_SY_WORDS + SOK_HARD_CAP);
+    HIPCHK(hipMemsetAsync(sync, 0, (size_t)(SOK_SY_WORDS + SOK_HARD_CAP) * 4, st));
+    if (h->P.prob == PCGRL_PROB_SMB) return launch_smb(h, sync, list_a, mode_a, list_b, mode_b, parity, rst_list, clr, st, inline_reset);
+    return launch_search(h, sync, list_a, mode_a, list_b, mode_b, parity, rst_list, clr, st);
+}
 
+#if PCGRL_IN_PART(PART_STATS)
 template <int PROB>
 static int launch_reset_p(pcgrl_env* h, int list, int park_list, int parity, int clr, hipStream_t st) {
     const PcgrlParams& P = h->P;
@@ -623,7 +693,7 @@ static int launch_reset_p(pcgrl_env* h, int list, int park_list, int parity, int
     return PCGRL_OK;
 }
 // map generation + start stats of every environment on the reset list
-static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int clr, hipStream_t st) {
+PCGRL_LOCAL int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int clr, hipStream_t st) {
     switch (h->P.prob) {
         case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, list, park_list, parity, clr, st);
         case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, list, park_list, parity, clr, st);
@@ -633,6 +703,19 @@ static int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int c
         default: return launch_reset_p<PCGRL_PROB_SOKOBAN>(h, list, park_list, parity, clr, st);
     }
 }
+
+PCGRL_LOCAL int launch_planes_from_map(pcgrl_env* h, const uint8_t* maps, hipStream_t st) {     // pcgrl_set_maps
+    const PcgrlParams& P = h->P;
+    const size_t lds = 4 * (size_t)((P.width * P.height + 15) & ~15);
+    const int grid = grid_for(P.num_envs, 4, 4096);
+    if (P.mask_bytes == 4)
+        hipLaunchKernelGGL((k_planes_from_map<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
+    else
+        hipLaunchKernelGGL((k_planes_from_map<uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+#endif  // PART_STATS
 
 // pcgrl_rollout for the search problems: persistent blocks that own their environments for the whole tape (kernels_step_solver.h)
 static bool solver_rollout_applies(const pcgrl_env* h, int* envs_per_block) {
@@ -644,6 +727,7 @@ static bool solver_rollout_applies(const pcgrl_env* h, int* envs_per_block) {
     *envs_per_block = epb;
     return true;
 }
+#if PCGRL_IN_PART(PART_STEP_SOLVER)
 template <int PROB, int REP, class MaskT>
 static int launch_step_solver_t(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb) {
     const size_t lds = (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4;
@@ -663,13 +747,37 @@ static int launch_step_solver_p(pcgrl_env* h, const int32_t* actions, hipStream_
         default: return launch_step_solver_t<PROB, PCGRL_REP_TURTLE, MaskT>(h, actions, st, R, epb);
     }
 }
-static int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb) {
+PCGRL_LOCAL int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb) {
     const bool m4 = h->P.mask_bytes == 4;
     switch (h->P.prob) {
         case PCGRL_PROB_SOKOBAN: return m4 ? launch_step_solver_p<PCGRL_PROB_SOKOBAN, uint32_t>(h, actions, st, R, epb) : launch_step_solver_p<PCGRL_PROB_SOKOBAN, uint64_t>(h, actions, st, R, epb);
         case PCGRL_PROB_MDUNGEON: return m4 ? launch_step_solver_p<PCGRL_PROB_MDUNGEON, uint32_t>(h, actions, st, R, epb) : launch_step_solver_p<PCGRL_PROB_MDUNGEON, uint64_t>(h, actions, st, R, epb);
         default: return m4 ? launch_step_solver_p<PCGRL_PROB_DDAVE, uint32_t>(h, actions, st, R, epb) : launch_step_solver_p<PCGRL_PROB_DDAVE, uint64_t>(h, actions, st, R, epb);
     }
+}
+
+#endif  // PART_STEP_SOLVER
+
+#if PCGRL_IN_PART(PART_CORE)
+// the wrapped observation of every environment with the stand-alone kernel (kernels_obs.h)
+static int launch_obs(pcgrl_env* h, const ObsSpec& S, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const int grid = (P.num_envs + OBS_EPB - 1) / OBS_EPB;
+    if (P.nplanes == 1 && S.depth == 1 && S.ow <= 64 && S.pad <= 1) {      // binary: an output row is one shifted plane word
+        if (P.mask_bytes == 4) hipLaunchKernelGGL(k_obs<1>, dim3(grid), dim3(256), 0, st, P, h->B, S);
+        else hipLaunchKernelGGL(k_obs<2>, dim3(grid), dim3(256), 0, st, P, h->B, S);
+    } else hipLaunchKernelGGL(k_obs<0>, dim3(grid), dim3(256), 0, st, P, h->B, S);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+static int obs_spec(const pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot, ObsSpec* S) {
+    if (out_h < 1 || out_w < 1 || out_h > 4096 || out_w > 4096 || pad_value < 0 || pad_value > 255) return PCGRL_EINVAL;
+    if (centered && h->P.rep == PCGRL_REP_WIDE) return PCGRL_EINVAL;   // Cropped needs a cursor (wrappers.py:170)
+    if (((uintptr_t)out & 15) != 0) return PCGRL_EINVAL;
+    const int depth = onehot ? h->P.ntiles : 1;
+    if ((size_t)OBS_EPB * out_h * out_w * depth >= ((size_t)1 << 24) / 4) return PCGRL_EINVAL;      // offsets inside a block's stretch stay small (obs_div)
+    *S = ObsSpec{out, out_h, out_w, depth, centered ? 1 : 0, pad_value};
+    return PCGRL_OK;
 }
 
 extern "C" {
@@ -683,6 +791,7 @@ static int reset_one(pcgrl_env* h, void* stream) {
     int rc = launch_reset(h, WL_RST, WL_SOL2, par, sok ? -1 : (par ^ 1), st);
     if (rc) return rc;
     if (sok && (rc = launch_solver(h, 0, WL_SOL2, MODE_START, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
+    if (h->B.obs.out && (rc = launch_obs(h, h->B.obs, st))) return rc;
     return PCGRL_OK;
 }
 
@@ -702,8 +811,7 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream, bool* us
         for (int k = 0; k < 6; k++) if ((rc = prof_mark(h, st))) return rc;
         return PCGRL_OK;
     }
-    rc = (h->P.mask_bytes == 4) ? launch_update_m<uint32_t>(h, actions, par, st) : launch_update_m<uint64_t>(h, actions, par, st);
-    if (rc) return rc;
+    if ((rc = launch_update(h, actions, par, st))) return rc;
     if ((rc = prof_mark(h, st))) return rc;
     // The last kernel of the step clears the other parity's work-list counters.  Every problem but Sokoban is
     // two launches: k_stats also resets the environments whose episode ended (auto_reset).
@@ -764,6 +872,8 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (rc) return rc;
     if (used_lists) h->parity ^= 1;
     if (h->profiling) h->prof_steps++;
+    // the wrapped observation: the fused step kernel wrote it; every other pipeline gets one more launch
+    if (used_lists && h->B.obs.out && !h->obs_hold && (rc = launch_obs(h, h->B.obs, (hipStream_t)stream))) return rc;
     return PCGRL_OK;
 }
 
@@ -782,18 +892,23 @@ int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* r
     int epb = 0;
     if (solver_rollout_applies(h, &epb) && !h->profiling) {
         const RolloutArgs R = {steps, stride, reward_out, done_out, info_out};
-        return launch_step_solver(h, actions, st, R, epb);       // block-local work lists: the global lists and their parity are not touched
+        int rc = launch_step_solver(h, actions, st, R, epb);       // block-local work lists: the global lists and their parity are not touched
+        if (rc == PCGRL_OK && h->B.obs.out) rc = launch_obs(h, h->B.obs, st);
+        return rc;
     }
+    h->obs_hold = 1;            // one image at the end of the tape, not one per step
     for (int t = 0; t < steps; t++) {
         int rc = pcgrl_step(h, actions + (size_t)t * stride, stream);
-        if (rc) return rc;
+        if (rc) { h->obs_hold = 0; return rc; }
         if (reward_out || done_out || info_out) {
             hipLaunchKernelGGL(k_copy_step_outputs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->B, (int)n,
                                reward_out ? reward_out + (size_t)t * n : nullptr, done_out ? done_out + (size_t)t * n : nullptr,
                                info_out ? info_out + (size_t)t * n * 10 : nullptr);
-            HIPCHK(hipGetLastError());
+            if (hipGetLastError() != hipSuccess) { h->obs_hold = 0; return PCGRL_EHIP; }
         }
     }
+    h->obs_hold = 0;
+    if (h->B.obs.out) return launch_obs(h, h->B.obs, st);
     return PCGRL_OK;
 }
 
@@ -844,15 +959,18 @@ int pcgrl_profile_read(pcgrl_env* h, double* phase_ms, int32_t* steps) {
 
 int pcgrl_observe(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
-    if (!out || out_h < 1 || out_w < 1) return PCGRL_EINVAL;
-    if (centered && h->P.rep == PCGRL_REP_WIDE) return PCGRL_EINVAL;   // Cropped needs a cursor (wrappers.py:170)
+    if (!out) return PCGRL_EINVAL;
     DeviceGuard guard(h->device);
-    const int depth = onehot ? h->P.ntiles : 1;
-    const size_t total = (size_t)h->P.num_envs * out_h * out_w;
-    const int grid = (int)((total + PCGRL_BLOCK - 1) / PCGRL_BLOCK < 16384 ? (total + PCGRL_BLOCK - 1) / PCGRL_BLOCK : 16384);
-    hipLaunchKernelGGL(k_obs_window, dim3(grid), dim3(PCGRL_BLOCK), 0, (hipStream_t)stream, h->P, h->B, out, out_h, out_w, centered, pad_value, depth);
-    HIPCHK(hipGetLastError());
-    return PCGRL_OK;
+    ObsSpec S;
+    int rc = obs_spec(h, out, out_h, out_w, centered, pad_value, onehot, &S);
+    if (rc) return rc;
+    return launch_obs(h, S, (hipStream_t)stream);
+}
+
+int pcgrl_bind_observation(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!out) { h->B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0}; return PCGRL_OK; }
+    return obs_spec(h, out, out_h, out_w, centered, pad_value, onehot, &h->B.obs);
 }
 
 int pcgrl_action_map(pcgrl_env* h, const int32_t* flat, int32_t* xyv, void* stream) {
@@ -876,22 +994,18 @@ int pcgrl_status(pcgrl_env* h, void* stream, int32_t* status) {
 static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const PcgrlParams& P = h->P;
-    const int n = P.num_envs, par = h->parity, cells = P.width * P.height;
-    const size_t lds = 4 * (size_t)((cells + 15) & ~15);
-    const int grid = grid_for(n, 4, 4096);
+    const int n = P.num_envs, par = h->parity;
     // (a caller that restores a checkpoint rewrites the rings and cursors and then comes here: drop the draw cache)
     if (h->B.fifo_tag) HIPCHK(hipMemsetAsync(h->B.fifo_tag, 0xFF, (size_t)n * 4, st));
-    if (P.mask_bytes == 4)
-        hipLaunchKernelGGL((k_planes_from_map<uint32_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
-    else
-        hipLaunchKernelGGL((k_planes_from_map<uint64_t>), dim3(grid), dim3(PCGRL_BLOCK), lds, st, P, h->B, maps);
-    HIPCHK(hipGetLastError());
+    int rc0 = launch_planes_from_map(h, maps, st);
+    if (rc0) return rc0;
     hipLaunchKernelGGL(k_fill_all, dim3((n + 255) / 256), dim3(256), 0, st, h->B, n, par, (int)WL_CHG);
     HIPCHK(hipGetLastError());
     const bool sok = solver_prob(P.prob), smb = P.prob == PCGRL_PROB_SMB;
     int rc = smb ? PCGRL_OK : launch_stats(h, WL_CHG, par, MODE_SETMAP, sok ? -1 : (par ^ 1), 0, st);
     if (rc) return rc;
     if (sok && (rc = launch_solver(h, 0, smb ? WL_CHG : WL_SOL2, MODE_SETMAP, -1, 0, par, WL_RST2, par ^ 1, st))) return rc;
+    if (h->B.obs.out && (rc = launch_obs(h, h->B.obs, st))) return rc;
     return PCGRL_OK;
 }
 
@@ -915,3 +1029,4 @@ int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
 }
 
 }  // extern "C"
+#endif  // PART_CORE

@@ -60,11 +60,7 @@ PCGRL_HD double range_reward(double nv, double ov, double lo, double hi) {
     if (nv > hi && ov < lo) return hi - nv + ov - lo;
     return hi - ov + nv - lo;
 }
-#if defined(__HIPCC__)
 #define PCGRL_INF (__builtin_huge_val())
-#else
-#define PCGRL_INF (__builtin_huge_val())
-#endif
 
 // The stats are small integers and every band bound is an integer or +-inf, so get_range_reward is
 // evaluated in integer arithmetic (INT_MAX / INT_MIN stand for +-inf: the comparisons and min/max then

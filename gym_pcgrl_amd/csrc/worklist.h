@@ -65,6 +65,9 @@ __device__ __forceinline__ void tl_mark(int tag) {
 #endif
 
 struct LocalLists;
+// The wrapped observation a handle keeps up to date (pcgrl_bind_observation; kernels_obs.h): uint8 [N][oh][ow][depth], written
+// by the last kernel of every step / reset.  out == nullptr: off.
+struct ObsSpec { uint8_t* out; int32_t oh, ow, depth, centered, pad; };
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
@@ -95,6 +98,7 @@ struct DevBufs {
     // (no ring access on the step's critical path) and refills it behind the barrier; every reset rebuilds it; the other
     // pipelines draw from the ring and mark it invalid (-1).
     uint32_t* fifo; int32_t* fifo_tag;
+    ObsSpec obs;
 };
 #define PCGRL_FIFO_N 8
 

@@ -79,6 +79,7 @@ class BatchedPcgrlEnv:
         self._needs_reset = True
         self._alloc_dims = None
         self._probs_dirty = False
+        self._obs_spec = None          # bind_observation(): (out tensor, h, w, centered, pad, onehot)
         self._update_spaces()
         self.seed(seed)
 
@@ -174,6 +175,7 @@ class BatchedPcgrlEnv:
             self._upload_seeds()
         if self._episode is not None:      # rebinding after a reallocation keeps the running episodes' sums
             self._bind_episode_stats()
+        self._apply_observation()
 
     def _upload_seeds(self):
         words = np.ascontiguousarray(self._seed_keys, dtype=np.uint32)      # [N, 3]: the MT19937 states are made on the device
@@ -301,6 +303,47 @@ class BatchedPcgrlEnv:
             decode = self._prob.decode_rows if self._prob.packed_rows else None
             ib = InfoBatch(self._prob.info_keys, info.view(T * self.num_envs, 10), self._max_iterations, self._max_changes, decode)
         return rew, done.view(torch.bool), ib
+
+    # ---- the wrapped observation (wrappers.py:215-248), written by the step itself
+    def bind_observation(self, out_h, out_w, centered, pad_value, onehot, out=None):
+        """From now on every reset() / step() / rollout() / set_maps() leaves the image the reference's composite wrappers
+        would produce -- uint8 [N, out_h, out_w, D], D = 1 or the number of tiles (one-hot); centred on the cursor and padded
+        with `pad_value`, or the map from its origin -- in the returned tensor (`out`, or a new one).  Where the step is one
+        fused kernel it writes the image from its on-chip copy of the state; no extra launch."""
+        torch = self._torch
+        depth = self.get_num_tiles() if onehot else 1
+        shape = (self.num_envs, int(out_h), int(out_w), depth)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        self._check_obs_target(out, shape)
+        self._obs_spec = (out, int(out_h), int(out_w), int(bool(centered)), int(pad_value), int(bool(onehot)))
+        self._apply_observation()
+        return out
+
+    def _check_obs_target(self, out, shape):
+        torch = self._torch
+        if out.dtype != torch.uint8 or tuple(out.shape) != tuple(shape) or not out.is_contiguous() or out.device != self.device or out.data_ptr() % 16:
+            raise ValueError("observation target: expected a contiguous, 16-byte aligned uint8 tensor of shape %s on %s" % (tuple(shape), self.device))
+
+    def set_observation_target(self, out):
+        """Redirect the bound observation to another tensor of the same shape (e.g. row t+1 of a rollout buffer)."""
+        old = self._obs_spec
+        if old is None:
+            raise RuntimeError("call bind_observation() first")
+        self._check_obs_target(out, old[0].shape)
+        self._obs_spec = (out,) + old[1:]
+        self._apply_observation()
+
+    def unbind_observation(self):
+        self._obs_spec = None
+        if self._handle is not None:
+            _lib.check(self._lib.pcgrl_bind_observation(self._handle, None, 0, 0, 0, 0, 0), "pcgrl_bind_observation")
+
+    def _apply_observation(self):
+        if self._obs_spec is None or self._handle is None:
+            return
+        out, h, w, centered, pad, onehot = self._obs_spec
+        _lib.check(self._lib.pcgrl_bind_observation(self._handle, C.c_void_p(out.data_ptr()), h, w, centered, pad, onehot), "pcgrl_bind_observation")
 
     # gym.vector-style split call
     def step_async(self, actions):

@@ -1,4 +1,8 @@
-"""gym / gymnasium integration, active only when one of them is importable (neither is on the MI355X image).
+"""gym integration, active only when a gym with the reference's API is importable (none is on the MI355X image).
+
+"The reference's API" is gym <= 0.25: `reset() -> obs`, `step() -> (obs, reward, done, info)` (pcgrl_env.py:66-76,129-150).
+gym >= 0.26 and gymnasium changed both (`(obs, info)`, five-tuple steps) and wrap every `make()` in checkers that reject the old
+shapes, so this package does not register itself there -- it would only produce ids that fail at the first reset().
 
 The reference registers '{prob}-{rep}-v0' for every problem x representation when it is imported
 (gym_pcgrl/__init__.py:6-12), its PcgrlEnv is a gym.Env (envs/pcgrl_env.py:14), and its wrappers start from
@@ -11,18 +15,28 @@ import importlib
 import sys
 
 
+def _old_api(g):
+    """True for a gym with four-tuple steps: version below 0.26 (a module without a version -- the test shim -- counts)."""
+    v = getattr(g, "__version__", None)
+    if v is None:
+        return True
+    try:
+        major, minor = (int(x) for x in str(v).split(".")[:2])
+    except ValueError:
+        return False
+    return (major, minor) < (0, 26)
+
+
 def find_gym():
-    """The gym module to integrate with: an already imported `gym` / `gymnasium` (this is how a test shim is found too),
-    else whichever of the two imports; None when neither does."""
-    for name in ("gym", "gymnasium"):
-        if name in sys.modules:
-            return sys.modules[name]
-    for name in ("gym", "gymnasium"):
+    """The gym module to integrate with: an already imported `gym` (this is how a test shim is found too), else an
+    importable one; None when there is none or it has the new API (see the module docstring)."""
+    g = sys.modules.get("gym")
+    if g is None:
         try:
-            return importlib.import_module(name)
+            g = importlib.import_module("gym")
         except ImportError:
-            continue
-    return None
+            return None
+    return g if _old_api(g) else None
 
 
 def env_base():
@@ -78,7 +92,9 @@ def register_all(ids):
             continue
         try:
             register(id=env_id, entry_point="gym_pcgrl_amd.envs:PcgrlEnv", kwargs={"prob": prob, "rep": rep})
-        except Exception:      # gym.error.Error "Cannot re-register id": keep the existing registration
+        except Exception as ex:      # gym.error.Error "Cannot re-register id": keep the existing registration; anything else is a bug
+            if "register" not in str(ex).lower():
+                raise
             continue
         _registered.append(env_id)
         done.append(env_id)

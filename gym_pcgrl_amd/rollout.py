@@ -2,8 +2,9 @@
 reference's `train.py:86-94`: `model.learn` steps a VecEnv `n_steps` at a time and hands PPO the stacked
 observations, actions, rewards and episode starts).
 
-Everything stays on the GPU: the batched environment writes rewards/dones into its own tensors, the wrapped
-observation is one uint8 image tensor, and this module only copies them into preallocated `[T, N, ...]` storage.
+Everything stays on the GPU: the step writes the wrapped observation of step t+1 straight into row t+1 of the preallocated
+`[T, N, ...]` storage (the observation target of the environment is moved from row to row: no copy of the image, which is
+the bulk of a rollout's bytes); rewards / dones are small and copied from the environment's own tensors.
 No policy or optimiser lives here (out of scope): `policy(obs) -> actions` is any callable on device
 tensors.
 """
@@ -44,18 +45,24 @@ class RolloutCollector:
         self.buffer = RolloutBuffer(self.torch, n_steps, vec_env.num_envs, vec_env.observation_space.shape, ashape, dev)
         self._obs = None
         self._start = self.torch.ones(vec_env.num_envs, dtype=self.torch.bool, device=dev)
-        self.episode_returns, self.episode_lengths = [], []
+        self.episode_returns, self.episode_lengths = [], []      # per step, the last `keep_steps` steps (default: one rollout)
+        self.keep_steps = int(n_steps)
 
     def collect(self, policy):
         torch, b = self.torch, self.buffer
+        w = self.env.env                                  # the image wrapper below the Monitor layer: no host sync
         if self._obs is None:
+            w.set_observation_target(b.obs[0])            # the first observation lands in row 0
             self._obs = self.env.reset()
+        else:
+            b.obs[0].copy_(b.last_obs)                    # one copy per rollout: where the previous one stopped
+            self._obs = b.obs[0]
         for t in range(b.n_steps):
-            b.obs[t].copy_(self._obs)
             b.episode_starts[t].copy_(self._start)
             actions = policy(self._obs)
             b.actions[t].copy_(actions)
-            self._obs, rew, done, _ = self.env.env.step(actions)     # the wrapper below the Monitor layer: no host sync
+            w.set_observation_target(b.obs[t + 1] if t + 1 < b.n_steps else b.last_obs)     # the step writes the next row itself
+            self._obs, rew, done, _ = w.step(actions)
             b.rewards[t].copy_(rew)
             b.dones[t].copy_(done)
             self._start = done.to(torch.bool).clone()
@@ -64,5 +71,6 @@ class RolloutCollector:
                 m = b.dones[t]
                 self.episode_returns.append(torch.where(m, st["last_return"], torch.full_like(st["last_return"], float("nan"))))
                 self.episode_lengths.append(torch.where(m, st["last_length"], torch.zeros_like(st["last_length"])))
-        b.last_obs.copy_(self._obs)
+                if len(self.episode_returns) > self.keep_steps:      # a bounded window (a trainer reads it once per rollout)
+                    del self.episode_returns[0], self.episode_lengths[0]
         return b

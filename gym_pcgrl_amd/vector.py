@@ -6,7 +6,8 @@ batched `observation_space` / `action_space`).  A subclass of gym.vector.VectorE
 Observations are dicts of arrays with a leading environment axis -- numpy copies by default (the gym.vector contract), or
 the live device tensors with `to_numpy=False` (zero copy; overwritten by the next step).  A done environment is reset
 inside step() and the observation returned for it is the first one of its next episode, as gym.vector does; `infos` is
-the reference's list of per-environment dicts (pcgrl_env.py:144-148), built lazily (`infos` supports len / [] / iter).
+the reference's list of per-environment dicts (pcgrl_env.py:144-148), built lazily (`infos` supports len / [] / iter) from a
+host snapshot of the step's info table (with `to_numpy=False`: from the live device table, valid until the next step).
 """
 from collections import OrderedDict
 
@@ -111,8 +112,12 @@ class PcgrlVectorEnv(gym_compat.vector_env_base()):
         obs, rew, done, info = self.env.step(self._actions)
         self._actions = None
         if self.to_numpy:
-            return self._obs(obs), rew.cpu().numpy(), done.cpu().numpy(), LazyInfos(info)
-        return obs, rew, done, LazyInfos(info)
+            # host copies all round: the info table is snapshotted now (the dicts are still built on first use), so an `infos`
+            # kept across the next step() / reset() still describes THIS step
+            from .envs.batched_env import InfoBatch
+            snap = InfoBatch(info.keys, info.table.cpu(), info.max_iterations, info.max_changes, info._decode)
+            return self._obs(obs), rew.cpu().numpy(), done.cpu().numpy(), LazyInfos(snap)
+        return obs, rew, done, LazyInfos(info)      # zero copy: a live view, overwritten by the next step
 
     def step(self, actions):
         self.step_async(actions)

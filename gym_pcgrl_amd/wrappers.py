@@ -7,8 +7,10 @@
   ActionMapImagePCGRLWrapper(game)            wide: action = flat index into (H, W, tiles) (ActionMap :111-154),
       observation = the (one-hot) map image
 
-Here they wrap a BatchedPcgrlEnv: observations are one uint8 tensor [N, h, w, depth] written by a HIP kernel
-(`pcgrl_observe`), actions are decoded on the device (`pcgrl_action_map`).  Same names, same constructor
+Here they wrap a BatchedPcgrlEnv: observations are one uint8 tensor [N, h, w, depth] that the step itself keeps up to date
+(`pcgrl_bind_observation`: the fused step kernel writes the image from its on-chip copy of the state, other pipelines add one
+store-stream kernel), actions are decoded on the device (`pcgrl_action_map`).  The tensor returned by reset() / step() is
+overwritten by the next step, like every other output of the batched environment.  Same names, same constructor
 arguments plus `num_envs`/`seed`/`device`; values equal the reference's wrappers element for element.
 """
 import ctypes as C
@@ -29,26 +31,36 @@ class _ImageWrapper:
         self.num_envs = self.pcgrl_env.num_envs
         self.one_hot = "binary" not in self.game           # wrappers.py:222-224 / :244-246
         self._obs = None
+        self._bound = None
 
-    def _alloc(self, h, w):
-        torch = self.pcgrl_env._torch
-        depth = self.pcgrl_env.get_num_tiles() if self.one_hot else 1
-        if self._obs is None or tuple(self._obs.shape) != (self.num_envs, h, w, depth):
-            self._obs = torch.empty((self.num_envs, h, w, depth), dtype=torch.uint8, device=self.pcgrl_env.device)
+    def _window(self):
+        raise NotImplementedError
+
+    def _bind(self):
+        """(Re)bind the image to the environment when its shape changed (first use, adjust_param(width/height))."""
+        h, w, centered, pad = self._window()
+        key = (h, w, centered, pad, self.one_hot)
+        if self._bound != key:
+            self._obs = self.pcgrl_env.bind_observation(h, w, centered, pad, self.one_hot)
+            self._bound = key
         return self._obs
 
-    def _observe(self, h, w, centered, pad_value):
-        e = self.pcgrl_env
-        out = self._alloc(h, w)
-        _lib.check(e._lib.pcgrl_observe(e._handle, C.c_void_p(out.data_ptr()), h, w, int(centered), int(pad_value),
-                                        int(self.one_hot), e._stream()), "pcgrl_observe")
-        return out
+    def set_observation_target(self, out):
+        """The next images go to `out` (same shape; e.g. a row of a rollout buffer)."""
+        self._bind()
+        self.pcgrl_env.set_observation_target(out)
+        self._obs = out
+
+    def reset(self):
+        self._bind()
+        self.pcgrl_env.reset()
+        return self._obs
 
     def seed(self, seed=None):
         return self.pcgrl_env.seed(seed)
 
     def adjust_param(self, **kwargs):
-        self.pcgrl_env.adjust_param(**kwargs)
+        self.pcgrl_env.adjust_param(**kwargs)          # (a new map size: the image is bound again by the next reset())
 
     def close(self):
         self.pcgrl_env.close()
@@ -62,16 +74,12 @@ class CroppedImagePCGRLWrapper(_ImageWrapper):
         self.size = int(crop_size)
         self.pad_value = self.pcgrl_env.get_border_tile()
 
-    def _image(self):
-        return self._observe(self.size, self.size, True, self.pad_value)
-
-    def reset(self):
-        self.pcgrl_env.reset()
-        return self._image()
+    def _window(self):
+        return self.size, self.size, True, self.pad_value
 
     def step(self, actions):
-        _, reward, done, info = self.pcgrl_env.step(actions)
-        return self._image(), reward, done, info
+        _, reward, done, info = self.pcgrl_env.step(actions)          # the step wrote the image
+        return self._obs, reward, done, info
 
 
 class ActionMapImagePCGRLWrapper(_ImageWrapper):
@@ -82,13 +90,9 @@ class ActionMapImagePCGRLWrapper(_ImageWrapper):
                                       "only uses it there, utils.py:49-50)")
         self._xyv = None
 
-    def _image(self):
+    def _window(self):
         p = self.pcgrl_env._prob
-        return self._observe(int(p._height), int(p._width), False, 0)
-
-    def reset(self):
-        self.pcgrl_env.reset()
-        return self._image()
+        return int(p._height), int(p._width), False, 0
 
     def step(self, actions):
         e = self.pcgrl_env
@@ -99,4 +103,4 @@ class ActionMapImagePCGRLWrapper(_ImageWrapper):
             self._xyv = torch.empty((self.num_envs, 3), dtype=torch.int32, device=e.device)
         _lib.check(e._lib.pcgrl_action_map(e._handle, C.c_void_p(a.data_ptr()), C.c_void_p(self._xyv.data_ptr()), e._stream()), "pcgrl_action_map")
         _, reward, done, info = e.step(self._xyv)
-        return self._image(), reward, done, info
+        return self._obs, reward, done, info

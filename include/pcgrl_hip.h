@@ -37,7 +37,7 @@ extern "C" {
  * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps).  6: + pcgrl_rollout.
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
  *    clamped actions. */
-#define PCGRL_ABI_VERSION 7
+#define PCGRL_ABI_VERSION 8
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -144,6 +144,14 @@ int pcgrl_set_maps(pcgrl_env* env, const uint8_t* maps, void* stream);
  * map itself from its origin (ActionMapImagePCGRLWrapper :234-248, out_h = H, out_w = W). */
 int pcgrl_observe(pcgrl_env* env, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value,
                   int32_t onehot, void* stream);
+/* The same image kept up to date by the step itself: after this call every pcgrl_reset / pcgrl_step / pcgrl_rollout /
+ * pcgrl_set_maps leaves the image of the state it returns in `out` (DEVICE uint8 [N][out_h][out_w][D], 16-byte aligned,
+ * caller-owned).  Where the step is one fused kernel (binary, zelda; maps of at most 16 rows) that kernel writes the image from
+ * its on-chip copy of the state -- no extra launch, no read of the byte map; elsewhere one extra kernel follows the step.  This
+ * is what wrappers.py:215-248 + utils.make_vec_envs :60-71 hand the policy per step.  May be called again at any time with
+ * another `out` (a rollout buffer row); out = NULL switches it off.  Only records the target: nothing is written by the call. */
+int pcgrl_bind_observation(pcgrl_env* env, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered,
+                           int32_t pad_value, int32_t onehot);
 /* ActionMap.step for the wide representation (wrappers.py:139-154): flat DEVICE i32 [N] index into
  * (H, W, tiles) -> xyv DEVICE i32 [N,3] = (x, y, tile), the action pcgrl_step takes. */
 int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* stream);

@@ -348,6 +348,88 @@ def test_wrapper_observations_match_reference(path):
         assert np.array_equal(obs.cpu().numpy(), d["obs"][t]), t
 
 
+def _expected_image(m, pos, oh, ow, centered, pad, depth):
+    """wrappers.py restated with numpy: Cropped.transform :197-206 (np.pad with the border tile, window at the cursor),
+    OneHotEncoding.transform :101-104 (np.eye(dim)[map]), ToImage.transform :53-60.  m [N,H,W], pos [N,2] = (x, y)."""
+    n, H, W = m.shape
+    out = np.full((n, oh, ow), pad, dtype=np.int64)
+    for i in range(n):
+        if centered:
+            ph, pw = oh // 2 + oh, ow // 2 + ow          # generous padding: windows of any size fit
+            padded = np.pad(m[i].astype(np.int64), ((ph, ph), (pw, pw)), constant_values=pad)
+            x, y = int(pos[i, 0]), int(pos[i, 1])
+            out[i] = padded[y + ph - oh // 2: y + ph - oh // 2 + oh, x + pw - ow // 2: x + pw - ow // 2 + ow]
+        else:
+            hh, ww = min(oh, H), min(ow, W)
+            out[i, :hh, :ww] = m[i, :hh, :ww]
+    if depth == 1:
+        return out[..., None].astype(np.uint8)
+    return np.eye(depth, dtype=np.uint8)[out]
+
+
+@pytest.mark.parametrize("prob,rep,calls,n,oh,ow,centered,onehot", [
+    # the fused step kernel writes the image (binary / zelda, at most 16 rows, single-cell representations)
+    ("binary", "narrow", (), 200, 28, 28, 1, 0), ("binary", "turtle", (), 65, 5, 7, 1, 0), ("binary", "narrow", (), 64, 31, 17, 1, 1),
+    ("binary", "wide", (), 130, 14, 14, 0, 0), ("binary", "narrow", (dict(width=30, height=9),), 70, 40, 66, 1, 0),
+    ("binary", "narrow", (dict(width=40, height=12),), 50, 12, 40, 0, 0),
+    ("zelda", "narrow", (), 100, 22, 22, 1, 1), ("zelda", "wide", (dict(width=11, height=16),), 129, 16, 11, 0, 1),
+    ("zelda", "turtle", (), 64, 9, 9, 1, 0), ("zelda", "wide", (), 77, 7, 11, 0, 0),
+    # one more kernel after the step (k_obs): search problems, tall maps, block representations, smb's byte maps
+    ("sokoban", "narrow", (), 150, 10, 10, 1, 1), ("sokoban", "wide", (), 33, 5, 5, 0, 1), ("mdungeon", "turtle", (), 70, 14, 14, 1, 1),
+    ("ddave", "narrow", (), 41, 22, 22, 1, 1), ("binary", "turtle", (dict(width=64, height=64),), 20, 28, 28, 1, 0),
+    ("binary", "narrow", (dict(width=20, height=30),), 66, 28, 28, 1, 1), ("zelda", "narrowcast", (), 48, 22, 22, 1, 1),
+    ("binary", "narrowmulti", (), 35, 28, 28, 1, 0), ("smb", "narrow", (dict(width=30, height=8),), 9, 12, 20, 1, 1),
+], ids=lambda v: str(v) if not isinstance(v, tuple) else "adj%d" % len(v))
+def test_bound_observation_every_step(prob, rep, calls, n, oh, ow, centered, onehot):
+    """pcgrl_bind_observation: after reset, after every step (auto-resets included) and after a rollout the bound tensor
+    holds the wrappers' image of the returned state -- fused into k_step where that kernel runs, k_obs elsewhere; batch
+    sizes that leave a partial last block, windows larger than the map, images that are not a multiple of 16 bytes."""
+    torch = _torch()
+    env = _make(prob, rep, n, list(calls) + [dict(change_percentage=0.3, solver_power=200)], seed=77)
+    if prob == "smb":
+        env._prob._solver_power = 300
+    pad = env.get_border_tile()
+    depth = env.get_num_tiles() if onehot else 1
+    img = env.bind_observation(oh, ow, centered, pad, onehot)
+    obs = env.reset()
+    has_pos = env._rep.has_pos
+
+    def check(tag):
+        m = env._bufs["map"].cpu().numpy()
+        pos = env._bufs["pos"].cpu().numpy() if has_pos else np.zeros((n, 2), np.uint8)
+        exp = _expected_image(m, pos, oh, ow, centered, pad, depth)
+        got = img.cpu().numpy()
+        bad = np.nonzero((got != exp).reshape(n, -1).any(1))[0]
+        assert bad.size == 0, (tag, bad[:5])
+
+    check("reset")
+    sp = env.single_action_space
+    rs = np.random.RandomState(5)
+    T = 12 if prob == "smb" else 40
+    draw = (lambda: rs.randint(0, sp.n, size=(n,))) if hasattr(sp, "n") else (lambda: np.stack([rs.randint(0, int(k), size=(n,)) for k in sp.nvec], -1))
+    ndone = 0
+    for t in range(T):
+        _, _, done, _ = env.step(torch.as_tensor(draw().astype(np.int32), device="cuda"))
+        ndone += int(done.sum().item())
+        check(("step", t))
+    tape = np.stack([draw() for _ in range(7)]).astype(np.int32)
+    env.rollout(torch.as_tensor(tape, device="cuda"))
+    check("rollout")
+    # redirecting the target, the explicit call, and switching the feature off
+    other = torch.zeros_like(img)
+    env.set_observation_target(other)
+    before = img.clone()
+    env.step(torch.as_tensor(draw().astype(np.int32), device="cuda"))
+    assert torch.equal(img, before)
+    img = other
+    check("retarget")
+    env.unbind_observation()
+    env.step(torch.as_tensor(draw().astype(np.int32), device="cuda"))
+    assert torch.equal(other, img)
+    assert env.check_status() == 0
+    env.close()
+
+
 # ------------------------------------------------------------------ edge shapes (layout corners of the kernels)
 @pytest.mark.parametrize("prob,rep,w,h", [
     ("binary", "narrow", 1, 1), ("binary", "turtle", 1, 9), ("binary", "wide", 9, 1), ("binary", "narrow", 32, 16),
