@@ -8,11 +8,17 @@
 // contiguous stretch of the output -- and every thread produces 16-byte pieces of it in registers and stores them as
 // dwordx4, a wavefront covering 1 KB of consecutive addresses per store instruction.  Nothing of the image is staged: the
 // tile of an output cell comes from the environment's row bit planes (k_step: its LDS copy of the block's state, so the
-// fused step writes the observation without reading the byte map at all; binary maps: a whole output row is one shifted
-// plane word and 16 cells expand to 16 bytes with four multiplies) or from the byte map (cached narrow loads).
-//   obs_write_block   the device routine (k_step calls it at the end of the launch; k_obs is a kernel around it)
-//   k_obs             the stand-alone kernel: pcgrl_reset, pcgrl_set_maps, pcgrl_observe and the steps of the configurations
-//                     that do not run the fused step kernel
+// fused step writes the observation without reading the byte map at all) or from the byte map (cached narrow loads).
+// What a piece costs in instructions decides whether the stream reaches the memory system's rate, so the two shapes the
+// trainer uses have their own lean routines, selected once per call (kernel-uniform):
+//   rows (binary, tile ids)   an output row is one shifted plane word; sixteen cells = sixteen bits of one or two rows,
+//                             expanded to bytes with four 24-bit multiplies
+//   hot8 (one-hot, 8 tiles)   zelda, mdungeon: two cells per piece, three plane bits each
+//   obs_pieces_any            everything else, byte by byte (other depths, images that are not a multiple of 16 bytes, huge windows)
+//   obs_write_block           all images of a block's environments; k_step calls it at the end of the launch, k_obs is a kernel
+//                             around it
+//   k_obs            the stand-alone kernel: pcgrl_reset, pcgrl_set_maps, pcgrl_observe and the steps of the configurations
+//                    that do not run the fused step kernel
 #pragma once
 
 struct ObsView {          // one block's view: environments [0, ne) relative to the block's first one
@@ -20,53 +26,43 @@ struct ObsView {          // one block's view: environments [0, ne) relative to 
     int oh, ow, depth, centered, pad, W, H;
 };
 
-// exact floor(i / d) while i * d < 2^32 (cell index / row length, byte / depth: a few thousand at most):  __umulhi(i, obs_magic(d))
+// exact floor(i / d) while i * d < 2^32:  __umulhi(i, obs_magic(d))   (the general routine; 32-bit multiplies are slow)
 __device__ __forceinline__ uint32_t obs_magic(int d) { return 0xFFFFFFFFu / (uint32_t)d + 1u; }
-// exact floor(o / d) for 0 <= o < 2^24 (byte offset in a block's stretch / bytes per image): float estimate, corrected
+// exact floor(o / d) for 0 <= o < 2^24: float estimate, corrected
 __device__ __forceinline__ int obs_div(int o, int d, float inv) {
     int q = (int)((float)o * inv);
     q -= (q * d > o) ? 1 : 0;
     q += ((q + 1) * d <= o) ? 1 : 0;
     return q;
 }
+// floor(i / d) as three full-rate instructions; exact where the call sites say why ((i + 1/2) / d is at least 1/(2d) away from
+// an integer, and the float product is off by less than that)
+__device__ __forceinline__ int obs_fdiv(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
 
 // Tile source: row bit planes [env][G rows][NPL planes] of MaskT (global memory or the LDS copy of k_step)
 template <class MaskT, int NPL>
 struct ObsPlanes {
     const MaskT* pl; int G;
-    static constexpr bool kRows = NPL == 1;
+    static constexpr int kPlanes = NPL;
+    static constexpr bool kWord32 = sizeof(MaskT) == 4;
     __device__ __forceinline__ int tile(int e, int y, int x) const {
         const MaskT* p = pl + ((size_t)e * G + y) * NPL;
         int t = (int)((p[0] >> x) & 1);
         if (NPL > 1) t |= ((int)((p[1] >> x) & 1) << 1) | ((int)((p[2] >> x) & 1) << 2);
         return t;
     }
-    __device__ __forceinline__ uint64_t row(int e, int y) const { return (uint64_t)pl[((size_t)e * G + y) * NPL]; }
+    __device__ __forceinline__ const MaskT* row(int e, int y) const { return pl + (e * G + y) * NPL; }
 };
 // Tile source: the byte map [env][H][W]
 struct ObsBytes {
     const uint8_t* map; int W, H;
-    static constexpr bool kRows = false;
+    static constexpr int kPlanes = 0;
+    static constexpr bool kWord32 = false;
     __device__ __forceinline__ int tile(int e, int y, int x) const { return (int)map[((size_t)e * H + y) * W + x]; }
-    __device__ __forceinline__ uint64_t row(int, int) const { return 0; }
+    __device__ __forceinline__ const uint32_t* row(int, int) const { return nullptr; }
 };
 
-// bit c (c < ow <= 64) = tile of output cell (r, c) of a one-plane (binary) map whose window starts at (oy, ox)
-template <class Src>
-__device__ __forceinline__ uint64_t obs_row_bits(const Src& src, const ObsView& V, int e, int r, int oy, int ox) {
-    const uint64_t all = V.ow >= 64 ? ~0ull : ((1ull << V.ow) - 1ull);
-    const uint64_t padbits = V.pad ? all : 0ull;
-    const int y = r + oy;
-    if ((unsigned)y >= (unsigned)V.H) return padbits;
-    const uint64_t m = src.row(e, y);
-    const uint64_t in = V.W >= 64 ? ~0ull : ((1ull << V.W) - 1ull);
-    uint64_t bits, valid;
-    if (ox >= 0) { bits = ox < 64 ? (m & in) >> ox : 0ull; valid = ox < 64 ? in >> ox : 0ull; }
-    else { bits = ox > -64 ? (m & in) << -ox : 0ull; valid = ox > -64 ? in << -ox : 0ull; }
-    valid &= all;
-    return (bits & valid) | (padbits & ~valid);
-}
-
+// ---- general routine: any depth, any size; `rem` = byte offset inside the image of environment e
 template <class Src>
 __device__ __forceinline__ int obs_cell(const Src& src, const ObsView& V, int e, int i, uint32_t mg_ow, int oy, int ox) {
     const int r = (int)__umulhi((uint32_t)i, mg_ow), c = i - r * V.ow;
@@ -74,7 +70,6 @@ __device__ __forceinline__ int obs_cell(const Src& src, const ObsView& V, int e,
     if ((unsigned)y >= (unsigned)V.H || (unsigned)x >= (unsigned)V.W) return V.pad;
     return src.tile(e, y, x);
 }
-// one byte of an environment's image (the pieces that straddle two images, and the tail of a partial block)
 template <class Src>
 __device__ __forceinline__ uint32_t obs_byte(const Src& src, const ObsView& V, const uint8_t* pos, int e, int rem, uint32_t mg_ow, uint32_t mg_d) {
     const int oy = V.centered ? (int)pos[2 * e + 1] - V.oh / 2 : 0, ox = V.centered ? (int)pos[2 * e] - V.ow / 2 : 0;
@@ -82,65 +77,119 @@ __device__ __forceinline__ uint32_t obs_byte(const Src& src, const ObsView& V, c
     const int t = obs_cell(src, V, e, i, mg_ow, oy, ox);
     return V.depth == 1 ? (uint32_t)t : (uint32_t)(d == t);
 }
+template <class Src>
+__device__ __attribute__((noinline)) void obs_pieces_any(Src src, uint8_t* out, int oh, int ow, int depth, int centered, int pad, int W, int H,
+                                                           const uint8_t* pos, int ne, int q0, int q1, int tail, int tid, int nthreads) {
+    const ObsView V = {out, oh, ow, depth, centered, pad, W, H};
+    const int per_env = oh * ow * depth, total = ne * per_env;
+    const uint32_t mg_ow = obs_magic(ow), mg_d = obs_magic(depth);
+    const float inv_env = 1.0f / (float)per_env;
+    for (int q = q0 + tid; q < q1; q += nthreads) {
+        const int o = q << 4;
+        int e = obs_div(o, per_env, inv_env), rem = o - e * per_env;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            w[k >> 2] |= obs_byte(src, V, pos, e, rem, mg_ow, mg_d) << (8 * (k & 3));
+            if (++rem == per_env) { rem = 0; ++e; }
+        }
+        reinterpret_cast<uint4*>(out)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (tail) for (int o = (total & ~15) + tid; o < total; o += nthreads) {     // last bytes of a partial block
+        const int e = obs_div(o, per_env, inv_env), rem = o - e * per_env;
+        out[o] = (uint8_t)obs_byte(src, V, pos, e, rem, mg_ow, mg_d);
+    }
+}
 
-// The images of environments [0, ne) of a block, written by the `nthreads` threads that call this (tid = 0 .. nthreads-1).
-// pos: the block's cursors [ne][2] (x, y), read only when the window is centred.
+// ---- binary, tile ids, 32-bit plane words: W <= 32, 16 <= ow <= 32, oh * ow <= 4096, images a multiple of 16 bytes
+// signed shift: m >> s for s in [-32, 31] (negative = left), low 32 bits
+__device__ __forceinline__ uint32_t obs_shr(uint32_t m, int s) { return (uint32_t)(((uint64_t)m << 32) >> (32 + s)); }
+template <class Src>
+__device__ __forceinline__ uint32_t obs_row32(const Src& src, const ObsView& V, int e, int r, int oy, int ox, uint32_t valid, uint32_t padbits) {
+    // bit c = tile of output cell (r, c): the plane word of map row r + oy moved by ox; cells outside the map = pad
+    const int y = r + oy;
+    const bool in = (unsigned)y < (unsigned)V.H;
+    const uint32_t m = (uint32_t)src.row(e, in ? y : 0)[0];
+    const uint32_t v = in ? valid : 0u;
+    return (obs_shr(m, ox) & v) | (padbits & ~v);
+}
+// ---- one-hot over eight tiles, three planes: ow <= 64, oh * ow <= 4096 (an image is then always a multiple of 16 bytes when
+// its number of cells is even; odd: the general routine)
+template <bool INSIDE, class Src>
+__device__ __forceinline__ uint2 obs_hot8(const Src& src, const ObsView& V, int e, int i, int oy, int ox, float inv_ow) {
+    // (i < 4096: the quotient is below 4096 / ow, the float product off by < 2^-11 / ow... at most 2^-10 for ow = 1; margin 1/(2 ow) >= 1/128)
+    const int r = obs_fdiv(i, inv_ow), c = i - (int)__umul24(r, V.ow);
+    const int y = r + oy, x = c + ox;
+    const bool in = INSIDE || ((unsigned)y < (unsigned)V.H && (unsigned)x < (unsigned)V.W);
+    const auto* p = src.row(e, in ? y : 0);
+    const int xs = in ? x : 0;
+    int t = (int)((p[0] >> xs) & 1) | ((int)((p[1] >> xs) & 1) << 1) | ((int)((p[2] >> xs) & 1) << 2);
+    t = in ? t : V.pad;
+    const uint32_t bit = 1u << ((t & 3) << 3);
+    return make_uint2(t < 4 ? bit : 0u, t < 4 ? 0u : bit);
+}
+// Which routine a call takes (kernel-uniform).  0: general, 1: rows (binary ids), 2: one-hot over eight tiles
+template <class Src>
+__device__ __forceinline__ int obs_mode(const ObsView& V) {
+    const int cells = V.oh * V.ow, per_env = cells * V.depth;
+    if ((per_env & 15) != 0 || cells > 4096) return 0;
+    if (Src::kPlanes == 1 && Src::kWord32 && V.depth == 1 && V.ow >= 16 && V.ow <= 32 && V.W <= 32 && V.pad <= 1) return 1;
+    if (Src::kPlanes == 3 && Src::kWord32 && V.depth == 8 && V.ow <= 64 && V.pad <= 7) return 2;
+    return 0;
+}
+
+// The images of a block's environments [0, ne) (one contiguous stretch of ne * oh * ow * depth bytes), written by the `nthreads`
+// threads (whole wavefronts) that call this, tid = 0 .. nthreads-1.  pos: the block's cursors [ne][2] (x, y), read only when
+// the window is centred.  The lean routines go environment by environment, a wavefront each: environment, window origin
+// and validity masks are then wave-uniform (scalar registers), a lane's work is one piece.
 template <class Src>
 __device__ __forceinline__ void obs_write_block(const Src& src, const ObsView& V, const uint8_t* pos, int ne, int tid, int nthreads) {
-    const int per_env = V.oh * V.ow * V.depth;
-    const int total = ne * per_env;
-    const uint32_t mg_ow = obs_magic(V.ow), mg_d = obs_magic(V.depth);
-    const float inv_env = 1.0f / (float)per_env;
-    const bool rows = Src::kRows && V.depth == 1 && V.ow <= 64 && V.pad <= 1;
+    const int mode = obs_mode<Src>(V);
+    if (mode == 0) {
+        obs_pieces_any<Src>(src, V.out, V.oh, V.ow, V.depth, V.centered, V.pad, V.W, V.H, pos, ne, 0, (ne * V.oh * V.ow * V.depth) >> 4, 1, tid, nthreads);
+        return;
+    }
+    const int ppe = (V.oh * V.ow * V.depth) >> 4;                 // pieces per image (<= 2048: 32 KB)
+    const float inv_ow = 1.0f / (float)V.ow;
+    const int lane = tid & 63, nw = nthreads >> 6;
     uint4* out4 = reinterpret_cast<uint4*>(V.out);
-    for (int q = tid; q < (total >> 4); q += nthreads) {
-        const int o = q << 4;
-        const int e = obs_div(o, per_env, inv_env), rem = o - e * per_env;
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        if (rem + 16 <= per_env) {
-            const int oy = V.centered ? (int)pos[2 * e + 1] - V.oh / 2 : 0, ox = V.centered ? (int)pos[2 * e] - V.ow / 2 : 0;
-            if (rows) {
-                // sixteen cells = sixteen bits taken from one to three consecutive output rows
-                int r = (int)__umulhi((uint32_t)rem, mg_ow), c0 = rem - r * V.ow, filled = 0;
-                uint32_t acc = 0;
-                while (filled < 16) {
-                    const uint64_t bits = obs_row_bits(src, V, e, r, oy, ox) >> c0;
-                    const int n = (V.ow - c0) < (16 - filled) ? (V.ow - c0) : (16 - filled);
-                    acc |= ((uint32_t)bits & ((1u << n) - 1u)) << filled;
-                    filled += n; r++; c0 = 0;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = (((acc >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u;   // bit j -> byte j
-            } else if (V.depth == 8) {
-                const int i = rem >> 3;
-                const uint64_t a = 1ull << (8 * obs_cell(src, V, e, i, mg_ow, oy, ox));
-                const uint64_t b = 1ull << (8 * obs_cell(src, V, e, i + 1, mg_ow, oy, ox));
-                w[0] = (uint32_t)a; w[1] = (uint32_t)(a >> 32); w[2] = (uint32_t)b; w[3] = (uint32_t)(b >> 32);
-            } else if (V.depth == 1) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) w[k >> 2] |= (uint32_t)obs_cell(src, V, e, rem + k, mg_ow, oy, ox) << (8 * (k & 3));
-            } else {
-                int i = (int)__umulhi((uint32_t)rem, mg_d), d = rem - i * V.depth;
-                int t = obs_cell(src, V, e, i, mg_ow, oy, ox);
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    w[k >> 2] |= (uint32_t)(d == t) << (8 * (k & 3));
-                    if (++d == V.depth) { d = 0; ++i; t = obs_cell(src, V, e, i, mg_ow, oy, ox); }
-                }
+    for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < ne; e += nw) {
+        int oy = 0, ox = 0;
+        if (V.centered) {
+            const uint32_t p = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<const uint16_t*>(pos)[e]);
+            ox = (int)(p & 255u) - (V.ow >> 1); oy = (int)(p >> 8) - (V.oh >> 1);
+        }
+        uint4* oe = out4 + e * ppe;
+        if (Src::kPlanes == 1) {
+            const uint32_t all = V.ow >= 32 ? ~0u : ((1u << V.ow) - 1u);
+            const uint32_t in = V.W >= 32 ? ~0u : ((1u << V.W) - 1u);
+            const uint32_t valid = obs_shr(in, ox) & all, padbits = V.pad ? all : 0u;
+            for (int j = lane; j < ppe; j += 64) {
+                // (rem < 4096, ow >= 16: the quotient is below 256 and the float product off by < 2^-15, against a margin of 1/(2 ow) >= 1/64)
+                const int rem = j << 4, r0 = obs_fdiv(rem, inv_ow), c0 = rem - (int)__umul24(r0, V.ow);
+                const uint32_t a = obs_row32(src, V, e, r0, oy, ox, valid, padbits);
+                const uint32_t b = obs_row32(src, V, e, r0 + 1, oy, ox, valid, padbits);       // (past the last row only when c0 + 16 <= ow: not used then)
+                const uint32_t acc = (uint32_t)((((uint64_t)b << V.ow) | a) >> c0);
+                uint4 w;
+                w.x = __umul24(acc & 15u, 0x204081u) & 0x01010101u;                              // bit j -> byte j
+                w.y = __umul24((acc >> 4) & 15u, 0x204081u) & 0x01010101u;
+                w.z = __umul24((acc >> 8) & 15u, 0x204081u) & 0x01010101u;
+                w.w = __umul24((acc >> 12) & 15u, 0x204081u) & 0x01010101u;
+                oe[j] = w;
             }
-        } else {      // the piece straddles two images
-            int ee = e, rr = rem;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                w[k >> 2] |= obs_byte(src, V, pos, ee, rr, mg_ow, mg_d) << (8 * (k & 3));
-                if (++rr == per_env) { rr = 0; ++ee; }
+        } else if (Src::kPlanes == 3) {
+            if (!V.centered && V.oh == V.H && V.ow == V.W) {       // the map itself: no cell is outside
+                for (int j = lane; j < ppe; j += 64) {
+                    const uint2 a = obs_hot8<true>(src, V, e, 2 * j, 0, 0, inv_ow), b = obs_hot8<true>(src, V, e, 2 * j + 1, 0, 0, inv_ow);
+                    oe[j] = make_uint4(a.x, a.y, b.x, b.y);
+                }
+            } else {
+                for (int j = lane; j < ppe; j += 64) {
+                    const uint2 a = obs_hot8<false>(src, V, e, 2 * j, oy, ox, inv_ow), b = obs_hot8<false>(src, V, e, 2 * j + 1, oy, ox, inv_ow);
+                    oe[j] = make_uint4(a.x, a.y, b.x, b.y);
+                }
             }
         }
-        out4[q] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    for (int o = (total & ~15) + tid; o < total; o += nthreads) {     // tail of a partial last block
-        const int e = obs_div(o, per_env, inv_env), rem = o - e * per_env;
-        V.out[o] = (uint8_t)obs_byte(src, V, pos, e, rem, mg_ow, mg_d);
     }
 }
 
@@ -153,21 +202,27 @@ __device__ __forceinline__ ObsView obs_view(const PcgrlParams& P, const ObsSpec&
 }
 
 #define OBS_EPB 64       /* environments per block of k_obs (a multiple of 16: every block's stretch starts 16-byte aligned) */
-// SRC 0: byte map; 1: one u32 plane (binary); 2: one u64 plane (binary, wide or tall maps)
+// SRC 0: byte map; 1: one u32 plane (binary); 3: three u32 planes (zelda, sokoban, mdungeon, ddave on maps of at most 32 columns).
+// With planes the block first copies the planes and cursors of its environments into LDS (one coalesced burst; dynamic LDS:
+// OBS_EPB * (group * SRC * 4 + 2) bytes): a piece is a chain of two or three dependent reads, which must not be trips to memory.
 template <int SRC>
 __global__ __launch_bounds__(256) void k_obs(PcgrlParams P, DevBufs B, ObsSpec S) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t obs_lds[];
     const int e0 = blockIdx.x * OBS_EPB;
     const int ne = (P.num_envs - e0) < OBS_EPB ? (P.num_envs - e0) : OBS_EPB;
     const ObsView V = obs_view(P, S, e0);
-    const uint8_t* pos = B.pos + (size_t)e0 * 2;
     if (SRC == 0) {
         const ObsBytes src = {B.map + (size_t)e0 * P.width * P.height, P.width, P.height};
-        obs_write_block(src, V, pos, ne, (int)threadIdx.x, 256);
-    } else if (SRC == 1) {
-        const ObsPlanes<uint32_t, 1> src = {reinterpret_cast<const uint32_t*>(B.planes) + (size_t)e0 * P.group, P.group};
-        obs_write_block(src, V, pos, ne, (int)threadIdx.x, 256);
+        obs_write_block(src, V, B.pos + (size_t)e0 * 2, ne, (int)threadIdx.x, 256);
     } else {
-        const ObsPlanes<uint64_t, 1> src = {reinterpret_cast<const uint64_t*>(B.planes) + (size_t)e0 * P.group, P.group};
-        obs_write_block(src, V, pos, ne, (int)threadIdx.x, 256);
+        constexpr int NPL = SRC == 1 ? 1 : 3;
+        const int env_bytes = P.group * NPL * 4;                        // a multiple of 16
+        const uint4* g = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(B.planes) + (size_t)e0 * env_bytes);
+        for (int i = threadIdx.x; i < (ne * env_bytes) >> 4; i += 256) reinterpret_cast<uint4*>(obs_lds)[i] = g[i];
+        uint8_t* lpos = obs_lds + OBS_EPB * env_bytes;
+        if ((int)threadIdx.x < ne) reinterpret_cast<uint16_t*>(lpos)[threadIdx.x] = reinterpret_cast<const uint16_t*>(B.pos)[e0 + threadIdx.x];
+        __syncthreads();
+        const ObsPlanes<uint32_t, NPL> src = {reinterpret_cast<const uint32_t*>(obs_lds), P.group};
+        obs_write_block(src, V, lpos, ne, (int)threadIdx.x, 256);
     }
 }

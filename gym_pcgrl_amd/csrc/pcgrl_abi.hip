@@ -763,10 +763,12 @@ PCGRL_LOCAL int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStre
 static int launch_obs(pcgrl_env* h, const ObsSpec& S, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const int grid = (P.num_envs + OBS_EPB - 1) / OBS_EPB;
-    if (P.nplanes == 1 && S.depth == 1 && S.ow <= 64 && S.pad <= 1) {      // binary: an output row is one shifted plane word
-        if (P.mask_bytes == 4) hipLaunchKernelGGL(k_obs<1>, dim3(grid), dim3(256), 0, st, P, h->B, S);
-        else hipLaunchKernelGGL(k_obs<2>, dim3(grid), dim3(256), 0, st, P, h->B, S);
-    } else hipLaunchKernelGGL(k_obs<0>, dim3(grid), dim3(256), 0, st, P, h->B, S);
+    // from the row bit planes (staged in LDS) where the lean routines of kernels_obs.h apply -- binary tile ids, one-hot over
+    // eight tiles --, else from the byte map
+    const size_t lds = (size_t)OBS_EPB * (P.group * P.nplanes * 4 + 2);
+    if (P.nplanes == 1 && P.mask_bytes == 4 && S.depth == 1) hipLaunchKernelGGL(k_obs<1>, dim3(grid), dim3(256), lds, st, P, h->B, S);
+    else if (P.nplanes == 3 && P.mask_bytes == 4 && S.depth == 8) hipLaunchKernelGGL(k_obs<3>, dim3(grid), dim3(256), lds, st, P, h->B, S);
+    else hipLaunchKernelGGL(k_obs<0>, dim3(grid), dim3(256), 0, st, P, h->B, S);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
