@@ -124,6 +124,7 @@ def run_leg(torch, device, workload, steps, warmup, steady_warmup, seed=0):
     return leg
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK = 1.0e12  # wave64 VALU instructions per second, whole chip: measured (profiles/r3a_round3/valu_calibration.md); 1 024 SIMDs x 2.4 GHz / 2.45
 
 
 def make_actions(torch, rep, steps, n, W, H, nt, device, seed, flat=False):
@@ -413,7 +414,7 @@ def main():
     if rank == 0:
         # dominant kernel (k_stats; for sokoban the solver): its share of the step from the event pass -- the idle
         # intervals of that pass measure the cost of an event pair, which is subtracted -- and, from the committed
-        # SQ counters, how close it runs to the VALU issue limit (one wave64 VALU instruction per SIMD per 4 cycles)
+        # SQ counters, how close it runs to the VALU issue limit (measured: one wave64 VALU instruction per SIMD per 2.45 cycles)
         ph = {k: 1e3 * v / max(prof_steps, 1) for k, v in phase_ms.items()}
         ev_us = min(ph.values()) if ph else 0.0
         # binary maps of <= 16 rows run the whole step as ONE launch (k_step): the "stats" interval is then empty and
@@ -430,7 +431,7 @@ def main():
         valu, valu_src = measured_valu(a.workload, "k_step" if fused else "k_stats") if n == n_default else (None, None)
         dominant = {"name": dom_name, "avg_us": dom_us, "event_pair_overhead_us": ev_us}
         if valu and dom_us > 0 and not solver:
-            peak = 256 * 4 * 2.4e9 / 4          # SIMDs x clock / 4 cycles per wave64 VALU instruction
+            peak = VALU_ISSUE_PEAK              # measured on this GPU: profiles/r3a_round3/valu_calibration.md (tools/valu_calib.hip)
             dominant.update({"valu_wave_instr_per_launch": valu, "valu_source": valu_src,
                              "valu_issue_rate": valu / (dom_us * 1e-6), "valu_issue_peak": peak,
                              "valu_issue_frac": valu / (dom_us * 1e-6) / peak})

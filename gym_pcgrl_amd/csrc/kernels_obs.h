@@ -101,15 +101,16 @@ __device__ __attribute__((noinline)) void obs_pieces_any(Src src, uint8_t* out, 
     }
 }
 
-// ---- binary, tile ids, 32-bit plane words: W <= 32, 16 <= ow <= 32, oh * ow <= 4096, images a multiple of 16 bytes
-// signed shift: m >> s for s in [-32, 31] (negative = left), low 32 bits
+// ---- binary, tile ids: W <= 32 (64 with 64-bit plane words), 16 <= ow <= 32, oh * ow <= 4096, images a multiple of 16 bytes
+// signed shift: m >> s (negative s = left), low 32 bits; s in [-32, 31] for a 32-bit word, in [-32, 63] for a 64-bit one
 __device__ __forceinline__ uint32_t obs_shr(uint32_t m, int s) { return (uint32_t)(((uint64_t)m << 32) >> (32 + s)); }
+__device__ __forceinline__ uint32_t obs_shr(uint64_t m, int s) { return s >= 0 ? (uint32_t)(m >> s) : (uint32_t)(m << -s); }
 template <class Src>
 __device__ __forceinline__ uint32_t obs_row32(const Src& src, const ObsView& V, int e, int r, int oy, int ox, uint32_t valid, uint32_t padbits) {
     // bit c = tile of output cell (r, c): the plane word of map row r + oy moved by ox; cells outside the map = pad
     const int y = r + oy;
     const bool in = (unsigned)y < (unsigned)V.H;
-    const uint32_t m = (uint32_t)src.row(e, in ? y : 0)[0];
+    const auto m = src.row(e, in ? y : 0)[0];            // (uint32_t or uint64_t: the map may be wider than the window)
     const uint32_t v = in ? valid : 0u;
     return (obs_shr(m, ox) & v) | (padbits & ~v);
 }
@@ -128,14 +129,85 @@ __device__ __forceinline__ uint2 obs_hot8(const Src& src, const ObsView& V, int 
     const uint32_t bit = 1u << ((t & 3) << 3);
     return make_uint2(t < 4 ? bit : 0u, t < 4 ? 0u : bit);
 }
-// Which routine a call takes (kernel-uniform).  0: general, 1: rows (binary ids), 2: one-hot over eight tiles
-template <class Src>
-__device__ __forceinline__ int obs_mode(const ObsView& V) {
-    const int cells = V.oh * V.ow, per_env = cells * V.depth;
+// Which routine an image takes.  0: general, 1: rows (binary ids), 2: one-hot over eight tiles.  (Host and device: the fused
+// step kernel only carries the lean routines -- the host sends the other shapes to k_obs.)
+__host__ __device__ inline int obs_lean_mode(int nplanes, bool word32, int W, int oh, int ow, int depth, int pad) {
+    const int cells = oh * ow, per_env = cells * depth;
     if ((per_env & 15) != 0 || cells > 4096) return 0;
-    if (Src::kPlanes == 1 && Src::kWord32 && V.depth == 1 && V.ow >= 16 && V.ow <= 32 && V.W <= 32 && V.pad <= 1) return 1;
-    if (Src::kPlanes == 3 && Src::kWord32 && V.depth == 8 && V.ow <= 64 && V.pad <= 7) return 2;
+    if (nplanes == 1 && depth == 1 && ow >= 16 && ow <= 32 && W <= (word32 ? 32 : 64) && pad <= 1) return 1;      // (a window row is one 32-bit word)
+    if (nplanes == 3 && word32 && depth == 8 && ow <= 64 && pad <= 7) return 2;
     return 0;
+}
+template <class Src>
+__device__ __forceinline__ int obs_mode(const ObsView& V) { return obs_lean_mode(Src::kPlanes, Src::kWord32, V.W, V.oh, V.ow, V.depth, V.pad); }
+
+// The image of environment e with the lean routine of the source (obs_mode != 0), by one wavefront: environment, window origin
+// and validity masks are wave-uniform (scalar registers), a lane's work is one piece.
+template <class Src>
+__device__ __forceinline__ void obs_write_env_lean(const Src& src, const ObsView& V, const uint8_t* pos, int e, int lane) {
+    const int ppe = (V.oh * V.ow * V.depth) >> 4;                 // pieces per image (<= 2048: 32 KB)
+    const float inv_ow = 1.0f / (float)V.ow;
+    int oy = 0, ox = 0;
+    if (V.centered) {
+        const uint32_t p = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<const uint16_t*>(pos)[e]);
+        ox = (int)(p & 255u) - (V.ow >> 1); oy = (int)(p >> 8) - (V.oh >> 1);
+    }
+    uint4* oe = reinterpret_cast<uint4*>(V.out) + e * ppe;
+    if (Src::kPlanes == 1) {
+        const uint32_t all = V.ow >= 32 ? ~0u : ((1u << V.ow) - 1u);
+        typedef decltype(src.row(0, 0)[0] + 0) WordT;            // uint32_t / uint64_t
+        const WordT in = V.W >= (int)(8 * sizeof(WordT)) ? ~(WordT)0 : (((WordT)1 << V.W) - 1);
+        const uint32_t valid = obs_shr(in, ox) & all, padbits = V.pad ? all : 0u;
+        for (int j = lane; j < ppe; j += 64) {
+            // (rem < 4096, ow >= 16: the quotient is below 256 and the float product off by < 2^-15, against a margin of 1/(2 ow) >= 1/64)
+            const int rem = j << 4, r0 = obs_fdiv(rem, inv_ow), c0 = rem - (int)__umul24(r0, V.ow);
+            const uint32_t a = obs_row32(src, V, e, r0, oy, ox, valid, padbits);
+            const uint32_t b = obs_row32(src, V, e, r0 + 1, oy, ox, valid, padbits);       // (past the last row only when c0 + 16 <= ow: not used then)
+            const uint32_t acc = (uint32_t)((((uint64_t)b << V.ow) | a) >> c0);
+            uint4 w;
+            w.x = __umul24(acc & 15u, 0x204081u) & 0x01010101u;                              // bit j -> byte j
+            w.y = __umul24((acc >> 4) & 15u, 0x204081u) & 0x01010101u;
+            w.z = __umul24((acc >> 8) & 15u, 0x204081u) & 0x01010101u;
+            w.w = __umul24((acc >> 12) & 15u, 0x204081u) & 0x01010101u;
+            oe[j] = w;
+        }
+    } else if (Src::kPlanes == 3) {
+        if (!V.centered && V.oh == V.H && V.ow == V.W) {       // the map itself: no cell is outside
+            for (int j = lane; j < ppe; j += 64) {
+                const uint2 a = obs_hot8<true>(src, V, e, 2 * j, 0, 0, inv_ow), b = obs_hot8<true>(src, V, e, 2 * j + 1, 0, 0, inv_ow);
+                oe[j] = make_uint4(a.x, a.y, b.x, b.y);
+            }
+        } else {
+            for (int j = lane; j < ppe; j += 64) {
+                const uint2 a = obs_hot8<false>(src, V, e, 2 * j, oy, ox, inv_ow), b = obs_hot8<false>(src, V, e, 2 * j + 1, oy, ox, inv_ow);
+                oe[j] = make_uint4(a.x, a.y, b.x, b.y);
+            }
+        }
+    }
+}
+// k_step's form (lean shapes only; `nthreads` threads = whole wavefronts call it): every image, a wavefront per environment --
+// or, `delta` (the wide representation's map image, one-hot over eight tiles; the target still holds the image of the previous
+// state): the piece that holds map cell (x, y) of every environment with `changed[e]` (x, y from its action act[e * 3 ..]) and
+// the whole image of every environment with `fresh[e]` (its episode ended: a new map).
+template <class Src>
+__device__ __forceinline__ void obs_write_block_lean(const Src& src, const ObsView& V, const uint8_t* pos, int ne, bool delta, const int32_t* act,
+                                                     const uint8_t* changed, const uint8_t* fresh, int tid, int nthreads) {
+    const int lane = tid & 63, nw = nthreads >> 6;
+    if (delta && Src::kPlanes == 3) {
+        const float inv_ow = 1.0f / (float)V.ow;
+        const int ppe = (V.oh * V.ow * V.depth) >> 4;
+        for (int e = tid; e < ne; e += nthreads) {
+            if (!changed[e] || fresh[e]) continue;
+            int x = act[3 * e], y = act[3 * e + 1];
+            x = x < 0 ? 0 : (x > V.W - 1 ? V.W - 1 : x); y = y < 0 ? 0 : (y > V.H - 1 ? V.H - 1 : y);      // (update_env clamps the same way)
+            if (x >= V.ow || y >= V.oh) continue;                       // (a window smaller than the map)
+            const int i = (y * V.ow + x) & ~1;                          // first cell of the piece (8 bytes a cell: a piece is two cells of one image)
+            const uint2 a = obs_hot8<false>(src, V, e, i, 0, 0, inv_ow), b = obs_hot8<false>(src, V, e, i + 1, 0, 0, inv_ow);
+            reinterpret_cast<uint4*>(V.out)[e * ppe + (i >> 1)] = make_uint4(a.x, a.y, b.x, b.y);
+        }
+    }
+    for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < ne; e += nw)
+        if (!(delta && Src::kPlanes == 3) || fresh[e]) obs_write_env_lean(src, V, pos, e, lane);
 }
 
 // The images of a block's environments [0, ne) (one contiguous stretch of ne * oh * ow * depth bytes), written by the `nthreads`
@@ -144,53 +216,11 @@ __device__ __forceinline__ int obs_mode(const ObsView& V) {
 // and validity masks are then wave-uniform (scalar registers), a lane's work is one piece.
 template <class Src>
 __device__ __forceinline__ void obs_write_block(const Src& src, const ObsView& V, const uint8_t* pos, int ne, int tid, int nthreads) {
-    const int mode = obs_mode<Src>(V);
-    if (mode == 0) {
+    if (obs_mode<Src>(V) == 0) {
         obs_pieces_any<Src>(src, V.out, V.oh, V.ow, V.depth, V.centered, V.pad, V.W, V.H, pos, ne, 0, (ne * V.oh * V.ow * V.depth) >> 4, 1, tid, nthreads);
         return;
     }
-    const int ppe = (V.oh * V.ow * V.depth) >> 4;                 // pieces per image (<= 2048: 32 KB)
-    const float inv_ow = 1.0f / (float)V.ow;
-    const int lane = tid & 63, nw = nthreads >> 6;
-    uint4* out4 = reinterpret_cast<uint4*>(V.out);
-    for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < ne; e += nw) {
-        int oy = 0, ox = 0;
-        if (V.centered) {
-            const uint32_t p = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<const uint16_t*>(pos)[e]);
-            ox = (int)(p & 255u) - (V.ow >> 1); oy = (int)(p >> 8) - (V.oh >> 1);
-        }
-        uint4* oe = out4 + e * ppe;
-        if (Src::kPlanes == 1) {
-            const uint32_t all = V.ow >= 32 ? ~0u : ((1u << V.ow) - 1u);
-            const uint32_t in = V.W >= 32 ? ~0u : ((1u << V.W) - 1u);
-            const uint32_t valid = obs_shr(in, ox) & all, padbits = V.pad ? all : 0u;
-            for (int j = lane; j < ppe; j += 64) {
-                // (rem < 4096, ow >= 16: the quotient is below 256 and the float product off by < 2^-15, against a margin of 1/(2 ow) >= 1/64)
-                const int rem = j << 4, r0 = obs_fdiv(rem, inv_ow), c0 = rem - (int)__umul24(r0, V.ow);
-                const uint32_t a = obs_row32(src, V, e, r0, oy, ox, valid, padbits);
-                const uint32_t b = obs_row32(src, V, e, r0 + 1, oy, ox, valid, padbits);       // (past the last row only when c0 + 16 <= ow: not used then)
-                const uint32_t acc = (uint32_t)((((uint64_t)b << V.ow) | a) >> c0);
-                uint4 w;
-                w.x = __umul24(acc & 15u, 0x204081u) & 0x01010101u;                              // bit j -> byte j
-                w.y = __umul24((acc >> 4) & 15u, 0x204081u) & 0x01010101u;
-                w.z = __umul24((acc >> 8) & 15u, 0x204081u) & 0x01010101u;
-                w.w = __umul24((acc >> 12) & 15u, 0x204081u) & 0x01010101u;
-                oe[j] = w;
-            }
-        } else if (Src::kPlanes == 3) {
-            if (!V.centered && V.oh == V.H && V.ow == V.W) {       // the map itself: no cell is outside
-                for (int j = lane; j < ppe; j += 64) {
-                    const uint2 a = obs_hot8<true>(src, V, e, 2 * j, 0, 0, inv_ow), b = obs_hot8<true>(src, V, e, 2 * j + 1, 0, 0, inv_ow);
-                    oe[j] = make_uint4(a.x, a.y, b.x, b.y);
-                }
-            } else {
-                for (int j = lane; j < ppe; j += 64) {
-                    const uint2 a = obs_hot8<false>(src, V, e, 2 * j, oy, ox, inv_ow), b = obs_hot8<false>(src, V, e, 2 * j + 1, oy, ox, inv_ow);
-                    oe[j] = make_uint4(a.x, a.y, b.x, b.y);
-                }
-            }
-        }
-    }
+    for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < ne; e += nthreads >> 6) obs_write_env_lean(src, V, pos, e, tid & 63);
 }
 
 // The observation target of a handle (pcgrl_bind_observation): part of DevBufs.
@@ -202,9 +232,10 @@ __device__ __forceinline__ ObsView obs_view(const PcgrlParams& P, const ObsSpec&
 }
 
 #define OBS_EPB 64       /* environments per block of k_obs (a multiple of 16: every block's stretch starts 16-byte aligned) */
-// SRC 0: byte map; 1: one u32 plane (binary); 3: three u32 planes (zelda, sokoban, mdungeon, ddave on maps of at most 32 columns).
-// With planes the block first copies the planes and cursors of its environments into LDS (one coalesced burst; dynamic LDS:
-// OBS_EPB * (group * SRC * 4 + 2) bytes): a piece is a chain of two or three dependent reads, which must not be trips to memory.
+// SRC 0: byte map; 1: one u32 plane (binary); 2: one u64 plane (binary, maps wider than 32 columns); 3: three u32 planes (zelda,
+// sokoban, mdungeon, ddave on maps of at most 32 columns).  With planes the block first copies the planes and cursors of its
+// environments into LDS (one coalesced burst; dynamic LDS: OBS_EPB * (bytes of an environment's planes + 2)): a piece is a chain of
+// two or three dependent reads, which must not be trips to memory.
 template <int SRC>
 __global__ __launch_bounds__(256) void k_obs(PcgrlParams P, DevBufs B, ObsSpec S) {
     extern __shared__ __attribute__((aligned(16))) uint8_t obs_lds[];
@@ -215,14 +246,15 @@ __global__ __launch_bounds__(256) void k_obs(PcgrlParams P, DevBufs B, ObsSpec S
         const ObsBytes src = {B.map + (size_t)e0 * P.width * P.height, P.width, P.height};
         obs_write_block(src, V, B.pos + (size_t)e0 * 2, ne, (int)threadIdx.x, 256);
     } else {
-        constexpr int NPL = SRC == 1 ? 1 : 3;
-        const int env_bytes = P.group * NPL * 4;                        // a multiple of 16
+        constexpr int NPL = SRC == 3 ? 3 : 1;
+        typedef typename std::conditional<SRC == 2, uint64_t, uint32_t>::type WordT;
+        const int env_bytes = P.group * NPL * (int)sizeof(WordT);       // a multiple of 16
         const uint4* g = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(B.planes) + (size_t)e0 * env_bytes);
         for (int i = threadIdx.x; i < (ne * env_bytes) >> 4; i += 256) reinterpret_cast<uint4*>(obs_lds)[i] = g[i];
         uint8_t* lpos = obs_lds + OBS_EPB * env_bytes;
         if ((int)threadIdx.x < ne) reinterpret_cast<uint16_t*>(lpos)[threadIdx.x] = reinterpret_cast<const uint16_t*>(B.pos)[e0 + threadIdx.x];
         __syncthreads();
-        const ObsPlanes<uint32_t, NPL> src = {reinterpret_cast<const uint32_t*>(obs_lds), P.group};
+        const ObsPlanes<WordT, NPL> src = {reinterpret_cast<const WordT*>(obs_lds), P.group};
         obs_write_block(src, V, lpos, ne, (int)threadIdx.x, 256);
     }
 }

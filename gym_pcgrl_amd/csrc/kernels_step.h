@@ -327,8 +327,12 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     // ---- the wrapped observation of the block's environments (pcgrl_bind_observation), straight from the LDS copy: the row
     // planes are the map, the cursors are there too -- no byte map is read.  A store stream that overlaps with the blocks that
     // are still computing (the step is latency-bound, the memory system nearly idle).
-    if (Bg.obs.out) {
+    // (only the shapes with a lean routine -- kernels_obs.h: binary tile ids, one-hot over eight tiles -- are written here, the
+    // host sends the others to k_obs: Bg.obs.fused.  Wide representation, single step, the target still holding the previous
+    // image: only what changed, Bg.obs.delta.)
+    if (Bg.obs.out && Bg.obs.fused) {
         const ObsPlanes<MaskT, NPL> src = {reinterpret_cast<const MaskT*>(smem + L.planes), G};
-        obs_write_block(src, obs_view(P, Bg.obs, e0), smem + L.pos, ne, (int)threadIdx.x, TPB);
+        obs_write_block_lean(src, obs_view(P, Bg.obs, e0), smem + L.pos, ne, REP == PCGRL_REP_WIDE && !MULTI && Bg.obs.delta, act_lds, s_loc.dirty,
+                             smem + L.done, (int)threadIdx.x, TPB);
     }
 }

@@ -94,6 +94,8 @@ struct pcgrl_env {
     // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
     int no_wide, wide_waves, wide_grid, fused_zelda, no_fused, step_epb, smb_heap;
     int profiling;
+    int obs_incremental;       // pcgrl_bind_observation(incremental): the bound target is the library's to update in place
+    const uint8_t* obs_synced; // the buffer that holds the image of the current state (written by the last step / reset), or NULL
     int obs_hold;     // inside pcgrl_rollout's loop of steps: the bound observation is written once, at the end
     std::vector<hipEvent_t> events;
     size_t ev_used;
@@ -277,7 +279,7 @@ int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
     if (!out) return PCGRL_EINVAL;
     pcgrl_env* h = new pcgrl_env();
     h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
-    h->profiling = 0; h->ev_used = 0; h->prof_steps = 0; h->obs_hold = 0;
+    h->profiling = 0; h->ev_used = 0; h->prof_steps = 0; h->obs_hold = 0; h->obs_incremental = 0; h->obs_synced = nullptr;
     memset(&h->B, 0, sizeof(h->B));
     h->cfg = *c;
     fill_params(c, &h->P);
@@ -357,7 +359,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         B.champ = s + scratch_bytes_base(&h->cfg);
         HIPCHK(hipMemsetAsync(B.champ, 0, champ_bytes(&h->cfg), (hipStream_t)stream));
     }
-    B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0};
+    B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0, 0, 0};
     B.fifo = nullptr; B.fifo_tag = nullptr;
     if (fifo_bytes(&h->cfg)) {
         uint8_t* f = s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg);
@@ -765,11 +767,13 @@ static int launch_obs(pcgrl_env* h, const ObsSpec& S, hipStream_t st) {
     const int grid = (P.num_envs + OBS_EPB - 1) / OBS_EPB;
     // from the row bit planes (staged in LDS) where the lean routines of kernels_obs.h apply -- binary tile ids, one-hot over
     // eight tiles --, else from the byte map
-    const size_t lds = (size_t)OBS_EPB * (P.group * P.nplanes * 4 + 2);
+    const size_t lds = (size_t)OBS_EPB * (P.group * P.nplanes * P.mask_bytes + 2);
     if (P.nplanes == 1 && P.mask_bytes == 4 && S.depth == 1) hipLaunchKernelGGL(k_obs<1>, dim3(grid), dim3(256), lds, st, P, h->B, S);
+    else if (P.nplanes == 1 && P.mask_bytes == 8 && S.depth == 1) hipLaunchKernelGGL(k_obs<2>, dim3(grid), dim3(256), lds, st, P, h->B, S);
     else if (P.nplanes == 3 && P.mask_bytes == 4 && S.depth == 8) hipLaunchKernelGGL(k_obs<3>, dim3(grid), dim3(256), lds, st, P, h->B, S);
     else hipLaunchKernelGGL(k_obs<0>, dim3(grid), dim3(256), 0, st, P, h->B, S);
     HIPCHK(hipGetLastError());
+    if (S.out == h->B.obs.out) h->obs_synced = S.out;       // a full image of the current state
     return PCGRL_OK;
 }
 static int obs_spec(const pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot, ObsSpec* S) {
@@ -778,7 +782,8 @@ static int obs_spec(const pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out
     if (((uintptr_t)out & 15) != 0) return PCGRL_EINVAL;
     const int depth = onehot ? h->P.ntiles : 1;
     if ((size_t)OBS_EPB * out_h * out_w * depth >= ((size_t)1 << 24) / 4) return PCGRL_EINVAL;      // offsets inside a block's stretch stay small (obs_div)
-    *S = ObsSpec{out, out_h, out_w, depth, centered ? 1 : 0, pad_value};
+    *S = ObsSpec{out, out_h, out_w, depth, centered ? 1 : 0, pad_value, 0, 0};
+    S->fused = obs_lean_mode(h->P.nplanes, h->P.mask_bytes == 4, h->P.width, out_h, out_w, depth, pad_value) != 0 ? 1 : 0;
     return PCGRL_OK;
 }
 
@@ -870,12 +875,14 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (!actions) return PCGRL_EINVAL;
     DeviceGuard guard(h->device);
     bool used_lists = true;
+    h->B.obs.delta = (h->B.obs.out && h->B.obs.fused && h->obs_incremental && !h->obs_hold && h->obs_synced == h->B.obs.out) ? 1 : 0;
     int rc = step_one(h, actions, stream, &used_lists);
     if (rc) return rc;
+    if (h->B.obs.out && !h->obs_hold) h->obs_synced = h->B.obs.out;      // (every path below leaves the image of the new state there)
     if (used_lists) h->parity ^= 1;
     if (h->profiling) h->prof_steps++;
     // the wrapped observation: the fused step kernel wrote it; every other pipeline gets one more launch
-    if (used_lists && h->B.obs.out && !h->obs_hold && (rc = launch_obs(h, h->B.obs, (hipStream_t)stream))) return rc;
+    if ((used_lists || !h->B.obs.fused) && h->B.obs.out && !h->obs_hold && (rc = launch_obs(h, h->B.obs, (hipStream_t)stream))) return rc;
     return PCGRL_OK;
 }
 
@@ -887,9 +894,14 @@ int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* r
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->P.num_envs, stride = n * action_width(h->P.rep);
+    h->obs_synced = nullptr;          // a tape ends with a full image of the state it ends in
+    h->B.obs.delta = 0;
     if (fused_step_applies(h, true) && !h->profiling) {
         const RolloutArgs R = {steps, stride, reward_out, done_out, info_out};
-        return launch_step(h, actions, h->parity, st, R);     // no work lists, no parity flip (see step_one)
+        int rc = launch_step(h, actions, h->parity, st, R);     // no work lists, no parity flip (see step_one)
+        if (rc == PCGRL_OK && h->B.obs.out && !h->B.obs.fused) rc = launch_obs(h, h->B.obs, st);
+        if (rc == PCGRL_OK) h->obs_synced = h->B.obs.out;
+        return rc;
     }
     int epb = 0;
     if (solver_rollout_applies(h, &epb) && !h->profiling) {
@@ -969,10 +981,18 @@ int pcgrl_observe(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int3
     return launch_obs(h, S, (hipStream_t)stream);
 }
 
-int pcgrl_bind_observation(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot) {
+int pcgrl_bind_observation(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot,
+                           int32_t incremental) {
     if (!h || !h->bound) return PCGRL_ESTATE;
-    if (!out) { h->B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0}; return PCGRL_OK; }
-    return obs_spec(h, out, out_h, out_w, centered, pad_value, onehot, &h->B.obs);
+    if (!out) { h->B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0, 0, 0}; h->obs_synced = nullptr; return PCGRL_OK; }
+    ObsSpec S;
+    int rc = obs_spec(h, out, out_h, out_w, centered, pad_value, onehot, &S);
+    if (rc) return rc;
+    const ObsSpec& O = h->B.obs;
+    if (!(O.out == S.out && O.oh == S.oh && O.ow == S.ow && O.depth == S.depth && O.centered == S.centered && O.pad == S.pad)) h->obs_synced = nullptr;
+    h->B.obs = S;
+    h->obs_incremental = incremental ? 1 : 0;
+    return PCGRL_OK;
 }
 
 int pcgrl_action_map(pcgrl_env* h, const int32_t* flat, int32_t* xyv, void* stream) {

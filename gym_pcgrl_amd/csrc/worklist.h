@@ -67,7 +67,9 @@ __device__ __forceinline__ void tl_mark(int tag) {
 struct LocalLists;
 // The wrapped observation a handle keeps up to date (pcgrl_bind_observation; kernels_obs.h): uint8 [N][oh][ow][depth], written
 // by the last kernel of every step / reset.  out == nullptr: off.
-struct ObsSpec { uint8_t* out; int32_t oh, ow, depth, centered, pad; };
+struct ObsSpec { uint8_t* out; int32_t oh, ow, depth, centered, pad;
+                 int32_t fused,        // k_step writes the image itself (a shape with a lean routine, kernels_obs.h); else k_obs follows the step
+                         delta; };     // ... and may update it in place: `out` holds the image of the state the step starts from
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid

@@ -305,18 +305,21 @@ class BatchedPcgrlEnv:
         return rew, done.view(torch.bool), ib
 
     # ---- the wrapped observation (wrappers.py:215-248), written by the step itself
-    def bind_observation(self, out_h, out_w, centered, pad_value, onehot, out=None):
+    def bind_observation(self, out_h, out_w, centered, pad_value, onehot, out=None, incremental=True):
         """From now on every reset() / step() / rollout() / set_maps() leaves the image the reference's composite wrappers
         would produce -- uint8 [N, out_h, out_w, D], D = 1 or the number of tiles (one-hot); centred on the cursor and padded
         with `pad_value`, or the map from its origin -- in the returned tensor (`out`, or a new one).  Where the step is one
-        fused kernel it writes the image from its on-chip copy of the state; no extra launch."""
+        fused kernel it writes the image from its on-chip copy of the state; no extra launch.  `incremental` (default): the
+        tensor is the environment's to maintain -- do not write into it -- so that a step may update it in place where that
+        is cheaper (a window that does not follow a cursor changes in one cell per step); after set_observation_target() the
+        next step writes a full image into the new tensor."""
         torch = self._torch
         depth = self.get_num_tiles() if onehot else 1
         shape = (self.num_envs, int(out_h), int(out_w), depth)
         if out is None:
             out = torch.empty(shape, dtype=torch.uint8, device=self.device)
         self._check_obs_target(out, shape)
-        self._obs_spec = (out, int(out_h), int(out_w), int(bool(centered)), int(pad_value), int(bool(onehot)))
+        self._obs_spec = (out, int(out_h), int(out_w), int(bool(centered)), int(pad_value), int(bool(onehot)), int(bool(incremental)))
         self._apply_observation()
         return out
 
@@ -337,13 +340,13 @@ class BatchedPcgrlEnv:
     def unbind_observation(self):
         self._obs_spec = None
         if self._handle is not None:
-            _lib.check(self._lib.pcgrl_bind_observation(self._handle, None, 0, 0, 0, 0, 0), "pcgrl_bind_observation")
+            _lib.check(self._lib.pcgrl_bind_observation(self._handle, None, 0, 0, 0, 0, 0, 0), "pcgrl_bind_observation")
 
     def _apply_observation(self):
         if self._obs_spec is None or self._handle is None:
             return
-        out, h, w, centered, pad, onehot = self._obs_spec
-        _lib.check(self._lib.pcgrl_bind_observation(self._handle, C.c_void_p(out.data_ptr()), h, w, centered, pad, onehot), "pcgrl_bind_observation")
+        out, h, w, centered, pad, onehot, inc = self._obs_spec
+        _lib.check(self._lib.pcgrl_bind_observation(self._handle, C.c_void_p(out.data_ptr()), h, w, centered, pad, onehot, inc), "pcgrl_bind_observation")
 
     # gym.vector-style split call
     def step_async(self, actions):

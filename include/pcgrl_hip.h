@@ -149,9 +149,13 @@ int pcgrl_observe(pcgrl_env* env, uint8_t* out, int32_t out_h, int32_t out_w, in
  * caller-owned).  Where the step is one fused kernel (binary, zelda; maps of at most 16 rows) that kernel writes the image from
  * its on-chip copy of the state -- no extra launch, no read of the byte map; elsewhere one extra kernel follows the step.  This
  * is what wrappers.py:215-248 + utils.make_vec_envs :60-71 hand the policy per step.  May be called again at any time with
- * another `out` (a rollout buffer row); out = NULL switches it off.  Only records the target: nothing is written by the call. */
+ * another `out` (a rollout buffer row); out = NULL switches it off.  Only records the target: nothing is written by the call.
+ * incremental != 0: the caller will not write into `out`; a step whose target is the buffer the previous step (or reset) left
+ * its image in may then update it in place -- for a window that does not follow a cursor (wide representation) that is one
+ * 16-byte piece per changed environment and the full image only where an episode ended, instead of every byte.  Binding
+ * another buffer, or incremental = 0, always gives full images. */
 int pcgrl_bind_observation(pcgrl_env* env, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered,
-                           int32_t pad_value, int32_t onehot);
+                           int32_t pad_value, int32_t onehot, int32_t incremental);
 /* ActionMap.step for the wide representation (wrappers.py:139-154): flat DEVICE i32 [N] index into
  * (H, W, tiles) -> xyv DEVICE i32 [N,3] = (x, y, tile), the action pcgrl_step takes. */
 int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* stream);

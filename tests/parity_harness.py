@@ -64,6 +64,22 @@ def draw_config(rs, only=None):
     return prob, rep, (w, h), calls, E, T, seed0
 
 
+MAP_EVERY = 5      # stepping: the cursor and the heat map are compared at every step, the whole map every MAP_EVERY steps and at the end
+
+
+def _obs_mismatch(obs, exp, t, has_pos, sel=None):
+    """Observation of step t (device tensors, optionally the rows `sel`) against the oracle's: cursor and heat map always,
+    the map every MAP_EVERY steps.  -> None or the name of what differs."""
+    pick = (lambda x: x) if sel is None else (lambda x: x[sel])
+    if has_pos and not np.array_equal(pick(obs["pos"]).cpu().numpy().astype(np.int64), np.stack([x["pos"][t] for x in exp])):
+        return "pos"
+    if not np.array_equal(pick(obs["heatmap"]).cpu().numpy().astype(np.int64), np.stack([x["heatmap"][t] for x in exp]).astype(np.int64)):
+        return "heatmap"
+    if t % MAP_EVERY == 0 and not np.array_equal(pick(obs["map"]).cpu().numpy(), np.stack([x["maps"][t] for x in exp])):
+        return "map"
+    return None
+
+
 def _oracle_rollouts(prob, rep, calls, seeds, acts_by_env):
     out = []
     for seed, a in zip(seeds, acts_by_env):
@@ -72,7 +88,7 @@ def _oracle_rollouts(prob, rep, calls, seeds, acts_by_env):
             o.adjust_param(**kw)
         o.seed(int(seed))
         o.reset()
-        out.append(o.rollout(a, want_heat=False))
+        out.append(o.rollout(a))
     return out
 
 
@@ -114,8 +130,16 @@ def run_config(prob, rep, calls, E, T, seed0, rs, use_rollout, mixed=False, step
                 np.array_equal(np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64), np.stack([x["info"][t] for x in exp]))
             if not ok:
                 return "MISMATCH %s %s %s E %d seed %d step %d" % (prob, rep, calls, E, seed0, t)
+            bad = _obs_mismatch(obs, exp, t, env._rep.has_pos)
+            if bad:
+                return "OBS MISMATCH (%s) %s %s %s E %d seed %d step %d" % (bad, prob, rep, calls, E, seed0, t)
+        # the state the tape / the steps end in: map, cursor, heat map
         if not np.array_equal(obs["map"].cpu().numpy(), np.stack([x["maps"][-1] for x in exp])):
             return "MAP MISMATCH %s %s %s E %d seed %d" % (prob, rep, calls, E, seed0)
+        if env._rep.has_pos and not np.array_equal(obs["pos"].cpu().numpy().astype(np.int64), np.stack([x["pos"][-1] for x in exp])):
+            return "POS MISMATCH %s %s %s E %d seed %d" % (prob, rep, calls, E, seed0)
+        if not np.array_equal(obs["heatmap"].cpu().numpy().astype(np.int64), np.stack([x["heatmap"][-1] for x in exp]).astype(np.int64)):
+            return "HEATMAP MISMATCH %s %s %s E %d seed %d" % (prob, rep, calls, E, seed0)
         env.check_status()
     finally:
         env.close()
@@ -183,7 +207,12 @@ def fullsize_case(name, use_rollout, max_steps=None):
                 assert np.array_equal(rew[ti].cpu().numpy(), np.array([x["reward"][t] for x in exp])), ("reward", name, t)
                 assert np.array_equal(np.stack([info[k][ti].cpu().numpy() for k in keys], 1).astype(np.int64),
                                       np.stack([x["info"][t] for x in exp])), ("info", name, t)
+                bad = _obs_mismatch(obs, exp, t, env._rep.has_pos, ti)
+                assert bad is None, (bad, name, t)
         assert np.array_equal(obs["map"][ti].cpu().numpy(), np.stack([x["maps"][-1] for x in exp])), ("map", name)
+        if env._rep.has_pos:
+            assert np.array_equal(obs["pos"][ti].cpu().numpy().astype(np.int64), np.stack([x["pos"][-1] for x in exp])), ("pos", name)
+        assert np.array_equal(obs["heatmap"][ti].cpu().numpy().astype(np.int64), np.stack([x["heatmap"][-1] for x in exp]).astype(np.int64)), ("heatmap", name)
         env.check_status()
     finally:
         env.close()

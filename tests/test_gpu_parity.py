@@ -1155,6 +1155,49 @@ def test_fuzz_slice(chunk):
 
 
 @pytest.mark.gpu
+def test_hypothesis_configurations():
+    """property-style search over the configuration space with hypothesis -- (problem, representation,
+    width, height, change_percentage, flags, batch size, seed) drawn by its strategies (and shrunk to a minimal failing
+    configuration when one fails); every step of the HIP path against the CPU oracle: reward, done, info, cursor, heat map,
+    and the map every few steps.  Derandomised: the same examples on every run."""
+    _torch()
+    import parity_harness as ph
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    sizes = {"binary": (40, 40), "zelda": (40, 40), "sokoban": (7, 7), "mdungeon": (12, 12), "ddave": (12, 12), "smb": (40, 14)}
+
+    @st.composite
+    def configs(draw):
+        prob = draw(st.sampled_from(sorted(sizes)))
+        rep = draw(st.sampled_from(ph.REPS))
+        wmax, hmax = sizes[prob]
+        w = draw(st.integers(1, wmax))
+        h = draw(st.integers(3 if prob == "smb" else 1, hmax))
+        calls = [dict(width=w, height=h), dict(change_percentage=draw(st.sampled_from([0.05, 0.2, 0.5, 1.0])))]
+        if prob in ("sokoban", "mdungeon", "ddave"):
+            calls.append(dict(solver_power=draw(st.sampled_from([30, 200, 1000]))))
+        if rep.startswith("narrow") and draw(st.booleans()):
+            calls.append(dict(random_tile=False))
+        if rep.startswith("turtle") and draw(st.booleans()):
+            calls.append(dict(warp=True))
+        if draw(st.integers(0, 4)) == 0:
+            calls.append(dict(random_start=False))
+        E = draw(st.sampled_from([1, 7, 64, 65, 130]))
+        mode = draw(st.sampled_from(["steps", "steps", "rollout", "mixed"]))
+        return prob, rep, calls, E, draw(st.integers(1, 10 ** 6)), mode
+
+    @settings(max_examples=30, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+    @given(configs())
+    def check(cfg):
+        prob, rep, calls, E, seed0, mode = cfg
+        T = 24 if prob == "smb" else 60
+        err = ph.run_config(prob, rep, calls, E, T, seed0, np.random.RandomState(seed0 % 1000), mode == "rollout", mode == "mixed")
+        assert err is None, err
+
+    check()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("use_rollout", [False, True], ids=["steps", "rollout"])
 @pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "M1", "D1", "S1"])
 def test_full_size_vs_oracle(name, use_rollout):

@@ -47,7 +47,7 @@ __global__ void k_salu_dep(uint32_t* out, uint32_t y) {
     uint32_t x = blockIdx.x;
     for (int i = 0; i < N_ITER; i++) {
 #pragma unroll
-        for (int k = 0; k < UNROLL; k++) asm volatile("s_add_u32 %0, %0, %1" : "+s"(x) : "s"(y));
+        for (int k = 0; k < UNROLL; k++) asm volatile("s_add_u32 %0, %0, %1" : "+s"(x) : "s"(y) : "scc");
     }
     if (x == 0x12345u) out[0] = x;
 }
@@ -67,50 +67,37 @@ __global__ void k_lds_dep(uint32_t* out, uint32_t y) {
     }
     if (o == 0x12345u) out[0] = o;
 }
-// v_readlane with a uniform lane index followed by a VALU use (the register-resident tables of the search kernels)
-__global__ void k_readlane_dep(uint32_t* out, uint32_t y) {
-    uint32_t x = threadIdx.x * 7u + y;
-    uint32_t idx = y & 63u;
-    for (int i = 0; i < N_ITER; i++) {
-#pragma unroll
-        for (int k = 0; k < UNROLL / 2; k++) {
-            uint32_t s;
-            asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(s) : "v"(x), "s"(idx));
-            asm volatile("s_and_b32 %0, %1, 63" : "=s"(idx) : "s"(s));
-        }
-    }
-    if (idx == 0x12345u) out[0] = idx;
-}
-
 typedef void (*kern_t)(uint32_t*, uint32_t);
 int main() {
     uint32_t* out;
-    hipMalloc(&out, 256);
+    (void)hipMalloc(&out, 256);
     hipDeviceProp_t prop;
-    hipGetDeviceProperties(&prop, 0);
+    (void)hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     printf("device: %s, %d CUs, %d MHz\n", prop.name, cus, prop.clockRate / 1000);
+    fflush(stdout);
     struct { const char* name; kern_t k; double per_iter; } K[] = {
         {"VALU v_add_u32, dependent chain", k_valu_dep, UNROLL}, {"VALU v_add_u32, 8 independent chains", k_valu_indep, UNROLL},
         {"VALU v_mul_lo_u32, dependent chain", k_mul_dep, UNROLL}, {"SALU s_add_u32, dependent chain", k_salu_dep, UNROLL},
-        {"LDS ds_read_b32 + wait, dependent chain", k_lds_dep, UNROLL}, {"v_readlane_b32 + s_and_b32, dependent chain (pairs)", k_readlane_dep, UNROLL / 2}};
+        {"LDS ds_read_b32 + wait, dependent chain", k_lds_dep, UNROLL}};
     printf("| chain | wavefronts / SIMD | chip wave-instr/s | cycles / instr seen by one wavefront (2.4 GHz) |\n|---|---|---|---|\n");
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (auto& kk : K)
         for (int w = 1; w <= 8; w *= 2) {
             const dim3 grid(cus * w), block(256);
             kk.k<<<grid, block>>>(out, 3);       // warm-up
-            hipDeviceSynchronize();
-            hipEventRecord(e0);
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(e0);
             for (int r = 0; r < 5; r++) kk.k<<<grid, block>>>(out, 3);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
             float ms = 0;
-            hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             const double t = ms * 1e-3 / 5, instr = (double)N_ITER * kk.per_iter;
             const double waves = (double)cus * w * 4;
             printf("| %s | %d | %.3e | %.2f |\n", kk.name, w, waves * instr / t, t * 2.4e9 / instr);
+            fflush(stdout);
         }
     return 0;
 }
