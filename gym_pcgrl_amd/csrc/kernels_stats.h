@@ -305,7 +305,9 @@ __device__ __forceinline__ void block_regions_and_path(DevGroup<64, MaskT>& g, M
     const int bh = (H + ts - 1) / ts;
     const int row_lo = tw * bh, row_hi = (row_lo + bh < H) ? row_lo + bh : H;
     int tiny_regions, tiny_path;
+    TL(20);
     const MaskT nontiny = rlp_prepare(g, pass, tiny_regions, tiny_path);
+    TL(21);
     if (tw == 0) {
         s_rest[lane] = nontiny;
         if (lane == 0) { *s_regions = tiny_regions; *s_best = tiny_path; *s_owner = -1; }
@@ -322,8 +324,10 @@ __device__ __forceinline__ void block_regions_and_path(DevGroup<64, MaskT>& g, M
             rest = sh.load_rest();
         } while (g.any(rest));
     }
+    TL(22);
     if (lane == 0 && regions) atomicAdd(s_regions, regions);
     __syncthreads();
+    TL(23);
     // one of the wavefronts whose own best sweep equals the final maximum writes its component
     if (lane == 0 && my_best > tiny_path && my_best == *s_best) atomicCAS(s_owner, -1, tw);
     __syncthreads();
@@ -376,6 +380,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag, s_cur;
     __shared__ int2 s_pre;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    TL_INIT(); TL(1);
     DevGroup<64, MaskT> g;
     // with the in-kernel reset, k_update puts the environments that are certain to be reset on WL_RST: those come first;
     // the incremental items of a step (WL_INC) are taken, a wavefront each, by the blocks that have no full item
@@ -388,6 +393,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     const int wave_lds = PCGRL_MT_N * 4 + ((W * H + 15) & ~15);
     uint32_t* mt = reinterpret_cast<uint32_t*>(smem);
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
+    // the block-wide reset's buffers (raw MT19937 words, the map's bit string): in the scratch sets of wavefronts 1 .. NWAVES-1,
+    // which only the incremental items at the end of the kernel use (the host sizes the allocation for both: launch_stats_p)
+    uint32_t* rst_raw = reinterpret_cast<uint32_t*>(smem + wave_lds);
+    uint64_t* rst_bits = reinterpret_cast<uint64_t*>(smem + wave_lds + (size_t)8 * W * H);
     const MaskT rowmask = row_valid<MaskT>(lane, W, H);
     for (int item = blockIdx.x; item < n; item += gridDim.x) {
         const bool lone = item < n_rst;                      // certain reset (block-uniform)
@@ -404,9 +413,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             if (threadIdx.x == 0) s_pre = reinterpret_cast<const int2*>(B.counters)[e];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64>(P, B, e, gen_map, mt, tiles, &s_cur);     // (every wavefront helps: reset_env.h)
-            MaskT n0, n1, n2;
-            planes_from_tiles<MaskT>(P, tiles, planes_e, lane, n0, n1, n2, wv == 0);
+            TL(24);
+            const MaskT n0 = block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64, MaskT>(P, B, e, gen_map, mt, tiles, rst_raw, rst_bits, &s_cur);     // (every wavefront helps: reset_env.h)
+            if (wv == 0) planes_e[lane] = n0;
+            TL(26);
             constexpr int TS = NWAVES / 2;
             const int team = wv / TS, tw = wv % TS;
             const MaskT pass = team == 0 ? (reset_only ? (MaskT)0 : (MaskT)(~b_old & rowmask)) : (MaskT)(~n0 & rowmask);
@@ -435,9 +445,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         }
         __syncthreads();
         if (inline_reset && s_flag) {   // block-uniform: PcgrlEnv.reset of this environment, then its start stats
-            block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64>(P, B, e, gen_map, mt, tiles, &s_cur);
-            MaskT b0, b1, b2;
-            planes_from_tiles<MaskT>(P, tiles, planes_e, lane, b0, b1, b2, wv == 0);
+            const MaskT b0 = block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64, MaskT>(P, B, e, gen_map, mt, tiles, rst_raw, rst_bits, &s_cur);
+            if (wv == 0) planes_e[lane] = b0;
             block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);
             if (threadIdx.x == 0) {
                 int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
@@ -446,6 +455,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         }
         __syncthreads();
     }
+    TL(27);
     if (n_inc > 0) {
         // incremental items: by the blocks beyond the full items if there are any, else by all
         const int first = ((int)gridDim.x > n) ? n : 0;
@@ -457,4 +467,5 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
                 wave_incremental_item<MaskT>(P, B, g, wl_get(B, WL_INC, s_pref_inc, j), parity, inline_reset, gen_map, mtw, tilesw, lane, rowmask);
         }
     }
+    TL(28);
 }

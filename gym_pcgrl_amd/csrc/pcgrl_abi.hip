@@ -495,7 +495,12 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     const int lone0 = !(mode == MODE_STEP && inline_reset) ? 0 : ((PROB == PCGRL_PROB_BINARY && P.group == 16 && P.rep <= PCGRL_REP_TURTLE) ? 1 : 2);
     if (PROB == PCGRL_PROB_BINARY && P.group == 64 && !h->no_wide) {   // block per item (k_stats_wide); PCGRL_NO_WIDE=1: A/B switch
         const int nw = h->wide_waves;
-        const size_t lds1 = inline_reset ? (size_t)(nw == 8 ? 8 : 4) * (PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15)) : 0;
+        // per wavefront an MT19937 ring + the tile bytes of a map; the block-wide reset keeps its raw words (8 bytes a cell) and the
+        // map's bit string in the sets of wavefronts 1.. (kernels_stats.h): at least that much
+        const size_t set1 = PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15);
+        const size_t need1 = set1 + (size_t)8 * P.width * P.height + 8 * ((size_t)(P.width * P.height + 63) / 64 + 2);
+        const size_t sets1 = (size_t)(nw == 8 ? 8 : 4) * set1;
+        const size_t lds1 = inline_reset ? (sets1 > need1 ? sets1 : need1) : 0;
         const int gridw = P.num_envs < h->wide_grid ? P.num_envs : h->wide_grid;
         // wavefronts per map: with the incremental route only ~10 % of the changes (and the resets) come here, so the launch
         // is latency-bound and more wavefronts per map pay (PCGRL_WIDE_WAVES overrides for experiments)

@@ -498,18 +498,27 @@ PCGRL_D typename B::mask_t rlp_choose_seed(B& g, typename B::mask_t rest, int ro
 }
 // my_best / my_champ: the longest sweep result of THIS group so far and its component (the group whose my_best equals
 // the final shared maximum holds a champion component for binary_incremental).
+#if defined(PCGRL_TIMELINE) && defined(__HIPCC__)
+__device__ __forceinline__ void tl_mark(int tag);       // worklist.h (developer builds: tools/timeline_wide.py)
+#define PCGRL_TLA(tag) tl_mark(tag)
+#else
+#define PCGRL_TLA(tag) do {} while (0)
+#endif
 template <class B, class Shared>
 PCGRL_D void rlp_process_seed(B& g, typename B::mask_t seed, const PcgFillCtx<B>& ctx, Shared& sh, int& regions, int& my_best,
                               typename B::mask_t& my_champ) {
     typedef typename B::mask_t M;
     const M comp = pcg_component(g, seed, ctx);
+    PCGRL_TLA(30);
     if (!sh.retire(g, comp)) return;
     ++regions;
     const int best = sh.best();
     if (g.popcount_sum(comp) - 1 > best) {
+        PCGRL_TLA(31);
         const int e = pcg_double_sweep(g, comp, best);
         if (e > my_best) { my_best = e; my_champ = comp; }
         sh.raise(e);
+        PCGRL_TLA(32);
     }
 }
 template <class B, class Shared>

@@ -181,16 +181,28 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
 
 
 
-// The same reset by a whole block (k_stats_wide: maps of up to 64 x 64 cells, 8 192 MT19937 words per map).  One wavefront
-// makes 128 words per round -- 64 rounds for such a map, ~38 us, with the other wavefronts of the block waiting for it: the
-// longest chain of a C5 step.  MT19937's recurrence reaches back 227 words, so 224 threads make 224 words per round (every
-// operand still an old word: all reads, a barrier, all writes), 37 rounds.  Same draws, same order, same results as
-// wave_reset_env; `s_cur`: one shared word.  Every thread of the block calls this; it ends with a block barrier.
-template <int PROB, int NTHREADS>
-__device__ __forceinline__ void block_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt, uint8_t* tiles, int* s_cur) {
-    static_assert(NTHREADS >= 256, "224 generating threads");
-    constexpr int RW = 224;                                  // words per round: even, below 227
-    const int tid = (int)threadIdx.x, lane = tid & 63;
+// The same reset by a whole block (k_stats_wide: binary maps of up to 64 x 64 cells, 8 192 MT19937 words per map).  One
+// wavefront makes 128 words per round -- 64 rounds for such a map, ~38 us, with the other wavefronts of the block waiting for
+// it: the longest chain of a C5 step.  Here (round 3; the in-kernel timeline showed 14 us for the map and 7 us for turning its
+// bytes into row masks):
+//   1. the raw words.  MT19937's recurrence x[k+624] = f(x[k], x[k+1], x[k+397]) reaches back 227 words; a thread that has just
+//      made word k also holds the one operand of word k+227 that is new (x[k+624]), so 227 threads make TWO words each per round
+//      -- 454 words between two barriers, 19 rounds for 8 192 words -- and nothing else happens in a round: the words go to a
+//      buffer in LDS (`raw`, 2 * cells words: the per-wavefront scratch sets the block reset does not use);
+//   2. the tiles, a thread per cell: tempering, numpy's 53-bit double, the cdf comparison (RandomState.choice, helper.py:310-312),
+//      byte stores to map / first map -- all of it parallel over the cells; a wavefront's 64 cells give 64 bits of the map's
+//      bit string with one ballot (`cellbits`);
+//   3. the row masks: lane r cuts its W bits out of that bit string (no loop over the bytes of a row).
+// Same draws, same order, same results as wave_reset_env; `s_cur`: one shared word.  Every thread of the block calls this; it
+// ends with a block barrier.  Returns the mask of row `lane` (bit x = tile bit 0 of cell (x, lane)) in every wavefront;
+// `tiles` still receives the tile bytes.
+template <int PROB, int NTHREADS, class MaskT>
+__device__ __forceinline__ MaskT block_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt, uint8_t* tiles, uint32_t* raw,
+                                                 uint64_t* cellbits, int* s_cur) {
+    static_assert(NTHREADS >= 256, "227 generating threads");
+    static_assert(PROB == PCGRL_PROB_BINARY, "one plane: the tall-map path of the binary problem");
+    constexpr int RW = 227;                                  // words of one reach of the recurrence; a round makes 2 * RW
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int W = P.width, H = P.height, cells = W * H;
     uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
     uint8_t* map_g = B.map + (size_t)e * cells;
@@ -205,39 +217,59 @@ __device__ __forceinline__ void block_reset_env(const PcgrlParams& P, const DevB
         int sl = curs.y + off; sl = sl >= PCGRL_MT_N ? sl - PCGRL_MT_N : sl;
         pw = B.rng_prob[(size_t)e * PCGRL_MT_N + sl];
     }
+    const int nchunks = (cells + 63) >> 6;
+    if (tid <= nchunks) cellbits[tid] = 0ull;                 // (one word beyond the last: step 3 reads two)
     __syncthreads();
     if (gen_map) {
-        constexpr int NT = PROB == PCGRL_PROB_BINARY ? 2 : PROB == PCGRL_PROB_SOKOBAN ? 5 : (PROB == PCGRL_PROB_DDAVE || PROB == PCGRL_PROB_SMB) ? 7 : 8;
-        double cdf[NT];
-        if (PROB == PCGRL_PROB_BINARY) {
-            double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};
-            pcgrl_build_cdf(p, 2, cdf);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NT; i++) cdf[i] = P.cdf[i];
-        }
         const int nwords = 2 * cells;
-        for (int w0 = 0; w0 < nwords; w0 += RW) {
-            const bool on = tid < RW && w0 + tid < nwords;
-            const int s = mt_wrap(cur + (tid < RW ? tid : 0));
-            uint32_t y = 0;
-            if (on) y = mt_twist(mt[s], mt[mt_wrap(s + 1)], mt[mt_wrap(s + PCGRL_MT_M)]);
-            __syncthreads();                                  // every operand was read before any slot is rewritten
-            if (on) mt[s] = y;
-            const uint32_t yo = __shfl_down(y, 1, 64);        // the odd word of the pair lives in the next lane of the same wavefront
-            if (on && !(tid & 1)) {
-                const int c = (w0 + tid) >> 1;                // cell c draws words 2c, 2c + 1 (helper.py:310-312, RandomState.choice)
-                const double u = mt_to_double(mt_temper(y), mt_temper(yo));
-                const uint8_t t = (uint8_t)pcgrl_pick_tile_c<NT>(cdf, u);
-                tiles[c] = t; map_g[c] = t; old_g[c] = t;
+        for (int w0 = 0; w0 < nwords; w0 += 2 * RW) {
+            const bool on1 = tid < RW && w0 + tid < nwords, on2 = tid < RW && w0 + RW + tid < nwords;
+            const int s1 = mt_wrap(cur + (tid < RW ? tid : 0)), s2 = mt_wrap(s1 + RW);
+            uint32_t y1 = 0, y2 = 0;
+            if (on1) {
+                const uint32_t a0 = mt[s1], a1 = mt[mt_wrap(s1 + 1)], am = mt[mt_wrap(s1 + PCGRL_MT_M)];
+                const uint32_t b0 = mt[s2], b1 = mt[mt_wrap(s2 + 1)];
+                y1 = mt_twist(a0, a1, am);
+                y2 = mt_twist(b0, b1, y1);                    // x[(k + 227) + 397] = x[k + 624]: the word just made
             }
-            const int adv = (nwords - w0) < RW ? (nwords - w0) : RW;
-            cur = mt_wrap(cur + adv);
+            __syncthreads();                                  // every operand was read before any slot is rewritten
+            if (on1) { mt[s1] = y1; raw[w0 + tid] = y1; }
+            if (on2) { mt[s2] = y2; raw[w0 + RW + tid] = y2; }
+            const int adv = (nwords - w0) < 2 * RW ? (nwords - w0) : 2 * RW;
+            cur = mt_wrap(mt_wrap(cur + (adv > RW ? RW : adv)) + (adv > RW ? adv - RW : 0));
             __syncthreads();
         }
+        double cdf[2];
+        {
+            double p[2] = {B.tile_p[2 * e], B.tile_p[2 * e + 1]};
+            pcgrl_build_cdf(p, 2, cdf);
+        }
+        for (int ch = wv; ch < nchunks; ch += NTHREADS / 64) {
+            const int c = ch * 64 + lane;                     // cell c draws words 2c, 2c + 1 (helper.py:310-312, RandomState.choice)
+            uint8_t t = 0;
+            if (c < cells) {
+                const double u = mt_to_double(mt_temper(raw[2 * c]), mt_temper(raw[2 * c + 1]));
+                t = (uint8_t)pcgrl_pick_tile_c<2>(cdf, u);
+                tiles[c] = t; map_g[c] = t; old_g[c] = t;
+            }
+            const uint64_t bits = __ballot(t & 1);
+            if (lane == 0) cellbits[ch] = bits;
+        }
     } else {
-        for (int c = tid; c < cells; c += NTHREADS) { const uint8_t t = old_g[c]; tiles[c] = t; map_g[c] = t; }
-        __syncthreads();
+        for (int ch = wv; ch < nchunks; ch += NTHREADS / 64) {
+            const int c = ch * 64 + lane;
+            uint8_t t = 0;
+            if (c < cells) { t = old_g[c]; tiles[c] = t; map_g[c] = t; }
+            const uint64_t bits = __ballot(t & 1);
+            if (lane == 0) cellbits[ch] = bits;
+        }
+    }
+    __syncthreads();
+    MaskT row = 0;
+    if (lane < H) {
+        const int o = lane * W, wd = o >> 6, sh = o & 63;
+        const uint64_t lo = cellbits[wd] >> sh, hi = sh ? cellbits[wd + 1] << (64 - sh) : 0ull;
+        row = (MaskT)((lo | hi) & (W >= 64 ? ~0ull : ((1ull << W) - 1ull)));
     }
     if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33
         if (tid == 0) {
@@ -276,4 +308,5 @@ __device__ __forceinline__ void block_reset_env(const PcgrlParams& P, const DevB
         }
     }
     __syncthreads();
+    return row;
 }
