@@ -6,10 +6,10 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 W=${1:-C2}; shift
 WHAT="${*:-trace sq mem}"
-B="python bench.py --workload $W --no-cpu-baseline --no-rollout"
+B="python bench.py --workload $W --no-cpu-baseline --no-rollout --no-legs"
 for what in $WHAT; do
   case $what in
-    rtrace) rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${W}R -o ${W}R -- python bench.py --workload $W --no-cpu-baseline --steps 200 > gpurun_out/prof_${W}R.log 2>&1 ;;   # with the pcgrl_rollout leg: k_step<..., true> / k_step_solver
+    rtrace) rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${W}R -o ${W}R -- python bench.py --workload $W --no-cpu-baseline --no-legs --steps 200 > gpurun_out/prof_${W}R.log 2>&1 ;;   # with the pcgrl_rollout leg: k_step<..., true> / k_step_solver
     trace) rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$W -o $W -- $B --steps 100 > gpurun_out/prof_$W.log 2>&1 ;;
     sq) rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq_$W -o $W -- $B --steps 100 --warmup 20 > gpurun_out/pmc_sq_$W.log 2>&1
         rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU --output-format csv -d gpurun_out/pmc_sq2_$W -o $W -- $B --steps 100 --warmup 20 > gpurun_out/pmc_sq2_$W.log 2>&1 ;;
