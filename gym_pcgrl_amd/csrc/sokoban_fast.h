@@ -181,6 +181,16 @@ PCGRL_D void sokf_siftup_root(HP heap, int endpos) {
     sokf_siftdown(heap, pos);
 }
 
+#if defined(PCGRL_SMB_PROF) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer builds: tools/sok_prof.py)
+#define SKP_DECL unsigned long long skp_t = clock64(), skp_a[6] = {0, 0, 0, 0, 0, 0}
+#define SKP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = clock64(); skp_a[i] += n_ - skp_t; skp_t = n_; } while (0)
+#define SKP_FLUSH(it) do { if (g_tl_buf && k >= 0) { for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_tl_buf[32 + i_], skp_a[i_]); atomicAdd(&g_tl_buf[38], (unsigned long long)(it)); atomicAdd(&g_tl_buf[39], 1ull); } } while (0)
+#else
+#define SKP_DECL do {} while (0)
+#define SKP(i) do {} while (0)
+#define SKP_FLUSH(it) do {} while (0)
+#endif
 // One search.  `table` must be all zeros; `cache`
 // is room for four nodes (LDS on the device).  Same contract as sok_search otherwise.
 template <int NW, class HP, class TP, class Hook, class Kids>
@@ -203,9 +213,11 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
     SokFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;   // cache[j] = pool[cache_base + j], j < cache_n
     int result_h = root.h, result_depth = 0;
+    SKP_DECL;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
         iterations++;
         if (hook(iterations)) { aborted = true; break; }
+        SKP(0);
         int cur;
         SokFastNode nd = ahead;
         if (k >= 0) {
@@ -225,6 +237,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             ahead_idx = -1;
             if (head < npool) { ahead_idx = head; ahead = pool[head]; }
         }
+        SKP(1);
         const uint64_t cr = nd.cr;
         const int node_player = (int)(nd.ph & 0xFFu), node_h = (int)(nd.ph >> 16), node_depth = (int)nd.depth;
         uint64_t cb[NW];
@@ -242,12 +255,14 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             if (v == key) { seen = true; break; }
             slot = (slot + 1) & (uint32_t)table_mask;
         }
+        SKP(2);
         if (seen) continue;
         table[slot] = key;
         cache_base = npool; cache_n = 0;
         if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) { have_best = true; best_h = node_h; best_depth = node_depth; }
         SokChild kid[4];                        // Node.getChildren: L, R, U, D
         kids(F, cr, cb, node_player, node_h, kid);
+        SKP(3);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -264,7 +279,9 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             }
             npool++;
         }
+        SKP(4);
     }
+    SKP_FLUSH(iterations);
     if (!win) { result_h = best_h; result_depth = best_depth; }
     out_h = result_h; out_depth = result_depth; out_iters = iterations;
     out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < npool);

@@ -86,8 +86,8 @@ class ActionMapImagePCGRLWrapper(_ImageWrapper):
     def __init__(self, game, num_envs=1, seed=None, device=None, **kwargs):
         super().__init__(game, num_envs, seed, device, kwargs)
         if self.pcgrl_env._rep.name != "wide":
-            raise NotImplementedError("the batched ActionMap is provided for the wide representation (the reference's trainer "
-                                      "only uses it there, utils.py:49-50)")
+            raise NotImplementedError("this composite is the trainer's wide-representation wrapper (utils.py:49-50); for a representation with "
+                                      "a cursor compose ToImage(OneHotEncoding(ActionMap(env), 'map'), ['map']) from the classes below")
         self._xyv = None
 
     def _window(self):
@@ -104,3 +104,181 @@ class ActionMapImagePCGRLWrapper(_ImageWrapper):
         _lib.check(e._lib.pcgrl_action_map(e._handle, C.c_void_p(a.data_ptr()), C.c_void_p(self._xyv.data_ptr()), e._stream()), "pcgrl_action_map")
         _, reward, done, info = e.step(self._xyv)
         return self._obs, reward, done, info
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The reference's single-purpose wrappers as separately composable classes (gym_pcgrl/wrappers.py:18-206), batched: they wrap a
+# BatchedPcgrlEnv (or one another) and transform its dict-of-tensors observation with a few torch calls on the device.  The two
+# composites above are what a trainer should use (one fused image per step); these exist so that code written against the
+# reference's building blocks -- e.g. ToImage(OneHotEncoding(Cropped(env, 22, pad, 'map'), 'map'), ['map', 'heatmap']) -- runs
+# unchanged on the batch.  Values equal the reference's element for element (one-hot planes are uint8 0/1 where the
+# reference's np.eye gives float64 0/1).
+def _pcgrl_env_of(env):
+    while not hasattr(env, "_bufs"):
+        env = env.env
+    return env
+
+
+class _ObsWrapper:
+    def __init__(self, game, num_envs, seed, device, kwargs):
+        if isinstance(game, str):
+            game = make_batched(game, num_envs=num_envs, seed=seed, **({"device": device} if device else {}))
+        self.env = game
+        self.pcgrl_env = _pcgrl_env_of(game)
+        self.pcgrl_env.adjust_param(**kwargs)
+        self.num_envs = self.pcgrl_env.num_envs
+        self.action_space = getattr(game, "action_space", None)
+        self.observation_space = getattr(game, "observation_space", None)
+
+    def transform(self, obs):
+        return obs
+
+    def reset(self):
+        return self.transform(self.env.reset())
+
+    def step(self, actions):
+        obs, reward, done, info = self.env.step(actions)
+        return self.transform(obs), reward, done, info
+
+    def seed(self, seed=None):
+        return self.env.seed(seed)
+
+    def adjust_param(self, **kwargs):
+        self.pcgrl_env.adjust_param(**kwargs)
+
+    def get_border_tile(self):
+        return self.pcgrl_env.get_border_tile()
+
+    def get_num_tiles(self):
+        return self.pcgrl_env.get_num_tiles()
+
+    def close(self):
+        self.env.close()
+
+    def _spaces_copy(self):
+        from collections import OrderedDict
+
+        from . import spaces
+        return spaces.Dict(OrderedDict(self.env.observation_space.spaces.items()))
+
+
+class Cropped(_ObsWrapper):
+    """wrappers.py:163-206: obs[name] [N,H,W] -> the crop_size window centred on the cursor, padded with pad_value."""
+
+    def __init__(self, game, crop_size, pad_value, name, num_envs=1, seed=None, device=None, **kwargs):
+        super().__init__(game, num_envs, seed, device, kwargs)
+        import numpy as np
+
+        from . import spaces
+        sp = self.env.observation_space.spaces
+        assert "pos" in sp, "This wrapper only works for representations thave have a position"
+        assert name in sp, "This wrapper only works if you have a {} key".format(name)
+        assert len(sp[name].shape) == 2, "This wrapper only works on 2D arrays."
+        self.name, self.size, self.pad, self.pad_value = name, int(crop_size), int(crop_size) // 2, int(pad_value)
+        self.observation_space = self._spaces_copy()
+        self.observation_space.spaces[name] = spaces.Box(low=0, high=int(np.max(sp[name].high)), shape=(self.size, self.size), dtype=np.uint8)
+
+    def transform(self, obs):
+        torch = self.pcgrl_env._torch
+        m = obs[self.name]
+        n, h, w = m.shape
+        padded = torch.nn.functional.pad(m, (self.pad, self.pad, self.pad, self.pad), value=self.pad_value)
+        pos = obs["pos"].to(torch.long)                       # [N, 2] = (x, y)
+        ar = torch.arange(self.size, device=m.device)
+        rows = (pos[:, 1:2] + ar[None, :])[:, :, None].expand(n, self.size, self.size)
+        cols = (pos[:, 0:1] + ar[None, :])[:, None, :].expand(n, self.size, self.size)
+        out = type(obs)(obs)
+        out[self.name] = padded[torch.arange(n, device=m.device)[:, None, None], rows, cols]
+        return out
+
+
+class OneHotEncoding(_ObsWrapper):
+    """wrappers.py:67-104: obs[name] -> np.eye(dim)[obs[name]] (a trailing axis of `dim` planes)."""
+
+    def __init__(self, game, name, num_envs=1, seed=None, device=None, **kwargs):
+        super().__init__(game, num_envs, seed, device, kwargs)
+        import numpy as np
+
+        from . import spaces
+        sp = self.env.observation_space.spaces
+        assert name in sp, "This wrapper only works for representations thave have a {} key".format(name)
+        self.name = name
+        self.dim = int(np.max(sp[name].high)) - int(np.min(sp[name].low)) + 1
+        self.observation_space = self._spaces_copy()
+        self.observation_space.spaces[name] = spaces.Box(low=0, high=1, shape=tuple(sp[name].shape) + (self.dim,), dtype=np.uint8)
+
+    def transform(self, obs):
+        torch = self.pcgrl_env._torch
+        out = type(obs)(obs)
+        out[self.name] = torch.nn.functional.one_hot(obs[self.name].to(torch.long), self.dim).to(torch.uint8)
+        return out
+
+
+class ToImage(_ObsWrapper):
+    """wrappers.py:18-60: the named entries stacked along a trailing axis into one [N, h, w, depth] tensor (the last layer)."""
+
+    def __init__(self, game, names, num_envs=1, seed=None, device=None, **kwargs):
+        super().__init__(game, num_envs, seed, device, kwargs)
+        import numpy as np
+
+        from . import spaces
+        sp = self.env.observation_space.spaces
+        self.shape, depth, max_value = None, 0, 0
+        for n in names:
+            assert n in sp, "This wrapper only works if your observation_space is spaces.Dict with the input names."
+            if self.shape is None:
+                self.shape = sp[n].shape
+            new_shape = sp[n].shape
+            depth += 1 if len(new_shape) <= 2 else new_shape[2]
+            assert self.shape[0] == new_shape[0] and self.shape[1] == new_shape[1], "This wrapper only works when all objects have same width and height"
+            max_value = max(max_value, int(np.max(sp[n].high)))
+        self.names = list(names)
+        self.observation_space = spaces.Box(low=0, high=max_value, shape=(self.shape[0], self.shape[1], depth), dtype=np.uint8)
+
+    def transform(self, obs):
+        torch = self.pcgrl_env._torch
+        parts = [obs[n].reshape(obs[n].shape[0], self.shape[0], self.shape[1], -1) for n in self.names]
+        dt = parts[0].dtype
+        for p in parts[1:]:
+            dt = torch.promote_types(dt, p.dtype)             # (np.append promotes the same way; the values are what counts)
+        return torch.cat([p.to(dt) for p in parts], dim=3) if len(parts) > 1 else parts[0]
+
+
+class ActionMap(_ObsWrapper):
+    """wrappers.py:111-160: the action is a flat index into (h, w, tiles).  Without a cursor it becomes the wide representation's
+    [x, y, tile]; with one (narrow / turtle) the reference's rule is kept literally: where the cursor stands on (x, y) the inner
+    environment is stepped with `tile`, elsewhere with the tile value that is already under the cursor."""
+
+    def __init__(self, game, num_envs=1, seed=None, device=None, **kwargs):
+        super().__init__(game, num_envs, seed, device, kwargs)
+        from . import spaces
+        sp = self.env.observation_space.spaces
+        assert "map" in sp, "This wrapper only works if you have a map key"
+        self.one_hot = len(sp["map"].shape) > 2
+        self.h, self.w = int(sp["map"].shape[0]), int(sp["map"].shape[1])
+        self.dim = self.pcgrl_env.get_num_tiles()
+        self.action_space = spaces.Discrete(self.h * self.w * self.dim)
+        self.old_obs = None
+
+    def reset(self):
+        self.old_obs = self.env.reset()
+        return self.old_obs
+
+    def step(self, actions):
+        torch = self.pcgrl_env._torch
+        a = torch.as_tensor(actions, device=self.pcgrl_env.device).to(torch.long).reshape(self.num_envs)
+        v = a % self.dim
+        x = (a // self.dim) % self.w
+        y = a // (self.dim * self.w)
+        if "pos" in self.old_obs:
+            pos = self.old_obs["pos"].to(torch.long)
+            m = self.old_obs["map"]
+            o_v = m[torch.arange(self.num_envs, device=m.device), pos[:, 1], pos[:, 0]]
+            if self.one_hot:
+                o_v = o_v.argmax(-1)
+            inner = torch.where((pos[:, 0] == x) & (pos[:, 1] == y), v, o_v.to(torch.long))
+            out = self.env.step(inner.to(torch.int32))
+        else:
+            out = self.env.step(torch.stack([x, y, v], 1).to(torch.int32))
+        self.old_obs = out[0]
+        return out
