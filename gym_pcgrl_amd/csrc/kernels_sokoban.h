@@ -98,13 +98,14 @@ __device__ __forceinline__ void sok_report(const PcgrlParams& P, const DevBufs& 
 template <class Hook>
 __device__ __forceinline__ bool sok_run_agent(const DevBufs& B, int power, const SokLevel& L, SokNode& work, const SokNode& root, SokNode* pool,
                                               uint32_t* lds, SokFastNode* cache, uint32_t* g_heap, uint32_t* g_table, int tsize, int fast, int k,
-                                              int& hh, int& dd, int& it, bool& exhausted, Hook hook, int lane, int table_off = SOK_LDS_HEAP) {
+                                              int& hh, int& dd, int& it, bool& exhausted, Hook hook, int lane, int table_off = SOK_LDS_HEAP,
+                                              SokDuoBox* duo = nullptr) {
     if (fast) {
         const SokKidsLanes kids = {lane};
         uint64_t* tab = reinterpret_cast<uint64_t*>(lds + table_off);
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool);
-        if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids);
-        return sok_search_fast<4>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids);
+        if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids, duo);
+        return sok_search_fast<4>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids, duo);
     }
     if (lane != 0) return false;
     if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
@@ -115,16 +116,20 @@ __device__ __forceinline__ bool sok_run_agent(const DevBufs& B, int power, const
 // Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  `sync`/`hard` are this launch's
 // zeroed scheduling words.  Environments that finish their episode here go to `rst_list`.
 // (a template only so that every part of the library can include this header: instantiated where it is launched)
+// Two wavefronts per block: the search wavefront (everything below) and the heap server of its A* searches (sokoban_fast.h).
 template <int PART_TAG>
-__global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
+__global__ __launch_bounds__(128) void k_sokoban(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
                                                 int rst_list, int32_t* sync, int32_t* hard, int clear_parity) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sok_lds[];
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
     const int n = n_a + n_b;
+    __shared__ SokDuoBox s_box;
+    if (threadIdx.x >= 64) { sok_duo_server(sok_lds, &s_box, lane); return; }
+    SokDuoBox* const duo = B.sok_use_lds ? &s_box : nullptr;       // (the heap has to be the LDS one)
     __shared__ SokLevel s_L;             // level + node workspace in LDS: they are indexed dynamically
     __shared__ SokNode s_root, s_work;
     __shared__ int s_spawned, s_fast;
@@ -205,12 +210,12 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
                     if (s_spawned) { if (lane == 0) sok_report(P, B, e, 0, win, hh, dd, exhausted, mode, parity, rst_list); reported = 1; go = 0; }
                     else go = !(win || exhausted);
                 } else if (kind == 1) {
-                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, SokNoHook(), lane);
+                    win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, SokNoHook(), lane, SOK_LDS_HEAP, duo);
                     go = !win;
                 } else {
                     SokPollHook hook = {B.sok_stop + e, 4 - a};
                     if (sok_ld(B.sok_stop + e) < 4 - a) {
-                        win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, hook, lane);
+                        win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, KS[a], hh, dd, it, exhausted, hook, lane, SOK_LDS_HEAP, duo);
                     }
                     if (lane == 0) sok_report(P, B, e, a, win, hh, dd, false, mode, parity, rst_list);
                     reported = 1;
@@ -233,4 +238,6 @@ __global__ __launch_bounds__(64) void k_sokoban(PcgrlParams P, DevBufs B, int li
             atomicAdd(sync + SOK_SY_BFS_DONE, 1);
         }
     }
+    s_box.session = 0;          // the heap server leaves with us
+    sok_duo_sync();
 }

@@ -666,7 +666,7 @@ PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_
     else if (h->P.prob == PCGRL_PROB_MDUNGEON)
         hipLaunchKernelGGL(k_mdungeon<0>, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
     else
-        hipLaunchKernelGGL(k_sokoban<0>, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
+        hipLaunchKernelGGL(k_sokoban<0>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
                            sync, sync + SOK_SY_WORDS, clr);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;

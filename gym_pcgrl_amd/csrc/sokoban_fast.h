@@ -181,7 +181,29 @@ PCGRL_D void sokf_siftup_root(HP heap, int endpos) {
     sokf_siftdown(heap, pos);
 }
 
-#if defined(PCGRL_SMB_PROF) && defined(__HIP_DEVICE_COMPILE__)
+// ---- Two wavefronts per A* search (k_sokoban; round 3).  A wavefront that is alone on its SIMD gets one instruction per 5-9
+// cycles (profiles/r3a_round3/valu_calibration.md), and a second wavefront on the same compute unit runs at full speed beside it:
+// the only way to shorten a pop is to split its work.  Of a pop's ~3 900 cycles (tools/sok_prof.py) the heap operations -- the
+// repair after the removal of the top, the appends of the children -- are 2 400 and everything else (loop head, node, crate
+// bitboard, win test, visited probe, four children with their heuristics) 1 500, and the heap only ever needs the children's
+// packed words.  So a second wavefront, the *heap server*, owns the heap: it appends the children of pop i, publishes the new
+// top (= pop i+1), and removes and repairs for pop i+1 right away -- while the search wavefront expands that node.  The removal
+// is speculative (the search may end at this pop: cap, win, abandoned); a heap that is thrown away does not care.  Two block
+// barriers per pop, (A) children -> server and (B) top -> search; `SokDuoBox` in LDS carries both.  The array operations are
+// those of the one-wavefront form in the same order, so the pop order, iteration counts and results are the same.
+struct SokDuoBox {
+    int session;             // outer handshake: 1 = a search starts, 0 = leave the kernel
+    int npush;               // (A) search -> server: children of this pop (0..4), or -1 = the search is over
+    uint32_t push[4];
+    int cur;                 // (B) server -> search: pool index of the heap top = the next pop, -1 = the heap is empty
+    int ahead_idx;           // (A) server -> search: the top the repair left (-1: none): the next pop unless a child beats it
+};
+#if defined(__HIPCC__)
+// (LDS traffic only has to have landed: the box and the heap live there; global loads may stay in flight across it)
+__device__ __forceinline__ void sok_duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory"); }
+#endif
+
+#if defined(PCGRL_SMB_PROF) && defined(__HIPCC__)
 extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer builds: tools/sok_prof.py)
 #define SKP_DECL unsigned long long skp_t = clock64(), skp_a[6] = {0, 0, 0, 0, 0, 0}
 #define SKP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = clock64(); skp_a[i] += n_ - skp_t; skp_t = n_; } while (0)
@@ -196,7 +218,7 @@ extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer bu
 template <int NW, class HP, class TP, class Hook, class Kids>
 PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP table, int table_mask,
                              SokFastNode* cache, const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
-                             bool& out_exhausted, Hook hook, Kids kids) {
+                             bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr) {
     SokFastLevel<NW> F;
     sokf_level(L, F);
     const int nc = F.nc;
@@ -213,6 +235,71 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
     SokFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;   // cache[j] = pool[cache_base + j], j < cache_n
     int result_h = root.h, result_depth = 0;
+#if defined(__HIPCC__)
+    if (duo && k >= 0) {
+        // the search wavefront of a two-wavefront A* search: see SokDuoBox.  (heap[0] = the root's word is in place.)
+        duo->session = 1;
+        sok_duo_sync();                                  // (0) wakes the heap server of this block
+        bool empty = false;
+        for (;;) {
+            sok_duo_sync();                              // (B) the server has published the next pop
+            const int cur = duo->cur;
+            if (cur < 0) { empty = true; break; }
+            if (iterations >= power) break;
+            iterations++;
+            if (hook(iterations)) { aborted = true; break; }
+            SokFastNode nd = ahead;
+            if (cur != ahead_idx) {
+                if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
+                else nd = pool[cur];
+            }
+            const uint64_t cr = nd.cr;
+            const int node_player = (int)(nd.ph & 0xFFu), node_h = (int)(nd.ph >> 16), node_depth = (int)nd.depth;
+            uint64_t cb[NW];
+            for (int i = 0; i < NW; i++) cb[i] = 0;
+            for (int i = 0; i < nc; i++) sokf_flip<NW>(cb, (int)((cr >> (8 * i)) & 0xFF));
+            if (sokf_covers<NW>(cb, F.tmask)) { win = true; result_h = node_h; result_depth = node_depth; break; }   // engine.py:272-280
+            const uint64_t key = (cr << 8) | (uint64_t)node_player;
+            uint64_t hs = key * 0x9E3779B97F4A7C15ull;
+            uint32_t slot = (uint32_t)(hs >> 40) & (uint32_t)table_mask;
+            bool seen = false;
+            for (;;) {
+                const uint64_t v = table[slot];
+                if (v == 0) break;
+                if (v == key) { seen = true; break; }
+                slot = (slot + 1) & (uint32_t)table_mask;
+            }
+            int npush = 0;
+            if (!seen) {
+                table[slot] = key;
+                cache_base = npool; cache_n = 0;
+                if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) { have_best = true; best_h = node_h; best_depth = node_depth; }
+                SokChild kid[4];                        // Node.getChildren: L, R, U, D
+                kids(F, cr, cb, node_player, node_h, kid);
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    if (!kid[d].ok) continue;
+                    SokFastNode ch;
+                    ch.cr = kid[d].cr; ch.ph = (uint32_t)kid[d].np | ((uint32_t)kid[d].h << 16); ch.depth = (uint32_t)(node_depth + 1);
+                    pool[npool] = ch;
+                    cache[cache_n++] = ch;
+                    duo->push[npush++] = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1)) << 16) | (uint32_t)npool;
+                    npool++;
+                }
+            }
+            duo->npush = npush;
+            sok_duo_sync();                              // (A) the children are in the box; the server's repair is done
+            ahead_idx = duo->ahead_idx;                  // the top the repair left: fetched now, in flight while the server appends
+            if (ahead_idx >= 0) ahead = pool[ahead_idx];
+        }
+        duo->npush = -1;                                 // cap, empty heap, win or abandoned: the server leaves the search
+        sok_duo_sync();                                  // (A)
+        if (!win) { result_h = best_h; result_depth = best_depth; }
+        out_h = result_h; out_depth = result_depth; out_iters = iterations;
+        out_exhausted = !win && !aborted && empty;
+        return win;
+    }
+#endif
     SKP_DECL;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
         iterations++;
@@ -287,3 +374,37 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
     out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < npool);
     return win;
 }
+
+#if defined(__HIPCC__)
+// The heap server: the second wavefront of a k_sokoban block (see SokDuoBox).  Waits for searches (barrier 0), owns their heap
+// -- appends, publishes the top, removes it and repairs -- and leaves when the block does.  Lane 0 works; the barriers are the
+// wavefront's.
+__device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, int lane) {
+    // (every lane runs the same chain on the same addresses: the values are wave-uniform, so the compiler keeps the index
+    //  arithmetic and the comparisons on the scalar unit -- 10 % faster than one lane under an exec mask)
+    (void)lane;
+    for (;;) {
+        sok_duo_sync();                                 // (0) a search starts, or the block is done
+        if (box->session == 0) return;
+        int n = 1;                                      // the root's word is in heap[0]
+        for (;;) {
+            box->cur = n > 0 ? (int)(heap[0] & 0xFFFFu) : -1;
+            sok_duo_sync();                             // (B)
+            int ahead = -1;
+            if (n > 0) {                                // heappop: the last entry goes to the root and sinks (CPython _siftup)
+                const uint32_t last = heap[--n];
+                if (n > 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (every lane has read `last` before any lane overwrites the root)
+                    heap[0] = last; sokf_siftup_root(heap, n); ahead = (int)(heap[0] & 0xFFFFu);
+                }
+            }
+            box->ahead_idx = ahead;
+            sok_duo_sync();                             // (A)
+            const int m = box->npush;
+            if (m < 0) break;
+            for (int j = 0; j < m; j++) { heap[n + j] = box->push[j]; sokf_siftdown(heap, n + j); }      // heappush, in the children's order
+            n += m;
+        }
+    }
+}
+#endif

@@ -34,3 +34,7 @@ print("%.2f ms/step; A* searches %d per step, %.0f pops each" % (dt / steps * 1e
 for i, nm in enumerate(["loop head + poll", "pop: top, node, repair, prefetch", "bitboard, win, visited probe", "best + four children", "pushes (pool, cache, heap)"]):
     print("  %-34s %7.0f cycles/pop %5.1f%%" % (nm, a[32 + i] / it, 100 * a[32 + i] / a[32:37].sum()))
 print("  total %.0f cycles/pop" % (a[32:37].sum() / it))
+sn = max(a[46], 1)
+print("heap server, cycles per served pop (%d pops):" % a[46])
+for i, nm in enumerate(["wait for (1)", "repair + look-ahead issue", "wait for (2)", "appends", "look-ahead node -> box", "between searches"]):
+    print("  %-28s %7.0f" % (nm, a[40 + i] / sn))
