@@ -82,7 +82,7 @@ struct DdKidsSerial {     // one lane makes the four children one after the othe
 template <class HP, class TP, class Hook, class Kids>
 PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* pool, HP heap, TP table, int table_mask, DdFastNode* cache,
                             const DdNode& root, int k, int power, uint64_t& ret_key, int& ret_h, int& ret_depth, int& ret_jumps, int& out_iters,
-                            bool& out_exhausted, Hook hook, Kids kids) {
+                            bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr) {
     int npool = 0, head = 0, heapn = 0, iterations = 0, best_h = 0, best_depth = 0, best_aj = 0;
     bool have_best = false, aborted = false, win = false;
     uint64_t best_key = 0;
@@ -96,6 +96,73 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
     DdFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;
     ret_key = n0.key; ret_h = root.h; ret_depth = 0; ret_jumps = 0;
+#if defined(__HIPCC__)
+    if (duo && k >= 0) {
+        // the search wavefront of a two-wavefront A* search (sokoban_fast.h, SokDuoBox; the same split as in mdungeon_fast.h):
+        // the block's heap server owns the heap.  Same operations in the same order as the loop below.
+        duo->session = 1;
+        sok_duo_sync();                                  // (0)
+        bool empty = false;
+        for (;;) {
+            sok_duo_sync();                              // (B) the next pop
+            const int ent = duo->cur;
+            if (ent < 0) { empty = true; break; }
+            if (iterations >= power) break;
+            iterations++;
+            if (hook(iterations)) { aborted = true; break; }
+            int npush = 0;
+            if (!((uint32_t)ent & MDF_FLAG)) {
+                const int cur = ent & 0x7FFF;
+                DdFastNode nd = ahead;
+                if (cur != ahead_idx) {
+                    if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
+                    else nd = pool[cur];
+                }
+                const uint64_t key = nd.key;
+                const int node_player = (int)((key >> 48) & 0xFF);
+                const int node_h = (int)(nd.hd & 0xFFFFu) - DD_PRIO_BIAS, node_depth = (int)(nd.hd >> 16), node_aj = (int)nd.aj;
+                if (!(key & DDF_KEY_THERE) && node_player == L.door) {   // checkWin
+                    win = true; ret_key = key; ret_h = node_h; ret_depth = node_depth; ret_jumps = node_aj >> 2; break;
+                }
+                uint32_t slot;
+                if (!mdf_lookup(table, table_mask, key, slot)) {
+                    table[slot] = key;
+                    cache_base = npool; cache_n = 0;
+                    if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) {
+                        have_best = true; best_h = node_h; best_depth = node_depth; best_key = key; best_aj = node_aj;
+                    }
+                    const bool ground = sok_bit(L.solid, node_player + L.w), ceiling = sok_bit(L.solid, node_player - L.w);
+                    DdChild kid[4];                         // stay, left, right, jump -- always four
+                    kids(L, F, table, table_mask, key, node_aj, ground, ceiling, kid);
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        uint32_t ent_c = MDF_FLAG;
+                        if (!kid[d].drop) {
+                            DdFastNode c;
+                            c.key = kid[d].key; c.hd = (uint32_t)(kid[d].h + DD_PRIO_BIAS) | ((uint32_t)(node_depth + 1) << 16); c.aj = (uint32_t)kid[d].aj;
+                            pool[npool] = c;
+                            cache[cache_n++] = c;
+                            ent_c = (uint32_t)npool;
+                            npool++;
+                        }
+                        duo->push[npush++] = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1) + DD_PRIO_BIAS) << 16) | ent_c;
+                    }
+                }
+            }
+            duo->npush = npush;
+            sok_duo_sync();                              // (A)
+            const int top = duo->ahead_idx;
+            ahead_idx = -1;
+            if (top >= 0 && !((uint32_t)top & MDF_FLAG)) { ahead_idx = top & 0x7FFF; ahead = pool[ahead_idx]; }
+        }
+        duo->npush = -1;                                 // the server leaves the search
+        sok_duo_sync();                                  // (A)
+        if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; ret_jumps = best_aj >> 2; }
+        out_iters = iterations;
+        out_exhausted = !win && !aborted && empty;
+        return win;
+    }
+#endif
     while (iterations < power && (k >= 0 ? heapn > 0 : head < heapn)) {
         iterations++;
         if (hook(iterations)) { aborted = true; break; }

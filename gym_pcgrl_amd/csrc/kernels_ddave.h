@@ -62,7 +62,8 @@ __device__ __forceinline__ void dd_report(const PcgrlParams& P, const DevBufs& B
 // go to `rst_list`.
 // (a template only so that every part of the library can include this header: instantiated where it is launched)
 template <int PART_TAG>
-__global__ __launch_bounds__(64) void k_ddave(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
+// Two wavefronts per block: the search wavefront (everything below) and the heap server of its A* searches (sokoban_fast.h).
+__global__ __launch_bounds__(128) void k_ddave(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
                                               int rst_list, int32_t* sync, int clear_parity) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dd_lds[];
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
@@ -72,9 +73,12 @@ __global__ __launch_bounds__(64) void k_ddave(PcgrlParams P, DevBufs B, int list
     __shared__ DdFastNode s_cache[4];
     __shared__ int s_fast;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
+    __shared__ SokDuoBox s_box;
+    if (threadIdx.x >= 64) { sok_duo_server(dd_lds, &s_box, lane); return; }
+    SokDuoBox* const duo = B.sok_use_lds ? &s_box : nullptr;       // (the heap has to be the LDS one)
     const int n = n_a + n_b;
     DdNode* pool = reinterpret_cast<DdNode*>(B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride);
     uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(64) void k_ddave(PcgrlParams P, DevBufs B, int list
                     int hh = 0, dd = 0, jj = 0;
                     const DdKidsLanes kids = {lane};
                     win = dd_search_fast(s_L, s_F, reinterpret_cast<DdFastNode*>(pool), dd_lds, reinterpret_cast<uint64_t*>(dd_lds + SOK_LDS_HEAP),
-                                         tsize - 1, s_cache, s_root, KS[a], P.solver_power, key, hh, dd, jj, it, exhausted, hook, kids);
+                                         tsize - 1, s_cache, s_root, KS[a], P.solver_power, key, hh, dd, jj, it, exhausted, hook, kids, duo);
                     ddf_result(s_F, key, hh, dd, jj, win, out4);
                 } else if (B.sok_use_lds)   // two instantiations: LDS pointers compile to ds_* instructions
                     win = dd_search(s_L, pool, dd_lds, dd_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
@@ -132,4 +136,6 @@ __global__ __launch_bounds__(64) void k_ddave(PcgrlParams P, DevBufs B, int list
         }
         __threadfence_block();
     }
+    s_box.session = 0;          // the heap server leaves with us
+    sok_duo_sync();
 }

@@ -74,8 +74,9 @@ __device__ __forceinline__ void md_report(const PcgrlParams& P, const DevBufs& B
 // Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  Environments that finish their episode here
 // go to `rst_list`.
 // (a template only so that every part of the library can include this header: instantiated where it is launched)
+// Two wavefronts per block: the search wavefront (everything below) and the heap server of its A* searches (sokoban_fast.h).
 template <int PART_TAG>
-__global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
+__global__ __launch_bounds__(128) void k_mdungeon(PcgrlParams P, DevBufs B, int list_a, int mode_a, int list_b, int mode_b, int parity,
                                                  int rst_list, int32_t* sync, int clear_parity) {
     extern __shared__ __attribute__((aligned(16))) uint32_t md_lds[];
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
@@ -85,10 +86,13 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
     __shared__ MdFastNode s_cache[4];
     __shared__ int s_fast;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int n_a = wl_load_prefix(B, parity, list_a, s_pref_a);
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
     const int n = n_a + n_b;
+    __shared__ SokDuoBox s_box;
+    if (threadIdx.x >= 64) { sok_duo_server(md_lds, &s_box, lane); return; }
+    SokDuoBox* const duo = B.sok_use_lds ? &s_box : nullptr;       // (the heap has to be the LDS one)
     MdNode* pool = reinterpret_cast<MdNode*>(B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride);
     uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
     uint32_t* g_table = B.sok_use_lds ? nullptr : B.sok_table + (size_t)blockIdx.x * B.sok_table_size;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
                     int hh = 0, dd = 0;
                     const MdKidsLanes kids = {lane};
                     win = md_search_fast(s_L, s_F, reinterpret_cast<MdFastNode*>(pool), md_lds, reinterpret_cast<uint64_t*>(md_lds + SOK_LDS_HEAP),
-                                         tsize - 1, s_cache, s_root, KS[a], P.solver_power, key, hh, dd, it, exhausted, hook, kids);
+                                         tsize - 1, s_cache, s_root, KS[a], P.solver_power, key, hh, dd, it, exhausted, hook, kids, duo);
                     mdf_result(s_F, key, hh, dd, win, out5);
                 } else if (B.sok_use_lds) {   // two instantiations: LDS pointers compile to ds_* instructions
                     win = md_search(s_L, pool, md_lds, md_lds + SOK_LDS_HEAP, tsize - 1, s_work, s_root, KS[a], P.solver_power, it, exhausted, hook);
@@ -148,4 +152,6 @@ __global__ __launch_bounds__(64) void k_mdungeon(PcgrlParams P, DevBufs B, int l
         }
         __threadfence_block();
     }
+    s_box.session = 0;          // the heap server leaves with us
+    sok_duo_sync();
 }

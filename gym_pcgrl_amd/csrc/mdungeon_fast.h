@@ -120,7 +120,7 @@ extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer bu
 template <class HP, class TP, class Hook, class Kids>
 PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* pool, HP heap, TP table, int table_mask, MdFastNode* cache,
                             const MdNode& root, int k, int power, uint64_t& ret_key, int& ret_h, int& ret_depth, int& out_iters,
-                            bool& out_exhausted, Hook hook, Kids kids) {
+                            bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr) {
     int npool = 0, head = 0, heapn = 0, iterations = 0, best_h = 0, best_depth = 0;
     bool have_best = false, aborted = false, win = false;
     uint64_t best_key = 0;
@@ -134,6 +134,72 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
     MdFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;   // cache[j] = pool[cache_base + j], j < cache_n
     ret_key = n0.key; ret_h = root.h; ret_depth = 0;
+#if defined(__HIPCC__)
+    if (duo && k >= 0) {
+        // the search wavefront of a two-wavefront A* search (sokoban_fast.h, SokDuoBox): the heap belongs to the block's heap
+        // server, which appends the children of a pop, publishes the new top and removes / repairs for it while this
+        // wavefront expands it.  Same operations in the same order as the loop below.
+        duo->session = 1;
+        sok_duo_sync();                                  // (0)
+        bool empty = false;
+        for (;;) {
+            sok_duo_sync();                              // (B) the next pop
+            const int ent = duo->cur;
+            if (ent < 0) { empty = true; break; }
+            if (iterations >= power) break;
+            iterations++;
+            if (hook(iterations)) { aborted = true; break; }
+            int npush = 0;
+            if (!((uint32_t)ent & MDF_FLAG)) {           // (a flagged entry -- lost, or visited before it was queued -- is only counted)
+                const int cur = ent & 0x7FFF;
+                MdFastNode nd = ahead;
+                if (cur != ahead_idx) {
+                    if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
+                    else nd = pool[cur];
+                }
+                const uint64_t key = nd.key;
+                const uint64_t alive = key & MDF_ALIVE_MASK;
+                const int node_player = (int)((key >> 48) & 0xFF), node_health = (int)(key >> 56);
+                const int node_h = (int)(nd.hd & 0xFFFFu) - MD_PRIO_BIAS, node_depth = (int)(nd.hd >> 16);
+                if (node_player == L.door) { win = true; ret_key = key; ret_h = node_h; ret_depth = node_depth; break; }   // checkWin
+                uint32_t slot;
+                if (!mdf_lookup(table, table_mask, key, slot)) {
+                    table[slot] = key;
+                    cache_base = npool; cache_n = 0;
+                    if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) {
+                        have_best = true; best_h = node_h; best_depth = node_depth; best_key = key;
+                    }
+                    MdChild kid[4];                         // Node.getChildren: L, R, U, D -- always four
+                    kids(L, F, table, table_mask, key, alive, node_player, node_health, kid);
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        uint32_t ent_c = MDF_FLAG;
+                        if (!kid[d].drop) {
+                            MdFastNode c;
+                            c.key = kid[d].key; c.hd = (uint32_t)(kid[d].h + MD_PRIO_BIAS) | ((uint32_t)(node_depth + 1) << 16); c.pad = 0;
+                            pool[npool] = c;
+                            cache[cache_n++] = c;
+                            ent_c = (uint32_t)npool;
+                            npool++;
+                        }
+                        duo->push[npush++] = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1) + MD_PRIO_BIAS) << 16) | ent_c;
+                    }
+                }
+            }
+            duo->npush = npush;
+            sok_duo_sync();                              // (A)
+            const int top = duo->ahead_idx;              // the top the repair left: fetched now, in flight while the server appends
+            ahead_idx = -1;
+            if (top >= 0 && !((uint32_t)top & MDF_FLAG)) { ahead_idx = top & 0x7FFF; ahead = pool[ahead_idx]; }
+        }
+        duo->npush = -1;                                 // the server leaves the search
+        sok_duo_sync();                                  // (A)
+        if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; }
+        out_iters = iterations;
+        out_exhausted = !win && !aborted && empty;
+        return win;
+    }
+#endif
     MDP_DECL;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < heapn)) {
         iterations++;

@@ -662,9 +662,9 @@ PCGRL_LOCAL int search_device_setup(pcgrl_env* h) {   // the search kernels use 
 PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st) {
     const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
     if (h->P.prob == PCGRL_PROB_DDAVE)
-        hipLaunchKernelGGL(k_ddave<0>, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
+        hipLaunchKernelGGL(k_ddave<0>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
     else if (h->P.prob == PCGRL_PROB_MDUNGEON)
-        hipLaunchKernelGGL(k_mdungeon<0>, dim3(SOK_BLOCKS), dim3(64), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
+        hipLaunchKernelGGL(k_mdungeon<0>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
     else
         hipLaunchKernelGGL(k_sokoban<0>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list,
                            sync, sync + SOK_SY_WORDS, clr);

@@ -195,8 +195,9 @@ struct SokDuoBox {
     int session;             // outer handshake: 1 = a search starts, 0 = leave the kernel
     int npush;               // (A) search -> server: children of this pop (0..4), or -1 = the search is over
     uint32_t push[4];
-    int cur;                 // (B) server -> search: pool index of the heap top = the next pop, -1 = the heap is empty
-    int ahead_idx;           // (A) server -> search: the top the repair left (-1: none): the next pop unless a child beats it
+    int cur;                 // (B) server -> search: low 16 bits of the heap top (the pool index, in mdungeon_fast.h with its flag
+                             //     bit) = the next pop, -1 = the heap is empty
+    int ahead_idx;           // (A) server -> search: the same of the top the repair left (-1: none): the next pop unless a child beats it
 };
 #if defined(__HIPCC__)
 // (LDS traffic only has to have landed: the box and the heap live there; global loads may stay in flight across it)
@@ -381,7 +382,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
 // wavefront's.
 __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, int lane) {
     // (every lane runs the same chain on the same addresses: the values are wave-uniform, so the compiler keeps the index
-    //  arithmetic and the comparisons on the scalar unit -- 10 % faster than one lane under an exec mask)
+    //  arithmetic and the comparisons on the scalar unit -- a few per cent faster than one lane under an exec mask)
     (void)lane;
     for (;;) {
         sok_duo_sync();                                 // (0) a search starts, or the block is done
