@@ -28,7 +28,7 @@ def registered_ids():
 
 
 def register_with_gym():
-    """Register every id with gym / gymnasium when one of them is importable (gym_pcgrl/__init__.py:6-12 does this on
+    """Register every id with gym when one with the reference's four-tuple API is importable (gym_pcgrl/__init__.py:6-12 does this on
     import; so does this package, below).  Returns the ids registered by this call."""
     from . import gym_compat
     if gym_compat.find_gym() is None:
@@ -60,4 +60,4 @@ def make_batched(env_id, num_envs, **kwargs):
 
 
 
-register_with_gym()      # no-op without gym / gymnasium (neither is on the MI355X image)
+register_with_gym()      # no-op without a gym of the reference's era (none is on the MI355X image)

@@ -15,7 +15,7 @@ from .batched_env import BatchedPcgrlEnv
 
 
 class PcgrlEnv(gym_compat.env_base()):
-    """A gym.Env when gym / gymnasium is importable (pcgrl_env.py:14), a plain class otherwise."""
+    """A gym.Env when a gym with the four-tuple API is importable (pcgrl_env.py:14; gym_compat.find_gym), a plain class otherwise."""
     metadata = {"render.modes": ["human", "rgb_array"]}
 
     def __init__(self, prob="binary", rep="narrow", device=None):
