@@ -162,7 +162,8 @@ PCGRL_D void sok_init_deadlocks(SokLevel& L) {
 // --- CPython heapq on packed entries (priority << 16 | node index); only `<` on priorities ---------
 // The heap/table pointer types are template parameters so that, once inlined, the compiler knows the
 // address space (LDS vs global) and emits ds_* / global_* instead of flat accesses.
-PCGRL_D bool sok_lt(uint32_t a, uint32_t b) { return (a >> 16) < (b >> 16); }
+// priority(a) < priority(b) on packed words (priority << 16 | payload): a < (b with its payload cleared) -- one AND, one compare
+PCGRL_D bool sok_lt(uint32_t a, uint32_t b) { return a < (b & 0xFFFF0000u); }
 template <class HP>
 PCGRL_D void sok_siftdown(HP heap, int startpos, int pos) {
     const uint32_t newitem = heap[pos];
