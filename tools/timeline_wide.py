@@ -52,7 +52,15 @@ for rep_i in range(3):
     nsw = (tag == 31).sum(axis=2)
     print("   components per wavefront (blocks with any): mean %.1f max %d; sweeps per wavefront mean %.2f max %d" % (
         ncomp[ncomp.sum(axis=1) > 0].mean(), ncomp.max(), nsw[ncomp.sum(axis=1) > 0].mean(), nsw.max()))
-    worst = np.argsort(np.nan_to_num(items))[-3:]
+    busy = (tag == 20).any(axis=2).any(axis=1)                  # blocks that computed statistics of a map
+    worst = np.argsort(np.where(busy, np.nan_to_num(items), -1.0))[-2:]
+    lone = (tag == 24).any(axis=2).any(axis=1)
+    for nm, sel in (("reset items", lone), ("full items", busy & ~lone)):
+        if sel.any():
+            st = np.nanmin(np.where(tag == 20, tm, np.nan).reshape(nblk, -1), axis=1)
+            en = np.nanmax(np.where(tag == 23, tm, np.nan).reshape(nblk, -1), axis=1)
+            d = (en - st)[sel]
+            print("   %-12s n %4d  statistics phase: p50 %.1f  p90 %.1f  max %.1f us; ends: p50 %.1f max %.1f" % (nm, int(sel.sum()), np.nanpercentile(d, 50), np.nanpercentile(d, 90), np.nanmax(d), np.nanpercentile(items[sel], 50), np.nanmax(items[sel])))
     for b in worst:
         print("block", int(b), "items done %.1f" % items[b])
         for w in range(WAVES):
