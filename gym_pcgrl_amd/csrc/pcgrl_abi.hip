@@ -1,27 +1,31 @@
 // C ABI of the batched PCGRL environment and, through the kernels_*.h headers it includes, its HIP
-// kernels (gfx950 / CDNA4): one translation unit.
+// kernels (gfx950 / CDNA4).  One source, compiled in eight parts side by side (PCGRL_PART below).
 //
-// One `pcgrl_step` is two launches on the caller's stream (binary, zelda); Sokoban adds its solver passes:
-//
-//   k_update   thread per environment.  Representation.update (narrow_rep.py:99-114, wide_rep.py:67-70,
-//              turtle_rep.py:101-129), counters + heatmap (pcgrl_env.py:130-137).  Unchanged
-//              environments are finished here (reward 0, done, info); changed ones -- and unchanged ones
-//              whose episode ended, flagged "reset only" -- are compacted into a sharded work list,
-//              bucketed by expected difficulty (LDS histogram, one atomic per bucket per 256-thread block).
-//   k_stats    one lane group (16 lanes = one DPP row, or a full wavefront for maps taller than 16) per
-//              work item: Problem.get_stats as row-bitboard programs (pcgrl_algos.h), get_reward,
-//              get_episode_over, get_debug_info (pcgrl_env.py:138-148).  An environment whose episode ended
-//              is reset right there by its wavefront (reset_env.h): PcgrlEnv.reset (pcgrl_env.py:66-76) --
-//              the MT19937 ring is staged in LDS and the wave produces 128 words per round, tiles are drawn
-//              with numpy's choice() rule, written coalesced as uint8 and turned into row bit planes; cursor
-//              draw; BinaryProblem.reset (binary_prob.py:68-72); start stats (problem.py:45-46) on the rows
-//              that are already in registers.
-//   k_reset    one wavefront per environment on a reset list: pcgrl_reset, and the Sokoban step.
-//   k_sokoban  (Sokoban only) the solver jobs parked by k_stats / k_reset: kernels_sokoban.h.
+// One `pcgrl_step` on the caller's stream is
+//   * ONE launch, k_step (kernels_step.h), for the binary and zelda problems on maps of at most 16 rows with the single-cell
+//     representations: a block stages the state of its 64 / 128 / 256 environments in LDS and does Representation.update,
+//     the statistics, rewards, episode ends and in-kernel resets from there -- and writes the wrapped observation when one is
+//     bound (pcgrl_bind_observation, kernels_obs.h);
+//   * else the pipeline
+//       k_update   thread per environment.  Representation.update (narrow_rep.py:99-114, wide_rep.py:67-70,
+//                  turtle_rep.py:101-129), counters + heatmap (pcgrl_env.py:130-137).  Unchanged environments are finished
+//                  here (reward 0, done, info); changed ones -- and unchanged ones whose episode ended, flagged "reset
+//                  only" -- are compacted into sharded work lists, ordered by what the next kernel will have to do.
+//       k_stats    one lane group (16 lanes = one DPP row, or a full wavefront / a block of eight for maps taller than 16) per
+//                  work item: Problem.get_stats as row-bitboard programs (pcgrl_algos.h), get_reward, get_episode_over,
+//                  get_debug_info (pcgrl_env.py:138-148).  An environment whose episode ended is reset right there
+//                  (reset_env.h): PcgrlEnv.reset (pcgrl_env.py:66-76) -- the MT19937 ring staged in LDS, tiles drawn with
+//                  numpy's choice() rule, cursor draw, BinaryProblem.reset (binary_prob.py:68-72), start stats
+//                  (problem.py:45-46).
+//       k_reset    one wavefront per environment on a reset list: pcgrl_reset, and the steps of the search problems.
+//       k_sokoban / k_mdungeon / k_ddave / k_smb   the solver jobs parked by k_stats / k_reset: the exact searches of the
+//                  reference's engines (two wavefronts per A* search: sokoban_fast.h).
+//       k_obs      the wrapped observation, when one is bound.
+//   pcgrl_rollout runs a whole tape of actions in one launch (k_step's loop form; k_step_solver for the search problems).
 //
 // State is structure-of-arrays over the environment axis, all in HBM, owned by the caller
 // (include/pcgrl_hip.h).  The uint8 map is the observation; the kernels compute on `planes`
-// (row bitboards of the tile-id bits, [N][group][nplanes]) which k_update keeps in sync, so the
+// (row bitboards of the tile-id bits, [N][group][nplanes]) which the update keeps in sync, so the
 // statistics never re-read or transpose the byte map.  No MFMA: integer/bit work only.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
