@@ -103,15 +103,16 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
         duo->session = 1;
         sok_duo_sync();                                  // (0)
         bool empty = false;
+        uint32_t cur_word = (uint32_t)(2 * root.h + DD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
         for (;;) {
-            sok_duo_sync();                              // (B) the next pop
-            const int ent = duo->cur;
-            if (ent < 0) { empty = true; break; }
+            if (cur_word == SOK_DUO_NONE) { empty = true; break; }
             if (iterations >= power) break;
             iterations++;
             if (hook(iterations)) { aborted = true; break; }
+            const uint32_t ent = cur_word & 0xFFFFu;
             int npush = 0;
-            if (!((uint32_t)ent & MDF_FLAG)) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (!(ent & MDF_FLAG)) {
                 const int cur = ent & 0x7FFF;
                 DdFastNode nd = ahead;
                 if (cur != ahead_idx) {
@@ -145,17 +146,24 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
                             ent_c = (uint32_t)npool;
                             npool++;
                         }
-                        duo->push[npush++] = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1) + DD_PRIO_BIAS) << 16) | ent_c;
+                        const uint32_t word = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1) + DD_PRIO_BIAS) << 16) | ent_c;
+                        w[d] = word;                          // (always four children: d == npush)
+                        duo->push[iterations & 1][npush++] = word;
                     }
                 }
             }
-            duo->npush = npush;
-            sok_duo_sync();                              // (A)
-            const int top = duo->ahead_idx;
+            duo->npush[iterations & 1] = npush;
+            sok_duo_sync();                              // (A) children one way, the top the repair left the other
+            const uint32_t aw = duo->ahead_word[iterations & 1];
+            uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j < npush && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
+            cur_word = nxt;
             ahead_idx = -1;
-            if (top >= 0 && !((uint32_t)top & MDF_FLAG)) { ahead_idx = top & 0x7FFF; ahead = pool[ahead_idx]; }
+            if (aw != SOK_DUO_NONE && nxt == aw && !(aw & MDF_FLAG)) { ahead_idx = (int)(aw & 0x7FFFu); ahead = pool[ahead_idx]; }
         }
-        duo->npush = -1;                                 // the server leaves the search
+        duo->npush[0] = -1; duo->npush[1] = -1;          // the server leaves the search
         sok_duo_sync();                                  // (A)
         if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; ret_jumps = best_aj >> 2; }
         out_iters = iterations;

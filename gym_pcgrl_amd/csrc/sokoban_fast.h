@@ -186,19 +186,24 @@ PCGRL_D void sokf_siftup_root(HP heap, int endpos) {
 // the only way to shorten a pop is to split its work.  Of a pop's ~3 900 cycles (tools/sok_prof.py) the heap operations -- the
 // repair after the removal of the top, the appends of the children -- are 2 400 and everything else (loop head, node, crate
 // bitboard, win test, visited probe, four children with their heuristics) 1 500, and the heap only ever needs the children's
-// packed words.  So a second wavefront, the *heap server*, owns the heap: it appends the children of pop i, publishes the new
-// top (= pop i+1), and removes and repairs for pop i+1 right away -- while the search wavefront expands that node.  The removal
-// is speculative (the search may end at this pop: cap, win, abandoned); a heap that is thrown away does not care.  Two block
-// barriers per pop, (A) children -> server and (B) top -> search; `SokDuoBox` in LDS carries both.  The array operations are
-// those of the one-wavefront form in the same order, so the pop order, iteration counts and results are the same.
+// packed words.  So a second wavefront, the *heap server*, owns the heap: while the search wavefront expands the node of pop i
+// the server removes that top and repairs (CPython heappop); at barrier (A) the two trade -- the children's words one way, the
+// word of the top the repair left the other -- and the server appends the children (heappush, in their order) while the search
+// wavefront is already on pop i + 1: the next top is the one the repair left unless a child has a strictly smaller priority, and
+// then it is the first child with the smallest priority (a child climbs past everything that is not smaller than the root, or
+// stays below the root), so the search wavefront works it out from the words it holds.  The removal is speculative (the search
+// may end at this pop: cap, win, abandoned); a heap that is thrown away does not care.  ONE block barrier per pop; `SokDuoBox`
+// in LDS carries the trade.  The array operations are those of the one-wavefront form in the same order, so the pop order,
+// iteration counts and results are the same.
 struct SokDuoBox {
     int session;             // outer handshake: 1 = a search starts, 0 = leave the kernel
-    int npush;               // (A) search -> server: children of this pop (0..4), or -1 = the search is over
-    uint32_t push[4];
-    int cur;                 // (B) server -> search: low 16 bits of the heap top (the pool index, in mdungeon_fast.h with its flag
-                             //     bit) = the next pop, -1 = the heap is empty
-    int ahead_idx;           // (A) server -> search: the same of the top the repair left (-1: none): the next pop unless a child beats it
+    // two sets, used alternately (pop parity): with one barrier per pop the search wavefront is already filling in the children
+    // of the next pop while the server still reads these
+    int npush[2];            // (A) search -> server: children of this pop (0..4), or -1 = the search is over
+    uint32_t push[2][4];
+    uint32_t ahead_word[2];  // (A) server -> search: the packed word of the top the repair left (SOK_DUO_NONE: the heap is empty)
 };
+#define SOK_DUO_NONE 0xFFFFFFFFu
 #if defined(__HIPCC__)
 // (LDS traffic only has to have landed: the box and the heap live there; global loads may stay in flight across it)
 __device__ __forceinline__ void sok_duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory"); }
@@ -242,13 +247,13 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
         duo->session = 1;
         sok_duo_sync();                                  // (0) wakes the heap server of this block
         bool empty = false;
+        uint32_t cur_word = (uint32_t)(2 * root.h + k * root.depth) << 16;     // the root's word: pool index 0
         for (;;) {
-            sok_duo_sync();                              // (B) the server has published the next pop
-            const int cur = duo->cur;
-            if (cur < 0) { empty = true; break; }
+            if (cur_word == SOK_DUO_NONE) { empty = true; break; }
             if (iterations >= power) break;
             iterations++;
             if (hook(iterations)) { aborted = true; break; }
+            const int cur = (int)(cur_word & 0xFFFFu);
             SokFastNode nd = ahead;
             if (cur != ahead_idx) {
                 if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
@@ -271,6 +276,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
                 slot = (slot + 1) & (uint32_t)table_mask;
             }
             int npush = 0;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
             if (!seen) {
                 table[slot] = key;
                 cache_base = npool; cache_n = 0;
@@ -284,16 +290,24 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
                     ch.cr = kid[d].cr; ch.ph = (uint32_t)kid[d].np | ((uint32_t)kid[d].h << 16); ch.depth = (uint32_t)(node_depth + 1);
                     pool[npool] = ch;
                     cache[cache_n++] = ch;
-                    duo->push[npush++] = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1)) << 16) | (uint32_t)npool;
+                    const uint32_t word = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1)) << 16) | (uint32_t)npool;
+                    if (npush == 0) w[0] = word; else if (npush == 1) w[1] = word; else if (npush == 2) w[2] = word; else w[3] = word;
+                    duo->push[iterations & 1][npush++] = word;
                     npool++;
                 }
             }
-            duo->npush = npush;
-            sok_duo_sync();                              // (A) the children are in the box; the server's repair is done
-            ahead_idx = duo->ahead_idx;                  // the top the repair left: fetched now, in flight while the server appends
-            if (ahead_idx >= 0) ahead = pool[ahead_idx];
+            duo->npush[iterations & 1] = npush;
+            sok_duo_sync();                              // (A) children one way, the top the repair left the other
+            const uint32_t aw = duo->ahead_word[iterations & 1];
+            uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j < npush && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
+            cur_word = nxt;
+            ahead_idx = -1;
+            if (aw != SOK_DUO_NONE && nxt == aw) { ahead_idx = (int)(aw & 0xFFFFu); ahead = pool[ahead_idx]; }
         }
-        duo->npush = -1;                                 // cap, empty heap, win or abandoned: the server leaves the search
+        duo->npush[0] = -1; duo->npush[1] = -1;          // cap, empty heap, win or abandoned: the server leaves the search
         sok_duo_sync();                                  // (A)
         if (!win) { result_h = best_h; result_depth = best_depth; }
         out_h = result_h; out_depth = result_depth; out_iters = iterations;
@@ -388,22 +402,20 @@ __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, i
         sok_duo_sync();                                 // (0) a search starts, or the block is done
         if (box->session == 0) return;
         int n = 1;                                      // the root's word is in heap[0]
-        for (;;) {
-            box->cur = n > 0 ? (int)(heap[0] & 0xFFFFu) : -1;
-            sok_duo_sync();                             // (B)
-            int ahead = -1;
-            if (n > 0) {                                // heappop: the last entry goes to the root and sinks (CPython _siftup)
-                const uint32_t last = heap[--n];
+        for (int pop = 1;; pop++) {                     // (the search wavefront's `iterations`: the parity selects the set)
+            uint32_t aw = SOK_DUO_NONE;
+            if (n > 0) {                                // heappop of the entry the search wavefront is expanding: the last entry goes
+                const uint32_t last = heap[--n];        // to the root and sinks (CPython _siftup)
                 if (n > 0) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (every lane has read `last` before any lane overwrites the root)
-                    heap[0] = last; sokf_siftup_root(heap, n); ahead = (int)(heap[0] & 0xFFFFu);
+                    heap[0] = last; sokf_siftup_root(heap, n); aw = heap[0];
                 }
             }
-            box->ahead_idx = ahead;
+            box->ahead_word[pop & 1] = aw;
             sok_duo_sync();                             // (A)
-            const int m = box->npush;
+            const int m = box->npush[pop & 1];
             if (m < 0) break;
-            for (int j = 0; j < m; j++) { heap[n + j] = box->push[j]; sokf_siftdown(heap, n + j); }      // heappush, in the children's order
+            for (int j = 0; j < m; j++) { heap[n + j] = box->push[pop & 1][j]; sokf_siftdown(heap, n + j); }      // heappush, in the children's order
             n += m;
         }
     }
