@@ -103,6 +103,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
         duo->session = 1;
         sok_duo_sync();                                  // (0)
         bool empty = false;
+        int turn = 1;                                    // the pop the coming barrier (A) belongs to (SokDuoBox: its parity selects the set)
         uint32_t cur_word = (uint32_t)(2 * root.h + DD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
         for (;;) {
             if (cur_word == SOK_DUO_NONE) { empty = true; break; }
@@ -148,13 +149,14 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
                         }
                         const uint32_t word = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1) + DD_PRIO_BIAS) << 16) | ent_c;
                         w[d] = word;                          // (always four children: d == npush)
-                        duo->push[iterations & 1][npush++] = word;
+                        duo->push[turn & 1][npush++] = word;
                     }
                 }
             }
-            duo->npush[iterations & 1] = npush;
+            duo->npush[turn & 1] = npush;
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
-            const uint32_t aw = duo->ahead_word[iterations & 1];
+            const uint32_t aw = duo->ahead_word[turn & 1];
+            turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -163,7 +165,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
             ahead_idx = -1;
             if (aw != SOK_DUO_NONE && nxt == aw && !(aw & MDF_FLAG)) { ahead_idx = (int)(aw & 0x7FFFu); ahead = pool[ahead_idx]; }
         }
-        duo->npush[0] = -1; duo->npush[1] = -1;          // the server leaves the search
+        duo->npush[turn & 1] = -1;                       // the server leaves the search
         sok_duo_sync();                                  // (A)
         if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; ret_jumps = best_aj >> 2; }
         out_iters = iterations;

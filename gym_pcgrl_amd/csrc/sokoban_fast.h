@@ -153,6 +153,27 @@ template <class HP>
 PCGRL_D void sokf_siftup_root(HP heap, int endpos) {
     int pos = 0;
     const uint32_t newitem = heap[0];
+    // three levels a round while all eight great-grandchildren exist: one LDS round trip (fourteen words) and three
+    // compare-and-select steps instead of three round trips
+    while (8 * pos + 14 < endpos) {
+        const int c1 = 2 * pos + 1, g = 4 * pos + 3, t = 8 * pos + 7;
+        const uint32_t a0 = heap[c1], a1 = heap[c1 + 1];
+        const uint32_t g0 = heap[g], g1 = heap[g + 1], g2 = heap[g + 2], g3 = heap[g + 3];
+        const uint32_t t0 = heap[t], t1 = heap[t + 1], t2 = heap[t + 2], t3 = heap[t + 3];
+        const uint32_t t4 = heap[t + 4], t5 = heap[t + 5], t6 = heap[t + 6], t7 = heap[t + 7];
+        const bool r1 = !sok_lt(a0, a1);
+        const uint32_t u0 = r1 ? t4 : t0, u1 = r1 ? t5 : t1, u2 = r1 ? t6 : t2, u3 = r1 ? t7 : t3;
+        const uint32_t b0 = r1 ? g2 : g0, b1 = r1 ? g3 : g1;
+        heap[pos] = r1 ? a1 : a0;
+        const int p1 = c1 + (r1 ? 1 : 0);
+        const bool r2 = !sok_lt(b0, b1);
+        const uint32_t e0 = r2 ? u2 : u0, e1 = r2 ? u3 : u1;
+        heap[p1] = r2 ? b1 : b0;
+        const int p2 = 2 * p1 + 1 + (r2 ? 1 : 0);
+        const bool r3 = !sok_lt(e0, e1);
+        heap[p2] = r3 ? e1 : e0;
+        pos = 2 * p2 + 1 + (r3 ? 1 : 0);
+    }
     while (4 * pos + 6 < endpos) {
         const int c1 = 2 * pos + 1, g = 4 * pos + 3;
         const uint32_t a0 = heap[c1], a1 = heap[c1 + 1];
@@ -209,12 +230,37 @@ struct SokDuoBox {
 __device__ __forceinline__ void sok_duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory"); }
 #endif
 
+// The lanes of a search run in lockstep on the same values, but the compiler cannot know: every `if` on a loaded value
+// becomes a divergent branch (save exec, mask, restore, merge the loop masks: ~40 scalar instructions a pop that do nothing).
+// SOK_UNI(c) states the uniformity -- a ballot that is compared with zero is a scalar condition -- and SOK_SCALAR(x) moves a
+// uniform value to the scalar file.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SOK_UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#define SOK_SCALAR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define SOK_UNI(c) (c)
+#define SOK_SCALAR(x) ((uint32_t)(x))
+#endif
+
 #if defined(PCGRL_SMB_PROF) && defined(__HIPCC__)
 extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer builds: tools/sok_prof.py)
 #define SKP_DECL unsigned long long skp_t = clock64(), skp_a[6] = {0, 0, 0, 0, 0, 0}
 #define SKP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = clock64(); skp_a[i] += n_ - skp_t; skp_t = n_; } while (0)
 #define SKP_FLUSH(it) do { if (g_tl_buf && k >= 0) { for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_tl_buf[32 + i_], skp_a[i_]); atomicAdd(&g_tl_buf[38], (unsigned long long)(it)); atomicAdd(&g_tl_buf[39], 1ull); } } while (0)
+// (the two-wavefront loops; only searches of at least PCGRL_SKD_MIN_POPS pops are counted: -DPCGRL_SKD_MIN_POPS=4000 looks at
+//  the capped searches a lockstep step waits for)
+#ifndef PCGRL_SKD_MIN_POPS
+#define PCGRL_SKD_MIN_POPS 0
+#endif
+#define SKD_DECL unsigned long long skd_t = clock64(), skd_a[6] = {0, 0, 0, 0, 0, 0}
+#define SKD_MARK(i) do { const unsigned long long n_ = clock64(); skd_a[i] += n_ - skd_t; skd_t = n_; } while (0)
+#define SKD_MARKW(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SKD_MARK(i); } while (0)
+#define SKD_FLUSH(base, it) do { if (g_tl_buf && (it) >= PCGRL_SKD_MIN_POPS) { for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_tl_buf[(base) + i_], skd_a[i_]); atomicAdd(&g_tl_buf[(base) + 6], (unsigned long long)(it)); atomicAdd(&g_tl_buf[(base) + 7], 1ull); } } while (0)
 #else
+#define SKD_DECL do {} while (0)
+#define SKD_MARK(i) do {} while (0)
+#define SKD_MARKW(i) do {} while (0)
+#define SKD_FLUSH(base, it) do {} while (0)
 #define SKP_DECL do {} while (0)
 #define SKP(i) do {} while (0)
 #define SKP_FLUSH(it) do {} while (0)
@@ -246,43 +292,50 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
         // the search wavefront of a two-wavefront A* search: see SokDuoBox.  (heap[0] = the root's word is in place.)
         duo->session = 1;
         sok_duo_sync();                                  // (0) wakes the heap server of this block
+        SKD_DECL;
         bool empty = false;
+        int turn = 1;                                    // the pop the coming barrier (A) belongs to: its parity selects the set
         uint32_t cur_word = (uint32_t)(2 * root.h + k * root.depth) << 16;     // the root's word: pool index 0
         for (;;) {
-            if (cur_word == SOK_DUO_NONE) { empty = true; break; }
+            if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
             iterations++;
-            if (hook(iterations)) { aborted = true; break; }
+            if (SOK_UNI(hook(iterations))) { aborted = true; break; }
             const int cur = (int)(cur_word & 0xFFFFu);
             SokFastNode nd = ahead;
-            if (cur != ahead_idx) {
-                if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
+            if (SOK_UNI(cur != ahead_idx)) {
+                if (SOK_UNI((unsigned)(cur - cache_base) < (unsigned)cache_n)) nd = cache[cur - cache_base];
                 else nd = pool[cur];
             }
             const uint64_t cr = nd.cr;
+            SKD_MARKW(2);
             const int node_player = (int)(nd.ph & 0xFFu), node_h = (int)(nd.ph >> 16), node_depth = (int)nd.depth;
+            const uint64_t key = (cr << 8) | (uint64_t)node_player;
+            const uint64_t hs = key * 0x9E3779B97F4A7C15ull;
+            uint32_t slot = (uint32_t)(hs >> 40) & (uint32_t)table_mask;
+            uint64_t v = table[slot];                    // (the visited probe is in flight while the crate bitboard is made)
             uint64_t cb[NW];
             for (int i = 0; i < NW; i++) cb[i] = 0;
             for (int i = 0; i < nc; i++) sokf_flip<NW>(cb, (int)((cr >> (8 * i)) & 0xFF));
-            if (sokf_covers<NW>(cb, F.tmask)) { win = true; result_h = node_h; result_depth = node_depth; break; }   // engine.py:272-280
-            const uint64_t key = (cr << 8) | (uint64_t)node_player;
-            uint64_t hs = key * 0x9E3779B97F4A7C15ull;
-            uint32_t slot = (uint32_t)(hs >> 40) & (uint32_t)table_mask;
+            if (SOK_UNI(sokf_covers<NW>(cb, F.tmask))) { win = true; result_h = node_h; result_depth = node_depth; break; }   // engine.py:272-280
             bool seen = false;
             for (;;) {
-                const uint64_t v = table[slot];
-                if (v == 0) break;
-                if (v == key) { seen = true; break; }
+                if (SOK_UNI(v == 0)) break;
+                if (SOK_UNI(v == key)) { seen = true; break; }
                 slot = (slot + 1) & (uint32_t)table_mask;
+                v = table[slot];
             }
+            SKD_MARKW(3);
             int npush = 0;
             uint32_t w[4] = {0u, 0u, 0u, 0u};
             if (!seen) {
                 table[slot] = key;
                 cache_base = npool; cache_n = 0;
-                if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) { have_best = true; best_h = node_h; best_depth = node_depth; }
+                const bool better = !have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth);
+                best_h = better ? node_h : best_h; best_depth = better ? node_depth : best_depth; have_best = true;
                 SokChild kid[4];                        // Node.getChildren: L, R, U, D
                 kids(F, cr, cb, node_player, node_h, kid);
+                SKD_MARKW(4);
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     if (!kid[d].ok) continue;
@@ -292,23 +345,29 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
                     cache[cache_n++] = ch;
                     const uint32_t word = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1)) << 16) | (uint32_t)npool;
                     if (npush == 0) w[0] = word; else if (npush == 1) w[1] = word; else if (npush == 2) w[2] = word; else w[3] = word;
-                    duo->push[iterations & 1][npush++] = word;
+                    duo->push[turn & 1][npush++] = word;
                     npool++;
                 }
             }
-            duo->npush[iterations & 1] = npush;
+            duo->npush[turn & 1] = npush;
+            SKD_MARK(0);
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
-            const uint32_t aw = duo->ahead_word[iterations & 1];
+            SKD_MARK(1);
+            const uint32_t aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
+            turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (j < npush && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
             cur_word = nxt;
             ahead_idx = -1;
-            if (aw != SOK_DUO_NONE && nxt == aw) { ahead_idx = (int)(aw & 0xFFFFu); ahead = pool[ahead_idx]; }
+            if (SOK_UNI(aw != SOK_DUO_NONE && nxt == aw)) { ahead_idx = (int)(aw & 0xFFFFu); ahead = pool[ahead_idx]; }
+            SKD_MARK(5);
         }
-        duo->npush[0] = -1; duo->npush[1] = -1;          // cap, empty heap, win or abandoned: the server leaves the search
+        duo->npush[turn & 1] = -1;                       // cap, empty heap, win or abandoned: the server leaves the search (only the
+                                                         // set of the coming barrier is written: the server may still be reading the other)
         sok_duo_sync();                                  // (A)
+        SKD_FLUSH(32, iterations);
         if (!win) { result_h = best_h; result_depth = best_depth; }
         out_h = result_h; out_depth = result_depth; out_iters = iterations;
         out_exhausted = !win && !aborted && empty;
@@ -402,7 +461,9 @@ __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, i
         sok_duo_sync();                                 // (0) a search starts, or the block is done
         if (box->session == 0) return;
         int n = 1;                                      // the root's word is in heap[0]
-        for (int pop = 1;; pop++) {                     // (the search wavefront's `iterations`: the parity selects the set)
+        SKD_DECL;
+        int pop = 1;
+        for (;; pop++) {                     // (the search wavefront's `iterations`: the parity selects the set)
             uint32_t aw = SOK_DUO_NONE;
             if (n > 0) {                                // heappop of the entry the search wavefront is expanding: the last entry goes
                 const uint32_t last = heap[--n];        // to the root and sinks (CPython _siftup)
@@ -412,12 +473,15 @@ __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, i
                 }
             }
             box->ahead_word[pop & 1] = aw;
+            SKD_MARK(0);
             sok_duo_sync();                             // (A)
+            SKD_MARK(1);
             const int m = box->npush[pop & 1];
             if (m < 0) break;
             for (int j = 0; j < m; j++) { heap[n + j] = box->push[pop & 1][j]; sokf_siftdown(heap, n + j); }      // heappush, in the children's order
             n += m;
         }
+        if (lane == 0) SKD_FLUSH(40, pop);
     }
 }
 #endif

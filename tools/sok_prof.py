@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Where the cycles of a Sokoban A* pop go (GPU box): a copy of the library with -DPCGRL_SMB_PROF (sok_search_fast sums the cycles of
-its phases, with a full wait at every mark, into a debug buffer), the C4 workload stepped, cycles per pop printed.
-    python tools/sok_prof.py"""
+its phases, with a full wait at every mark, into a debug buffer), the C4 workload stepped, cycles per pop of the two wavefronts printed (own work / waiting at the barrier).
+    python tools/sok_prof.py [min_pops]"""
 import ctypes as C, os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gym_pcgrl_amd import _lib
 so = "/tmp/libpcgrl_hip_sokprof.so"
-subprocess.check_call(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPCGRL_SMB_PROF"] + _lib.SOURCES + ["-o", so], stderr=subprocess.DEVNULL)
+MIN_POPS = int(sys.argv[1]) if len(sys.argv) > 1 else 0       # only searches of at least that many pops
+subprocess.check_call(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPCGRL_SMB_PROF", "-DPCGRL_SKD_MIN_POPS=%d" % MIN_POPS] + _lib.SOURCES + ["-o", so], stderr=subprocess.DEVNULL)
 _lib.SO = so
 import torch, bench
 from gym_pcgrl_amd.envs import BatchedPcgrlEnv
@@ -31,10 +32,8 @@ _lib.check(L.pcgrl_debug_timeline(None), "tl")
 a = buf.cpu().numpy().astype(np.float64)
 it = max(a[38], 1)
 print("%.2f ms/step; A* searches %d per step, %.0f pops each" % (dt / steps * 1e3, a[39] / steps, it / max(a[39], 1)))
-for i, nm in enumerate(["loop head + poll", "pop: top, node, repair, prefetch", "bitboard, win, visited probe", "best + four children", "pushes (pool, cache, heap)"]):
-    print("  %-34s %7.0f cycles/pop %5.1f%%" % (nm, a[32 + i] / it, 100 * a[32 + i] / a[32:37].sum()))
-print("  total %.0f cycles/pop" % (a[32:37].sum() / it))
+print("search wavefront, cycles per pop:")
+for i, nm in [(2, "loop head, node"), (3, "bitboard, win test, visited probe"), (4, "best + four children"), (0, "pool / cache / box writes"), (1, "waiting at the barrier"), (5, "next top, look-ahead issue")]:
+    print("  %-36s %6.0f" % (nm, a[32 + i] / it))
 sn = max(a[46], 1)
-print("heap server, cycles per served pop (%d pops):" % a[46])
-for i, nm in enumerate(["wait for (1)", "repair + look-ahead issue", "wait for (2)", "appends", "look-ahead node -> box", "between searches"]):
-    print("  %-28s %7.0f" % (nm, a[40 + i] / sn))
+print("heap server:      %.0f cycles of own work + %.0f waiting at the barrier, per pop" % (a[40] / sn, a[41] / sn))
