@@ -450,13 +450,70 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
 }
 
 #if defined(__HIPCC__)
+// heappop's repair, six levels of the heap a round, on the server's 63 lanes.  CPython's _siftup walks the smaller-child path to a
+// leaf moving every child up, puts the displaced last entry there and lets it climb back (_siftdown) while it is strictly smaller
+// than its parent.  The priorities along that path never decrease, so the climb ends exactly where a top-down walk that stops at
+// the first node whose smaller child is strictly greater than the entry (or that has no child) would have put it, and nothing
+// below that node changes: same array, one pass.  A round covers the 63 nodes of the six levels below `pos`: lane j owns node j
+// of that subtree (breadth-first), reads its two children with one ds_read2, and one compare each gives the "right child is not
+// greater" bit and the "stop here" bit of all 63 nodes at once (two ballots).  A node is on the path when the direction bits of
+// its ancestors lead to it and none of them stops: per lane two constant 64-bit masks (A: its ancestors, D: those it hangs under
+// as a right child) and `(R & A) == D && !(S & A)` -- no walk.  The nodes on the path take their smaller child, the one that
+// stops takes the entry; otherwise the deepest one's choice is the next round's `pos`.  ~45 instructions and one LDS round trip
+// for six levels (the scalar walk: ~20 instructions and a third of a round trip per level).
+struct SokDuoLanes { int lj, cj1; uint64_t A, D; };     // lane j: level and offset in the subtree, ancestor masks
+__device__ __forceinline__ SokDuoLanes sok_duo_lanes(int lane) {
+    SokDuoLanes T;
+    const int j1 = lane + 1;
+    T.lj = 31 - __builtin_clz(j1);
+    T.cj1 = j1 - (1 << T.lj) - 1;
+    T.A = 0; T.D = 0;
+    for (int k = 1; k <= T.lj; k++) {
+        const int a = (j1 >> k) - 1;
+        T.A |= 1ull << a;
+        if ((j1 >> (k - 1)) & 1) T.D |= 1ull << a;
+    }
+    return T;
+}
+// heap[0..n) with the root vacant: `item` (the old last entry) goes in; returns the new root's word.
+__device__ __forceinline__ uint32_t sok_duo_repair(uint32_t* heap, int n, uint32_t item, int lane, const SokDuoLanes& T) {
+    int pos = 0;
+    uint32_t top = item;
+    for (;;) {
+        const int q = ((pos + 1) << T.lj) + T.cj1;
+        const int lc = 2 * q + 1;
+        const bool has = lane < 63 && lc < n;
+        uint32_t a = 0, b = 0;
+        if (has) { a = heap[lc]; b = heap[lc + 1]; }             // (index n still belongs to the heap's room)
+        const bool r = has && lc + 1 < n && !sok_lt(a, b);
+        const uint32_t m = r ? b : a;
+        const bool stop = !has || sok_lt(item, m);
+        const uint64_t R = __builtin_amdgcn_ballot_w64(r), S = __builtin_amdgcn_ballot_w64(stop);
+        const bool on = lane < 63 && (R & T.A) == T.D && (S & T.A) == 0;
+        const uint64_t OP = __builtin_amdgcn_ballot_w64(on);
+        if (on && !stop) heap[q] = m;
+        if (pos == 0 && !(S & 1ull)) top = (uint32_t)__builtin_amdgcn_readlane((int)m, 0);
+        const uint64_t ST = OP & S;
+        if (ST != 0) {                                            // exactly one node: the entry's place
+            const int t = __builtin_ctzll(ST);
+            const int qt = __builtin_amdgcn_readlane(q, t);
+            heap[qt] = item;
+            break;
+        }
+        const int d = 63 - __builtin_clzll(OP);                  // a node of the sixth level: the path goes on under it
+        const int qd = __builtin_amdgcn_readlane(q, d);
+        pos = 2 * qd + 1 + (int)((R >> d) & 1ull);
+    }
+    return top;
+}
+
 // The heap server: the second wavefront of a k_sokoban block (see SokDuoBox).  Waits for searches (barrier 0), owns their heap
 // -- appends, publishes the top, removes it and repairs -- and leaves when the block does.  Lane 0 works; the barriers are the
 // wavefront's.
 __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, int lane) {
-    // (every lane runs the same chain on the same addresses: the values are wave-uniform, so the compiler keeps the index
-    //  arithmetic and the comparisons on the scalar unit -- a few per cent faster than one lane under an exec mask)
-    (void)lane;
+    // (the appends: every lane runs the same chain on the same addresses -- the values are wave-uniform, so the compiler keeps
+    //  the index arithmetic and the comparisons on the scalar unit; the repair after a removal: sok_duo_repair)
+    const SokDuoLanes T = sok_duo_lanes(lane);
     for (;;) {
         sok_duo_sync();                                 // (0) a search starts, or the block is done
         if (box->session == 0) return;
@@ -467,10 +524,7 @@ __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, i
             uint32_t aw = SOK_DUO_NONE;
             if (n > 0) {                                // heappop of the entry the search wavefront is expanding: the last entry goes
                 const uint32_t last = heap[--n];        // to the root and sinks (CPython _siftup)
-                if (n > 0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (every lane has read `last` before any lane overwrites the root)
-                    heap[0] = last; sokf_siftup_root(heap, n); aw = heap[0];
-                }
+                if (n > 0) aw = sok_duo_repair(heap, n, last, lane, T);
             }
             box->ahead_word[pop & 1] = aw;
             SKD_MARK(0);
@@ -480,6 +534,7 @@ __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, i
             if (m < 0) break;
             for (int j = 0; j < m; j++) { heap[n + j] = box->push[pop & 1][j]; sokf_siftdown(heap, n + j); }      // heappush, in the children's order
             n += m;
+            SKD_MARKW(2);
         }
         if (lane == 0) SKD_FLUSH(40, pop);
     }

@@ -36,4 +36,4 @@ print("search wavefront, cycles per pop:")
 for i, nm in [(2, "loop head, node"), (3, "bitboard, win test, visited probe"), (4, "best + four children"), (0, "pool / cache / box writes"), (1, "waiting at the barrier"), (5, "next top, look-ahead issue")]:
     print("  %-36s %6.0f" % (nm, a[32 + i] / it))
 sn = max(a[46], 1)
-print("heap server:      %.0f cycles of own work + %.0f waiting at the barrier, per pop" % (a[40] / sn, a[41] / sn))
+print("heap server:      remove + repair %.0f, appends %.0f, waiting at the barrier %.0f cycles per pop" % (a[40] / sn, a[42] / sn, a[41] / sn))
