@@ -106,33 +106,33 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
         int turn = 1;                                    // the pop the coming barrier (A) belongs to (SokDuoBox: its parity selects the set)
         uint32_t cur_word = (uint32_t)(2 * root.h + DD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
         for (;;) {
-            if (cur_word == SOK_DUO_NONE) { empty = true; break; }
+            if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
             iterations++;
-            if (hook(iterations)) { aborted = true; break; }
+            if (SOK_UNI(hook(iterations))) { aborted = true; break; }
             const uint32_t ent = cur_word & 0xFFFFu;
             int npush = 0;
             uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (!(ent & MDF_FLAG)) {
+            if (SOK_UNI(!(ent & MDF_FLAG))) {
                 const int cur = ent & 0x7FFF;
                 DdFastNode nd = ahead;
-                if (cur != ahead_idx) {
-                    if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
+                if (SOK_UNI(cur != ahead_idx)) {
+                    if (SOK_UNI((unsigned)(cur - cache_base) < (unsigned)cache_n)) nd = cache[cur - cache_base];
                     else nd = pool[cur];
                 }
                 const uint64_t key = nd.key;
                 const int node_player = (int)((key >> 48) & 0xFF);
                 const int node_h = (int)(nd.hd & 0xFFFFu) - DD_PRIO_BIAS, node_depth = (int)(nd.hd >> 16), node_aj = (int)nd.aj;
-                if (!(key & DDF_KEY_THERE) && node_player == L.door) {   // checkWin
+                if (SOK_UNI(!(key & DDF_KEY_THERE) && node_player == L.door)) {   // checkWin
                     win = true; ret_key = key; ret_h = node_h; ret_depth = node_depth; ret_jumps = node_aj >> 2; break;
                 }
                 uint32_t slot;
-                if (!mdf_lookup(table, table_mask, key, slot)) {
+                if (!mdf_lookup_uni(table, table_mask, key, slot)) {
                     table[slot] = key;
                     cache_base = npool; cache_n = 0;
-                    if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) {
-                        have_best = true; best_h = node_h; best_depth = node_depth; best_key = key; best_aj = node_aj;
-                    }
+                    const bool better = !have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth);
+                    have_best = true; best_h = better ? node_h : best_h; best_depth = better ? node_depth : best_depth;
+                    best_key = better ? key : best_key; best_aj = better ? node_aj : best_aj;
                     const bool ground = sok_bit(L.solid, node_player + L.w), ceiling = sok_bit(L.solid, node_player - L.w);
                     DdChild kid[4];                         // stay, left, right, jump -- always four
                     kids(L, F, table, table_mask, key, node_aj, ground, ceiling, kid);
@@ -155,7 +155,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
             }
             duo->npush[turn & 1] = npush;
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
-            const uint32_t aw = duo->ahead_word[turn & 1];
+            const uint32_t aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
             turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
 #pragma unroll
@@ -163,7 +163,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
                 if (j < npush && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
             cur_word = nxt;
             ahead_idx = -1;
-            if (aw != SOK_DUO_NONE && nxt == aw && !(aw & MDF_FLAG)) { ahead_idx = (int)(aw & 0x7FFFu); ahead = pool[ahead_idx]; }
+            if (SOK_UNI(aw != SOK_DUO_NONE && nxt == aw && !(aw & MDF_FLAG))) { ahead_idx = (int)(aw & 0x7FFFu); ahead = pool[ahead_idx]; }
         }
         duo->npush[turn & 1] = -1;                       // the server leaves the search
         sok_duo_sync();                                  // (A)

@@ -70,6 +70,19 @@ PCGRL_D bool mdf_lookup(TP table, int table_mask, uint64_t key, uint32_t& slot) 
     }
 }
 
+// (the same probe where every lane looks up the same key: scalar branches, see SOK_UNI in sokoban_fast.h)
+template <class TP>
+PCGRL_D bool mdf_lookup_uni(TP table, int table_mask, uint64_t key, uint32_t& slot) {
+    const uint64_t hs = key * 0x9E3779B97F4A7C15ull;
+    slot = (uint32_t)(hs >> 40) & (uint32_t)table_mask;
+    for (;;) {
+        const uint64_t v = table[slot];
+        if (SOK_UNI(v == 0)) return false;
+        if (SOK_UNI(v == key)) return true;
+        slot = (slot + 1) & (uint32_t)table_mask;
+    }
+}
+
 // Child d (0..3 = L, R, U, D) of the state (alive, player, health) with key `key`: its key, heuristic, and whether it
 // is dropped when popped (lost, equal to the parent, or already visited).
 struct MdChild { uint64_t key; int h; int drop; };
@@ -145,32 +158,31 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
         int turn = 1;                                    // the pop the coming barrier (A) belongs to (SokDuoBox: its parity selects the set)
         uint32_t cur_word = (uint32_t)(2 * root.h + MD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
         for (;;) {
-            if (cur_word == SOK_DUO_NONE) { empty = true; break; }
+            if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
             iterations++;
-            if (hook(iterations)) { aborted = true; break; }
+            if (SOK_UNI(hook(iterations))) { aborted = true; break; }
             const uint32_t ent = cur_word & 0xFFFFu;
             int npush = 0;
             uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (!(ent & MDF_FLAG)) {           // (a flagged entry -- lost, or visited before it was queued -- is only counted)
+            if (SOK_UNI(!(ent & MDF_FLAG))) {           // (a flagged entry -- lost, or visited before it was queued -- is only counted)
                 const int cur = ent & 0x7FFF;
                 MdFastNode nd = ahead;
-                if (cur != ahead_idx) {
-                    if ((unsigned)(cur - cache_base) < (unsigned)cache_n) nd = cache[cur - cache_base];
+                if (SOK_UNI(cur != ahead_idx)) {
+                    if (SOK_UNI((unsigned)(cur - cache_base) < (unsigned)cache_n)) nd = cache[cur - cache_base];
                     else nd = pool[cur];
                 }
                 const uint64_t key = nd.key;
                 const uint64_t alive = key & MDF_ALIVE_MASK;
                 const int node_player = (int)((key >> 48) & 0xFF), node_health = (int)(key >> 56);
                 const int node_h = (int)(nd.hd & 0xFFFFu) - MD_PRIO_BIAS, node_depth = (int)(nd.hd >> 16);
-                if (node_player == L.door) { win = true; ret_key = key; ret_h = node_h; ret_depth = node_depth; break; }   // checkWin
+                if (SOK_UNI(node_player == L.door)) { win = true; ret_key = key; ret_h = node_h; ret_depth = node_depth; break; }   // checkWin
                 uint32_t slot;
-                if (!mdf_lookup(table, table_mask, key, slot)) {
+                if (!mdf_lookup_uni(table, table_mask, key, slot)) {
                     table[slot] = key;
                     cache_base = npool; cache_n = 0;
-                    if (!have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth)) {
-                        have_best = true; best_h = node_h; best_depth = node_depth; best_key = key;
-                    }
+                    const bool better = !have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth);
+                    have_best = true; best_h = better ? node_h : best_h; best_depth = better ? node_depth : best_depth; best_key = better ? key : best_key;
                     MdChild kid[4];                         // Node.getChildren: L, R, U, D -- always four
                     kids(L, F, table, table_mask, key, alive, node_player, node_health, kid);
 #pragma unroll
@@ -192,7 +204,7 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
             }
             duo->npush[turn & 1] = npush;
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
-            const uint32_t aw = duo->ahead_word[turn & 1];
+            const uint32_t aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
             turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
 #pragma unroll
@@ -200,7 +212,7 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
                 if (j < npush && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
             cur_word = nxt;
             ahead_idx = -1;
-            if (aw != SOK_DUO_NONE && nxt == aw && !(aw & MDF_FLAG)) { ahead_idx = (int)(aw & 0x7FFFu); ahead = pool[ahead_idx]; }
+            if (SOK_UNI(aw != SOK_DUO_NONE && nxt == aw && !(aw & MDF_FLAG))) { ahead_idx = (int)(aw & 0x7FFFu); ahead = pool[ahead_idx]; }
         }
         duo->npush[turn & 1] = -1;                       // the server leaves the search
         sok_duo_sync();                                  // (A)
