@@ -134,23 +134,23 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
                     have_best = true; best_h = better ? node_h : best_h; best_depth = better ? node_depth : best_depth;
                     best_key = better ? key : best_key; best_aj = better ? node_aj : best_aj;
                     const bool ground = sok_bit(L.solid, node_player + L.w), ceiling = sok_bit(L.solid, node_player - L.w);
-                    DdChild kid[4];                         // stay, left, right, jump -- always four
-                    kids(L, F, table, table_mask, key, node_aj, ground, ceiling, kid);
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        uint32_t ent_c = MDF_FLAG;
-                        if (!kid[d].drop) {
-                            DdFastNode c;
-                            c.key = kid[d].key; c.hd = (uint32_t)(kid[d].h + DD_PRIO_BIAS) | ((uint32_t)(node_depth + 1) << 16); c.aj = (uint32_t)kid[d].aj;
-                            pool[npool] = c;
-                            cache[cache_n++] = c;
-                            ent_c = (uint32_t)npool;
-                            npool++;
-                        }
-                        const uint32_t word = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1) + DD_PRIO_BIAS) << 16) | ent_c;
-                        w[d] = word;                          // (always four children: d == npush)
-                        duo->push[turn & 1][npush++] = word;
+                    // stay, left, right, jump -- always four.  Lane d makes child d and files it itself (mdungeon_fast.h)
+                    const DdChild mine = kids.mine(L, F, table, table_mask, key, node_aj, ground, ceiling);
+                    const uint32_t keepm = (uint32_t)__builtin_amdgcn_ballot_w64(!mine.drop) & 15u;
+                    const int rank = __builtin_popcount(keepm & ((1u << (kids.lane & 3)) - 1u));
+                    uint32_t ent_c = MDF_FLAG;
+                    if (!mine.drop) {
+                        DdFastNode c;
+                        c.key = mine.key; c.hd = (uint32_t)(mine.h + DD_PRIO_BIAS) | ((uint32_t)(node_depth + 1) << 16); c.aj = (uint32_t)mine.aj;
+                        pool[npool + rank] = c;
+                        cache[rank] = c;
+                        ent_c = (uint32_t)(npool + rank);
                     }
+                    const uint32_t word = ((uint32_t)(2 * mine.h + k * (node_depth + 1) + DD_PRIO_BIAS) << 16) | ent_c;
+                    duo->push[turn & 1][kids.lane & 3] = word;
+                    cache_n = __builtin_popcount(keepm); npool += cache_n; npush = 4;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) w[d] = (uint32_t)__builtin_amdgcn_readlane((int)word, d);
                 }
             }
             duo->npush[turn & 1] = npush;

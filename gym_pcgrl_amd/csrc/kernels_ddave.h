@@ -16,6 +16,12 @@ struct DdPollHook {
 // The four children of a pop, one per lane (lanes 0..3 run the compact search in lockstep).
 struct DdKidsLanes {
     int lane;
+    // this lane's child only (two-wavefront searches: each lane files its own child)
+    template <class TP>
+    __device__ __forceinline__ DdChild mine(const DdLevel& L, const DdFastLevel& F, TP table, int table_mask, uint64_t key, int aj, bool ground,
+                                            bool ceiling) const {
+        return ddf_child(L, F, table, table_mask, key, aj, ground, ceiling, lane & 3);
+    }
     template <class TP>
     __device__ __forceinline__ void operator()(const DdLevel& L, const DdFastLevel& F, TP table, int table_mask, uint64_t key, int aj, bool ground,
                                                bool ceiling, DdChild* out) const {

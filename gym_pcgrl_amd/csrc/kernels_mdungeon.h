@@ -29,6 +29,12 @@ struct MdPollHook {
 // uniform across them).  The results come back through v_readlane, i.e. as scalars.
 struct MdKidsLanes {
     int lane;
+    // this lane's child only (two-wavefront searches: each lane files its own child)
+    template <class TP>
+    __device__ __forceinline__ MdChild mine(const MdLevel& L, const MdFastLevel& F, TP table, int table_mask, uint64_t key, uint64_t alive,
+                                            int player, int health) const {
+        return mdf_child(L, F, table, table_mask, key, alive, player, health, lane & 3);
+    }
     template <class TP>
     __device__ __forceinline__ void operator()(const MdLevel& L, const MdFastLevel& F, TP table, int table_mask, uint64_t key, uint64_t alive,
                                                int player, int health, MdChild* out) const {

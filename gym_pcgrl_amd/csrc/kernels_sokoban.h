@@ -45,6 +45,11 @@ struct SokPollHook {      // A*: stop when the result cannot be selected any mor
 // uniform across them).  The results come back through v_readlane, i.e. as scalars.
 struct SokKidsLanes {
     int lane;
+    // this lane's child only (two-wavefront searches: each lane files its own child)
+    template <int NW>
+    __device__ __forceinline__ SokChild mine(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h) const {
+        return sokf_child<NW>(F, cr, cb, player, h, lane & 3);
+    }
     template <int NW>
     __device__ __forceinline__ void operator()(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, SokChild* out) const {
         const SokChild mine = sokf_child<NW>(F, cr, cb, player, h, lane & 3);

@@ -183,23 +183,24 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
                     cache_base = npool; cache_n = 0;
                     const bool better = !have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth);
                     have_best = true; best_h = better ? node_h : best_h; best_depth = better ? node_depth : best_depth; best_key = better ? key : best_key;
-                    MdChild kid[4];                         // Node.getChildren: L, R, U, D -- always four
-                    kids(L, F, table, table_mask, key, alive, node_player, node_health, kid);
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        uint32_t ent_c = MDF_FLAG;
-                        if (!kid[d].drop) {
-                            MdFastNode c;
-                            c.key = kid[d].key; c.hd = (uint32_t)(kid[d].h + MD_PRIO_BIAS) | ((uint32_t)(node_depth + 1) << 16); c.pad = 0;
-                            pool[npool] = c;
-                            cache[cache_n++] = c;
-                            ent_c = (uint32_t)npool;
-                            npool++;
-                        }
-                        const uint32_t word = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1) + MD_PRIO_BIAS) << 16) | ent_c;
-                        w[d] = word;                          // (always four children: d == npush)
-                        duo->push[turn & 1][npush++] = word;
+                    // Node.getChildren: L, R, U, D -- always four.  Lane d makes child d and files it itself: its word in the
+                    // server's box and, unless it is dropped, its node in the pool and the cache at its rank among the kept ones
+                    const MdChild mine = kids.mine(L, F, table, table_mask, key, alive, node_player, node_health);
+                    const uint32_t keepm = (uint32_t)__builtin_amdgcn_ballot_w64(!mine.drop) & 15u;
+                    const int rank = __builtin_popcount(keepm & ((1u << (kids.lane & 3)) - 1u));
+                    uint32_t ent_c = MDF_FLAG;
+                    if (!mine.drop) {
+                        MdFastNode c;
+                        c.key = mine.key; c.hd = (uint32_t)(mine.h + MD_PRIO_BIAS) | ((uint32_t)(node_depth + 1) << 16); c.pad = 0;
+                        pool[npool + rank] = c;
+                        cache[rank] = c;
+                        ent_c = (uint32_t)(npool + rank);
                     }
+                    const uint32_t word = ((uint32_t)(2 * mine.h + k * (node_depth + 1) + MD_PRIO_BIAS) << 16) | ent_c;
+                    duo->push[turn & 1][kids.lane & 3] = word;
+                    cache_n = __builtin_popcount(keepm); npool += cache_n; npush = 4;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) w[d] = (uint32_t)__builtin_amdgcn_readlane((int)word, d);
                 }
             }
             duo->npush[turn & 1] = npush;

@@ -327,27 +327,30 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             }
             SKD_MARKW(3);
             int npush = 0;
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            uint32_t w[4] = {SOK_DUO_NONE, SOK_DUO_NONE, SOK_DUO_NONE, SOK_DUO_NONE};
             if (!seen) {
                 table[slot] = key;
                 cache_base = npool; cache_n = 0;
                 const bool better = !have_best || node_h < best_h || (node_h == best_h && node_depth < best_depth);
                 best_h = better ? node_h : best_h; best_depth = better ? node_depth : best_depth; have_best = true;
-                SokChild kid[4];                        // Node.getChildren: L, R, U, D
-                kids(F, cr, cb, node_player, node_h, kid);
+                // Node.getChildren: L, R, U, D -- lane d makes child d and files it itself (pool, cache, the server's box) at its
+                // rank among the children that exist: one masked store each instead of four rounds of scalar copies
+                const SokChild mine = kids.mine(F, cr, cb, node_player, node_h);
                 SKD_MARKW(4);
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    if (!kid[d].ok) continue;
+                const uint32_t okm = (uint32_t)__builtin_amdgcn_ballot_w64(mine.ok != 0) & 15u;
+                const int rank = __builtin_popcount(okm & ((1u << (kids.lane & 3)) - 1u));
+                const uint32_t word = ((uint32_t)(2 * mine.h + k * (node_depth + 1)) << 16) | (uint32_t)(npool + rank);
+                if (mine.ok) {
                     SokFastNode ch;
-                    ch.cr = kid[d].cr; ch.ph = (uint32_t)kid[d].np | ((uint32_t)kid[d].h << 16); ch.depth = (uint32_t)(node_depth + 1);
-                    pool[npool] = ch;
-                    cache[cache_n++] = ch;
-                    const uint32_t word = ((uint32_t)(2 * kid[d].h + k * (node_depth + 1)) << 16) | (uint32_t)npool;
-                    if (npush == 0) w[0] = word; else if (npush == 1) w[1] = word; else if (npush == 2) w[2] = word; else w[3] = word;
-                    duo->push[turn & 1][npush++] = word;
-                    npool++;
+                    ch.cr = mine.cr; ch.ph = (uint32_t)mine.np | ((uint32_t)mine.h << 16); ch.depth = (uint32_t)(node_depth + 1);
+                    pool[npool + rank] = ch;
+                    cache[rank] = ch;
+                    duo->push[turn & 1][rank] = word;
                 }
+                npush = __builtin_popcount(okm);
+                cache_n = npush; npool += npush;
+#pragma unroll
+                for (int d = 0; d < 4; d++) w[d] = (okm >> d) & 1u ? (uint32_t)__builtin_amdgcn_readlane((int)word, d) : SOK_DUO_NONE;
             }
             duo->npush[turn & 1] = npush;
             SKD_MARK(0);
@@ -357,8 +360,8 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (j < npush && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
+            for (int j = 0; j < 4; j++)                  // (w[d]: child d's word, SOK_DUO_NONE if there is none)
+                if (w[j] != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
             cur_word = nxt;
             ahead_idx = -1;
             if (SOK_UNI(aw != SOK_DUO_NONE && nxt == aw)) { ahead_idx = (int)(aw & 0xFFFFu); ahead = pool[ahead_idx]; }
