@@ -154,6 +154,7 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
         // wavefront expands it.  Same operations in the same order as the loop below.
         duo->session = 1;
         sok_duo_sync();                                  // (0)
+        SKD_DECL;
         bool empty = false;
         int turn = 1;                                    // the pop the coming barrier (A) belongs to (SokDuoBox: its parity selects the set)
         uint32_t cur_word = (uint32_t)(2 * root.h + MD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
@@ -204,7 +205,9 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
                 }
             }
             duo->npush[turn & 1] = npush;
+            SKD_MARK(0);
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
+            SKD_MARK(1);
             const uint32_t aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
             turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
@@ -217,6 +220,7 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
         }
         duo->npush[turn & 1] = -1;                       // the server leaves the search
         sok_duo_sync();                                  // (A)
+        SKD_FLUSH(32, iterations);
         if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; }
         out_iters = iterations;
         out_exhausted = !win && !aborted && empty;
