@@ -510,6 +510,21 @@ __device__ __forceinline__ uint32_t sok_duo_repair(uint32_t* heap, int n, uint32
     return top;
 }
 
+// heappush on the server's lanes: `item` goes to the new leaf `p` and climbs while it is strictly smaller than its parent
+// (CPython _siftdown).  Lane k reads ancestor k of p (at most 16 levels), one ballot says which of them the item beats, the run of
+// ones from the parent up is the climb: those ancestors move down one place each and the item lands above them.  One LDS round
+// trip and a dozen instructions whatever the climb (the scalar loop: a round trip and ~12 instructions per two levels).
+__device__ __forceinline__ void sok_duo_append(uint32_t* heap, int p, uint32_t item, int lane) {
+    const int up = (p + 1) >> (lane + 1);                            // ancestor `lane` of p is heap[up - 1]; 0: above the root
+    const bool valid = lane < 16 && up != 0;
+    uint32_t v = 0;
+    if (valid) v = heap[up - 1];
+    const uint32_t beats = (uint32_t)__builtin_amdgcn_ballot_w64(valid && sok_lt(item, v));
+    const int c = __builtin_ctz(~beats);                             // (bit 16 is never set)
+    if (lane < c) heap[((p + 1) >> lane) - 1] = v;                   // ancestor k moves to where ancestor k - 1 (k = 0: the leaf) was
+    if (lane == 0) heap[((p + 1) >> c) - 1] = item;
+}
+
 // The heap server: the second wavefront of a k_sokoban block (see SokDuoBox).  Waits for searches (barrier 0), owns their heap
 // -- appends, publishes the top, removes it and repairs -- and leaves when the block does.  Lane 0 works; the barriers are the
 // wavefront's.
@@ -535,7 +550,9 @@ __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, i
             SKD_MARK(1);
             const int m = box->npush[pop & 1];
             if (m < 0) break;
-            for (int j = 0; j < m; j++) { heap[n + j] = box->push[pop & 1][j]; sokf_siftdown(heap, n + j); }      // heappush, in the children's order
+            const uint32_t mine = box->push[pop & 1][lane & 3];   // (one read for the four words)
+            for (int j = 0; j < m; j++)                           // heappush, in the children's order
+                sok_duo_append(heap, n + j, (uint32_t)__builtin_amdgcn_readlane((int)mine, j), lane);
             n += m;
             SKD_MARKW(2);
         }
