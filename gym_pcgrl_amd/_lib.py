@@ -41,11 +41,11 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
 
 
-ABI_VERSION = 8          # include/pcgrl_hip.h PCGRL_ABI_VERSION
+ABI_VERSION = 9          # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
-           "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout", "pcgrl_bind_observation")
+           "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout", "pcgrl_bind_observation", "pcgrl_selftest_heap")
 NPHASE = 6
 # the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
 # other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
@@ -137,6 +137,7 @@ def load():
     L.pcgrl_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.pcgrl_bind_observation.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.pcgrl_action_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcgrl_selftest_heap.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     L.pcgrl_profile.argtypes = [C.c_void_p, C.c_int]
     L.pcgrl_bind_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

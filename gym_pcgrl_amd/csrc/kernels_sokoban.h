@@ -118,6 +118,35 @@ __device__ __forceinline__ bool sok_run_agent(const DevBufs& B, int power, const
     return sok_search(L, pool, g_heap, g_table, tsize - 1, work, root, k, power, hh, dd, it, exhausted, hook);
 }
 
+// pcgrl_selftest_heap: the heap server's two primitives (sok_duo_append / sok_duo_repair) driven by a tape of operations, so that
+// a test can hold them against CPython's heapq slot for slot.  ops[i] = a packed word to push, or 0xFFFFFFFF = pop (the popped
+// word goes to pops[], 0xFFFFFFFF for an empty heap).  One wavefront; the heap (at most `cap` words) in dynamic LDS.
+template <int PART_TAG>
+__global__ __launch_bounds__(64) void k_selftest_heap(const uint32_t* ops, int n_ops, int cap, uint32_t* pops, uint32_t* heap_out, int32_t* n_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t st_heap[];
+    const int lane = threadIdx.x;
+    const SokDuoLanes T = sok_duo_lanes(lane);
+    int n = 0, np = 0;
+    for (int i = 0; i < n_ops; i++) {
+        const uint32_t w = ops[i];
+        if (w != 0xFFFFFFFFu) { if (n < cap) { sok_duo_append(st_heap, n, w, lane); n++; } continue; }
+        uint32_t top = 0xFFFFFFFFu;
+        if (n > 0) {
+            top = st_heap[0];
+            const uint32_t last = st_heap[--n];
+            if (n > 0) {
+                const uint32_t root = sok_duo_repair(st_heap, n, last, lane, T);
+                if (root != st_heap[0]) top = 0xFFFFFFFEu;       // (the word the server hands the search wavefront is the new root)
+            }
+        }
+        if (lane == 0) pops[np] = top;
+        np++;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) heap_out[i] = st_heap[i];
+    if (lane == 0) *n_out = n;
+}
+
 // Jobs = list_a (mode_a) followed by list_b (mode_b); list_b < 0: none.  `sync`/`hard` are this launch's
 // zeroed scheduling words.  Environments that finish their episode here go to `rst_list`.
 // (a template only so that every part of the library can include this header: instantiated where it is launched)

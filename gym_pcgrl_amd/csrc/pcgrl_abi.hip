@@ -675,6 +675,14 @@ PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
+int pcgrl_selftest_heap(const uint32_t* ops, int32_t n_ops, uint32_t* pops, uint32_t* heap_out, int32_t* n_out, void* stream) {
+    if (!ops || !pops || !heap_out || !n_out || n_ops < 0) return PCGRL_EINVAL;
+    const int cap = 16384;                               // 64 KB of LDS: fifteen levels, deeper than any search's heap
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_selftest_heap<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap * 4));
+    hipLaunchKernelGGL(k_selftest_heap<0>, dim3(1), dim3(64), (size_t)cap * 4, (hipStream_t)stream, ops, n_ops, cap, pops, heap_out, n_out);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
 #endif  // PART_SEARCH
 static int launch_solver(pcgrl_env* h, int slot, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr,
                          hipStream_t st, int inline_reset = 0) {

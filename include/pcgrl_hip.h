@@ -37,7 +37,7 @@ extern "C" {
  * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps).  6: + pcgrl_rollout.
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
  *    clamped actions. */
-#define PCGRL_ABI_VERSION 8
+#define PCGRL_ABI_VERSION 9
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -166,6 +166,13 @@ int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* st
  * default).  Call after pcgrl_bind. */
 int pcgrl_bind_episode_stats(pcgrl_env* env, double* ep_return, int32_t* ep_length, double* last_return,
                              int32_t* last_length, void* stream);
+/* Test hook, no reference counterpart: runs the heap primitives of the two-wavefront searches (the CPython heapq of
+ * sokoban/engine.py:96-119, mdungeon/engine.py, ddave/engine.py: heappush / heappop on entries compared by priority only)
+ * over a tape of operations on the current device.  ops DEVICE u32 [n_ops]: a packed word (priority << 16 | payload) to push, or
+ * 0xFFFFFFFF = pop.  pops DEVICE u32 [number of pops]: the popped words in order (0xFFFFFFFF: the heap was empty); heap_out DEVICE
+ * u32 [16384] and n_out DEVICE i32 [1]: the heap array afterwards.  At most 16 384 entries are kept (further pushes are dropped).
+ * tests/test_gpu_parity.py holds the result against Python's heapq slot for slot. */
+int pcgrl_selftest_heap(const uint32_t* ops, int32_t n_ops, uint32_t* pops, uint32_t* heap_out, int32_t* n_out, void* stream);
 /* Sticky device status word, 0 = fine.  Bit 0 (1): a sokoban level had more crates than the solver supports.
  * Bit 1 (2): an action outside the action space was clamped into it (the reference raises IndexError or writes the
  * bad value: narrow_rep.py:101-103, wide_rep.py:68-69, turtle_rep.py:101-129, wrappers.py:139-154).  Bit 2 (4):

@@ -1040,6 +1040,59 @@ def test_rollout_many_long_searches_per_block():
             assert torch.equal(sa[k], sb[k]), k
 
 
+class _HeapWord:
+    """An entry of the searches' queues: compared by priority only, like Node.__lt__ (sokoban/engine.py:49-50)."""
+    __slots__ = ("w",)
+
+    def __init__(self, w):
+        self.w = w
+
+    def __lt__(self, other):
+        return (self.w >> 16) < (other.w >> 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,spread,n_ops,p_push", [(0, 1, 30000, 0.75), (1, 2, 30000, 0.7), (2, 3, 60000, 0.62), (3, 40, 60000, 0.6),
+                                                      (4, 400, 40000, 0.8), (5, 2, 3000, 0.5)])
+def test_heap_server_primitives_match_heapq(seed, spread, n_ops, p_push):
+    """The heap server of the two-wavefront searches (sok_duo_append: heappush on lanes; sok_duo_repair: heappop's repair six
+    levels a round) against CPython's heapq on a tape of pushes and pops: same pops, same array afterwards, slot for slot.
+    Few distinct priorities (ties decide the order), a drifting floor like an A* queue, heaps up to fourteen levels deep, a
+    drain at the end."""
+    import ctypes as C
+    import heapq
+    torch = _torch()
+    from gym_pcgrl_amd import _lib
+    L = _lib.load()
+    rs = np.random.RandomState(seed)
+    ops, h, pops = [], [], []
+    idx = 0
+    for i in range(n_ops):
+        drain = i > 0.8 * n_ops
+        if rs.rand() < (0.3 if drain else p_push) and len(h) < 16384:
+            w = (min(0xFFF0, i // 400 + int(rs.randint(spread))) << 16) | (idx & 0xFFFF)
+            idx += 1
+            heapq.heappush(h, _HeapWord(w))
+            ops.append(w)
+        else:
+            ops.append(0xFFFFFFFF)
+            pops.append(heapq.heappop(h).w if h else 0xFFFFFFFF)
+    dev = "cuda:0"
+    t_ops = torch.from_numpy(np.array(ops, np.uint32).view(np.int32)).to(dev)
+    t_pops = torch.zeros((max(len(pops), 1),), dtype=torch.int32, device=dev)
+    t_heap = torch.zeros((16384,), dtype=torch.int32, device=dev)
+    t_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _lib.check(L.pcgrl_selftest_heap(C.c_void_p(t_ops.data_ptr()), len(ops), C.c_void_p(t_pops.data_ptr()), C.c_void_p(t_heap.data_ptr()),
+                                     C.c_void_p(t_n.data_ptr()), None), "pcgrl_selftest_heap")
+    torch.cuda.synchronize()
+    n = int(t_n.item())
+    assert n == len(h)
+    got_pops = t_pops.cpu().numpy().view(np.uint32)[:len(pops)]
+    assert np.array_equal(got_pops, np.array(pops, np.uint32)), "first difference at pop %d" % int(np.argmax(got_pops != np.array(pops, np.uint32)))
+    assert np.array_equal(t_heap.cpu().numpy().view(np.uint32)[:n], np.array([x.w for x in h], np.uint32))
+    assert max(len(pops), 1) > 100
+
+
 @pytest.mark.gpu
 def test_device_seeding_matches_numpy():
     """pcgrl_seed_words: MT19937 init_by_array on the device against numpy's RandomState.seed(list) -- keys of two words
