@@ -215,7 +215,8 @@ PCGRL_D void sokf_siftup_root(HP heap, int endpos) {
 // stays below the root), so the search wavefront works it out from the words it holds.  The removal is speculative (the search
 // may end at this pop: cap, win, abandoned); a heap that is thrown away does not care.  ONE block barrier per pop; `SokDuoBox`
 // in LDS carries the trade.  The array operations are those of the one-wavefront form in the same order, so the pop order,
-// iteration counts and results are the same.
+// iteration counts and results are the same (tests: the fixtures' iteration counts; the heap primitives alone against Python's
+// heapq through pcgrl_selftest_heap).
 struct SokDuoBox {
     int session;             // outer handshake: 1 = a search starts, 0 = leave the kernel
     // two sets, used alternately (pop parity): with one barrier per pop the search wavefront is already filling in the children
@@ -525,9 +526,9 @@ __device__ __forceinline__ void sok_duo_append(uint32_t* heap, int p, uint32_t i
     if (lane == 0) heap[((p + 1) >> c) - 1] = item;
 }
 
-// The heap server: the second wavefront of a k_sokoban block (see SokDuoBox).  Waits for searches (barrier 0), owns their heap
-// -- appends, publishes the top, removes it and repairs -- and leaves when the block does.  Lane 0 works; the barriers are the
-// wavefront's.
+// The heap server: the second wavefront of a k_sokoban / k_mdungeon / k_ddave block (see SokDuoBox).  Waits for searches (barrier 0),
+// owns their heap -- removes the top the search wavefront is expanding and repairs (sok_duo_repair), hands over the top that left,
+// appends the children (sok_duo_append) -- and leaves when the block does.  All 64 lanes take part; the barriers are the wavefront's.
 __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, int lane) {
     // (the appends: every lane runs the same chain on the same addresses -- the values are wave-uniform, so the compiler keeps
     //  the index arithmetic and the comparisons on the scalar unit; the repair after a removal: sok_duo_repair)
