@@ -398,36 +398,61 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     uint32_t* rst_raw = reinterpret_cast<uint32_t*>(smem + wave_lds);
     uint64_t* rst_bits = reinterpret_cast<uint64_t*>(smem + wave_lds + (size_t)8 * W * H);
     const MaskT rowmask = row_valid<MaskT>(lane, W, H);
-    for (int item = blockIdx.x; item < n; item += gridDim.x) {
-        const bool lone = item < n_rst;                      // certain reset (block-uniform)
-        const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item - n_rst);
+    // A certain reset is TWO items, for two blocks: the statistics of the map the step ended on (even items below 2 n_rst: the
+    // "old-map" half, which only reads the planes and hands regions / path over through B.wide_sync) and the reset proper with the
+    // statistics of the regenerated map (the odd item after it), which also finishes the step -- every wavefront of a block on one
+    // map instead of half of them on each.  The second half waits for "planes read" before it overwrites them and for the result
+    // before it finishes the step.  It cannot wait for ever: the grid is even (launch_stats_p), so an even block only ever gets
+    // even items -- old-map halves and full items, which wait for nobody -- and the block an odd one waits for is its left
+    // neighbour in the same round, which was dispatched before it.
+    const int n_items = n + n_rst;
+    const int epoch = B.wide_epoch;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const bool lone = item < 2 * n_rst;                  // certain reset (block-uniform, like everything below that is not per lane)
+        const bool old_half = lone && (item & 1) == 0;
+        const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item >> 1) : wl_get(B, list, s_pref, item - 2 * n_rst);
         const bool reset_only = (raw & WL_RESET_ONLY) != 0;
         const int e = raw & ~WL_RESET_ONLY;
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         MaskT* planes_e = reinterpret_cast<MaskT*>(B.planes) + (size_t)e * 64;
         MaskT* champ_e = B.champ ? reinterpret_cast<MaskT*>(B.champ) + (size_t)e * 64 : nullptr;
+        int32_t* sync_e = B.wide_sync + (size_t)e * 4;
+        if (old_half) {
+            if (reset_only) continue;                        // (an unchanged map: the step needs no statistics)
+            const MaskT b_old = planes_e[lane];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(sync_e + 0, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // the planes may go
+            block_regions_and_path(g, (MaskT)(~b_old & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], (MaskT*)nullptr);
+            if (threadIdx.x == 0) {
+                sync_e[2] = s_regions[0]; sync_e[3] = s_best[0];
+                __hip_atomic_store(sync_e + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            continue;
+        }
         if (lone) {
-            // Reset first, then the statistics of the map the step ended on (team 0, rows already in registers) and of the
-            // regenerated map (team 1) side by side; the step is finished with the counters read before the reset.
-            const MaskT b_old = reset_only ? (MaskT)0 : planes_e[lane];
+            // the reset, then the statistics of the regenerated map; the step is finished with the counters read before the reset
             if (threadIdx.x == 0) s_pre = reinterpret_cast<const int2*>(B.counters)[e];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             TL(24);
             const MaskT n0 = block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64, MaskT>(P, B, e, gen_map, mt, tiles, rst_raw, rst_bits, &s_cur);     // (every wavefront helps: reset_env.h)
+            if (!reset_only) {
+                if (threadIdx.x == 0) while (__hip_atomic_load(sync_e + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+                __syncthreads();
+            }
             if (wv == 0) planes_e[lane] = n0;
             TL(26);
-            constexpr int TS = NWAVES / 2;
-            const int team = wv / TS, tw = wv % TS;
-            const MaskT pass = team == 0 ? (reset_only ? (MaskT)0 : (MaskT)(~b_old & rowmask)) : (MaskT)(~n0 & rowmask);
-            block_regions_and_path(g, pass, tw, TS, lane, H, s_rest[team], &s_regions[team], &s_best[team], &s_owner[team],
-                                   team == 1 ? champ_e : (MaskT*)nullptr);
+            block_regions_and_path(g, (MaskT)(~n0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);
             if (threadIdx.x == 0) {
                 if (!reset_only) {
-                    int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], 0, 0, 0, 0, 0, 0};
+                    while (__hip_atomic_load(sync_e + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+                    int32_t s[PCGRL_MAX_STATS] = {__hip_atomic_load(sync_e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                  __hip_atomic_load(sync_e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0, 0, 0, 0, 0, 0};
                     finalize_item<PCGRL_PROB_BINARY>(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &s_pre);
                 }
-                int32_t st[PCGRL_MAX_STATS] = {s_regions[1], s_best[1], s_owner[1] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
+                int32_t st[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
                 finalize_item<PCGRL_PROB_BINARY>(P, B, e, st, MODE_START, parity, shard);
             }
             __syncthreads();
@@ -458,7 +483,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     TL(27);
     if (n_inc > 0) {
         // incremental items: by the blocks beyond the full items if there are any, else by all
-        const int first = ((int)gridDim.x > n) ? n : 0;
+        const int first = ((int)gridDim.x > n_items) ? n_items : 0;
         const int nblk = (int)gridDim.x - first;
         if ((int)blockIdx.x >= first) {
             uint32_t* mtw = reinterpret_cast<uint32_t*>(smem + (size_t)wv * wave_lds);

@@ -214,7 +214,8 @@ static size_t champ_bytes(const pcgrl_config* c) {
 static size_t fifo_words_bytes(const pcgrl_config* c) { return c->rep == PCGRL_NARROW ? align_up((size_t)c->num_envs * PCGRL_FIFO_N * 4, 256) : 0; }
 static size_t fifo_bytes(const pcgrl_config* c) { return c->rep == PCGRL_NARROW ? fifo_words_bytes(c) + align_up((size_t)c->num_envs * 4, 256) : 0; }
 static size_t scratch_bytes_base(const pcgrl_config* c);
-static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c) + fifo_bytes(c); }
+static size_t wide_sync_bytes(const pcgrl_config* c) { return (c->prob == PCGRL_BINARY && c->height > 16) ? align_up((size_t)c->num_envs * 16, 256) : 0; }
+static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c) + fifo_bytes(c) + wide_sync_bytes(c); }
 static size_t scratch_bytes_base(const pcgrl_config* c) {
     size_t b = wl_bytes(c);
     if (solver_prob(c->prob)) {           // (an MdNode is as large as a SokNode)
@@ -317,7 +318,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     // environment switches (A/B measurements, tests) are read here, once: no getenv on the step path
     h->no_wide = env_is_one("PCGRL_NO_WIDE") ? 1 : 0;
     { const char* wvs = getenv("PCGRL_WIDE_WAVES"); h->wide_waves = wvs ? atoi(wvs) : 8; }
-    { const char* wg = getenv("PCGRL_WIDE_GRID"); h->wide_grid = wg ? atoi(wg) : 16384; if (h->wide_grid < 1) h->wide_grid = 16384; }   // blocks of k_stats_wide   // C5: 4 -> 90 us/step, 8 -> 79, 16 -> 92
+    { const char* wg = getenv("PCGRL_WIDE_GRID"); h->wide_grid = wg ? atoi(wg) : 2048; if (h->wide_grid < 1) h->wide_grid = 2048; }   // blocks of k_stats_wide (they loop over the items; C5 steady: 768 .. 4096 -> 59.5 us/step, 8192 -> 63.5: a block costs ~4 us of prefix sums before its first item)
     { const char* fz = getenv("PCGRL_FUSED_ZELDA"); h->fused_zelda = (fz && fz[0] == '0') ? 0 : 1; }   // =0: zelda steps as k_update + k_stats
     h->no_fused = env_is_one("PCGRL_NO_FUSED") ? 1 : 0;
     {   // k_step: environments per block (see launch_step_pm).  The largest block that still gives (about) every compute unit one and
@@ -366,10 +367,15 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0, 0, 0};
     B.fifo = nullptr; B.fifo_tag = nullptr;
     if (fifo_bytes(&h->cfg)) {
-        uint8_t* f = s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg);
+        uint8_t* f = s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg);     // (wide_sync follows the draw cache: below)
         B.fifo = (uint32_t*)f;
         B.fifo_tag = (int32_t*)(f + fifo_words_bytes(&h->cfg));
         HIPCHK(hipMemsetAsync(B.fifo_tag, 0xFF, (size_t)h->cfg.num_envs * 4, (hipStream_t)stream));     // -1: nothing cached yet
+    }
+    B.wide_sync = nullptr; B.wide_epoch = 0;
+    if (wide_sync_bytes(&h->cfg)) {
+        B.wide_sync = (int32_t*)(s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg) + fifo_bytes(&h->cfg));
+        HIPCHK(hipMemsetAsync(B.wide_sync, 0, wide_sync_bytes(&h->cfg), (hipStream_t)stream));
     }
     {   // PCGRL_INLINE_RESET=0 routes resets through the reset list + k_reset instead (A/B measurements)
         const char* ir = getenv("PCGRL_INLINE_RESET");
@@ -505,7 +511,9 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
         const size_t need1 = set1 + (size_t)8 * P.width * P.height + 8 * ((size_t)(P.width * P.height + 63) / 64 + 2);
         const size_t sets1 = (size_t)(nw == 8 ? 8 : 4) * set1;
         const size_t lds1 = inline_reset ? (sets1 > need1 ? sets1 : need1) : 0;
-        const int gridw = P.num_envs < h->wide_grid ? P.num_envs : h->wide_grid;
+        int gridw = P.num_envs < h->wide_grid ? P.num_envs : h->wide_grid;
+        if (gridw > 1) gridw &= ~1;                                    // even: see the two halves of a certain reset in k_stats_wide
+        h->B.wide_epoch = (h->B.wide_epoch % 0x3FFFFFFF) + 1;          // this launch's word in wide_sync (never 0: the cleared state)
         // wavefronts per map: with the incremental route only ~10 % of the changes (and the resets) come here, so the launch
         // is latency-bound and more wavefronts per map pay (PCGRL_WIDE_WAVES overrides for experiments)
 #define LAUNCH_WIDE(NW) do { if (P.mask_bytes == 4) hipLaunchKernelGGL((k_stats_wide<uint32_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); \

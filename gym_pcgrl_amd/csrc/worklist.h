@@ -73,6 +73,8 @@ struct ObsSpec { uint8_t* out; int32_t oh, ow, depth, centered, pad;
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
+    int32_t* wide_sync;              // tall binary maps (k_stats_wide): i32 [N][4] = {epoch: planes read, epoch: result there, regions, path} --
+    int32_t wide_epoch;              //   how the two blocks of a certain reset (old map / new map) talk; the launch's epoch (host counter)
     const uint16_t* heat_end;        // end of the caller's heatmap buffer
     // optional episode statistics (pcgrl_bind_episode_stats): running return/length, latched at the end of an episode
     double* ep_return; int32_t* ep_length; double* last_return; int32_t* last_length;
@@ -272,6 +274,12 @@ __device__ __forceinline__ void block_append_bucketed(bool flag, int bucket, int
     else if (flag2) B.wl_items[list2][(size_t)shard2 * B.wl_cap[list2] + s_gbase[WL_NSHARD] + rank] = value2;
 }
 __device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int4& s0, const int4& s1) {
+    if (P.prob == PCGRL_PROB_BINARY && P.group == 64) {
+        // tall maps (k_stats_wide, a block per item, the blocks start in list order): the dearest first.  A full recomputation costs
+        // ~0.8 us per region plus ~0.1 us per step of the longest path (tools/timeline_wide.py); shard 0 = dearest
+        const int cost = (8 * max(s0.x, 0) + max(s0.y, 0)) / 24;        // ~0.4 us units
+        return WL_NSHARD - 1 - min(cost, WL_NSHARD - 1);
+    }
     if (P.prob == PCGRL_PROB_BINARY) {   // (path-length / 6, regions / 3), 8 x 8
         const int a = min(max(s0.y, 0) / 6, 7), b = min(max(s0.x, 0) / 3, 7);
         return a * 8 + b;
