@@ -275,9 +275,10 @@ __device__ __forceinline__ void block_append_bucketed(bool flag, int bucket, int
 }
 __device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int4& s0, const int4& s1) {
     if (P.prob == PCGRL_PROB_BINARY && P.group == 64) {
-        // tall maps (k_stats_wide, a block per item, the blocks start in list order): the dearest first.  A full recomputation costs
-        // ~0.8 us per region plus ~0.1 us per step of the longest path (tools/timeline_wide.py); shard 0 = dearest
-        const int cost = (8 * max(s0.x, 0) + max(s0.y, 0)) / 24;        // ~0.4 us units
+        // tall maps (k_stats_wide, a block per item, the blocks start in list order and only ~512 are resident): the dearest
+        // first.  A full recomputation costs ~0.8 us per region spread over the block's eight wavefronts plus ~0.1 us per step of the
+        // longest path on one of them (tools/timeline_wide.py): the two count alike; shard 0 = dearest
+        const int cost = (max(s0.x, 0) + max(s0.y, 0)) / 6;
         return WL_NSHARD - 1 - min(cost, WL_NSHARD - 1);
     }
     if (P.prob == PCGRL_PROB_BINARY) {   // (path-length / 6, regions / 3), 8 x 8
