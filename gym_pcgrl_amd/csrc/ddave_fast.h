@@ -112,7 +112,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
             if (SOK_UNI(hook(iterations))) { aborted = true; break; }
             const uint32_t ent = cur_word & 0xFFFFu;
             int npush = 0;
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            uint32_t cmin = SOK_DUO_NONE;              // the first child with the smallest priority (sok_duo_first_smallest)
             if (SOK_UNI(!(ent & MDF_FLAG))) {
                 const int cur = ent & 0x7FFF;
                 DdFastNode nd = ahead;
@@ -149,8 +149,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
                     const uint32_t word = ((uint32_t)(2 * mine.h + k * (node_depth + 1) + DD_PRIO_BIAS) << 16) | ent_c;
                     duo->push[turn & 1][kids.lane & 3] = word;
                     cache_n = __builtin_popcount(keepm); npool += cache_n; npush = 4;
-#pragma unroll
-                    for (int d = 0; d < 4; d++) w[d] = (uint32_t)__builtin_amdgcn_readlane((int)word, d);
+                    cmin = sok_duo_first_smallest(true, word, kids.lane);
                 }
             }
             duo->npush[turn & 1] = npush;
@@ -158,9 +157,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
             const uint32_t aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
             turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (j < npush && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
+if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cmin;
             cur_word = nxt;
             ahead_idx = -1;
             if (SOK_UNI(aw != SOK_DUO_NONE && nxt == aw && !(aw & MDF_FLAG))) { ahead_idx = (int)(aw & 0x7FFFu); ahead = pool[ahead_idx]; }

@@ -243,6 +243,22 @@ __device__ __forceinline__ void sok_duo_sync() { asm volatile("s_waitcnt lgkmcnt
 #define SOK_SCALAR(x) ((uint32_t)(x))
 #endif
 
+#if defined(__HIPCC__)
+// The first child with the smallest priority among the (up to) four children the lanes 0..3 of a search hold, as a scalar word
+// (SOK_DUO_NONE: no child): the minimum of (priority << 2 | lane) over the quad with two DPP steps, then one readlane -- instead of
+// four readlanes and a chain of scalar compares.  `have`: this lane has a child; `word`: its packed word.
+__device__ __forceinline__ uint32_t sok_duo_first_smallest(bool have, uint32_t word, int lane) {
+    const uint32_t key = have ? (((word >> 16) << 2) | (uint32_t)(lane & 3)) : 0xFFFFFFFFu;
+    uint32_t k1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)key, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    k1 = k1 < key ? k1 : key;
+    uint32_t k2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)k1, 0x4E, 0xF, 0xF, true);        // quad_perm [2,3,0,1]
+    k2 = k2 < k1 ? k2 : k1;
+    const uint32_t kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)k2);
+    if (kmin == 0xFFFFFFFFu) return SOK_DUO_NONE;
+    return (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(kmin & 3u));
+}
+#endif
+
 #if defined(PCGRL_SMB_PROF) && defined(__HIPCC__)
 extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer builds: tools/sok_prof.py)
 #define SKP_DECL unsigned long long skp_t = clock64(), skp_a[6] = {0, 0, 0, 0, 0, 0}
@@ -328,7 +344,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             }
             SKD_MARKW(3);
             int npush = 0;
-            uint32_t w[4] = {SOK_DUO_NONE, SOK_DUO_NONE, SOK_DUO_NONE, SOK_DUO_NONE};
+            uint32_t cmin = SOK_DUO_NONE;              // the first child with the smallest priority
             if (!seen) {
                 table[slot] = key;
                 cache_base = npool; cache_n = 0;
@@ -350,8 +366,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
                 }
                 npush = __builtin_popcount(okm);
                 cache_n = npush; npool += npush;
-#pragma unroll
-                for (int d = 0; d < 4; d++) w[d] = (okm >> d) & 1u ? (uint32_t)__builtin_amdgcn_readlane((int)word, d) : SOK_DUO_NONE;
+                cmin = sok_duo_first_smallest(mine.ok != 0, word, kids.lane);
             }
             duo->npush[turn & 1] = npush;
             SKD_MARK(0);
@@ -360,9 +375,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             const uint32_t aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
             turn++;
             uint32_t nxt = aw;                           // the next pop: that top, unless a child is strictly smaller (then the first smallest)
-#pragma unroll
-            for (int j = 0; j < 4; j++)                  // (w[d]: child d's word, SOK_DUO_NONE if there is none)
-                if (w[j] != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(w[j], nxt))) nxt = w[j];
+            if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cmin;
             cur_word = nxt;
             ahead_idx = -1;
             if (SOK_UNI(aw != SOK_DUO_NONE && nxt == aw)) { ahead_idx = (int)(aw & 0xFFFFu); ahead = pool[ahead_idx]; }
