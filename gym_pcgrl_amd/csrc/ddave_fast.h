@@ -109,7 +109,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
             if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
             iterations++;
-            if (SOK_UNI(hook(iterations))) { aborted = true; break; }
+            if ((iterations & SOK_POLL_MASK) == 0 && SOK_UNI(hook(iterations))) { aborted = true; break; }     // (the A* hooks poll at that rate)
             const uint32_t ent = cur_word & 0xFFFFu;
             int npush = 0;
             uint32_t cmin = SOK_DUO_NONE;              // the first child with the smallest priority (sok_duo_first_smallest)

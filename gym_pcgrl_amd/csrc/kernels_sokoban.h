@@ -22,7 +22,6 @@
 enum { SOK_SY_TICKET_A = 0, SOK_SY_TICKET_B = 1, SOK_SY_HARD = 2, SOK_SY_BFS_DONE = 3, SOK_SY_WORDS = 16 };
 #define SOK_HARD_CAP 4096          /* published levels per launch; beyond it a BFS block runs its A* agents itself */
 #define SOK_SPAWN_ITERS 256
-#define SOK_POLL_MASK 31
 
 __device__ __forceinline__ int sok_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -44,15 +43,15 @@ struct SokPollHook {      // A*: stop when the result cannot be selected any mor
 // The four children of a pop, one per lane (lanes 0..3 run the search in lockstep; everything else in it is
 // uniform across them).  The results come back through v_readlane, i.e. as scalars.
 struct SokKidsLanes {
-    int lane;
+    int lane, dir;      // dir: this lane's move as a cell offset (sokf_dir(lane & 3, level width)), made once per search
     // this lane's child only (two-wavefront searches: each lane files its own child)
     template <int NW>
     __device__ __forceinline__ SokChild mine(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h) const {
-        return sokf_child<NW>(F, cr, cb, player, h, lane & 3);
+        return sokf_child_dir<NW>(F, cr, cb, player, h, dir);
     }
     template <int NW>
     __device__ __forceinline__ void operator()(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, SokChild* out) const {
-        const SokChild mine = sokf_child<NW>(F, cr, cb, player, h, lane & 3);
+        const SokChild mine = sokf_child_dir<NW>(F, cr, cb, player, h, dir);
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.cr, d);
@@ -106,7 +105,7 @@ __device__ __forceinline__ bool sok_run_agent(const DevBufs& B, int power, const
                                               int& hh, int& dd, int& it, bool& exhausted, Hook hook, int lane, int table_off = SOK_LDS_HEAP,
                                               SokDuoBox* duo = nullptr) {
     if (fast) {
-        const SokKidsLanes kids = {lane};
+        const SokKidsLanes kids = {lane, sokf_dir(lane & 3, L.w)};
         uint64_t* tab = reinterpret_cast<uint64_t*>(lds + table_off);
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool);
         if (L.cells <= 64) return sok_search_fast<1>(L, fp, lds, tab, tsize - 1, cache, root, k, power, hh, dd, it, exhausted, hook, kids, duo);

@@ -18,6 +18,7 @@
 #include "sokoban_solver.h"
 
 #define SOKF_MAXC 7
+#define SOK_POLL_MASK 31           /* an A* agent looks at its stop word every 32 pops (the hooks in kernels_sokoban.h / _mdungeon.h / _ddave.h) */
 
 struct alignas(16) SokFastNode { uint64_t cr; uint32_t ph; uint32_t depth; };   // ph = player | h << 16
 
@@ -102,10 +103,10 @@ PCGRL_D int sokf_crate_index(uint64_t cr, int p) {
 // One child of Node.getChildren (State.update engine.py:298-327) for direction d = 0..3 (L, R, U, D): dropped if the
 // player did not move, if the pushed crate is blocked, or if after the push any crate stands on a deadlock cell.
 struct SokChild { uint64_t cr; int np, h, ok; };
+PCGRL_D int sokf_dir(int d, int w) { return (d & 2) ? ((d & 1) ? w : -w) : ((d & 1) ? 1 : -1); }      // L, R, U, D
 template <int NW>
-PCGRL_D SokChild sokf_child(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, int d) {
+PCGRL_D SokChild sokf_child_dir(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, int dir) {
     SokChild c;
-    const int dir = d == 0 ? -1 : (d == 1 ? 1 : (d == 2 ? -F.w : F.w));
     const int np = player + dir;
     c.cr = cr; c.np = np; c.h = h; c.ok = 0;
     if (sokf_bit<NW>(F.solid, np)) return c;                     // player did not move
@@ -122,6 +123,10 @@ PCGRL_D SokChild sokf_child(const SokFastLevel<NW>& F, uint64_t cr, const uint64
     }
     c.ok = 1;
     return c;
+}
+template <int NW>
+PCGRL_D SokChild sokf_child(const SokFastLevel<NW>& F, uint64_t cr, const uint64_t* cb, int player, int h, int d) {
+    return sokf_child_dir<NW>(F, cr, cb, player, h, sokf_dir(d, F.w));
 }
 // How the four children of a pop get made: one after the other (host, generic), or -- on the device -- by four
 // lanes at once (SokKidsLanes in kernels_sokoban.h), the rest of the search being uniform across those lanes.
@@ -317,7 +322,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
             if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
             iterations++;
-            if (SOK_UNI(hook(iterations))) { aborted = true; break; }
+            if ((iterations & SOK_POLL_MASK) == 0 && SOK_UNI(hook(iterations))) { aborted = true; break; }     // (the hooks of the A* agents poll at that rate)
             const int cur = (int)(cur_word & 0xFFFFu);
             SokFastNode nd = ahead;
             if (SOK_UNI(cur != ahead_idx)) {
