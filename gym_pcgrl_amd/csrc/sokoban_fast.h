@@ -534,13 +534,13 @@ __device__ __forceinline__ uint32_t sok_duo_repair(uint32_t* heap, int n, uint32
 // ones from the parent up is the climb: those ancestors move down one place each and the item lands above them.  One LDS round
 // trip and a dozen instructions whatever the climb (the scalar loop: a round trip and ~12 instructions per two levels).
 __device__ __forceinline__ void sok_duo_append(uint32_t* heap, int p, uint32_t item, int lane) {
-    const int up = (p + 1) >> (lane + 1);                            // ancestor `lane` of p is heap[up - 1]; 0: above the root
-    const bool valid = lane < 16 && up != 0;
+    const int up = lane < 16 ? (p + 1) >> (lane + 1) : 0;            // ancestor `lane` of p is heap[up - 1]; 0: above the root
+    const bool valid = up != 0;
     uint32_t v = 0;
     if (valid) v = heap[up - 1];
     const uint32_t beats = (uint32_t)__builtin_amdgcn_ballot_w64(valid && sok_lt(item, v));
     const int c = __builtin_ctz(~beats);                             // (bit 16 is never set)
-    if (lane < c) heap[((p + 1) >> lane) - 1] = v;                   // ancestor k moves to where ancestor k - 1 (k = 0: the leaf) was
+    if (lane < c) heap[((p + 1) >> (lane & 15)) - 1] = v;            // ancestor k moves to where ancestor k - 1 (k = 0: the leaf) was
     if (lane == 0) heap[((p + 1) >> c) - 1] = item;
 }
 
