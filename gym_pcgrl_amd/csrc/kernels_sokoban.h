@@ -21,7 +21,7 @@
 
 enum { SOK_SY_TICKET_A = 0, SOK_SY_TICKET_B = 1, SOK_SY_HARD = 2, SOK_SY_BFS_DONE = 3, SOK_SY_WORDS = 16 };
 #define SOK_HARD_CAP 4096          /* published levels per launch; beyond it a BFS block runs its A* agents itself */
-#define SOK_SPAWN_ITERS 256
+#define SOK_SPAWN_ITERS 128
 
 __device__ __forceinline__ int sok_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(128) void k_sokoban(PcgrlParams P, DevBufs B, int l
                 int hh = 0, dd = 0, it = 0;
                 bool exhausted = false, win = false;
                 if (kind == 1 && a == 0) {
-                    int sp = P.solver_power < SOK_SPAWN_ITERS ? P.solver_power : SOK_SPAWN_ITERS;
+                    int sp = P.solver_power < B.sok_spawn_iters ? P.solver_power : B.sok_spawn_iters;
                     SokSpawnHook hook = {sync, hard, sp, (e + 1) | (mode << 28), &s_spawned, lane, B.sok_hard_cap};
                     win = sok_run_agent(B, P.solver_power, s_L, s_work, s_root, pool, sok_lds, s_cache, g_heap, g_table, tsize, fast, -1, hh, dd, it, exhausted, hook, lane);
                     __threadfence_block();

@@ -403,6 +403,9 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
             B.md_only_agent = oa ? atoi(oa) : -1;
             const char* hc = getenv("PCGRL_SOK_HARD_CAP");
             B.sok_hard_cap = hc ? atoi(hc) : SOK_HARD_CAP;
+            const char* spn = getenv("PCGRL_SOK_SPAWN");
+            B.sok_spawn_iters = spn ? atoi(spn) : SOK_SPAWN_ITERS;
+            if (B.sok_spawn_iters < 1) B.sok_spawn_iters = SOK_SPAWN_ITERS;
             if (B.sok_hard_cap < 0 || B.sok_hard_cap > SOK_HARD_CAP) B.sok_hard_cap = SOK_HARD_CAP;
         }
         B.sok_table_size = sok_table_size(power);

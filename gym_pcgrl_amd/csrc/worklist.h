@@ -92,6 +92,7 @@ struct DevBufs {
     int32_t md_only_agent;           // >= 0: k_mdungeon runs only this agent (PCGRL_MD_ONLY_AGENT, timing experiments; results are then wrong)
     int32_t* sok_sync;               // [2 launches per step][SOK_SY_WORDS + SOK_HARD_CAP] scheduling words
     int32_t sok_pool_stride, sok_heap_stride, sok_table_size, sok_use_lds;
+    int32_t sok_spawn_iters;         // a Sokoban BFS still running after that many pops publishes its level (PCGRL_SOK_SPAWN: experiments)
     int32_t sok_hard_cap;            // levels k_sokoban may publish per launch (SOK_HARD_CAP; PCGRL_SOK_HARD_CAP lowers it for tests)
     int32_t sok_fast_maxc;           // most crates the register-resident search takes (SOKF_MAXC; -1: PCGRL_SOK_GENERIC=1 forces the generic one)
     int32_t inline_reset;   // k_stats resets finished environments itself (every problem but Sokoban)
