@@ -15,7 +15,9 @@ def agg(path):
     return d
 out = ["# %s (MI355X, rocprofv3)\n" % name,
        "Commands: `tools/profile_gpu.sh <workload> trace sq mem` = `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload W --steps 100 --no-cpu-baseline --no-rollout`,",
-       "then separate `--pmc` passes (SQ_* counters; FETCH_SIZE; WRITE_SIZE).  Bench lines: `bench_<W>.json`.\n"]
+       "then separate `--pmc` passes (SQ_* counters; FETCH_SIZE; WRITE_SIZE).  Bench lines: `bench_<W>.json`; the default line as the driver runs it: "
+       "`bench_default.json` (+ `.time`); cycles per pop of the two wavefronts of a capped A* search: `sok_prof.txt`, `md_prof_duo.txt` (`tools/sok_prof.py 4000`, "
+       "`tools/sok_prof.py 1000 mdungeon`); the image kernel's store stream: `obs_bench.txt`.\n"]
 for W in workloads:
     out.append("## %s\n" % W)
     if W.endswith("R"):
