@@ -372,12 +372,12 @@ __device__ __forceinline__ void wave_incremental_item(const PcgrlParams& P, cons
 
 template <class MaskT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
-                                                             int inline_reset, int gen_map) {
+                                                             int inline_reset, int gen_map, int pair_few) {
     // inline_reset: MT ring + tile bytes, one set per wavefront (the block-wide reset uses the first)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
     __shared__ MaskT s_rest[2][64];
-    __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag, s_cur;
+    __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag, s_flag2[2], s_cur;
     __shared__ int2 s_pre;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     TL_INIT(); TL(1);
@@ -405,11 +405,50 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     // before it finishes the step.  It cannot wait for ever: the grid is even (launch_stats_p), so an even block only ever gets
     // even items -- old-map halves and full items, which wait for nobody -- and the block an odd one waits for is its left
     // neighbour in the same round, which was dispatched before it.
-    const int n_items = n + n_rst;
+    // pair_few (a step; k_update ranks the list: difficulty_bucket): the full items of the list's second class -- maps with few regions,
+    // one long double sweep on which seven of eight wavefronts would only wait -- go two to a block, half of the wavefronts each, so
+    // that (nearly) every item of a step starts at once instead of a quarter of them behind the first to finish.
+    const int n_many = pair_few ? s_pref[WL_NSHARD / 2] : n_chg;
+    const int n_items = 2 * n_rst + n_many + (n_chg - n_many + 1) / 2;
     const int epoch = B.wide_epoch;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const bool lone = item < 2 * n_rst;                  // certain reset (block-uniform, like everything below that is not per lane)
         const bool old_half = lone && (item & 1) == 0;
+        if (item >= 2 * n_rst + n_many) {
+            constexpr int TS = NWAVES / 2;
+            const int team = wv / TS, tw = wv % TS;
+            const int idx0 = n_many + 2 * (item - 2 * n_rst - n_many);
+            const int e0 = wl_get(B, list, s_pref, idx0) & ~WL_RESET_ONLY;
+            const int e1 = idx0 + 1 < n_chg ? (wl_get(B, list, s_pref, idx0 + 1) & ~WL_RESET_ONLY) : -1;
+            const int et = team ? e1 : e0;
+            const int shard = (item >> 4) & (WL_NSHARD - 1);
+            MaskT pass = 0;
+            if (et >= 0) pass = (MaskT)(~(reinterpret_cast<const MaskT*>(B.planes) + (size_t)et * 64)[lane] & rowmask);
+            if (threadIdx.x < 2) s_flag2[threadIdx.x] = 0;
+            block_regions_and_path(g, pass, tw, TS, lane, H, s_rest[team], &s_regions[team], &s_best[team], &s_owner[team],
+                                   (et >= 0 && B.champ) ? reinterpret_cast<MaskT*>(B.champ) + (size_t)et * 64 : (MaskT*)nullptr);
+            if (tw == 0 && lane == 0 && et >= 0) {
+                int32_t s[PCGRL_MAX_STATS] = {s_regions[team], s_best[team], s_owner[team] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
+                const bool want = finalize_item<PCGRL_PROB_BINARY>(P, B, et, s, mode, parity, shard, !inline_reset);
+                s_flag2[team] = (want && inline_reset) ? 1 : 0;
+            }
+            __syncthreads();
+            for (int t = 0; t < 2; t++) {
+                if (!(inline_reset && s_flag2[t])) continue;     // block-uniform: PcgrlEnv.reset of that environment by the whole block, then its start stats
+                const int er = t ? e1 : e0;
+                MaskT* planes_r = reinterpret_cast<MaskT*>(B.planes) + (size_t)er * 64;
+                const MaskT b0 = block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64, MaskT>(P, B, er, gen_map, mt, tiles, rst_raw, rst_bits, &s_cur);
+                if (wv == 0) planes_r[lane] = b0;
+                block_regions_and_path(g, (MaskT)(~b0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0],
+                                       B.champ ? reinterpret_cast<MaskT*>(B.champ) + (size_t)er * 64 : (MaskT*)nullptr);
+                if (threadIdx.x == 0) {
+                    int32_t s[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
+                    finalize_item<PCGRL_PROB_BINARY>(P, B, er, s, MODE_START, parity, shard);
+                }
+                __syncthreads();
+            }
+            continue;
+        }
         const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item >> 1) : wl_get(B, list, s_pref, item - 2 * n_rst);
         const bool reset_only = (raw & WL_RESET_ONLY) != 0;
         const int e = raw & ~WL_RESET_ONLY;

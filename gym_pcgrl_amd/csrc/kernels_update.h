@@ -46,7 +46,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         const int4* tp = reinterpret_cast<const int4*>(B.start_stats + (size_t)e * 8);
         const int4 s0 = sp[0], s1 = sp[1], t0 = tp[0], t1 = tp[1];
 
-        bucket = difficulty_bucket(P, s0, s1);
+        bucket = difficulty_bucket(P, s0, s1, B.wide_few);
         const int iter = c.x + 1;
         int changes = c.y;
         int x = p0.x, y = p0.y;

@@ -96,7 +96,7 @@ struct pcgrl_env {
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
     int alloc_solver_power;
     // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
-    int no_wide, wide_waves, wide_grid, fused_zelda, no_fused, step_epb, smb_heap;
+    int no_wide, wide_waves, wide_grid, wide_pairs, fused_zelda, no_fused, step_epb, smb_heap;
     int profiling;
     int obs_incremental;       // pcgrl_bind_observation(incremental): the bound target is the library's to update in place
     const uint8_t* obs_synced; // the buffer that holds the image of the current state (written by the last step / reset), or NULL
@@ -318,6 +318,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     // environment switches (A/B measurements, tests) are read here, once: no getenv on the step path
     h->no_wide = env_is_one("PCGRL_NO_WIDE") ? 1 : 0;
     { const char* wvs = getenv("PCGRL_WIDE_WAVES"); h->wide_waves = wvs ? atoi(wvs) : 8; }
+    { const char* wp = getenv("PCGRL_WIDE_PAIRS"); h->wide_pairs = wp ? atoi(wp) : 1; }      // developer switch: 0 = every full item a block of its own
     { const char* wg = getenv("PCGRL_WIDE_GRID"); h->wide_grid = wg ? atoi(wg) : 2048; if (h->wide_grid < 1) h->wide_grid = 2048; }   // blocks of k_stats_wide (they loop over the items; C5 steady: 768 .. 4096 -> 59.5 us/step, 8192 -> 63.5: a block costs ~4 us of prefix sums before its first item)
     { const char* fz = getenv("PCGRL_FUSED_ZELDA"); h->fused_zelda = (fz && fz[0] == '0') ? 0 : 1; }   // =0: zelda steps as k_update + k_stats
     h->no_fused = env_is_one("PCGRL_NO_FUSED") ? 1 : 0;
@@ -373,6 +374,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         HIPCHK(hipMemsetAsync(B.fifo_tag, 0xFF, (size_t)h->cfg.num_envs * 4, (hipStream_t)stream));     // -1: nothing cached yet
     }
     B.wide_sync = nullptr; B.wide_epoch = 0;
+    { const char* wf = getenv("PCGRL_WIDE_FEW"); B.wide_few = wf ? atoi(wf) : WL_WIDE_FEW_REGIONS; }
     if (wide_sync_bytes(&h->cfg)) {
         B.wide_sync = (int32_t*)(s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg) + fifo_bytes(&h->cfg));
         HIPCHK(hipMemsetAsync(B.wide_sync, 0, wide_sync_bytes(&h->cfg), (hipStream_t)stream));
@@ -519,8 +521,10 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
         h->B.wide_epoch = (h->B.wide_epoch % 0x3FFFFFFF) + 1;          // this launch's word in wide_sync (never 0: the cleared state)
         // wavefronts per map: with the incremental route only ~10 % of the changes (and the resets) come here, so the launch
         // is latency-bound and more wavefronts per map pay (PCGRL_WIDE_WAVES overrides for experiments)
-#define LAUNCH_WIDE(NW) do { if (P.mask_bytes == 4) hipLaunchKernelGGL((k_stats_wide<uint32_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); \
-                             else hipLaunchKernelGGL((k_stats_wide<uint64_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen); } while (0)
+        // (a step of a single-cell representation: k_update ranked the list in two classes, the second goes two items to a block)
+        const int pair_few = (mode == MODE_STEP && list == WL_CHG && P.rep <= PCGRL_REP_TURTLE && h->wide_pairs) ? 1 : 0;
+#define LAUNCH_WIDE(NW) do { if (P.mask_bytes == 4) hipLaunchKernelGGL((k_stats_wide<uint32_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen, pair_few); \
+                             else hipLaunchKernelGGL((k_stats_wide<uint64_t, NW>), dim3(gridw), dim3(NW * 64), lds1, st, P, h->B, list, parity, mode, clr, inline_reset, gen, pair_few); } while (0)
         if (nw == 8) LAUNCH_WIDE(8); else LAUNCH_WIDE(4);
 #undef LAUNCH_WIDE
         HIPCHK(hipGetLastError());

@@ -14,6 +14,7 @@ enum { MODE_STEP = 0, MODE_START = 1, MODE_SETMAP = 2 };
 // consumers rebuild the dense index with a 64-entry prefix sum in LDS.  Counters are double-buffered
 // by step parity: the last kernel of a step zeroes the other parity's counters.
 #define WL_NSHARD 64
+#define WL_WIDE_FEW_REGIONS 32     /* tall binary maps: at most that many regions = "one sweep and little else" (difficulty_bucket) */
 #define WL_CSTRIDE 16
 // CHG: changed environments; RST: to reset; SOL: solver jobs of the step; SOL2: of the resets.  Sokoban only: RST2 =
 // environments whose episode the solver kernel ended, SOL3 = solver jobs of *their* resets.
@@ -74,6 +75,7 @@ struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
     int32_t* wide_sync;              // tall binary maps (k_stats_wide): i32 [N][4] = {epoch: planes read, epoch: result there, regions, path} --
+    int32_t wide_few;                //   (regions up to which a tall map counts as "few regions": WL_WIDE_FEW_REGIONS, PCGRL_WIDE_FEW for experiments)
     int32_t wide_epoch;              //   how the two blocks of a certain reset (old map / new map) talk; the launch's epoch (host counter)
     const uint16_t* heat_end;        // end of the caller's heatmap buffer
     // optional episode statistics (pcgrl_bind_episode_stats): running return/length, latched at the end of an episode
@@ -274,13 +276,16 @@ __device__ __forceinline__ void block_append_bucketed(bool flag, int bucket, int
     if (flag) B.wl_items[list][(size_t)bucket * B.wl_cap[list] + s_gbase[bucket] + rank] = value;
     else if (flag2) B.wl_items[list2][(size_t)shard2 * B.wl_cap[list2] + s_gbase[WL_NSHARD] + rank] = value2;
 }
-__device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int4& s0, const int4& s1) {
+__device__ __forceinline__ int difficulty_bucket(const PcgrlParams& P, const int4& s0, const int4& s1, int B_few = WL_WIDE_FEW_REGIONS) {
     if (P.prob == PCGRL_PROB_BINARY && P.group == 64) {
         // tall maps (k_stats_wide, a block per item, the blocks start in list order and only ~512 are resident): the dearest
         // first.  A full recomputation costs ~0.8 us per region spread over the block's eight wavefronts plus ~0.1 us per step of the
         // longest path on one of them (tools/timeline_wide.py): the two count alike; shard 0 = dearest
-        const int cost = (max(s0.x, 0) + max(s0.y, 0)) / 6;
-        return WL_NSHARD - 1 - min(cost, WL_NSHARD - 1);
+        // Two classes, the upper half of the shards for maps with few regions (one long double sweep on one wavefront and little
+        // else: those go two to a block in k_stats_wide), dearest first within a class.
+        const int cost = (max(s0.x, 0) + max(s0.y, 0)) / 12;
+        const int half = WL_NSHARD / 2;
+        return (s0.x <= B_few ? half : 0) + half - 1 - min(cost, half - 1);
     }
     if (P.prob == PCGRL_PROB_BINARY) {   // (path-length / 6, regions / 3), 8 x 8
         const int a = min(max(s0.y, 0) / 6, 7), b = min(max(s0.x, 0) / 3, 7);

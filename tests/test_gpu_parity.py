@@ -948,14 +948,16 @@ def test_paired_certain_resets(prob, rep, calls, E, T, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid,E", [("2", 96), ("6", 97), ("64", 160), ("2048", 160)])
-def test_tall_map_resets_split_over_two_blocks(grid, E, monkeypatch):
+@pytest.mark.parametrize("grid,E,few", [("2", 96, None), ("6", 97, "1000"), ("64", 160, "0"), ("2048", 160, None), ("2048", 130, "1000")])
+def test_tall_map_resets_split_over_two_blocks(grid, E, few, monkeypatch):
     """Tall binary maps (k_stats_wide): a certain reset is two work items for two blocks -- the statistics of the map the step
     ended on, and the reset with the statistics of the regenerated map -- that talk through DevBufs::wide_sync.  With
     change_percentage = 0.01 on a 20 x 24 map (max_changes 4) episodes end every few steps, for many environments in the same
     step; tiny grids make every block walk through several rounds of halves (the grid is made even: an odd block only ever waits
-    for its left neighbour)."""
+    for its left neighbour).  The full items of maps with few regions go two to a block (PCGRL_WIDE_FEW moves the line)."""
     monkeypatch.setenv("PCGRL_WIDE_GRID", grid)
+    if few is not None:        # which full items go two to a block (maps with at most that many regions): all of them / none
+        monkeypatch.setenv("PCGRL_WIDE_FEW", few)
     test_rollout_vs_oracle("binary", "turtle", (dict(width=20, height=24), dict(change_percentage=0.01)), E, 60)
     test_rollout_vs_oracle("binary", "wide", (dict(width=40, height=17), dict(change_percentage=0.004)), E, 40)
 
