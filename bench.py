@@ -56,7 +56,7 @@ WORKLOADS = {
 WRAPPED = {"C2w": ("cropped", 28), "C3w": ("actionmap", None)}
 # legs of the default run besides the headline workload: every BASELINE.json config (and smb, and the wrapped steps) gets a
 # driver-timed figure.  (steps, warmup, steady warm-up) are sized so that the whole default run stays well under a minute of GPU time.
-LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 15), "C2w": (20, 5, 800), "C3w": (20, 5, 800)}
+LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 45), "C2w": (20, 5, 800), "C3w": (20, 5, 800)}
 DOMINANT = {"C2": "k_step", "C3": "k_step", "C3d": "k_step", "C4": "k_sokoban", "C5": "k_stats_wide", "C5b": "k_stats_wide", "M1": "k_mdungeon",
             "D1": "k_ddave", "S1": "k_smb", "C2w": "k_step (writes the image)", "C3w": "k_step (writes the image)"}
 
