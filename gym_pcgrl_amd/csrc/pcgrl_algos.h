@@ -322,14 +322,18 @@ PCGRL_D int bfs_levels(B& g, typename B::mask_t src, typename B::mask_t pass, ty
     int it = 0;
     PCGRL_TRACE(g, 2);
     for (;;) {
+        // two levels per exit test: a level after the last one changes nothing (the bookkeeping selects on "changed"), so testing
+        // every other level costs at most one idle level at the end and saves a compare + scalar branch per level
         ++it;
         M n = pcg_expand(g, f) & pass;
-        // bookkeeping before the exit test: in the final round nothing changed, so these are no-ops there,
-        // and the select mask is the very compare the exit test uses
         last_it = g.isel_ne(n, f, it, last_it);
         prev = g.msel_ne(n, f, f, prev);
-        const bool more = g.wave_any(n ^ f);     // wave-uniform exit; a converged group just idles
-        f = n;
+        ++it;
+        M n2 = pcg_expand(g, n) & pass;
+        last_it = g.isel_ne(n2, n, it, last_it);
+        prev = g.msel_ne(n2, n, n, prev);
+        const bool more = g.wave_any(n2 ^ n);    // wave-uniform exit; a converged group just idles
+        f = n2;
         if (!more) break;
     }
     const int ecc = g.imax(last_it);
