@@ -320,20 +320,26 @@ PCGRL_D int bfs_levels(B& g, typename B::mask_t src, typename B::mask_t pass, ty
     M f = src, prev = src ^ src;
     I last_it = g.izero();
     int it = 0;
+    constexpr int kLevels = B::kGroup == 16 ? 2 : 4;
     PCGRL_TRACE(g, 2);
     for (;;) {
-        // two levels per exit test: a level after the last one changes nothing (the bookkeeping selects on "changed"), so testing
-        // every other level costs at most one idle level at the end and saves a compare + scalar branch per level
-        ++it;
-        M n = pcg_expand(g, f) & pass;
-        last_it = g.isel_ne(n, f, it, last_it);
-        prev = g.msel_ne(n, f, f, prev);
-        ++it;
-        M n2 = pcg_expand(g, n) & pass;
-        last_it = g.isel_ne(n2, n, it, last_it);
-        prev = g.msel_ne(n2, n, n, prev);
-        const bool more = g.wave_any(n2 ^ n);    // wave-uniform exit; a converged group just idles
-        f = n2;
+        // two (four on tall maps, whose sweeps run to hundreds of levels) levels per exit test: a level after the last one changes
+        // nothing (the bookkeeping selects on "changed"), so testing every few levels costs a few idle levels at the end and saves a
+        // compare + scalar branch per level
+        M n = f;
+        bool more = false;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int uu = 0; uu < kLevels; uu++) {
+            ++it;
+            const M nn = pcg_expand(g, n) & pass;
+            last_it = g.isel_ne(nn, n, it, last_it);
+            prev = g.msel_ne(nn, n, n, prev);
+            if (uu == kLevels - 1) more = g.wave_any(nn ^ n);    // wave-uniform exit; a converged group just idles
+            n = nn;
+        }
+        f = n;
         if (!more) break;
     }
     const int ecc = g.imax(last_it);
