@@ -356,12 +356,13 @@ PCGRL_D int bfs_dist(B& g, typename B::mask_t src, typename B::mask_t dst, typen
     M f = src;
     int t = 0;
     for (;;) {
-        M n = pcg_expand(g, f) & pass;
-        M fresh = n & ~f;
-        ++t;
-        if (g.any(fresh & dst)) return t;
-        if (!g.any(fresh)) return -1;
-        f = n;
+        // two levels per pair of tests (bfs_levels: a level after the last one adds nothing)
+        const M n1 = pcg_expand(g, f) & pass, fresh1 = n1 & ~f;
+        const M n2 = pcg_expand(g, n1) & pass, fresh2 = n2 & ~n1;
+        if (g.any((fresh1 | fresh2) & dst)) return g.any(fresh1 & dst) ? t + 1 : t + 2;
+        if (!g.any(fresh2)) return -1;
+        t += 2;
+        f = n2;
     }
 }
 
