@@ -269,15 +269,11 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         if (has_fifo && e < ne && u.k > 0 && !first) fifo_refill(B, e, u.k, u.cur0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // ring words, byte-map cells and heatmap increments have landed
         if (lane64 == 0) __hip_atomic_fetch_add(&s_loc.refill_done[sp], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     }
-    TL(3);
-    const int n0 = s_n[sp][0], n1 = s_n[sp][1], n2 = s_n[sp][2];
-    const int w_full = (n1 + GPW - 1) / GPW;
-    const int w_total = n0 + w_full + (n2 + GPW - 1) / GPW;
+    // (the other wavefronts take that barrier inside the first round of the task loop below: what the compiler hoists out of the
+    //  loop -- scalar loads of the parameter block, address arithmetic of every task kind: ~2.4 us on the timeline -- then runs
+    //  while they would only be waiting for the lists)
+    int n0 = 0, n1 = 0, n2 = 0, w_full = 0, w_total = 0;
     const int tiles_bytes = (W * H + 15) & ~15;
     uint32_t* mt = reinterpret_cast<uint32_t*>(reset_scratch + (size_t)wv * (PCGRL_MT_N * 4 + tiles_bytes));
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
@@ -286,10 +282,22 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     // Tasks in the order certain resets (the longest chains), full recomputations, incremental updates; a wavefront takes
     // the next one whenever it is free, so the block ends when the work is done, not when its unluckiest wavefront is
     // (a static split left the last wavefront of a block ~10 us behind the others).
-    for (;;) {
+    for (bool first_round = true;; first_round = false) {
+        if (first_round) {
+            if (wv >= NUPD) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            TL(3);
+            n0 = s_n[sp][0]; n1 = s_n[sp][1]; n2 = s_n[sp][2];
+            w_full = (n1 + GPW - 1) / GPW;
+            w_total = n0 + w_full + (n2 + GPW - 1) / GPW;
+        }
         int wid = 0;
         if (lane64 == 0) wid = atomicAdd(&s_n[sp][3], 1);
         wid = __builtin_amdgcn_readfirstlane(wid);
+        TL(18);
         if (wid >= w_total) break;
         const bool lone = wid < n0, inc = wid >= n0 + w_full;
         const int item = lone ? wid : (inc ? (wid - n0 - w_full) * GPW + gw : (wid - n0) * GPW + gw);

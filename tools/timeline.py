@@ -32,7 +32,7 @@ EPB = int(os.environ.get("PCGRL_STEP_EPB", "256" if 192 * 256 <= n <= 256 * 256 
 SLOTS, WAVES = 48, EPB // 16
 nblk = (n + EPB - 1) // EPB
 names = {1: "start", 2: "update done", 3: "lists ready", 4: "task: certain reset", 5: "task: full", 6: "task: incremental", 7: "task end", 8: "wave end",
-         9: "reset done", 10: "stats done", 11: "finalized", 12: "late reset", 13: "ring staged", 14: "map made", 15: "cursor drawn", 16: "reset stored", 17: "state staged"}
+         9: "reset done", 10: "stats done", 11: "finalized", 12: "late reset", 13: "ring staged", 14: "map made", 15: "cursor drawn", 16: "reset stored", 17: "state staged", 18: "ticket"}
 summ = []
 for rep_i in range(5):
     buf = torch.zeros((nblk * WAVES * SLOTS,), dtype=torch.int64, device=env.device)
