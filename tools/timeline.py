@@ -2,7 +2,10 @@
 """In-kernel timeline of one fused step (k_step) on the GPU box: builds a copy of the library with -DPCGRL_TIMELINE
 (wavefront-private marks of the 100 MHz wall clock at the phase boundaries), runs the workload into its steady state and
 prints where the time of a step goes: per-phase durations over the blocks and what the last blocks to finish were doing.
-    python tools/timeline.py [workload] [envs] [warm-up steps]"""
+    python tools/timeline.py [workload] [envs] [warm-up steps]
+(A mark reads the buffer pointer through the scalar cache: the first mark after an idle stretch can show ~2 us that are the mark's
+own miss -- "lists ready" -> "ticket" of the waiting wavefronts in k_step is that, the product build has no such gap.)
+"""
 import ctypes as C, json, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
