@@ -279,9 +279,11 @@ PCGRL_D typename B::mask_t pcg_component(B& g, typename B::mask_t seed, const Pc
     M f = pcg_fill_rows(g, seed, c.pass, c.rpass);
     for (;;) {
         M n = pcg_fill_cols(g, f, c);
-        n = pcg_fill_rows(g, n, c.pass, c.rpass);
-        if (!g.wave_any(n ^ f)) break;           // an extra round is harmless (n == f)
-        f = n;
+        f = pcg_fill_rows(g, n, c.pass, c.rpass);
+        // done when no passable cell borders the set (it grew from one seed, so it is then exactly the seed's component): a
+        // ten-instruction test instead of one more round of fills that finds nothing to add.  (An extra round is harmless: a
+        // group that is done idles while another one of the wavefront still grows.)
+        if (!g.wave_any(pcg_neighbours(g, f) & c.pass & ~f)) break;
     }
     return f;
 }
