@@ -91,6 +91,103 @@ def timed_steps(torch, device, step, acts, t0, k):
     return time.perf_counter() - w0, e0.elapsed_time(e1) / k
 
 
+def n1_facade_leg(budget_s=2.0):
+    """The reference-shaped single environment (`PcgrlEnv`, the N = 1 view: one launch and one device -> host round trip per
+    step, numpy observations, info dict): C1's GPU-side counterpart.  The reference's own Python env does 2 278 steps/s on one
+    Xeon core; this is what "drops in unchanged" costs when it is used one environment at a time."""
+    import numpy as np
+
+    import gym_pcgrl_amd
+    env = gym_pcgrl_amd.make("binary-narrow-v0")
+    env.seed(0)
+    env.reset()
+    rs = np.random.RandomState(0)
+    acts = rs.randint(0, 3, size=100000)
+    for t in range(50):
+        _, _, d, _ = env.step(int(acts[t]))
+        if d:
+            env.reset()
+    n, resets = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        _, _, d, _ = env.step(int(acts[50 + n]))
+        n += 1
+        if d:
+            env.reset()
+            resets += 1
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"workload": "binary-narrow-v0 14x14, ONE environment through gym_pcgrl_amd.make(): step() -> numpy obs, reward, done, info dict; reset() on done",
+            "value": n / dt, "unit": "env-steps/s", "us_per_step": dt / n * 1e6, "steps": n, "episodes": resets,
+            "reference_python_env_steps_per_s": 2278, "reference_hardware": "1 vCPU Xeon 2.1 GHz (BASELINE.md section 2; measured in the build container)"}
+
+
+def collector_leg(torch, device, n=65536, n_steps=8, warm_steps=2):
+    """`RolloutCollector` over `make_vec_envs("binary-narrow-v0", "narrow", n_cpu=65536)` with a stand-in policy in the loop: three
+    3x3 convolutions (32, 64, 64 filters) + a 512-unit layer + a 3-way head on the [N, 28, 28, 1] image, the shape of the reference's
+    `Cnn1` (model.py:9-15; random weights, bf16, no learner) -- env-steps/s of the loop a trainer runs, and the environment's share."""
+    import torch.nn.functional as F
+
+    from gym_pcgrl_amd.rollout import RolloutCollector
+    from gym_pcgrl_amd.utils import make_vec_envs
+    venv = make_vec_envs("binary-narrow-v0", "narrow", n_cpu=n, seed=0, device=str(device))
+    g = torch.Generator(device=device).manual_seed(7)
+    def mk(*shape):                                # He-initialised random weights
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        return (torch.randn(*shape, generator=g, device=device) * (2.0 / fan_in) ** 0.5).to(torch.bfloat16)
+
+    w1, w2, w3 = mk(32, 1, 3, 3), mk(64, 32, 3, 3), mk(64, 64, 3, 3)
+    fc, head = mk(512, 64 * 22 * 22), mk(3, 512)
+    chunk = 8192                                   # activations of a chunk: 8192 x 64 x 24 x 24 bf16 = 0.6 GB
+    t_env = [0.0]
+    marks = []
+
+    def policy(obs):
+        outs = []
+        with torch.no_grad():
+            for lo in range(0, obs.shape[0], chunk):
+                x = obs[lo:lo + chunk].permute(0, 3, 1, 2).to(torch.bfloat16)
+                x = F.relu(F.conv2d(x, w1)); x = F.relu(F.conv2d(x, w2)); x = F.relu(F.conv2d(x, w3))
+                x = F.relu(x.flatten(1) @ fc.t())
+                outs.append(torch.argmax((x @ head.t()).float() + torch.rand((x.shape[0], 3), generator=g, device=device), 1))
+        return torch.cat(outs)
+
+    col = RolloutCollector(venv, n_steps)
+    w = venv.env
+    step0 = w.step
+
+    def timed_step(actions):                       # GPU time of the environment's share: events around every step on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = step0(actions)
+        e1.record()
+        marks.append((e0, e1))
+        return out
+
+    w.step = timed_step
+    for _ in range(max(1, warm_steps // n_steps + 1)):       # first rollout: reset, MIOpen's kernel selection, allocator warm-up
+        col.collect(policy)
+    torch.cuda.synchronize(device)
+    marks.clear()
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    a0.record()
+    col.collect(policy)
+    a1.record()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    gpu_ms = a0.elapsed_time(a1)
+    env_ms = sum(e0.elapsed_time(e1) for e0, e1 in marks)
+    venv.close()
+    return {"workload": "RolloutCollector over make_vec_envs('binary-narrow-v0', 'narrow', n_cpu=%d): stand-in Cnn1-shaped policy (3 conv + fc512, bf16, random weights) "
+                        "-> actions -> wrapped step writing the [N,28,28,1] image into the rollout buffer" % n,
+            "envs": n, "steps": n_steps, "value": n * n_steps / dt, "unit": "env-steps/s", "ms_per_step": dt / n_steps * 1e3,
+            "gpu_ms_per_step": gpu_ms / n_steps, "env_gpu_ms_per_step": env_ms / n_steps, "env_share_of_gpu_time": env_ms / gpu_ms,
+            "direct_rows": bool(col.direct)}
+
+
 def run_leg(torch, device, workload, steps, warmup, steady_warmup, seed=0):
     """One short driver-timed measurement of another workload (rank 0, one GPU): first window after a reset + steady state."""
     prob, rep, calls, n, desc = WORKLOADS[workload]
@@ -141,7 +238,7 @@ def make_actions(torch, rep, steps, n, W, H, nt, device, seed, flat=False):
 
 
 def measured_traffic(workload):
-    """HBM bytes per step from the last committed rocprofv3 PMC passes (profiles/*/<W>_traffic.json: FETCH_SIZE and
+    """-> (bytes per step, file, hash of the kernel sources the passes ran on).  HBM bytes per step from the last committed rocprofv3 PMC passes (profiles/*/<W>_traffic.json: FETCH_SIZE and
     WRITE_SIZE summed over the step's kernels), corrected as calibrated on this GPU with tools/traffic_calib.hip
     (profiles/*/traffic_calibration.md): FETCH_SIZE reports half of the bytes of the 128-byte lines that are read, for
     wide coalesced and for narrow scattered reads alike, so fetched bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact for
@@ -150,9 +247,14 @@ def measured_traffic(workload):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", workload + "_traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     d = json.load(open(files[-1]))
-    return 2 * d["fetch_bytes_per_step"] + d["write_bytes_per_step"], os.path.relpath(files[-1], ROOT)
+    return 2 * d["fetch_bytes_per_step"] + d["write_bytes_per_step"], os.path.relpath(files[-1], ROOT), d.get("csrc_hash")
+
+
+def tree_hash():
+    from gym_pcgrl_amd import _lib
+    return _lib.source_hash()
 
 
 def measured_valu(workload, kernel="k_stats"):
@@ -161,12 +263,13 @@ def measured_valu(workload, kernel="k_stats"):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", workload + "_pmc.json")))
     if not files:
-        return None, None
-    per = json.load(open(files[-1]))["per_dispatch"]
+        return None, None, None
+    j = json.load(open(files[-1]))
+    per = j["per_dispatch"]
     d = per.get(kernel + "_wide") or per.get(kernel)      # tall binary maps run k_stats_wide
     if d is None and kernel == "k_step":
-        return None, None
-    return (d.get("SQ_INSTS_VALU") if d else None), os.path.relpath(files[-1], ROOT)
+        return None, None, None
+    return (d.get("SQ_INSTS_VALU") if d else None), os.path.relpath(files[-1], ROOT), j.get("csrc_hash")
 
 
 def cpu_baseline(prob, rep, calls, budget_s=12.0):
@@ -265,7 +368,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="process plumbing only (launcher, rendezvous, barrier, max-over-ranks reduction over gloo); "
                                                           "no GPU, no environment: the line carries value null and dry_run true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short legs of the other configs (the `configs` object of the default line)")
-    ap.add_argument("--legs", default="C3,C4,C5,S1,C2w,C3w", help="which legs the default line carries")
+    ap.add_argument("--legs", default="C3,C4,C5,S1,C2w,C3w,n1_facade,collector", help="which legs the default line carries")
     ap.add_argument("--steady-warmup", type=int, default=800, help="steps before the steady_state measurement (0: skip it)")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -428,11 +531,12 @@ def main():
             dom_us = gpu_ms_per_step * 1e3
         elif not solver:          # the event pass perturbs short steps: never more than the step minus the other kernel
             dom_us = min(dom_us, max(gpu_ms_per_step * 1e3 - max(ph.get("update", 0.0) - ev_us, 0.0), 0.0))
-        valu, valu_src = measured_valu(a.workload, "k_step" if fused else "k_stats") if n == n_default else (None, None)
+        head = tree_hash()
+        valu, valu_src, valu_head = measured_valu(a.workload, "k_step" if fused else "k_stats") if n == n_default else (None, None, None)
         dominant = {"name": dom_name, "avg_us": dom_us, "event_pair_overhead_us": ev_us}
         if valu and dom_us > 0 and not solver:
             peak = VALU_ISSUE_PEAK              # measured on this GPU: profiles/r3a_round3/valu_calibration.md (tools/valu_calib.hip)
-            dominant.update({"valu_wave_instr_per_launch": valu, "valu_source": valu_src,
+            dominant.update({"valu_wave_instr_per_launch": valu, "valu_source": valu_src, "valu_head": valu_head, "valu_stale": valu_head != head,
                              "valu_issue_rate": valu / (dom_us * 1e-6), "valu_issue_peak": peak,
                              "valu_issue_frac": valu / (dom_us * 1e-6) / peak})
         total_steps = float(n) * world * a.steps
@@ -441,7 +545,9 @@ def main():
         if wrapped:        # the trainer-shaped step also writes the policy's image: algorithmic bytes = the step's + the image
             b_alg += int(wrapper._obs.numel() // n)
         achieved = n * b_alg / (gpu_ms_per_step * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(a.workload) if n == n_default else (None, None)
+        # counter figures come from the committed PMC passes (a --pmc run cannot share a process with the timed loop); they are stamped
+        # with the hash of the kernel sources they were measured on, and the line says so when that is not this tree
+        traffic, traffic_src, traffic_head = measured_traffic(a.workload) if n == n_default else (None, None, None)
         out = {
             "metric": "env-steps/sec (whole node), binary-narrow 14x14 @ 65536 envs" if (a.workload == "C2" and n == n_default) else "env-steps/sec (whole node)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -452,6 +558,7 @@ def main():
                        "parallelism": "env-axis shard x%d, no collective on the step path" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_head": traffic_head, "tree_head": head, "traffic_stale": (traffic is not None and traffic_head != head),
                          "algorithmic_bytes_per_launch": n * b_alg,
                          "kernel": ("one step = one launch of k_step (state of 64 / 128 / 256 environments per block staged in LDS: update + stats + resets)" if fused else
                                     "one step = k_update + k_stats (resets inside k_stats); the search problems add k_reset + their search kernel"),
@@ -473,6 +580,14 @@ def main():
             for name in a.legs.split(","):
                 if name in LEGS:
                     legs[name] = run_leg(torch, device, name, *LEGS[name])
+            # what a user of the reference's surfaces gets: the single environment (C1's counterpart) and the trainer's loop
+            if "n1_facade" in a.legs.split(","):
+                legs["n1_facade"] = n1_facade_leg()
+            if "collector" in a.legs.split(","):
+                try:
+                    legs["collector"] = collector_leg(torch, device)
+                except Exception as ex:        # (a stand-in policy must not take the line down: e.g. no convolution backend on the box)
+                    legs["collector"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             for wname, bare in (("C2w", None), ("C3w", "C3")):       # wrapped step against the bare step of the same batch
                 if wname in legs:
                     base = gpu_ms_per_step if bare is None else legs.get(bare, {}).get("gpu_ms_per_step")

@@ -38,6 +38,17 @@ def register_with_gym():
     return gym_compat.register_all(_ENV_IDS)
 
 
+def register_with_gymnasium():
+    """The same for the new API (gymnasium, or gym >= 0.26): the ids are registered there with the five-tuple adapter
+    `gymnasium_compat.NewApiPcgrlEnv` as entry point.  Returns the ids registered by this call."""
+    from . import gymnasium_compat
+    if gymnasium_compat.find_gymnasium() is None:
+        return []
+    if not _ENV_IDS:
+        _register_all()
+    return gymnasium_compat.register_all(_ENV_IDS)
+
+
 def _lookup(env_id):
     if not _ENV_IDS:
         _register_all()
@@ -61,3 +72,4 @@ def make_batched(env_id, num_envs, **kwargs):
 
 
 register_with_gym()      # no-op without a gym of the reference's era (none is on the MI355X image)
+register_with_gymnasium()   # likewise for gymnasium / gym >= 0.26 (five-tuple adapter)

@@ -60,6 +60,20 @@ def sources_newer_than_lib():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """Content hash of the kernel sources (csrc/* and include/pcgrl_hip.h), 16 hex digits: the profile tools stamp it into
+    profiles/*/<W>_traffic.json / _pmc.json and bench.py compares it with the tree it runs from, so that a bench line cannot
+    silently carry counter figures measured on other code (no git on the GPU box: the hash is over file contents)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(ROOT, "include", "pcgrl_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 NPARTS = 8               # csrc/pcgrl_abi.hip: PCGRL_PART=0..7 (host ABI; stats; update; step binary; step zelda; search; smb; step_solver)
 
 

@@ -258,3 +258,34 @@ __global__ __launch_bounds__(256) void k_obs(PcgrlParams P, DevBufs B, ObsSpec S
         obs_write_block(src, V, lpos, ne, (int)threadIdx.x, 256);
     }
 }
+
+// Windows beyond the reach of k_obs's 24-bit block offsets (OBS_EPB * oh * ow * depth >= 2^22: a 228 x 228 x 13 crop of an smb level, a
+// 128 x 128 one-hot crop of a large map -- the reference's Cropped takes any crop_size, wrappers.py:163-206): the whole output as one
+// stream of 16-byte pieces with 64-bit offsets, the position inside an image (row, column, plane) carried along from byte to byte
+// instead of divided out.  From the byte map; not a fast path -- the lean routines above are what the trainer's shapes take.
+template <int>       // (a template so that the eight parts of the build may all see it: instantiated in the core part only)
+__global__ __launch_bounds__(256) void k_obs_huge(PcgrlParams P, DevBufs B, ObsSpec S) {
+    const size_t per_env = (size_t)S.oh * S.ow * S.depth, total = (size_t)P.num_envs * per_env;
+    const size_t npieces = (total + 15) >> 4;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < npieces; q += (size_t)gridDim.x * 256) {
+        const size_t o = q << 4;
+        int e = (int)(o / per_env);
+        uint32_t rem = (uint32_t)(o - (size_t)e * per_env);               // oh, ow <= 4096, depth <= 8: below 2^27
+        uint32_t i = rem / (uint32_t)S.depth;
+        int d = (int)(rem - i * (uint32_t)S.depth), r = (int)(i / (uint32_t)S.ow), c = (int)(i - (uint32_t)r * (uint32_t)S.ow);
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        const int nb = (total - o) < 16 ? (int)(total - o) : 16;
+        int oy = 0, ox = 0, t = -1;
+        for (int k = 0; k < nb; k++) {
+            if (t < 0) {        // a new cell: its tile (or the pad value outside the map)
+                if (S.centered) { oy = (int)B.pos[2 * (size_t)e + 1] - S.oh / 2; ox = (int)B.pos[2 * (size_t)e] - S.ow / 2; }
+                const int y = r + oy, x = c + ox;
+                t = ((unsigned)y < (unsigned)P.height && (unsigned)x < (unsigned)P.width) ? (int)B.map[((size_t)e * P.height + y) * P.width + x] : S.pad;
+            }
+            w[k >> 2] |= (S.depth == 1 ? (uint32_t)t : (uint32_t)(d == t)) << (8 * (k & 3));
+            if (++d == S.depth) { d = 0; t = -1; if (++c == S.ow) { c = 0; if (++r == S.oh) { r = 0; ++e; } } }
+        }
+        if (nb == 16) reinterpret_cast<uint4*>(S.out)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+        else for (int k = 0; k < nb; k++) S.out[o + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+    }
+}

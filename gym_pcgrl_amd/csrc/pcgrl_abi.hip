@@ -794,18 +794,29 @@ PCGRL_LOCAL int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStre
 
 #if PCGRL_IN_PART(PART_CORE)
 // the wrapped observation of every environment with the stand-alone kernel (kernels_obs.h)
+static bool obs_is_huge(const ObsSpec& S) { return (size_t)OBS_EPB * S.oh * S.ow * S.depth >= ((size_t)1 << 24) / 4; }   // offsets inside a block's stretch stay small (obs_div)
+static bool obs_same_spec(const ObsSpec& a, const ObsSpec& b) {
+    return a.out == b.out && a.oh == b.oh && a.ow == b.ow && a.depth == b.depth && a.centered == b.centered && a.pad == b.pad;
+}
 static int launch_obs(pcgrl_env* h, const ObsSpec& S, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const int grid = (P.num_envs + OBS_EPB - 1) / OBS_EPB;
     // from the row bit planes (staged in LDS) where the lean routines of kernels_obs.h apply -- binary tile ids, one-hot over
     // eight tiles --, else from the byte map
     const size_t lds = (size_t)OBS_EPB * (P.group * P.nplanes * P.mask_bytes + 2);
-    if (P.nplanes == 1 && P.mask_bytes == 4 && S.depth == 1) hipLaunchKernelGGL(k_obs<1>, dim3(grid), dim3(256), lds, st, P, h->B, S);
+    if (obs_is_huge(S)) {                  // beyond k_obs's 24-bit block offsets: the 64-bit stream (kernels_obs.h)
+        const size_t pieces = ((size_t)P.num_envs * S.oh * S.ow * S.depth + 15) >> 4;
+        const size_t g = (pieces + 255) / 256;
+        hipLaunchKernelGGL(k_obs_huge<0>, dim3((unsigned)(g < 65536 ? g : 65536)), dim3(256), 0, st, P, h->B, S);
+    } else if (P.nplanes == 1 && P.mask_bytes == 4 && S.depth == 1) hipLaunchKernelGGL(k_obs<1>, dim3(grid), dim3(256), lds, st, P, h->B, S);
     else if (P.nplanes == 1 && P.mask_bytes == 8 && S.depth == 1) hipLaunchKernelGGL(k_obs<2>, dim3(grid), dim3(256), lds, st, P, h->B, S);
     else if (P.nplanes == 3 && P.mask_bytes == 4 && S.depth == 8) hipLaunchKernelGGL(k_obs<3>, dim3(grid), dim3(256), lds, st, P, h->B, S);
     else hipLaunchKernelGGL(k_obs<0>, dim3(grid), dim3(256), 0, st, P, h->B, S);
     HIPCHK(hipGetLastError());
-    if (S.out == h->B.obs.out) h->obs_synced = S.out;       // a full image of the current state
+    // a full image of the current state in the bound target -- only when it was written with the bound geometry (pcgrl_observe
+    // may be handed the same tensor with another window: the target then does not hold what an in-place update builds on)
+    if (obs_same_spec(S, h->B.obs)) h->obs_synced = S.out;
+    else if (S.out == h->B.obs.out) h->obs_synced = nullptr;
     return PCGRL_OK;
 }
 static int obs_spec(const pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out_w, int32_t centered, int32_t pad_value, int32_t onehot, ObsSpec* S) {
@@ -813,7 +824,6 @@ static int obs_spec(const pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t out
     if (centered && h->P.rep == PCGRL_REP_WIDE) return PCGRL_EINVAL;   // Cropped needs a cursor (wrappers.py:170)
     if (((uintptr_t)out & 15) != 0) return PCGRL_EINVAL;
     const int depth = onehot ? h->P.ntiles : 1;
-    if ((size_t)OBS_EPB * out_h * out_w * depth >= ((size_t)1 << 24) / 4) return PCGRL_EINVAL;      // offsets inside a block's stretch stay small (obs_div)
     *S = ObsSpec{out, out_h, out_w, depth, centered ? 1 : 0, pad_value, 0, 0};
     S->fused = obs_lean_mode(h->P.nplanes, h->P.mask_bytes == 4, h->P.width, out_h, out_w, depth, pad_value) != 0 ? 1 : 0;
     return PCGRL_OK;
@@ -1021,7 +1031,7 @@ int pcgrl_bind_observation(pcgrl_env* h, uint8_t* out, int32_t out_h, int32_t ou
     int rc = obs_spec(h, out, out_h, out_w, centered, pad_value, onehot, &S);
     if (rc) return rc;
     const ObsSpec& O = h->B.obs;
-    if (!(O.out == S.out && O.oh == S.oh && O.ow == S.ow && O.depth == S.depth && O.centered == S.centered && O.pad == S.pad)) h->obs_synced = nullptr;
+    if (!obs_same_spec(O, S)) h->obs_synced = nullptr;
     h->B.obs = S;
     h->obs_incremental = incremental ? 1 : 0;
     return PCGRL_OK;

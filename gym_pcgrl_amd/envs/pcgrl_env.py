@@ -23,6 +23,7 @@ class PcgrlEnv(gym_compat.env_base()):
         self._prob = self._batched._prob
         self._rep = self._batched._rep
         self.viewer = None
+        self._pinned, self._action_buf = {}, None
         self._sync_spaces()
 
     def _sync_spaces(self):
@@ -46,24 +47,61 @@ class PcgrlEnv(gym_compat.env_base()):
         self._batched.adjust_param(**kwargs)
         self._sync_spaces()
 
-    def _np_obs(self, obs):
+    def _to_host(self, tensors):
+        """The step's outputs in ONE host round trip: every tensor is copied into its own pinned host buffer on the launch
+        stream (no wait in between), then the stream is waited for once.  (One `.cpu()` / `.item()` per output -- six of them --
+        was six synchronisations per step: bench.py's `n1_facade` leg.)"""
+        torch = self._batched._torch
+        out = []
+        for name, t in tensors:
+            buf = self._pinned.get(name)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                self._pinned[name] = buf
+            buf.copy_(t, non_blocking=True)
+            out.append(buf)
+        torch.cuda.current_stream(self._batched.device).synchronize()
+        return [b.numpy() for b in out]
+
+    def _np_obs(self, host):
         o = OrderedDict()
-        if "pos" in obs:
-            o["pos"] = obs["pos"][0].cpu().numpy().astype(np.uint8)
-        o["map"] = obs["map"][0].cpu().numpy().astype(np.uint8)
-        o["heatmap"] = obs["heatmap"][0].cpu().numpy().astype(np.float64)   # the reference's heatmap is float64
+        if "pos" in host:
+            o["pos"] = host["pos"][0].astype(np.uint8)
+        o["map"] = host["map"][0].astype(np.uint8)                  # (astype copies: the pinned buffers are reused by the next step)
+        o["heatmap"] = host["heatmap"][0].astype(np.float64)        # the reference's heatmap is float64
         return o
 
     def reset(self):
-        return self._np_obs(self._batched.reset())
+        obs = self._batched.reset()
+        names = list(obs)
+        return self._np_obs(dict(zip(names, self._to_host([(k, obs[k]) for k in names]))))
 
     def step(self, action):
-        a = np.asarray(action, dtype=np.int32).reshape(1, -1)
-        obs, reward, done, info = self._batched.step(a)
-        r = float(reward[0].item())
+        a = self._action_buf
+        if a is None:        # the action goes up through a pinned staging buffer as well (no pageable-memory copy per step)
+            torch = self._batched._torch
+            a = self._action_buf = torch.empty((1, self._batched._rep.action_width()), dtype=torch.int32).pin_memory()
+        a.numpy()[...] = np.asarray(action, dtype=np.int32).reshape(1, -1)
+        obs, reward, done, info = self._batched.step(a.to(self._batched.device, non_blocking=True))
+        names = list(obs)
+        host = self._to_host([(k, obs[k]) for k in names] + [("reward", reward), ("done", done), ("info", info.table)])
+        h = dict(zip(names + ["reward", "done", "info"], host))
+        r = float(h["reward"][0])
         if self._prob.name != "sokoban" and r == int(r):
             r = int(r)    # binary/zelda rewards are ints in the reference, sokoban's is a float (SURVEY Q8)
-        return self._np_obs(obs), r, bool(done[0].item()), info.to_list()[0]
+        return self._np_obs(h), r, bool(h["done"][0]), self._info_dict(info, h["info"])
+
+    def _info_dict(self, info, table):
+        """InfoBatch.to_list()[0] from the host copy of the info table."""
+        if info._decode is not None:
+            torch = self._batched._torch
+            vals = info._decode(torch.from_numpy(table), info.keys).numpy()
+        else:
+            vals = table
+        d = {k: int(vals[0][i]) for i, k in enumerate(info.keys)}
+        d["iterations"], d["changes"] = int(table[0][8]), int(table[0][9])
+        d["max_iterations"], d["max_changes"] = info.max_iterations, info.max_changes
+        return d
 
     def render(self, mode="human"):
         """pcgrl_env.py:161-175.  'rgb_array' returns the image; 'human' has no viewer here (gym's classic_control

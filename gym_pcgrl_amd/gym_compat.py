@@ -74,6 +74,21 @@ def convert_space(space):
 _registered = []
 
 
+def _registered_ids(g):
+    """The ids gym's registry already holds (set), or None when this gym does not expose them in a way we know."""
+    try:
+        reg = importlib.import_module(g.__name__ + ".envs.registration").registry
+    except (ImportError, AttributeError):
+        reg = getattr(getattr(g, "envs", None), "registry", None)
+    if reg is None:
+        return None
+    specs = getattr(reg, "env_specs", reg)          # gym <= 0.21: EnvRegistry.env_specs; 0.22-0.25: a dict
+    try:
+        return set(specs.keys())
+    except AttributeError:
+        return None
+
+
 def register_all(ids):
     """gym_pcgrl/__init__.py:6-12 for this package.  `ids`: {env id: (prob, rep)}.  Ids that something else registered
     already (the reference itself, or an earlier import) are left alone.  Returns the ids registered by this call."""
@@ -87,13 +102,17 @@ def register_all(ids):
     if register is None:
         return []
     done = []
+    taken = _registered_ids(g)
+    gym_error = getattr(getattr(g, "error", None), "Error", None)
     for env_id, (prob, rep) in sorted(ids.items()):
-        if env_id in _registered:
-            continue
+        if env_id in _registered or (taken is not None and env_id in taken):
+            continue                 # something else (the reference itself, an earlier import) owns the id: leave it alone
         try:
             register(id=env_id, entry_point="gym_pcgrl_amd.envs:PcgrlEnv", kwargs={"prob": prob, "rep": rep})
-        except Exception as ex:      # gym.error.Error "Cannot re-register id": keep the existing registration; anything else is a bug
-            if "register" not in str(ex).lower():
+        except Exception as ex:
+            # gym.error.Error("Cannot re-register id: ...") from a registry whose contents could not be listed above: keep the
+            # existing registration.  Anything that is not gym's own error class is a bug and propagates.
+            if gym_error is None or not isinstance(ex, gym_error):
                 raise
             continue
         _registered.append(env_id)

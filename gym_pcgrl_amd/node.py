@@ -1,0 +1,213 @@
+"""MultiGpuPcgrlEnv: ONE process drives the GPUs of a node -- the single-process counterpart of `sharding.ShardedPcgrlEnv`
+(one process per GPU) and the replacement for the reference's `SubprocVecEnv` of `n_cpu` worker processes (utils.py:60-71) when the
+trainer itself is one process.
+
+SURVEY.md 8e: the environment axis is cut into contiguous shards, shard g lives on `devices[g]` with its own handle of the C ABI
+(`pcgrl_create` ... -- a handle is bound to the device of its buffers, every launching entry point makes that device current for the
+call) and its own HIP stream; `step()` issues step k on EVERY device before anything waits, there is no collective and no
+cross-device traffic on the step path, and what comes back is either the list of per-device tensors (for a data-parallel learner that
+keeps each shard where it is) or one concatenation on pinned host memory / on one device.  Environment i is seeded with
+`seed + i` whatever the number of devices, so the results are bitwise independent of the sharding (the GPU tests hold
+G in {1, 2, 4, 8} against each other).
+
+`devices` may name the same GPU several times (two handles on two streams of one GPU): that is how the single-GPU test box
+exercises the multi-handle path, and a legitimate way to overlap two half-batches on one device.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .sharding import shard_range
+
+
+class ShardedTensor:
+    """The per-device pieces of one logical [N, ...] tensor, in shard order."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+
+    def __len__(self):
+        return sum(int(p.shape[0]) for p in self.parts)
+
+    def __iter__(self):
+        return iter(self.parts)
+
+    def __getitem__(self, g):
+        return self.parts[g]
+
+    def to(self, device):
+        """One tensor on `device` (peer copies; synchronises nothing on the host)."""
+        import torch
+        return torch.cat([p.to(device, non_blocking=True) for p in self.parts], 0)
+
+    def cpu(self):
+        import torch
+        return torch.cat([p.cpu() for p in self.parts], 0)
+
+
+class MultiGpuPcgrlEnv:
+    def __init__(self, prob="binary", rep="narrow", num_envs=1, devices=None, seed=0, auto_reset=True, gather="list"):
+        """gather: what reset()/step() return per output -- "list": a ShardedTensor of live per-device views (zero copy, no
+        host sync: the default); "host": one pinned host tensor (the copies are issued per stream, then every stream is
+        waited for -- the shape a central numpy/CPU consumer wants); a device string: one tensor on that device."""
+        import torch
+
+        from .envs import BatchedPcgrlEnv
+        self._torch = torch
+        if devices is None:
+            devices = ["cuda:%d" % i for i in range(max(torch.cuda.device_count(), 1))]
+        self.devices = [torch.device(d) for d in devices]
+        if not self.devices:
+            raise ValueError("MultiGpuPcgrlEnv needs at least one device")
+        for d in self.devices:
+            if d.type != "cuda":
+                raise RuntimeError("MultiGpuPcgrlEnv runs on AMD GPUs only (device=%r); there is no CPU fallback" % (d,))
+        self.num_envs = int(num_envs)
+        G = len(self.devices)
+        if self.num_envs < G:
+            raise ValueError("fewer environments (%d) than devices (%d)" % (self.num_envs, G))
+        self.gather = gather
+        self.ranges = [shard_range(self.num_envs, G, g) for g in range(G)]
+        if seed is None:
+            from . import seeding
+            seed = seeding.create_seed(None, max_bytes=7)
+        self.base_seed = int(seed) if np.ndim(seed) == 0 else None
+        self.shards, self.streams = [], []
+        for g, (lo, hi) in enumerate(self.ranges):
+            s = (self.base_seed + lo) if self.base_seed is not None else [int(v) for v in seed[lo:hi]]
+            self.shards.append(BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=hi - lo, device=self.devices[g], seed=s, auto_reset=auto_reset))
+            self.streams.append(torch.cuda.Stream(device=self.devices[g]))
+        self._pinned = {}
+        self._pending = None
+
+    # ------------------------------------------------------------------ the surface of BatchedPcgrlEnv
+    def __getattr__(self, name):          # spaces, get_border_tile, get_num_tiles, _prob, _rep, _max_changes ...: the same on every shard
+        if name in ("shards", "_torch"):
+            raise AttributeError(name)
+        return getattr(self.shards[0], name)
+
+    def _each(self, fn, fork=True):
+        """fn(g, shard) on every shard's own stream, all issued before anything waits.  Each stream first waits (on the device)
+        for what the caller's current stream of that device has queued -- its action tensors -- and the caller's stream then
+        waits for the shard's: the outputs can be consumed on the current stream like those of a single BatchedPcgrlEnv."""
+        torch = self._torch
+        outs = []
+        for g, sh in enumerate(self.shards):
+            st = self.streams[g]
+            cur = torch.cuda.current_stream(self.devices[g])
+            if fork:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(fn(g, sh))
+        for g in range(len(self.shards)):
+            torch.cuda.current_stream(self.devices[g]).wait_stream(self.streams[g])
+        return outs
+
+    def seed(self, seed=None):
+        if seed is None:
+            from . import seeding
+            seed = seeding.create_seed(None, max_bytes=7)
+        out = []
+        for (lo, hi), sh in zip(self.ranges, self.shards):
+            out += sh.seed(int(seed) + lo if np.ndim(seed) == 0 else [int(v) for v in seed[lo:hi]])
+        return out
+
+    def adjust_param(self, **kwargs):
+        for sh in self.shards:
+            sh.adjust_param(**kwargs)
+
+    def split(self, actions):
+        """[N(, k)] actions -> the per-shard pieces, each on its shard's device (a list is taken as already split)."""
+        torch = self._torch
+        if isinstance(actions, (list, tuple)) and len(actions) == len(self.shards) and all(torch.is_tensor(a) for a in actions):
+            return list(actions)
+        if isinstance(actions, ShardedTensor):
+            return actions.parts
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions))
+        return [a[lo:hi].to(self.devices[g], non_blocking=True) for g, (lo, hi) in enumerate(self.ranges)]
+
+    def _collect(self, name, parts):
+        """One output in the form `gather` asks for."""
+        torch = self._torch
+        if self.gather == "list":
+            return ShardedTensor(parts)
+        if self.gather == "host":
+            key = (name, tuple(parts[0].shape[1:]), parts[0].dtype)
+            buf = self._pinned.get(key)
+            if buf is None:
+                buf = torch.empty((self.num_envs,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype).pin_memory()
+                self._pinned[key] = buf
+            for g, ((lo, hi), p) in enumerate(zip(self.ranges, parts)):
+                with torch.cuda.stream(self.streams[g]):
+                    buf[lo:hi].copy_(p, non_blocking=True)
+            return buf
+        return ShardedTensor(parts).to(self.gather)
+
+    def _finish(self):
+        if self.gather == "host":          # the pinned copies were issued on the shards' streams
+            for st in self.streams:
+                st.synchronize()
+
+    def _obs(self, obs_list):
+        o = OrderedDict()
+        for k in obs_list[0]:
+            o[k] = self._collect("obs_" + k, [ob[k] for ob in obs_list])
+        return o
+
+    def reset(self):
+        obs = self._each(lambda g, sh: sh.reset())
+        out = self._obs(obs)
+        self._finish()
+        return out
+
+    def step(self, actions):
+        """pcgrl_env.py:129-150 for every environment of every shard.  Returns (obs, reward, done, infos): obs / reward / done in
+        the `gather` form, infos the list of the shards' InfoBatch objects (live device tables)."""
+        parts = self.split(actions)
+        res = self._each(lambda g, sh: sh.step(parts[g]))
+        out = (self._obs([r[0] for r in res]), self._collect("reward", [r[1] for r in res]),
+               self._collect("done", [r[2] for r in res]), [r[3] for r in res])
+        self._finish()
+        return out
+
+    def step_async(self, actions):
+        self._pending = self.step(actions)
+
+    def step_wait(self):
+        return self._pending
+
+    def rollout(self, actions, want_info=True):
+        """`T` steps on a tape [T, N(, k)] (or a list of per-shard tapes [T, n_g(, k)]): one pcgrl_rollout per device, all in
+        flight together.  Returns (reward [T, N], done [T, N], list of per-shard InfoBatch or None) with reward / done gathered
+        along the environment axis in the `gather` form ("list": ShardedTensor of [T, n_g] pieces)."""
+        torch = self._torch
+        if isinstance(actions, (list, tuple)):
+            tapes = list(actions)
+        else:
+            a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions))
+            tapes = [a[:, lo:hi].to(self.devices[g], non_blocking=True).contiguous() for g, (lo, hi) in enumerate(self.ranges)]
+        res = self._each(lambda g, sh: sh.rollout(tapes[g], want_info=want_info))
+        rew, done = [r[0] for r in res], [r[1] for r in res]
+        if self.gather == "list":
+            out = (ShardedTensor(rew), ShardedTensor(done), [r[2] for r in res])
+        else:
+            dev = "cpu" if self.gather == "host" else self.gather
+            out = (torch.cat([r.to(dev) for r in rew], 1), torch.cat([d.to(dev) for d in done], 1), [r[2] for r in res])
+        return out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def check_status(self):
+        return [sh.check_status() for sh in self.shards]
+
+    def close(self):
+        for sh in self.shards:
+            sh.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

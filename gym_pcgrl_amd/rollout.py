@@ -44,6 +44,11 @@ class RolloutCollector:
         ashape = () if hasattr(a, "n") else (len(a.nvec),)
         self.buffer = RolloutBuffer(self.torch, n_steps, vec_env.num_envs, vec_env.observation_space.shape, ashape, dev)
         self._obs = None
+        # The step writes its image straight into a buffer row when every row starts 16-byte aligned (pcgrl_bind_observation
+        # wants that); a row is num_envs * h * w * depth bytes, so e.g. three 10 x 10 x 5 environments do not qualify -- the
+        # wrapper's own tensor then stays bound and each image is copied into its row (what every collector did before round 3).
+        row_bytes = int(self.buffer.last_obs.numel())
+        self.direct = (row_bytes % 16 == 0 and self.buffer.obs.data_ptr() % 16 == 0 and self.buffer.last_obs.data_ptr() % 16 == 0)
         self._start = self.torch.ones(vec_env.num_envs, dtype=self.torch.bool, device=dev)
         self.episode_returns, self.episode_lengths = [], []      # per step, the last `keep_steps` steps (default: one rollout)
         self.keep_steps = int(n_steps)
@@ -51,9 +56,14 @@ class RolloutCollector:
     def collect(self, policy):
         torch, b = self.torch, self.buffer
         w = self.env.env                                  # the image wrapper below the Monitor layer: no host sync
+        direct = self.direct
         if self._obs is None:
-            w.set_observation_target(b.obs[0])            # the first observation lands in row 0
+            if direct:
+                w.set_observation_target(b.obs[0])        # the first observation lands in row 0
             self._obs = self.env.reset()
+            if not direct:
+                b.obs[0].copy_(self._obs)
+                self._obs = b.obs[0]
         else:
             b.obs[0].copy_(b.last_obs)                    # one copy per rollout: where the previous one stopped
             self._obs = b.obs[0]
@@ -61,8 +71,13 @@ class RolloutCollector:
             b.episode_starts[t].copy_(self._start)
             actions = policy(self._obs)
             b.actions[t].copy_(actions)
-            w.set_observation_target(b.obs[t + 1] if t + 1 < b.n_steps else b.last_obs)     # the step writes the next row itself
+            nxt = b.obs[t + 1] if t + 1 < b.n_steps else b.last_obs
+            if direct:
+                w.set_observation_target(nxt)             # the step writes the next row itself
             self._obs, rew, done, _ = w.step(actions)
+            if not direct:
+                nxt.copy_(self._obs)
+                self._obs = nxt
             b.rewards[t].copy_(rew)
             b.dones[t].copy_(done)
             self._start = done.to(torch.bool).clone()

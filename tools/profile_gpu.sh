@@ -7,6 +7,8 @@ mkdir -p gpurun_out
 W=${1:-C2}; shift
 WHAT="${*:-trace sq mem}"
 B="python bench.py --workload $W --no-cpu-baseline --no-rollout --no-legs"
+# the code the counters are measured on (bench.py flags figures from another tree as stale)
+python -c 'from gym_pcgrl_amd import _lib; print(_lib.source_hash())' > gpurun_out/srchash_$W.txt
 for what in $WHAT; do
   case $what in
     rtrace) rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${W}R -o ${W}R -- python bench.py --workload $W --no-cpu-baseline --no-legs --steps 200 > gpurun_out/prof_${W}R.log 2>&1 ;;   # with the pcgrl_rollout leg: k_step<..., true> / k_step_solver
