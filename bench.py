@@ -369,6 +369,8 @@ def main():
                                                           "no GPU, no environment: the line carries value null and dry_run true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short legs of the other configs (the `configs` object of the default line)")
     ap.add_argument("--legs", default="C3,C4,C5,S1,C2w,C3w,n1_facade,collector", help="which legs the default line carries")
+    ap.add_argument("--tuning", default="", help="developer switches of the library for A/B runs: field=value[,field=value...] "
+                                                 "(include/pcgrl_hip.h pcgrl_tuning, e.g. no_fused=1,step_epb=128)")
     ap.add_argument("--steady-warmup", type=int, default=800, help="steps before the steady_state measurement (0: skip it)")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -378,6 +380,13 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    if a.tuning:
+        from gym_pcgrl_amd import _lib as _pl
+        for kv in a.tuning.split(","):
+            k, v = kv.split("=")
+            _pl.TUNING_OVERRIDES[k.strip()] = int(v)
+        _pl.make_tuning()          # (unknown names fail here)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -553,7 +562,7 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": desc, "envs_per_gpu": n, "width": W, "height": H, "max_changes": env._max_changes,
+            "config": {"workload": desc, "envs_per_gpu": n, **({"tuning": a.tuning} if a.tuning else {}), "width": W, "height": H, "max_changes": env._max_changes,
                        "max_iterations": env._max_iterations, "actions": "uniform random, device-generated before the timed region",
                        "parallelism": "env-axis shard x%d, no collective on the step path" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -20,7 +20,7 @@ PCGRL_OK, PCGRL_EINVAL, PCGRL_EHIP, PCGRL_ESTATE = 0, -1, -2, -3
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "prob", "rep", "num_envs", "width", "height", "max_changes", "max_iterations",
+        "prob", "rep", "num_envs", "width", "height", "prob_width", "prob_height", "max_changes", "max_iterations",
         "random_start", "random_tile", "warp", "random_probs", "auto_reset", "target_path",
         "max_enemies", "target_enemy_dist", "max_crates", "target_solution", "solver_power", "max_potions",
         "max_treasures", "max_diamonds", "min_spikes", "target_jumps", "min_empty", "min_enemies", "min_jumps")] + [
@@ -33,6 +33,30 @@ class Layout(C.Structure):
                                   "info", "reward", "done", "tile_p", "rng_rep", "rng_prob", "rng_cursor", "scratch")]
 
 
+TUNING_FIELDS = ("no_fused", "fused_zelda", "step_epb", "no_inc", "inline_reset", "pair_min", "no_wide", "wide_waves", "wide_grid",
+                 "wide_pairs", "wide_few", "sok_generic", "sok_hard_cap", "sok_spawn", "md_only_agent", "smb_lds_heap")
+
+
+class Tuning(C.Structure):
+    """include/pcgrl_hip.h pcgrl_tuning: developer switches, -1 = the library's default."""
+    _fields_ = [(n, C.c_int32) for n in TUNING_FIELDS]
+
+
+# Process-wide overrides of the developer switches for tools/ and tests (the library itself reads no environment variables and
+# keeps no global state: this dict lives in the Python binding).  {field name: value}; BatchedPcgrlEnv(tuning={...}) takes
+# precedence.  tools/ fill it from PCGRL_* environment variables (tools/_tuning_env.py).
+TUNING_OVERRIDES = {}
+
+
+def make_tuning(overrides=None):
+    t = Tuning(*([-1] * len(TUNING_FIELDS)))
+    for k, v in list(TUNING_OVERRIDES.items()) + list((overrides or {}).items()):
+        if k not in TUNING_FIELDS:
+            raise KeyError("unknown tuning switch %r (known: %s)" % (k, ", ".join(TUNING_FIELDS)))
+        setattr(t, k, int(v))
+    return t
+
+
 BUFFER_NAMES = ("map", "old_map", "heatmap", "pos", "planes", "counters", "stats", "start_stats", "info", "reward",
                 "done", "tile_p", "rng_rep", "rng_prob", "rng_cursor", "scratch")
 
@@ -41,11 +65,12 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
 
 
-ABI_VERSION = 9          # include/pcgrl_hip.h PCGRL_ABI_VERSION
+ABI_VERSION = 10         # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
-           "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout", "pcgrl_bind_observation", "pcgrl_selftest_heap")
+           "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout", "pcgrl_bind_observation", "pcgrl_selftest_heap",
+           "pcgrl_tuning_defaults", "pcgrl_set_tuning", "pcgrl_clear_status")
 NPHASE = 6
 # the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
 # other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
@@ -139,6 +164,9 @@ def load():
     L.pcgrl_query_layout.argtypes = [C.POINTER(Config), C.POINTER(Layout)]
     L.pcgrl_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     L.pcgrl_destroy.argtypes = [C.c_void_p]
+    L.pcgrl_tuning_defaults.argtypes = [C.POINTER(Tuning)]
+    L.pcgrl_tuning_defaults.restype = None
+    L.pcgrl_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
     L.pcgrl_bind.argtypes = [C.c_void_p, C.POINTER(Buffers), C.c_void_p]
     L.pcgrl_configure.argtypes = [C.c_void_p, C.POINTER(Config)]
     L.pcgrl_seed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -153,6 +181,7 @@ def load():
     L.pcgrl_action_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_selftest_heap.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.pcgrl_clear_status.argtypes = [C.c_void_p, C.c_void_p]
     L.pcgrl_profile.argtypes = [C.c_void_p, C.c_int]
     L.pcgrl_bind_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]

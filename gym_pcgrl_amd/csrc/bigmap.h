@@ -1,0 +1,396 @@
+// Maps beyond the row-bitboard kernels: more than 64 rows or more than 64 columns (up to 255 x 255, the largest map whose cursor
+// fits the observation's uint8 `pos`, narrow_rep.py:60-64).  The reference takes any width / height (pcgrl_env.py:106-115,
+// probs/problem.py:66-72); the kernels of kernels_stats.h hold a map as one 32/64-bit row mask per lane, which ends at 64 x 64.
+// Part of the single translation unit pcgrl_abi.hip.
+//
+// Here ONE WAVEFRONT owns a map and keeps its rows as multi-word bit masks in LDS (KW = ceil(W / 64) 64-bit words per row, H rows:
+// 8 KB per mask for 255 x 255), built from the byte map -- such configurations keep no bit planes (pcgrl_layout.nplanes = 0, like smb),
+// Representation.update reads and writes the byte map alone.  The statistics are the same set programs as pcgrl_algos.h, restated
+// on word arrays (lane l takes words l, l + 64, ...):
+//   big_fill          the 4-connected component of a seed: in-place sweeps (monotone, so any order of the words is right) with
+//                     an O(1) run fill inside a word, confined to the rows the component has reached so far
+//   big_bfs_levels    helper.py:222-237 run_dikjstra as level-synchronous set expansion inside one component (three rotating
+//                     buffers: the last frontier is C & ~P when a level adds nothing); eccentricity = number of levels
+//   big_regions_path  helper.py:197-207 + :250-264: components in row-major order of their first cell, double sweep from that
+//                     cell, np.argmax = first cell of the last frontier; a component of k cells is only swept while k - 1 can
+//                     still raise the maximum (and the second sweep only while 2 * e1 can)
+//   big_bfs_dist      distance from a set to the nearest cell of another set (zelda_prob.py:98-110)
+// No incremental route, no champion cache: every change recomputes.  This is the general path, not the tuned one -- the
+// configurations BASELINE.json names all fit the row-bitboard kernels.
+#pragma once
+
+struct BigGeom {
+    int W, H, KW, NW;          // words per row, words per mask
+    uint32_t magic;            // floor(i / KW) = (i * magic) >> 16 for i < 1024 (KW <= 4)
+    uint64_t last;             // valid bits of the last word of a row
+};
+__device__ __forceinline__ BigGeom big_geom(int W, int H) {
+    BigGeom G;
+    G.W = W; G.H = H; G.KW = (W + 63) >> 6; G.NW = H * G.KW;
+    G.magic = 65536u / (uint32_t)G.KW + 1u;
+    const int tail = W - 64 * (G.KW - 1);
+    G.last = tail >= 64 ? ~0ull : ((1ull << tail) - 1ull);
+    return G;
+}
+__host__ __device__ inline int big_words(int W, int H) { return H * ((W + 63) >> 6); }
+#define BIG_NARRAYS 7          /* masks a wavefront keeps in LDS (k_big) */
+__host__ __device__ inline size_t big_wave_lds(int W, int H) {
+    // the MT19937 ring of the in-kernel reset + BIG_NARRAYS masks; the bit strings of the plane build (3 x (cells / 64 + 2) words)
+    // are laid over masks 3.. (3 * (cells/64 + 2) <= 3 * NW + 6 words)
+    return (size_t)PCGRL_MT_N * 4 + ((size_t)BIG_NARRAYS * big_words(W, H) + 8) * 8;
+}
+__device__ __forceinline__ int big_row(const BigGeom& G, int i) { return (int)(((uint32_t)i * G.magic) >> 16); }
+
+__device__ __forceinline__ int big_wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ bool big_any(bool p) { return __ballot(p) != 0; }
+// (the masks live in LDS and are read and written by all lanes of ONE wavefront: its ds instructions execute in order, so a
+//  compiler barrier between the phases is all the synchronisation there is)
+__device__ __forceinline__ void big_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+// s | its 4-neighbours, at word i (row r, word k of the row)
+__device__ __forceinline__ uint64_t big_expand_word(const uint64_t* s, int i, int r, int k, const BigGeom& G) {
+    const uint64_t c = s[i];
+    uint64_t n = c | (c << 1) | (c >> 1);
+    if (k > 0) n |= s[i - 1] >> 63;
+    if (k < G.KW - 1) n |= s[i + 1] << 63;
+    if (r > 0) n |= s[i - G.KW];
+    if (r < G.H - 1) n |= s[i + G.KW];
+    return n;
+}
+// every horizontal run of p (inside one word) that holds a bit of s (s a subset of p): the carry chain of an add, both ways
+__device__ __forceinline__ uint64_t big_runfill(uint64_t s, uint64_t p) {
+    const uint64_t hi = (((p + s) ^ p) & p) | s;
+    const uint64_t rp = __brevll(p), rs = __brevll(s);
+    const uint64_t lo = (((rp + rs) ^ rp) & rp) | rs;
+    return hi | __brevll(lo);
+}
+__device__ __forceinline__ void big_zero(uint64_t* a, int lo, int hi, int lane) { for (int i = lo + lane; i < hi; i += 64) a[i] = 0ull; }
+__device__ __forceinline__ int big_popcount(const uint64_t* a, int lo, int hi, int lane) {
+    int n = 0;
+    for (int i = lo + lane; i < hi; i += 64) n += __popcll(a[i]);
+    return big_wave_sum(n);
+}
+// First set cell in row-major order of `a` (or of a & ~b when b is given) among the words [lo, hi): word index (-1: none) and bit.
+__device__ __forceinline__ int big_first(const uint64_t* a, const uint64_t* b, int lo, int hi, int lane, int& bit) {
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        uint64_t v = 0ull;
+        if (i < hi) { v = a[i]; if (b) v &= ~b[i]; }
+        const uint64_t nz = __ballot(v != 0ull);
+        if (nz) {
+            const int l = __ffsll((unsigned long long)nz) - 1;
+            const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), vhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+            bit = vlo ? __ffs((int)vlo) - 1 : 32 + __ffs((int)vhi) - 1;
+            return base + l;
+        }
+    }
+    bit = 0;
+    return -1;
+}
+
+// The component of `pass` that holds the bits of f (f: zero outside rows [r0, r1], a subset of pass), in place.  On return
+// [r0, r1] is the component's row range.
+__device__ __forceinline__ void big_fill(uint64_t* f, const uint64_t* pass, const BigGeom& G, int lane, int& r0, int& r1) {
+    for (;;) {
+        const int a = r0 > 0 ? r0 - 1 : 0, b = r1 < G.H - 1 ? r1 + 1 : G.H - 1;
+        bool changed = false, top = false, bot = false;
+        for (int i = a * G.KW + lane; i < (b + 1) * G.KW; i += 64) {
+            const int r = big_row(G, i), k = i - r * G.KW;
+            const uint64_t p = pass[i], old = f[i];
+            uint64_t n = big_expand_word(f, i, r, k, G) & p;
+            if (n) n = big_runfill(n, p);
+            if (n != old) { f[i] = n; changed = true; top = top || r < r0; bot = bot || r > r1; }
+        }
+        big_sync();
+        if (!big_any(changed)) return;
+        if (big_any(top)) r0 -= 1;
+        if (big_any(bot)) r1 += 1;
+    }
+}
+
+// BFS inside `comp` (rows [r0, r1]) from the single cell (word i0, bit b0).  Returns the eccentricity; the last frontier is C & ~P
+// (for an eccentricity of 0 the source itself: P is then empty).  P, C, N: three scratch masks, rotated; the caller gets the
+// final roles back through the pointers.
+__device__ __forceinline__ int big_bfs_levels(const uint64_t* comp, int i0, int b0, const BigGeom& G, int r0, int r1, uint64_t*& P, uint64_t*& C,
+                                              uint64_t*& N, int lane) {
+    const int lo = r0 * G.KW, hi = (r1 + 1) * G.KW;
+    big_zero(P, lo, hi, lane); big_zero(C, lo, hi, lane); big_zero(N, lo, hi, lane);
+    big_sync();
+    if (lane == 0) C[i0] = 1ull << b0;
+    big_sync();
+    int ecc = 0;
+    for (;;) {
+        bool changed = false;
+        for (int i = lo + lane; i < hi; i += 64) {
+            const int r = big_row(G, i), k = i - r * G.KW;
+            // (rows outside [r0, r1] hold nothing of the component: the neighbours read across the range's edge are masked by comp)
+            uint64_t n = C[i] | (C[i] << 1) | (C[i] >> 1);
+            if (k > 0) n |= C[i - 1] >> 63;
+            if (k < G.KW - 1) n |= C[i + 1] << 63;
+            if (r > r0) n |= C[i - G.KW];
+            if (r < r1) n |= C[i + G.KW];
+            n &= comp[i];
+            N[i] = n;
+            changed = changed || n != C[i];
+        }
+        big_sync();
+        if (!big_any(changed)) return ecc;
+        ++ecc;
+        uint64_t* t = P; P = C; C = N; N = t;
+    }
+}
+
+// helper.py:197-207 calc_num_regions + :250-264 calc_longest_path over `pass`.  rest, comp, X, Y, Z: scratch masks (comp must be
+// all zero on entry and is on return).  want_path = false: regions only (zelda and the search problems).
+__device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t* rest, uint64_t* comp, uint64_t* X, uint64_t* Y, uint64_t* Z,
+                                                 const BigGeom& G, int lane, bool want_path, int& regions, int& path) {
+    regions = 0; path = 0;
+    // isolated cells: components of one cell, counted without a fill (path 0)
+    int n_iso = 0;
+    for (int i = lane; i < G.NW; i += 64) {
+        const int r = big_row(G, i), k = i - r * G.KW;
+        const uint64_t p = pass[i];
+        uint64_t nb = (p << 1) | (p >> 1);
+        if (k > 0) nb |= pass[i - 1] >> 63;
+        if (k < G.KW - 1) nb |= pass[i + 1] << 63;
+        if (r > 0) nb |= pass[i - G.KW];
+        if (r < G.H - 1) nb |= pass[i + G.KW];
+        const uint64_t iso = p & ~nb;
+        n_iso += __popcll(iso);
+        rest[i] = p & ~iso;
+    }
+    regions = big_wave_sum(n_iso);
+    big_sync();
+    int from = 0;
+    for (;;) {
+        int b0 = 0;
+        const int i0 = big_first(rest, nullptr, from, G.NW, lane, b0);
+        if (i0 < 0) break;
+        from = i0;
+        int r0 = big_row(G, i0), r1 = r0;
+        if (lane == 0) comp[i0] = 1ull << b0;
+        big_sync();
+        big_fill(comp, pass, G, lane, r0, r1);
+        const int lo = r0 * G.KW, hi = (r1 + 1) * G.KW;
+        ++regions;
+        if (want_path) {
+            const int size = big_popcount(comp, lo, hi, lane);
+            if (size - 1 > path) {
+                // the first cell of the component in row-major order is the seed itself (rest only ever loses whole components)
+                const int e1 = big_bfs_levels(comp, i0, b0, G, r0, r1, X, Y, Z, lane);
+                if (2 * e1 > path) {
+                    int b1 = 0;
+                    const int i1 = e1 == 0 ? i0 : big_first(Y, X, lo, hi, lane, b1);       // np.argmax: first cell of the last frontier
+                    if (e1 == 0) b1 = b0;
+                    const int e2 = big_bfs_levels(comp, i1, b1, G, r0, r1, X, Y, Z, lane);
+                    path = e2 > path ? e2 : path;
+                }
+            }
+        }
+        for (int i = lo + lane; i < hi; i += 64) { rest[i] &= ~comp[i]; comp[i] = 0ull; }
+        big_sync();
+    }
+}
+
+// Distance from the cells of C (the source set; overwritten) to the nearest cell of dst (dst not containing the source) through pass;
+// -1: none reachable (run_dikjstra leaves -1 there).  N: scratch mask.
+__device__ __forceinline__ int big_bfs_dist(uint64_t* C, const uint64_t* dst, const uint64_t* pass, uint64_t* N, const BigGeom& G, int lane) {
+    int t = 0;
+    for (;;) {
+        bool hit = false, grew = false;
+        for (int i = lane; i < G.NW; i += 64) {
+            const int r = big_row(G, i), k = i - r * G.KW;
+            const uint64_t n = big_expand_word(C, i, r, k, G) & pass[i], fresh = n & ~C[i];
+            N[i] = n;
+            hit = hit || (fresh & dst[i]) != 0ull;
+            grew = grew || fresh != 0ull;
+        }
+        big_sync();
+        ++t;
+        if (big_any(hit)) return t;
+        if (!big_any(grew)) return -1;
+        uint64_t* x = C; C = N; N = x;
+    }
+}
+
+// The bit planes of the tile ids of map m (global, u8 [H][W]) as row masks pl[b * NW + i] (NPL planes).  The map is one string
+// of cells: 64 consecutive cells give 64 bits of each plane's string with one ballot (eight loads in flight per round), and a
+// row word is cut out of the string.  `str`: scratch for the NPL strings of cells / 64 + 2 words each.
+template <int NPL>
+__device__ __forceinline__ void big_planes(const uint8_t* __restrict__ m, const BigGeom& G, uint64_t* pl, uint64_t* str, int lane) {
+    const int cells = G.W * G.H, nch = (cells + 63) >> 6, sw = nch + 2;
+    for (int c0 = 0; c0 < nch; c0 += 8) {
+        uint8_t t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int c = (c0 + u) * 64 + lane; t[u] = c < cells ? m[c] : (uint8_t)0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (c0 + u >= nch) break;          // wave-uniform
+            const uint64_t q0 = __ballot(t[u] & 1), q1 = NPL > 1 ? __ballot(t[u] & 2) : 0ull, q2 = NPL > 1 ? __ballot(t[u] & 4) : 0ull;
+            if (lane == 0) { str[c0 + u] = q0; if (NPL > 1) { str[sw + c0 + u] = q1; str[2 * sw + c0 + u] = q2; } }
+        }
+    }
+    if (lane < 2) { str[nch + lane] = 0ull; if (NPL > 1) { str[sw + nch + lane] = 0ull; str[2 * sw + nch + lane] = 0ull; } }
+    big_sync();
+    for (int i = lane; i < G.NW; i += 64) {
+        const int r = big_row(G, i), k = i - r * G.KW;
+        const int o = r * G.W + 64 * k, wd = o >> 6, sh = o & 63;
+        const uint64_t valid = k == G.KW - 1 ? G.last : ~0ull;
+#pragma unroll
+        for (int b = 0; b < NPL; b++) {
+            const uint64_t lo = str[b * sw + wd] >> sh, hi = sh ? str[b * sw + wd + 1] << (64 - sh) : 0ull;
+            pl[b * G.NW + i] = (lo | hi) & valid;
+        }
+    }
+    big_sync();
+}
+
+// helper.py:37-43, 56-62 get_floor_dist(map, ["player"], ["solid"]) on word arrays: all player bits fall together, a row per
+// round (floor_dist in pcgrl_algos.h).  A, Bm: scratch masks.
+__device__ __forceinline__ int big_floor_dist(const uint64_t* player, const uint64_t* solid, uint64_t* A, uint64_t* Bm, const BigGeom& G, int lane) {
+    for (int i = lane; i < G.NW; i += 64) A[i] = player[i];
+    big_sync();
+    int n_act = big_popcount(A, 0, G.NW, lane), result = 0, lost = 0;
+    for (int dy = 1; dy < G.H && n_act > 0; dy++) {
+        int moved = 0, hit = 0;
+        for (int i = lane; i < G.NW; i += 64) {
+            const uint64_t mv = i >= G.KW ? A[i - G.KW] : 0ull;          // row r receives row r - 1
+            const uint64_t h = mv & solid[i];
+            moved += __popcll(mv); hit += __popcll(h);
+            Bm[i] = mv & ~solid[i];
+        }
+        big_sync();
+        const int n_moved = big_wave_sum(moved), n_hit = big_wave_sum(hit);
+        lost += n_act - n_moved;
+        result += n_hit * (dy - 1);
+        n_act = n_moved - n_hit;
+        uint64_t* x = A; A = Bm; Bm = x;
+    }
+    return result + (lost + n_act) * (G.H - 1);
+}
+
+// Problem.get_stats of the map `m` by one wavefront (the search problems: without the planner).  `ar`: BIG_NARRAYS masks.
+// Returns true when a search kernel has to finish the job.  The tile classes are those of pcgrl_algos.h (zelda_masks,
+// sokoban_stats, mdungeon_stats, ddave_stats).
+template <int PROB>
+__device__ __forceinline__ bool big_item_stats(const PcgrlParams& P, const DevBufs& B, const uint8_t* __restrict__ m, const BigGeom& G, uint64_t* ar, int lane,
+                                               int32_t* s) {
+    const int NW = G.NW;
+    uint64_t *a0 = ar, *a1 = ar + NW, *a2 = ar + 2 * NW, *a3 = ar + 3 * NW, *a4 = ar + 4 * NW, *a5 = ar + 5 * NW, *a6 = ar + 6 * NW;
+    for (int k = 0; k < PCGRL_MAX_STATS; k++) s[k] = 0;
+    if (PROB == PCGRL_PROB_BINARY) {
+        big_planes<1>(m, G, a0, a3, lane);                                  // a0 = solid
+        for (int i = lane; i < NW; i += 64) {
+            const int r = big_row(G, i), k = i - r * G.KW;
+            a0[i] = ~a0[i] & (k == G.KW - 1 ? G.last : ~0ull);             // a0 = empty (binary_prob.py:82-86: passable = ["empty"])
+            a2[i] = 0ull;
+        }
+        big_sync();
+        int regions, path;
+        big_regions_path(a0, a1, a2, a3, a4, a5, G, lane, true, regions, path);
+        s[0] = regions; s[1] = path; s[2] = 0;                               // (s[2]: "there is a champion" -- never, on this path)
+        return false;
+    }
+    big_planes<3>(m, G, a0, a3, lane);                                      // a0, a1, a2 = bits 0, 1, 2 of the tile id
+    int cnt[5] = {0, 0, 0, 0, 0};
+    // one pass: the class counts, and the passable set of the region count in a3
+    for (int i = lane; i < NW; i += 64) {
+        const int r = big_row(G, i), k = i - r * G.KW;
+        const uint64_t v = k == G.KW - 1 ? G.last : ~0ull, b0 = a0[i], b1 = a1[i], b2 = a2[i];
+        const uint64_t c1 = ~b2 & ~b1 & b0 & v, c2 = ~b2 & b1 & ~b0 & v, c3 = ~b2 & b1 & b0 & v, c4 = b2 & ~b1 & ~b0 & v, c5 = b2 & ~b1 & b0 & v,
+                       c6 = b2 & b1 & ~b0 & v, c7 = b2 & b1 & b0 & v;
+        uint64_t walk;
+        if (PROB == PCGRL_PROB_ZELDA) {            // zelda_prob.py:45-46: 1 solid 2 player 3 key 4 door 5 bat 6 scorpion 7 spider
+            cnt[0] += __popcll(c2); cnt[1] += __popcll(c3); cnt[2] += __popcll(c4); cnt[3] += __popcll(c5 | c6 | c7);
+            walk = v & ~c1 & ~c4;
+        } else if (PROB == PCGRL_PROB_SOKOBAN) {   // sokoban_prob.py:44-45: 1 solid 2 player 3 crate 4 target
+            cnt[0] += __popcll(c2); cnt[1] += __popcll(c3); cnt[2] += __popcll(c4);
+            walk = v & ~c1;
+        } else if (PROB == PCGRL_PROB_MDUNGEON) {  // mdungeon_prob.py:49-50: 1 solid 2 player 3 exit 4 potion 5 treasure 6 goblin 7 ogre
+            cnt[0] += __popcll(c2); cnt[1] += __popcll(c3); cnt[2] += __popcll(c4); cnt[3] += __popcll(c5); cnt[4] += __popcll(c6 | c7);
+            walk = v & ~c1;
+        } else {                                   // ddave_prob.py:48-49: 1 solid 2 player 3 exit 4 diamond 5 key 6 spike
+            cnt[0] += __popcll(c2); cnt[1] += __popcll(c3); cnt[2] += __popcll(c5); cnt[3] += __popcll(c4); cnt[4] += __popcll(c6);
+            walk = v & ~c1 & ~c6;
+        }
+        a3[i] = walk;
+        a5[i] = 0ull;
+    }
+    big_sync();
+#pragma unroll
+    for (int q = 0; q < 5; q++) cnt[q] = big_wave_sum(cnt[q]);
+    int regions, unused;
+    big_regions_path(a3, a4, a5, nullptr, nullptr, nullptr, G, lane, false, regions, unused);
+    if (PROB == PCGRL_PROB_ZELDA) {                // zelda_prob.py:80-112
+        const int player = cnt[0], key = cnt[1], door = cnt[2], enemies = cnt[3];
+        int nearest = 0, path = 0;
+        if (player == 1 && regions == 1) {
+            // a3 = passable set of the sweep, a4 = source (then the growing set), a5 = target, a6 = scratch
+            if (enemies > 0) {                     // through empty | player | enemies: the key is NOT passable here (:98)
+                for (int i = lane; i < NW; i += 64) {
+                    const int r = big_row(G, i), k = i - r * G.KW;
+                    const uint64_t v = k == G.KW - 1 ? G.last : ~0ull, b0 = a0[i], b1 = a1[i], b2 = a2[i];
+                    a4[i] = ~b2 & b1 & ~b0 & v;                                          // player
+                    a5[i] = b2 & (b1 | b0) & v;                                          // enemies
+                    a3[i] = v & ~(~b2 & b0) & ~(b2 & ~b1 & ~b0);                         // not solid (1), not key (3), not door (4)
+                }
+                big_sync();
+                const int d = big_bfs_dist(a4, a5, a3, a6, G, lane);
+                nearest = d > 0 ? d : P.prob_width * P.prob_height;
+            }
+            if (key == 1 && door == 1) {           // player -> key through everything but solid and door, key -> door with the door (:104-110)
+                for (int i = lane; i < NW; i += 64) {
+                    const int r = big_row(G, i), k = i - r * G.KW;
+                    const uint64_t v = k == G.KW - 1 ? G.last : ~0ull, b0 = a0[i], b1 = a1[i], b2 = a2[i];
+                    a4[i] = ~b2 & b1 & ~b0 & v;                                          // player
+                    a5[i] = ~b2 & b1 & b0 & v;                                           // key
+                    a3[i] = v & ~(~b2 & ~b1 & b0) & ~(b2 & ~b1 & ~b0);                   // not solid, not door
+                }
+                big_sync();
+                path = big_bfs_dist(a4, a5, a3, a6, G, lane);
+                for (int i = lane; i < NW; i += 64) {
+                    const int r = big_row(G, i), k = i - r * G.KW;
+                    const uint64_t v = k == G.KW - 1 ? G.last : ~0ull, b0 = a0[i], b1 = a1[i], b2 = a2[i];
+                    a4[i] = ~b2 & b1 & b0 & v;                                           // key
+                    a5[i] = b2 & ~b1 & ~b0 & v;                                          // door
+                    a3[i] = v & ~(~b2 & ~b1 & b0);                                       // not solid
+                }
+                big_sync();
+                path += big_bfs_dist(a4, a5, a3, a6, G, lane);                            // -1 when the door is walled off
+            }
+        }
+        s[0] = player; s[1] = key; s[2] = door; s[3] = enemies; s[4] = regions; s[5] = nearest; s[6] = path;
+        return false;
+    }
+    if (PROB == PCGRL_PROB_SOKOBAN) {              // sokoban_prob.py:133-145 without the solver
+        s[0] = cnt[0]; s[1] = cnt[1]; s[2] = cnt[2]; s[3] = regions;
+        s[4] = P.prob_width * P.prob_height * (P.prob_width + P.prob_height); s[5] = 0;
+        return cnt[0] == 1 && cnt[1] == cnt[2] && cnt[1] > 0 && regions == 1;
+    }
+    if (PROB == PCGRL_PROB_MDUNGEON) {             // mdungeon_prob.py:139-157 without the planner (row layout: md_pack)
+        s[0] = cnt[0]; s[1] = cnt[1]; s[2] = cnt[2]; s[3] = cnt[3]; s[4] = cnt[4]; s[5] = regions;
+        s[6] = P.prob_width * P.prob_height; s[7] = 0;
+        return cnt[0] == 1 && cnt[1] == 1 && regions == 1;
+    }
+    // ddave_prob.py:141-161 without the planner (row layout: dd_pack).  The three counts that share slot 0 have eight bits each:
+    // a map with more than 255 player, exit or key tiles is reported through the status word instead of being packed wrongly.
+    if (cnt[0] > 255 || cnt[1] > 255 || cnt[2] > 255) { if (lane == 0) atomicOr(B.status, PCGRL_STATUS_TOO_MANY_CRATES); }
+    for (int i = lane; i < NW; i += 64) {
+        const int r = big_row(G, i), k = i - r * G.KW;
+        const uint64_t v = k == G.KW - 1 ? G.last : ~0ull, b0 = a0[i], b1 = a1[i], b2 = a2[i];
+        a4[i] = ~b2 & b1 & ~b0 & v;                                                      // player
+        a5[i] = ~b2 & ~b1 & b0 & v;                                                      // solid
+    }
+    big_sync();
+    s[0] = (cnt[0] & 255) | ((cnt[1] & 255) << 8) | ((cnt[2] & 255) << 16);
+    s[1] = big_floor_dist(a4, a5, a3, a6, G, lane);
+    s[2] = cnt[3]; s[3] = cnt[4]; s[4] = regions; s[5] = 0;
+    s[6] = P.prob_width * P.prob_height; s[7] = 0;
+    return cnt[0] == 1 && cnt[1] == 1 && cnt[2] == 1 && regions == 1;
+}

@@ -1,0 +1,83 @@
+// k_big: Problem.get_stats + reward / done / info (and the resets) of the changed environments on maps beyond the row-bitboard
+// kernels -- one wavefront per work item on multi-word row masks in LDS (bigmap.h).  Takes the place of k_stats, k_stats_wide and
+// k_reset for such configurations; same work lists, same finalize / park protocol, same in-kernel reset for the problems without a
+// search (binary, zelda).  Part of the single translation unit pcgrl_abi.hip.
+#pragma once
+
+// mode MODE_STEP:   items of WL_RST first (with the in-kernel reset: the environments that are certain to be reset -- the statistics
+//                   of the map the step ended on, the step's reward / done / info with the counters read before the reset, the
+//                   reset, the start statistics), then the items of `list` (statistics; an episode that ends is reset right here
+//                   when inline_reset, else pushed on the reset list by finalize_item)
+//      MODE_START:  PcgrlEnv.reset of every item of `list` (pcgrl_env.py:66-76), then its start statistics
+//      MODE_SETMAP: statistics of every item of `list`
+// park_list: where maps that need the planner go (the search problems; finish_or_park).
+template <int PROB>
+__global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity, int inline_reset, int gen_map,
+                                            int park_list) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t big_lds[];
+    __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1];
+    if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const bool with_rst = mode == MODE_STEP && inline_reset;
+    const int n_chg = wl_load_prefix(B, parity, list, s_pref);
+    const int n_rst = with_rst ? wl_load_prefix(B, parity, WL_RST, s_pref_rst) : 0;
+    const int W = P.width, H = P.height;
+    const size_t cells = (size_t)W * H;
+    const BigGeom G = big_geom(W, H);
+    uint8_t* base = big_lds + (size_t)wv * big_wave_lds(W, H);
+    uint32_t* mt = reinterpret_cast<uint32_t*>(base);
+    uint64_t* ar = reinterpret_cast<uint64_t*>(base + PCGRL_MT_N * 4);
+    for (int item = blockIdx.x * nwv + wv; item < n_rst + n_chg; item += gridDim.x * nwv) {
+        const bool lone = item < n_rst;
+        const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item - n_rst);
+        const bool reset_only = (raw & WL_RESET_ONLY) != 0;
+        const int e = raw & ~WL_RESET_ONLY;
+        const int shard = (item >> 4) & (WL_NSHARD - 1);
+        const uint8_t* m = B.map + (size_t)e * cells;
+        int32_t s[PCGRL_MAX_STATS];
+        if (mode != MODE_STEP) {
+            if (mode == MODE_START) {
+                wave_reset_env<PROB>(P, B, e, gen_map, mt, (uint8_t*)nullptr, lane);
+                __threadfence();               // the new map is read back from memory below
+            }
+            const bool ns = big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+            if (lane == 0) finish_or_park<PROB>(P, B, e, s, ns, mode, parity, shard, true, park_list);
+            continue;
+        }
+        int want = 0;
+        if (lone) {
+            // certain reset (or an unchanged environment whose episode ended): the step is finished with the counters read
+            // before the reset zeroes them
+            int2 pre = make_int2(0, 0);
+            if (!reset_only) {
+                if (lane == 0) pre = reinterpret_cast<const int2*>(B.counters)[e];
+                big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+                if (lane == 0) finalize_item<PROB>(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &pre);
+            }
+            want = 1;
+        } else {
+            const bool ns = big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+            if (lane == 0) want = finish_or_park<PROB>(P, B, e, s, ns, MODE_STEP, parity, shard, !inline_reset, park_list) ? 1 : 0;
+            want = __builtin_amdgcn_readfirstlane(want);
+        }
+        if (inline_reset && want) {
+            __builtin_amdgcn_wave_barrier();
+            wave_reset_env<PROB>(P, B, e, gen_map, mt, (uint8_t*)nullptr, lane);
+            __threadfence();
+            const bool ns = big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+            if (lane == 0) finish_or_park<PROB>(P, B, e, s, ns, MODE_START, parity, shard, true, park_list);
+        }
+    }
+}
+
+// pcgrl_set_maps on such maps: the byte maps are the whole state (no planes to rebuild).  Tile ids beyond the problem's are
+// clamped and reported, as k_planes_from_map does.
+template <int>
+__global__ __launch_bounds__(256) void k_copy_map(PcgrlParams P, DevBufs B, const uint8_t* __restrict__ src) {
+    const size_t total = (size_t)P.num_envs * P.width * P.height;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        uint8_t t = src[i];
+        if (t >= P.ntiles) { atomicOr(B.status, PCGRL_STATUS_BAD_TILE); t = (uint8_t)(P.ntiles - 1); }
+        B.map[i] = t;
+    }
+}

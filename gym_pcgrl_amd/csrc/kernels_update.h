@@ -299,7 +299,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         int dest = -1, v = e;
         if (first) { dest = 2; v = val; }
         else if (chg) { dest = cheap ? 1 : 0; v = (cheap || B.zelda_inc) ? inc_item : e; }
-        if (P.prob == PCGRL_PROB_BINARY && P.group == 64) {
+        if (P.prob == PCGRL_PROB_BINARY && P.group == 64 && !P.big) {
             // tall maps: the full recomputations ranked by what they are going to cost (difficulty_bucket), dearest first -- a launch
             // of k_stats_wide ends with its last item, and a dear item that starts late is what it ends with
             block_append_bucketed(dest == 0, bucket, v, B, parity, WL_CHG, s_hist, s_gbase, dest == 1, v, WL_INC);

@@ -71,12 +71,16 @@
 #include "reset_env.h"
 #include "kernels_stats.h"
 #include "kernels_reset.h"
+#include "bigmap.h"
+#include "kernels_big.h"
 #include "kernels_step.h"
 #include "kernels_sokoban.h"
 #include "kernels_mdungeon.h"
 #include "kernels_ddave.h"
 #include "kernels_smb.h"
 #include "kernels_step_solver.h"
+#include "search_big.h"
+#include "kernels_search_big.h"
 #if PCGRL_IN_PART(PART_CORE)
 #include "kernels_misc.h"
 #endif
@@ -95,7 +99,8 @@ struct pcgrl_env {
     int device;
     // optional per-phase timing with HIP events on the caller's stream (pcgrl_profile)
     int alloc_solver_power;
-    // switches read from the environment once, at pcgrl_bind (A/B measurements and tests)
+    // developer switches (pcgrl_set_tuning; A/B measurements and tests), resolved at pcgrl_bind
+    pcgrl_tuning tun;
     int no_wide, wide_waves, wide_grid, wide_pairs, fused_zelda, no_fused, step_epb, smb_heap;
     int profiling;
     int obs_incremental;       // pcgrl_bind_observation(incremental): the bound target is the library's to update in place
@@ -125,7 +130,7 @@ extern PCGRL_LOCAL thread_local int g_last_hip;
 #define HIPCHK(expr) do { hipError_t err_ = (expr); if (err_ != hipSuccess) { g_last_hip = (int)err_; return PCGRL_EHIP; } } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-static bool env_is_one(const char* name) { const char* v = getenv(name); return v && v[0] == '1'; }
+static int tun_or(int v, int dflt) { return v < 0 ? dflt : v; }       // a pcgrl_tuning field: negative = the library's default
 
 // A handle belongs to the device its buffers live on (found at pcgrl_bind).  Every entry point that launches makes that
 // device current for the duration of the call and puts the caller's device back: one host thread may drive several
@@ -141,17 +146,31 @@ struct DeviceGuard {
 
 // problems whose statistics need a search kernel after k_stats (the Sokoban solver, the MiniDungeons planner)
 static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGRL_MDUNGEON || prob == PCGRL_DDAVE || prob == PCGRL_SMB; }
+// Sizes (the reference takes any width / height / solver_power: pcgrl_env.py:106-115, probs/problem.py:66-72, sokoban_prob.py:60-73).
+//   * maps of up to 64 x 64 cells run on the row-bitboard kernels, larger ones -- up to 255 x 255, the largest map whose cursor
+//     fits the observation's uint8 `pos` (narrow_rep.py:60-64) -- on the general path of bigmap.h (big_map below);
+//   * a search problem (sokoban, mdungeon, ddave) whose bordered level has at most 256 cells, with solver_power <= 16383, runs the
+//     compact searches; larger levels -- up to 4096 bordered cells -- and solver_power up to 1 000 000 run the general searches of
+//     search_big.h (big_search below);
+//   * smb: its own limits (kernels_smb.h).
+#define PCGRL_MAX_DIM 255
+#define PCGRL_MAX_LEVEL_CELLS 4096
+#define PCGRL_MAX_SOLVER_POWER 1000000
+static bool big_map(const pcgrl_config* c) { return c->prob != PCGRL_SMB && (c->width > 64 || c->height > 64); }
+static bool big_search(const pcgrl_config* c) {
+    return solver_prob(c->prob) && c->prob != PCGRL_SMB && ((c->width + 2) * (c->height + 2) > 256 || c->solver_power > 16383);
+}
 static int validate_config(const pcgrl_config* c) {
     if (!c) return PCGRL_EINVAL;
     if (c->prob < 0 || c->prob > 5 || c->rep < 0 || c->rep > 5) return PCGRL_EINVAL;
     if (c->num_envs < 1) return PCGRL_EINVAL;
     if (c->prob == PCGRL_SMB) {   // the platformer's grid is (width + 6) x height cells, a column index fits a byte (kernels_smb.h)
         if (c->width < 1 || c->width > 250 || c->height < 3 || c->height > SMB_MAX_H) return PCGRL_EINVAL;
-    } else if (c->width < 1 || c->width > 64 || c->height < 1 || c->height > 64) return PCGRL_EINVAL;
+    } else if (c->width < 1 || c->width > PCGRL_MAX_DIM || c->height < 1 || c->height > PCGRL_MAX_DIM) return PCGRL_EINVAL;
     if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
-    if (solver_prob(c->prob)) {   // limits of the solver kernels (sokoban_solver.h, mdungeon_solver.h)
-        if (c->prob != PCGRL_SMB && (c->width + 2) * (c->height + 2) > 256) return PCGRL_EINVAL;
-        if (c->solver_power < 1 || c->solver_power > 16383) return PCGRL_EINVAL;
+    if (solver_prob(c->prob)) {
+        if (c->prob != PCGRL_SMB && (c->width + 2) * (c->height + 2) > PCGRL_MAX_LEVEL_CELLS) return PCGRL_EINVAL;
+        if (c->solver_power < 1 || c->solver_power > (c->prob == PCGRL_SMB ? 16383 : PCGRL_MAX_SOLVER_POWER)) return PCGRL_EINVAL;
     }
     return PCGRL_OK;
 }
@@ -161,9 +180,13 @@ static void fill_params(const pcgrl_config* c, PcgrlParams* P) {
     memset(P, 0, sizeof(*P));
     P->prob = c->prob; P->rep = c->rep; P->num_envs = c->num_envs;
     P->width = c->width; P->height = c->height;
-    P->prob_width = c->width; P->prob_height = c->height;
+    P->prob_width = c->prob_width > 0 ? c->prob_width : c->width;
+    P->prob_height = c->prob_height > 0 ? c->prob_height : c->height;
     P->ntiles = ntiles_of(c->prob);
-    P->nplanes = c->prob == PCGRL_BINARY ? 1 : (c->prob == PCGRL_SMB ? 0 : 3);      // smb: statistics from the byte map (kernels_smb.h)
+    P->big = big_map(c) ? 1 : 0;
+    P->big_search = big_search(c) ? 1 : 0;
+    // smb, and maps beyond 64 x 64 (bigmap.h): no bit planes, everything from the byte map
+    P->nplanes = (c->prob == PCGRL_SMB || P->big) ? 0 : (c->prob == PCGRL_BINARY ? 1 : 3);
     P->group = c->height <= 16 ? 16 : 64;
     P->mask_bytes = c->width <= 32 ? 4 : 8;
     P->max_changes = c->max_changes; P->max_iterations = c->max_iterations;
@@ -206,7 +229,7 @@ static size_t sok_pool_nodes(int power, int prob = -1) {
 static_assert(SS_SMALL_NODES >= 4 * SS_SMALL_POPS + 4, "a small-tier search pushes up to four nodes per pop");
 // rows of the champion component per environment (binary, maps of at most 16 x 32): the incremental statistics path
 static size_t champ_bytes(const pcgrl_config* c) {
-    if (c->prob != PCGRL_BINARY) return 0;
+    if (c->prob != PCGRL_BINARY || big_map(c)) return 0;
     if (c->height <= 16) return (c->width <= 32 && c->num_envs <= WL_INC_ENV_MASK) ? align_up((size_t)c->num_envs * 64, 256) : 0;
     return c->num_envs <= WL_INC64_ENV_MASK ? align_up((size_t)c->num_envs * 64 * (c->width > 32 ? 8 : 4), 256) : 0;
 }
@@ -214,10 +237,34 @@ static size_t champ_bytes(const pcgrl_config* c) {
 static size_t fifo_words_bytes(const pcgrl_config* c) { return c->rep == PCGRL_NARROW ? align_up((size_t)c->num_envs * PCGRL_FIFO_N * 4, 256) : 0; }
 static size_t fifo_bytes(const pcgrl_config* c) { return c->rep == PCGRL_NARROW ? fifo_words_bytes(c) + align_up((size_t)c->num_envs * 4, 256) : 0; }
 static size_t scratch_bytes_base(const pcgrl_config* c);
-static size_t wide_sync_bytes(const pcgrl_config* c) { return (c->prob == PCGRL_BINARY && c->height > 16) ? align_up((size_t)c->num_envs * 16, 256) : 0; }
+static size_t wide_sync_bytes(const pcgrl_config* c) { return (c->prob == PCGRL_BINARY && c->height > 16 && !big_map(c)) ? align_up((size_t)c->num_envs * 16, 256) : 0; }
 static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c) + fifo_bytes(c) + wide_sync_bytes(c); }
+// The arena of the general searches (search_big.h): per resident block a node pool (4 children per pop), a 64-bit heap and a
+// visited table of 32-bit node indices.  As many blocks as fit a 6 GB budget (at most SOK_BLOCKS, at least 4).
+struct BigArenaDims { int nblocks, nodes_cap, tsize, stride; size_t heap_off, table_off, block_bytes; };
+static BigArenaDims big_arena_of(const pcgrl_config* c) {
+    BigArenaDims A;
+    const int cells = (c->width + 2) * (c->height + 2), nwb = (cells + 63) / 64, inner = c->width * c->height;
+    A.nodes_cap = 4 * c->solver_power + 4;
+    A.tsize = 1024;
+    while (A.tsize < 2 * c->solver_power) A.tsize <<= 1;
+    A.stride = c->prob == PCGRL_SOKOBAN ? sokb_stride(inner < SOKB_MAXC ? inner : SOKB_MAXC) : mdb_stride(nwb);
+    A.heap_off = align_up((size_t)A.nodes_cap * A.stride, 256);
+    A.table_off = A.heap_off + align_up((size_t)A.nodes_cap * 8, 256);
+    A.block_bytes = A.table_off + align_up((size_t)A.tsize * 4, 256);
+    const size_t budget = (size_t)6 << 30;
+    size_t nb = budget / A.block_bytes;
+    nb = nb > SOK_BLOCKS ? SOK_BLOCKS : (nb < 4 ? 4 : nb);
+    if (nb > (size_t)c->num_envs) nb = (size_t)c->num_envs;
+    A.nblocks = (int)nb;
+    return A;
+}
 static size_t scratch_bytes_base(const pcgrl_config* c) {
     size_t b = wl_bytes(c);
+    if (big_search(c)) {
+        const BigArenaDims A = big_arena_of(c);
+        return b + (size_t)A.nblocks * A.block_bytes + sok_sched_bytes(c->num_envs);
+    }
     if (solver_prob(c->prob)) {           // (an MdNode is as large as a SokNode)
         const size_t nodes = sok_pool_nodes(c->solver_power, c->prob);
         b += SOK_BLOCKS * align_up(nodes * sizeof(SokNode), 256);
@@ -241,7 +288,7 @@ static int device_setup(pcgrl_env* h) {
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_mt_genrand), tab, sizeof(tab)));
     }
     if (h->cfg.prob == PCGRL_SMB) return smb_device_setup(h);
-    if (solver_prob(h->cfg.prob)) return search_device_setup(h);
+    if (solver_prob(h->cfg.prob) && !big_search(&h->cfg)) return search_device_setup(h);
     return PCGRL_OK;
 }
 
@@ -286,10 +333,23 @@ int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
     h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
     h->profiling = 0; h->ev_used = 0; h->prof_steps = 0; h->obs_hold = 0; h->obs_incremental = 0; h->obs_synced = nullptr;
     memset(&h->B, 0, sizeof(h->B));
+    pcgrl_tuning_defaults(&h->tun);
     h->cfg = *c;
     fill_params(c, &h->P);
     pcgrl_query_layout(c, &h->L);
     *out = h;
+    return PCGRL_OK;
+}
+
+void pcgrl_tuning_defaults(pcgrl_tuning* t) {
+    if (!t) return;
+    int32_t* f = reinterpret_cast<int32_t*>(t);
+    for (size_t i = 0; i < sizeof(pcgrl_tuning) / sizeof(int32_t); i++) f[i] = -1;
+}
+int pcgrl_set_tuning(pcgrl_env* h, const pcgrl_tuning* t) {
+    if (!h || !t) return PCGRL_EINVAL;
+    if (h->bound) return PCGRL_ESTATE;            // the switches are resolved by pcgrl_bind
+    h->tun = *t;
     return PCGRL_OK;
 }
 
@@ -315,23 +375,25 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     DeviceGuard guard(h->device);
     int rc0 = device_setup(h);
     if (rc0) return rc0;
-    // environment switches (A/B measurements, tests) are read here, once: no getenv on the step path
-    h->no_wide = env_is_one("PCGRL_NO_WIDE") ? 1 : 0;
-    { const char* wvs = getenv("PCGRL_WIDE_WAVES"); h->wide_waves = wvs ? atoi(wvs) : 8; }
-    { const char* wp = getenv("PCGRL_WIDE_PAIRS"); h->wide_pairs = wp ? atoi(wp) : 1; }      // developer switch: 0 = every full item a block of its own
-    { const char* wg = getenv("PCGRL_WIDE_GRID"); h->wide_grid = wg ? atoi(wg) : 2048; if (h->wide_grid < 1) h->wide_grid = 2048; }   // blocks of k_stats_wide (they loop over the items; C5 steady: 768 .. 4096 -> 59.5 us/step, 8192 -> 63.5: a block costs ~4 us of prefix sums before its first item)
-    { const char* fz = getenv("PCGRL_FUSED_ZELDA"); h->fused_zelda = (fz && fz[0] == '0') ? 0 : 1; }   // =0: zelda steps as k_update + k_stats
-    h->no_fused = env_is_one("PCGRL_NO_FUSED") ? 1 : 0;
+    // developer switches (pcgrl_set_tuning): resolved here, once -- nothing on the step path reads them, and the library reads no
+    // environment variables
+    const pcgrl_tuning& T = h->tun;
+    h->no_wide = tun_or(T.no_wide, 0) ? 1 : 0;
+    h->wide_waves = tun_or(T.wide_waves, 8);
+    h->wide_pairs = tun_or(T.wide_pairs, 1);           // 0 = every full item of a tall map a block of its own
+    h->wide_grid = tun_or(T.wide_grid, 2048);           // blocks of k_stats_wide (they loop over the items; C5 steady: 768 .. 4096 -> 59.5 us/step, 8192 -> 63.5: a block costs ~4 us of prefix sums before its first item)
+    if (h->wide_grid < 1) h->wide_grid = 2048;
+    h->fused_zelda = tun_or(T.fused_zelda, 1) ? 1 : 0;  // 0: zelda steps as k_update + k_stats
+    h->no_fused = tun_or(T.no_fused, 0) ? 1 : 0;
     {   // k_step: environments per block (see launch_step_pm).  The largest block that still gives (about) every compute unit one and
         // is resident in one round: 256 environments -> one block per CU (LDS), 128 -> two, 64 -> four.
-        const char* eb = getenv("PCGRL_STEP_EPB");
         const int n_ = h->cfg.num_envs;
-        h->step_epb = eb ? atoi(eb) : ((n_ >= 192 * 256 && n_ <= 256 * 256) ? 256 : (n_ >= 192 * 128 ? 128 : 64));
+        h->step_epb = T.step_epb > 0 ? T.step_epb : ((n_ >= 192 * 256 && n_ <= 256 * 256) ? 256 : (n_ >= 192 * 128 ? 128 : 64));
         if (h->step_epb != 128 && h->step_epb != 256) h->step_epb = 64;
-        const char* sh_ = getenv("PCGRL_SMB_LDS_HEAP");        // developer switch: heap words a k_smb search keeps in LDS
-        h->smb_heap = sh_ ? atoi(sh_) : SMB_LDS_HEAP;
+        h->smb_heap = T.smb_lds_heap > 0 ? T.smb_lds_heap : SMB_LDS_HEAP;        // heap words a k_smb search keeps in LDS
         if (h->smb_heap < 256 || h->smb_heap > 4096) h->smb_heap = SMB_LDS_HEAP;
     }
+    const bool no_inc = tun_or(T.no_inc, 0) != 0;       // every change takes the full statistics (A/B, tests)
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
     B.heat_end = B.heat + (size_t)h->cfg.num_envs * h->cfg.width * h->cfg.height;
@@ -355,13 +417,10 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     HIPCHK(hipMemsetAsync(B.wl_cnt, 0, WL_CNT_BYTES + 256, (hipStream_t)stream));
     B.sok_pool = nullptr; B.sok_heap = nullptr; B.sok_table = nullptr;
     B.zelda_inc = (h->cfg.prob == PCGRL_ZELDA && h->cfg.rep <= PCGRL_REP_TURTLE && h->cfg.height <= 16 && h->cfg.width <= 32 &&
-                   h->cfg.num_envs <= WL_INC_ENV_MASK && !getenv("PCGRL_NO_INC")) ? 1 : 0;
-    {
-        const char* pm = getenv("PCGRL_PAIR_MIN");
-        B.pair_min = pm ? atoi(pm) : 2048;
-    }
+                   h->cfg.num_envs <= WL_INC_ENV_MASK && !no_inc) ? 1 : 0;
+    B.pair_min = tun_or(T.pair_min, 2048);
     B.champ = nullptr;
-    if (champ_bytes(&h->cfg) && !getenv("PCGRL_NO_INC")) {      // PCGRL_NO_INC=1: every change takes the full statistics (A/B, tests)
+    if (champ_bytes(&h->cfg) && !no_inc) {
         B.champ = s + scratch_bytes_base(&h->cfg);
         HIPCHK(hipMemsetAsync(B.champ, 0, champ_bytes(&h->cfg), (hipStream_t)stream));
     }
@@ -374,16 +433,29 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         HIPCHK(hipMemsetAsync(B.fifo_tag, 0xFF, (size_t)h->cfg.num_envs * 4, (hipStream_t)stream));     // -1: nothing cached yet
     }
     B.wide_sync = nullptr; B.wide_epoch = 0;
-    { const char* wf = getenv("PCGRL_WIDE_FEW"); B.wide_few = wf ? atoi(wf) : WL_WIDE_FEW_REGIONS; }
+    B.wide_few = tun_or(T.wide_few, WL_WIDE_FEW_REGIONS);
     if (wide_sync_bytes(&h->cfg)) {
         B.wide_sync = (int32_t*)(s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg) + fifo_bytes(&h->cfg));
         HIPCHK(hipMemsetAsync(B.wide_sync, 0, wide_sync_bytes(&h->cfg), (hipStream_t)stream));
     }
-    {   // PCGRL_INLINE_RESET=0 routes resets through the reset list + k_reset instead (A/B measurements)
-        const char* ir = getenv("PCGRL_INLINE_RESET");
-        B.inline_reset = (!solver_prob(h->cfg.prob) && !(ir && ir[0] == '0')) ? 1 : 0;
-    }
-    if (solver_prob(h->cfg.prob)) {
+    // inline_reset = 0 routes resets through the reset list + k_reset instead (A/B measurements)
+    B.inline_reset = (!solver_prob(h->cfg.prob) && tun_or(T.inline_reset, 1) != 0) ? 1 : 0;
+    B.big_arena = nullptr;
+    if (big_search(&h->cfg)) {
+        // levels / solver_power beyond the compact searches: the general searches' arena, then the scheduling words
+        h->alloc_solver_power = h->cfg.solver_power;
+        const BigArenaDims A = big_arena_of(&h->cfg);
+        uint8_t* a = s + wl_bytes(&h->cfg);
+        B.big_arena = a;
+        a += (size_t)A.nblocks * A.block_bytes;
+        B.sok_res = (int32_t*)a;
+        B.sok_cnt = B.sok_res + (size_t)h->cfg.num_envs * 16;
+        B.sok_stop = B.sok_cnt + h->cfg.num_envs;
+        B.sok_sync = (int32_t*)(a + align_up((size_t)h->cfg.num_envs * 18 * 4, 256));
+        HIPCHK(hipMemsetAsync(a, 0, sok_sched_bytes(h->cfg.num_envs), (hipStream_t)stream));
+        B.sok_use_lds = 0; B.sok_fast_maxc = -1; B.md_only_agent = -1; B.sok_hard_cap = 0; B.sok_spawn_iters = SOK_SPAWN_ITERS;
+        B.sok_table_size = A.tsize; B.sok_pool_stride = 0; B.sok_heap_stride = 0;
+    } else if (solver_prob(h->cfg.prob)) {
         // the arena is sized for the solver_power the buffers were allocated with
         const int power = h->alloc_solver_power = h->cfg.solver_power;
         const size_t nodes = sok_pool_nodes(power, h->cfg.prob), hnodes = 4 * (size_t)power + 4;
@@ -398,18 +470,11 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         HIPCHK(hipMemsetAsync(a, 0, sok_sched_bytes(h->cfg.num_envs), (hipStream_t)stream));
         a += sok_sched_bytes(h->cfg.num_envs);
         B.sok_use_lds = power <= SOK_LDS_POWER || h->cfg.prob == PCGRL_SMB;     // (smb has its own heap split, kernels_smb.h)
-        {   // PCGRL_SOK_GENERIC=1: every level takes the generic search (tests)
-            const char* sg = getenv("PCGRL_SOK_GENERIC");
-            B.sok_fast_maxc = (sg && sg[0] == '1') ? -1 : SOKF_MAXC;
-            const char* oa = getenv("PCGRL_MD_ONLY_AGENT");
-            B.md_only_agent = oa ? atoi(oa) : -1;
-            const char* hc = getenv("PCGRL_SOK_HARD_CAP");
-            B.sok_hard_cap = hc ? atoi(hc) : SOK_HARD_CAP;
-            const char* spn = getenv("PCGRL_SOK_SPAWN");
-            B.sok_spawn_iters = spn ? atoi(spn) : SOK_SPAWN_ITERS;
-            if (B.sok_spawn_iters < 1) B.sok_spawn_iters = SOK_SPAWN_ITERS;
-            if (B.sok_hard_cap < 0 || B.sok_hard_cap > SOK_HARD_CAP) B.sok_hard_cap = SOK_HARD_CAP;
-        }
+        B.sok_fast_maxc = tun_or(T.sok_generic, 0) ? -1 : SOKF_MAXC;       // sok_generic: every level takes the generic search (tests)
+        B.md_only_agent = T.md_only_agent;                                  // (-1: all four agents)
+        B.sok_hard_cap = tun_or(T.sok_hard_cap, SOK_HARD_CAP);
+        B.sok_spawn_iters = T.sok_spawn > 0 ? T.sok_spawn : SOK_SPAWN_ITERS;
+        if (B.sok_hard_cap > SOK_HARD_CAP) B.sok_hard_cap = SOK_HARD_CAP;
         B.sok_table_size = sok_table_size(power);
         B.sok_heap_stride = (int32_t)(align_up(hnodes * 4, 256) / 4);
         if (!B.sok_use_lds) {
@@ -430,6 +495,7 @@ int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
         c->width != h->cfg.width || c->height != h->cfg.height)
         return PCGRL_EINVAL;
     if (h->bound && solver_prob(c->prob) && c->solver_power > h->alloc_solver_power) return PCGRL_EINVAL;   // arena too small: re-create
+    if (h->bound && big_search(c) != big_search(&h->cfg)) return PCGRL_EINVAL;                              // another search family, another arena: re-create
     h->cfg = *c;
     fill_params(c, &h->P);
     return PCGRL_OK;
@@ -541,7 +607,33 @@ static int launch_stats_p(pcgrl_env* h, int list, int parity, int mode, int clr,
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
+// Maps beyond 64 x 64 (bigmap.h, kernels_big.h): a wavefront per item, as many wavefronts per block as the LDS holds
+template <int PROB>
+static int launch_big_p(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, int park_list, hipStream_t st) {
+    const PcgrlParams& P = h->P;
+    const size_t per_wave = big_wave_lds(P.width, P.height);
+    int nw = (int)((size_t)(150 * 1024) / per_wave);
+    nw = nw > 4 ? 4 : nw;
+    if (nw < 1) return PCGRL_EINVAL;
+    const size_t lds = (size_t)nw * per_wave;
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big<PROB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = grid_for(P.num_envs, nw, 2048);
+    const int gen = (P.random_start || !h->has_old) ? 1 : 0;
+    hipLaunchKernelGGL((k_big<PROB>), dim3(grid), dim3(nw * 64), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen, park_list);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+static int launch_big(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, int park_list, hipStream_t st) {
+    switch (h->P.prob) {
+        case PCGRL_PROB_BINARY: return launch_big_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, inline_reset, park_list, st);
+        case PCGRL_PROB_ZELDA: return launch_big_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, inline_reset, park_list, st);
+        case PCGRL_PROB_MDUNGEON: return launch_big_p<PCGRL_PROB_MDUNGEON>(h, list, parity, mode, clr, 0, park_list, st);
+        case PCGRL_PROB_DDAVE: return launch_big_p<PCGRL_PROB_DDAVE>(h, list, parity, mode, clr, 0, park_list, st);
+        default: return launch_big_p<PCGRL_PROB_SOKOBAN>(h, list, parity, mode, clr, 0, park_list, st);
+    }
+}
 PCGRL_LOCAL int launch_stats(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, hipStream_t st) {
+    if (h->P.big) return launch_big(h, list, parity, mode, clr, inline_reset, -1, st);
     switch (h->P.prob) {
         case PCGRL_PROB_BINARY: return launch_stats_p<PCGRL_PROB_BINARY>(h, list, parity, mode, clr, inline_reset, st);
         case PCGRL_PROB_ZELDA: return launch_stats_p<PCGRL_PROB_ZELDA>(h, list, parity, mode, clr, inline_reset, st);
@@ -678,7 +770,22 @@ PCGRL_LOCAL int search_device_setup(pcgrl_env* h) {   // the search kernels use 
     HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PCGRL_OK;
 }
+template <int PROB>
+static int launch_search_big_p(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st) {
+    const BigArenaDims D = big_arena_of(&h->cfg);
+    const BigSearchArena A = {h->B.big_arena, D.block_bytes, D.heap_off, D.table_off, D.nodes_cap, D.tsize};
+    const int cells = (h->P.width + 2) * (h->P.height + 2);
+    const size_t lds = (((size_t)cells * 4 + 15) & ~(size_t)15) + (size_t)(BIG_MAX_WORDS + SOKB_MAXC / 64) * 8;
+    hipLaunchKernelGGL((k_search_big<PROB>), dim3(D.nblocks), dim3(64), lds, st, h->P, h->B, A, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
 PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st) {
+    if (h->P.big_search) {
+        if (h->P.prob == PCGRL_PROB_DDAVE) return launch_search_big_p<PCGRL_PROB_DDAVE>(h, sync, list_a, mode_a, list_b, mode_b, parity, rst_list, clr, st);
+        if (h->P.prob == PCGRL_PROB_MDUNGEON) return launch_search_big_p<PCGRL_PROB_MDUNGEON>(h, sync, list_a, mode_a, list_b, mode_b, parity, rst_list, clr, st);
+        return launch_search_big_p<PCGRL_PROB_SOKOBAN>(h, sync, list_a, mode_a, list_b, mode_b, parity, rst_list, clr, st);
+    }
     const size_t lds = h->B.sok_use_lds ? (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4 : 0;   // heap + 64-bit-key table
     if (h->P.prob == PCGRL_PROB_DDAVE)
         hipLaunchKernelGGL(k_ddave<0>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
@@ -728,6 +835,7 @@ static int launch_reset_p(pcgrl_env* h, int list, int park_list, int parity, int
 }
 // map generation + start stats of every environment on the reset list
 PCGRL_LOCAL int launch_reset(pcgrl_env* h, int list, int park_list, int parity, int clr, hipStream_t st) {
+    if (h->P.big) return launch_big(h, list, parity, MODE_START, clr, 0, park_list, st);
     switch (h->P.prob) {
         case PCGRL_PROB_BINARY: return launch_reset_p<PCGRL_PROB_BINARY>(h, list, park_list, parity, clr, st);
         case PCGRL_PROB_ZELDA: return launch_reset_p<PCGRL_PROB_ZELDA>(h, list, park_list, parity, clr, st);
@@ -740,6 +848,13 @@ PCGRL_LOCAL int launch_reset(pcgrl_env* h, int list, int park_list, int parity, 
 
 PCGRL_LOCAL int launch_planes_from_map(pcgrl_env* h, const uint8_t* maps, hipStream_t st) {     // pcgrl_set_maps
     const PcgrlParams& P = h->P;
+    if (P.big) {            // no planes to rebuild: the byte maps are the state
+        const size_t total = (size_t)P.num_envs * P.width * P.height;
+        const size_t g = (total + 255) / 256;
+        hipLaunchKernelGGL(k_copy_map<0>, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(256), 0, st, P, h->B, maps);
+        HIPCHK(hipGetLastError());
+        return PCGRL_OK;
+    }
     const size_t lds = 4 * (size_t)((P.width * P.height + 15) & ~15);
     const int grid = grid_for(P.num_envs, 4, 4096);
     if (P.mask_bytes == 4)
@@ -1052,6 +1167,13 @@ int pcgrl_status(pcgrl_env* h, void* stream, int32_t* status) {
     DeviceGuard guard(h->device);
     HIPCHK(hipMemcpyAsync(status, h->B.status, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return PCGRL_OK;
+}
+
+int pcgrl_clear_status(pcgrl_env* h, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    DeviceGuard guard(h->device);
+    HIPCHK(hipMemsetAsync(h->B.status, 0, sizeof(int32_t), (hipStream_t)stream));
     return PCGRL_OK;
 }
 

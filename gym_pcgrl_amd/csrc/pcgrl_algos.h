@@ -45,7 +45,8 @@ struct PcgrlParams {
     int32_t prob_width, prob_height;   // the Problem's own width/height (zelda_prob.py:99, sokoban_prob.py:140)
     int32_t max_potions, max_treasures;   // mdungeon_prob.py:25-26
     int32_t max_diamonds, min_spikes, target_jumps;   // ddave_prob.py:23-27
-    int32_t min_empty, min_enemies, min_jumps, pad_, pad2_;   // smb_prob.py:21-24
+    int32_t min_empty, min_enemies, min_jumps;   // smb_prob.py:21-24
+    int32_t big, big_search;   // the map is beyond the row-bitboard kernels (bigmap.h) / the level or solver_power beyond the compact searches (search_big.h)
     double target_col_enemies;         // mdungeon_prob.py:28
     double rewards[PCGRL_MAX_REWARDS];
     double cdf[PCGRL_MAX_TILES];

@@ -97,7 +97,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
                 mt[mt_wrap(s + 1)] = yb;
                 const double u = mt_to_double(mt_temper(ya), mt_temper(yb));
                 const uint8_t t = (uint8_t)pcgrl_pick_tile_c<NT>(cdf, u);
-                tiles[c] = t;
+                if (tiles) tiles[c] = t;              // (k_big passes no staging area: its maps are read back from memory)
                 map_g[c] = t;
                 old_g[c] = t;
             }
@@ -107,7 +107,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         }
     } else {
         // representation.py:44-45: restore the first map of this environment
-        for (int c = lane; c < cells; c += 64) { const uint8_t t = old_g[c]; tiles[c] = t; map_g[c] = t; }
+        for (int c = lane; c < cells; c += 64) { const uint8_t t = old_g[c]; if (tiles) tiles[c] = t; map_g[c] = t; }
     }
     __builtin_amdgcn_wave_barrier();
     TL(14);

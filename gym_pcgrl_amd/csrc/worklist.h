@@ -106,6 +106,7 @@ struct DevBufs {
     // pipelines draw from the ring and mark it invalid (-1).
     uint32_t* fifo; int32_t* fifo_tag;
     ObsSpec obs;
+    uint8_t* big_arena;              // search_big.h: per-block node pool + heap + visited table (levels / solver_power beyond the compact searches)
 };
 #define PCGRL_FIFO_N 8
 

@@ -56,7 +56,11 @@ class InfoBatch:
 class BatchedPcgrlEnv:
     metadata = {"render.modes": []}
 
-    def __init__(self, prob="binary", rep="narrow", num_envs=1, device=None, seed=None, auto_reset=True):
+    def __init__(self, prob="binary", rep="narrow", num_envs=1, device=None, seed=None, auto_reset=True, strict_actions=False, tuning=None):
+        """strict_actions: check after every step() / rollout() whether an action was outside the action space and raise IndexError
+        at the offending call, like the reference does (wide_rep.py:68-69 ...); costs a device synchronisation per step, so it is
+        off by default -- the actions are then clamped and the status word reports it (check_status()).
+        tuning: {switch: value} for the library's developer switches (include/pcgrl_hip.h pcgrl_tuning; A/B measurements, tests)."""
         import torch
         self._torch = torch
         self._lib = _lib.load()                      # fails loudly when the HIP library is absent
@@ -64,6 +68,8 @@ class BatchedPcgrlEnv:
         self._rep = REPRESENTATIONS[rep]()
         self.num_envs = int(num_envs)
         self.auto_reset = bool(auto_reset)
+        self.strict_actions = bool(strict_actions)
+        self._tuning = dict(tuning or {})
         if device is None:
             device = "cuda:0"
         self.device = torch.device(device)
@@ -77,6 +83,7 @@ class BatchedPcgrlEnv:
         self._rng = None
         self._episode = None          # RNG tensors survive re-allocation on width/height changes
         self._needs_reset = True
+        self._realloc = False
         self._alloc_dims = None
         self._probs_dirty = False
         self._obs_spec = None          # bind_observation(): (out tensor, h, w, centered, pad, onehot)
@@ -99,10 +106,13 @@ class BatchedPcgrlEnv:
         return len(self._prob.get_tile_types())
 
     # ------------------------------------------------------------------ config plumbing
-    def _config(self):
+    def _config(self, map_dims=None):
+        """map_dims: (width, height) of the allocated maps when they are not the problem's -- adjust_param(width, height) without a
+        reset(): the reference goes on stepping the old maps with the problem's new size in its formulas (pcgrl_env.py:106-115)."""
         c = _lib.Config()
         c.prob, c.rep, c.num_envs = PROB_IDS[self._prob.name], REP_IDS[self._rep.name], self.num_envs
-        c.width, c.height = int(self._prob._width), int(self._prob._height)
+        c.width, c.height = (int(self._prob._width), int(self._prob._height)) if map_dims is None else (int(map_dims[0]), int(map_dims[1]))
+        c.prob_width, c.prob_height = int(self._prob._width), int(self._prob._height)
         c.max_changes, c.max_iterations = int(self._max_changes), int(self._max_iterations)
         c.random_start, c.random_tile, c.warp, c.random_probs = 1, 1, 0, 0
         c.auto_reset = int(self.auto_reset)
@@ -162,6 +172,8 @@ class BatchedPcgrlEnv:
                 assert t.is_contiguous() and t.numel() * t.element_size() >= getattr(lay, name), name
         handle = C.c_void_p()
         _lib.check(self._lib.pcgrl_create(C.byref(cfg), C.byref(handle)), "pcgrl_create")
+        tun = _lib.make_tuning(self._tuning)
+        _lib.check(self._lib.pcgrl_set_tuning(handle, C.byref(tun)), "pcgrl_set_tuning")
         bufs = _lib.Buffers()
         for name in _lib.BUFFER_NAMES:
             setattr(bufs, name, b[name].data_ptr() if b[name] is not None else None)
@@ -216,14 +228,22 @@ class BatchedPcgrlEnv:
         self._rep.adjust_param(**kwargs)
         self._update_spaces()
         if self._handle is not None:
-            if (self._prob._width, self._prob._height) != self._alloc_dims:
-                self._needs_reset = True      # buffers are re-allocated by the next reset()
-            else:
-                cfg = self._config()
-                _lib.check(self._lib.pcgrl_configure(self._handle, C.byref(cfg)), "pcgrl_configure")
-                if self._prob._probs_touched:
-                    _lib.check(self._lib.pcgrl_set_tile_probs(self._handle, self._stream()), "pcgrl_set_tile_probs")
-                    self._prob._probs_touched = False
+            # A new width / height takes effect on the maps at the next reset() (representation.py:40-45: only reset() makes a map of
+            # the new size); until then the allocated maps go on being stepped, with the problem's new size in its formulas -- what
+            # the reference does.  Everything else is applied to the live handle.
+            stale = (self._prob._width, self._prob._height) != self._alloc_dims
+            cfg = self._config(self._alloc_dims if stale else None)
+            rc = self._lib.pcgrl_configure(self._handle, C.byref(cfg))
+            if rc == _lib.PCGRL_EINVAL and not self._needs_reset:
+                # the handle cannot take the change in place (a solver_power beyond what its arena was sized for, or one that moves the
+                # searches to the other kernel family): the buffers are re-allocated by the next reset(), which has to come first
+                self._realloc = True
+                self._needs_reset = True
+            elif rc != _lib.PCGRL_EINVAL:
+                _lib.check(rc, "pcgrl_configure")
+            if rc == 0 and self._prob._probs_touched:
+                _lib.check(self._lib.pcgrl_set_tile_probs(self._handle, self._stream()), "pcgrl_set_tile_probs")
+                self._prob._probs_touched = False
         self._probs_dirty = self._probs_dirty or self._prob._probs_touched
 
     def _obs(self):
@@ -237,8 +257,9 @@ class BatchedPcgrlEnv:
 
     def reset(self):
         """Reset every environment (pcgrl_env.py:66-76).  Returns the observation dict of tensors."""
-        if self._handle is None or (self._prob._width, self._prob._height) != self._alloc_dims:
+        if self._handle is None or (self._prob._width, self._prob._height) != self._alloc_dims or self._realloc:
             self._allocate()
+            self._realloc = False
         _lib.check(self._lib.pcgrl_reset(self._handle, self._stream()), "pcgrl_reset")
         self._needs_reset = False
         return self._obs()
@@ -260,10 +281,12 @@ class BatchedPcgrlEnv:
         (wide: x, y, tile).  Returns (obs, reward f64[N], done bool[N], InfoBatch); tensors are views
         of the live state and are overwritten by the next step."""
         if self._needs_reset:
-            raise RuntimeError("reset() must be called before step() (and again after adjust_param changed width/height)")
+            raise RuntimeError("reset() must be called before step()")
         a = self._as_actions(actions)
         self._last_actions = a   # keep the buffer alive until the launches are done
         _lib.check(self._lib.pcgrl_step(self._handle, C.c_void_p(a.data_ptr()), self._stream()), "pcgrl_step")
+        if self.strict_actions:
+            self.check_status()
         b = self._bufs
         decode = self._prob.decode_rows if self._prob.packed_rows else None
         info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
@@ -276,7 +299,7 @@ class BatchedPcgrlEnv:
         would leave them; where the whole step is one kernel (binary maps of at most 16 rows) the tape is ONE launch.
         `out`: optional preallocated (reward f64 [T,N], done u8 [T,N], info i32 [T,N,10] or None) on this device."""
         if self._needs_reset:
-            raise RuntimeError("reset() must be called before rollout() (and again after adjust_param changed width/height)")
+            raise RuntimeError("reset() must be called before rollout()")
         torch = self._torch
         a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
         T = int(a.shape[0])
@@ -298,6 +321,8 @@ class BatchedPcgrlEnv:
         _lib.check(self._lib.pcgrl_rollout(self._handle, C.c_void_p(a.data_ptr()), T, C.c_void_p(rew.data_ptr()),
                                            C.c_void_p(done.data_ptr()), C.c_void_p(info.data_ptr()) if want_info else None,
                                            self._stream()), "pcgrl_rollout")
+        if self.strict_actions:
+            self.check_status()
         ib = None
         if want_info:
             decode = self._prob.decode_rows if self._prob.packed_rows else None
@@ -402,8 +427,11 @@ class BatchedPcgrlEnv:
         """Raise if a kernel flagged an unsupported case (synchronises)."""
         st = C.c_int32()
         _lib.check(self._lib.pcgrl_status(self._handle, self._stream(), C.byref(st)), "pcgrl_status")
+        if st.value and self.strict_actions:       # report this call's problem only once: the word is sticky otherwise
+            _lib.check(self._lib.pcgrl_clear_status(self._handle, self._stream()), "pcgrl_clear_status")
         if st.value & 1:
-            raise RuntimeError("sokoban level with more than 32 crates: outside the solver kernel's limits")
+            raise RuntimeError("a level was outside the limits of a search kernel (a Sokoban level with more crates than the search takes -- 32 in the "
+                               "compact searches, 256 in the general ones -- or more than 255 tiles / collected things of one kind in a packed statistics row)")
         if st.value & 2:
             raise IndexError("an action outside the action space was passed to step()/rollout() (it was clamped into range; "
                              "the reference raises IndexError or writes the bad value)")

@@ -36,8 +36,9 @@ extern "C" {
  * 4: + the mdungeon problem: pcgrl_config grew (max_potions, max_treasures, target_col_enemies, rewards[12]).
  * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps).  6: + pcgrl_rollout.
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
- *    clamped actions. */
-#define PCGRL_ABI_VERSION 9
+ *    clamped actions.  10: + pcgrl_tuning / pcgrl_set_tuning (the library reads no environment variables any more); pcgrl_config
+ *    grew (prob_width, prob_height); maps up to 255 x 255, search levels up to 4096 bordered cells, solver_power up to 1 000 000. */
+#define PCGRL_ABI_VERSION 10
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -50,7 +51,12 @@ enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2, PCGRL_NARROW_CAST = 3
 typedef struct pcgrl_config {
     int32_t prob, rep;
     int32_t num_envs;
-    int32_t width, height;                 /* Problem._width/_height; 1..64 each (smb: width up to 250, height 3..32) */
+    int32_t width, height;                 /* the maps' width / height: 1..255 each (search problems: (width + 2) * (height + 2) <= 4096;
+                                              smb: width up to 250, height 3..32).  Up to 64 x 64 the row-bitboard kernels, beyond
+                                              them the general path (csrc/bigmap.h) */
+    int32_t prob_width, prob_height;       /* Problem._width/_height when they differ from the maps' -- adjust_param(width, height)
+                                              without a reset(): the reference goes on stepping the old maps with the problem's new
+                                              size in its formulas (pcgrl_env.py:106-115, zelda_prob.py:99); 0 = same as width / height */
     int32_t max_changes, max_iterations;   /* pcgrl_env.py:33-34 / :108-110, computed by the host */
     int32_t random_start, random_tile, warp, random_probs;
     int32_t auto_reset;                    /* 1: a done env is reset inside step (vector-env semantics) */
@@ -101,6 +107,29 @@ typedef struct pcgrl_buffers {
 
 typedef struct pcgrl_env pcgrl_env;
 
+/* Developer switches: which of several equivalent kernels / schedules a handle uses.  Every setting gives the same results (the
+ * tests run the alternatives against the same fixtures); they exist for A/B measurements and to force the rarely taken paths in
+ * tests.  A negative field = the library's default (pcgrl_tuning_defaults sets them all).  Set with pcgrl_set_tuning between
+ * pcgrl_create and pcgrl_bind; the library reads no environment variables and keeps no process-wide state. */
+typedef struct pcgrl_tuning {
+    int32_t no_fused;        /* 1: binary / zelda steps as k_update + k_stats instead of the one-launch k_step */
+    int32_t fused_zelda;     /* 0: zelda steps as two launches (binary unaffected) */
+    int32_t step_epb;        /* environments per block of k_step: 64, 128 or 256 (default: from the batch size) */
+    int32_t no_inc;          /* 1: no incremental statistics -- every change recomputes */
+    int32_t inline_reset;    /* 0: resets through the reset list + k_reset instead of inside the statistics kernel */
+    int32_t pair_min;        /* certain resets per launch from which a wavefront of k_stats takes two (default 2048) */
+    int32_t no_wide;         /* 1: tall binary maps (17..64 rows) on one wavefront per map instead of k_stats_wide */
+    int32_t wide_waves;      /* wavefronts per tall map: 4 or 8 (default 8) */
+    int32_t wide_grid;       /* blocks of k_stats_wide (default 2048) */
+    int32_t wide_pairs;      /* 0: every full item of a tall map a block of its own */
+    int32_t wide_few;        /* region count up to which a tall map's full item takes half a block (default 32) */
+    int32_t sok_generic;     /* 1: every Sokoban / MiniDungeons / Dave level takes the generic (not the register-resident) search */
+    int32_t sok_hard_cap;    /* levels k_sokoban may publish to idle blocks per launch (default 4096) */
+    int32_t sok_spawn;       /* pops after which a Sokoban BFS publishes its level (default 128) */
+    int32_t md_only_agent;   /* >= 0: the MiniDungeons planner runs only this agent (timing experiments: results are then wrong) */
+    int32_t smb_lds_heap;    /* heap words a k_smb search keeps in LDS (default 2048; tests: the overflow path) */
+} pcgrl_tuning;
+
 int pcgrl_abi_version(void);
 const char* pcgrl_error_string(int code);
 int pcgrl_last_hip_error(void);
@@ -108,6 +137,8 @@ int pcgrl_last_hip_error(void);
 int pcgrl_query_layout(const pcgrl_config* cfg, pcgrl_layout* out);
 int pcgrl_create(const pcgrl_config* cfg, pcgrl_env** out);
 int pcgrl_destroy(pcgrl_env* env);
+void pcgrl_tuning_defaults(pcgrl_tuning* t);
+int pcgrl_set_tuning(pcgrl_env* env, const pcgrl_tuning* t);   /* between pcgrl_create and pcgrl_bind (PCGRL_ESTATE afterwards) */
 int pcgrl_bind(pcgrl_env* env, const pcgrl_buffers* bufs, void* stream);
 /* Change parameters that do not alter buffer sizes (anything but prob/rep/num_envs/width/height). */
 int pcgrl_configure(pcgrl_env* env, const pcgrl_config* cfg);
@@ -173,11 +204,16 @@ int pcgrl_bind_episode_stats(pcgrl_env* env, double* ep_return, int32_t* ep_leng
  * u32 [16384] and n_out DEVICE i32 [1]: the heap array afterwards.  At most 16 384 entries are kept (further pushes are dropped).
  * tests/test_gpu_parity.py holds the result against Python's heapq slot for slot. */
 int pcgrl_selftest_heap(const uint32_t* ops, int32_t n_ops, uint32_t* pops, uint32_t* heap_out, int32_t* n_out, void* stream);
-/* Sticky device status word, 0 = fine.  Bit 0 (1): a sokoban level had more crates than the solver supports.
+/* Sticky device status word, 0 = fine.  Bit 0 (1): a level was outside a search kernel's limits -- a Sokoban level with more crates
+ * than the search takes (32 in the compact searches, 256 in the general ones of csrc/search_big.h), or more than 255 tiles / collected
+ * things of one kind in a packed statistics row (Dave, MiniDungeons on large maps): the statistics of that level are then not exact.
  * Bit 1 (2): an action outside the action space was clamped into it (the reference raises IndexError or writes the
  * bad value: narrow_rep.py:101-103, wide_rep.py:68-69, turtle_rep.py:101-129, wrappers.py:139-154).  Bit 2 (4):
  * pcgrl_set_maps was handed a tile id >= the number of tiles (clamped).  Synchronises the stream. */
 int pcgrl_status(pcgrl_env* env, void* stream, int32_t* status);
+/* Zero the status word (asynchronous on the stream): a caller that turns bit 1 into the reference's IndexError at the offending
+ * call clears it afterwards, so that the next call reports only its own actions. */
+int pcgrl_clear_status(pcgrl_env* env, void* stream);
 
 
 /* Per-phase GPU timing of pcgrl_step with HIP events recorded on the caller's stream (bench.py's

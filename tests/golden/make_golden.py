@@ -233,6 +233,106 @@ def gen_stats_zelda():
         save("stats_zelda_%dx%d" % (h, w), maps=np.array(maps), stats=res, keys=np.array(STAT_KEYS["zelda"]))
 
 
+def gen_stats_big():
+    """Maps beyond 64 x 64 (round 4): the reference takes any width / height (pcgrl_env.py:106-115, probs/problem.py:66-72)."""
+    rs = np.random.RandomState(101)
+    prob = PROBLEMS["binary"]()
+    for (h, w, nrand) in [(100, 100, 6), (65, 130, 6), (70, 200, 3), (255, 3, 4), (2, 255, 4)]:
+        prob._width, prob._height = w, h
+        t0 = time.time()
+        maps = adversarial_binary(h, w) + random_maps(rs, nrand, h, w, 2)
+        res = np.array([[int(stats_of(prob, m)[k]) for k in STAT_KEYS["binary"]] for m in maps], dtype=np.int64)
+        print("  binary %dx%d: %d maps, %.1fs" % (h, w, len(maps), time.time() - t0))
+        save("stats_binary_%dx%d" % (h, w), maps=np.array(maps), stats=res, keys=np.array(STAT_KEYS["binary"]))
+    prob = PROBLEMS["zelda"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng) in [(80, 70, 6, 40), (20, 130, 4, 40)]:
+        prob._width, prob._height = w, h
+        t0 = time.time()
+        maps = random_maps(rs, nrand, h, w, 8, pr) + engineer_zelda(rs, h, w, neng)
+        res = np.array([[int(stats_of(prob, m)[k]) for k in STAT_KEYS["zelda"]] for m in maps], dtype=np.int64)
+        print("  zelda %dx%d: %d maps, precondition hit %d, key/door branch %d, %.1fs" % (
+            h, w, len(maps), int(((res[:, 0] == 1) & (res[:, 4] == 1)).sum()),
+            int(((res[:, 0] == 1) & (res[:, 4] == 1) & (res[:, 1] == 1) & (res[:, 2] == 1)).sum()), time.time() - t0))
+        save("stats_zelda_%dx%d" % (h, w), maps=np.array(maps), stats=res, keys=np.array(STAT_KEYS["zelda"]))
+
+
+def gen_stats_big_search():
+    """The search problems beyond the compact searches (round 4): bordered levels of more than 256 cells, solver_power beyond
+    16 383 (sokoban_prob.py:60-73, mdungeon_prob.py:68-84, ddave_prob.py:67-82 take any)."""
+    rs = np.random.RandomState(211)
+    prob = PROBLEMS["sokoban"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng, max_k, power, smax) in [(20, 20, 4, 14, 3, 700, 0.3), (16, 24, 0, 8, 2, 2500, 0.12), (8, 8, 0, 8, 4, 20000, 0.03)]:
+        prob._width, prob._height, prob._solver_power = w, h, power
+        maps = random_maps(rs, nrand, h, w, 5, pr) + engineer_sokoban(rs, h, w, neng, max_k, smax)
+        t0 = time.time()
+        res, agents = [], []
+        for m in maps:
+            st = stats_of(prob, m)
+            row = [int(st[k]) if k != "sol-length" else len(st["solution"]) for k in STAT_KEYS["sokoban"]]
+            res.append(row)
+            if st["player"] == 1 and st["crate"] == st["target"] and st["crate"] > 0 and st["regions"] == 1:
+                iters, win, dist, sl = run_agents(prob, m)
+                assert dist == row[4] and sl == row[5], (dist, sl, row)
+                agents.append(iters + [win])
+            else:
+                agents.append([0, 0, 0, 0, -2])
+        res = np.array(res, dtype=np.int64); agents = np.array(agents, dtype=np.int64)
+        print("  sokoban %dx%d power %d: %d maps, solver ran %d, wins by agent %s, cap hits %d, %.1fs" % (
+            h, w, power, len(maps), int((agents[:, 4] > -2).sum()), [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)],
+            int((agents[:, :4] >= power).any(1).sum()), time.time() - t0))
+        save("stats_sokoban_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+             solver_power=np.array(power), keys=np.array(STAT_KEYS["sokoban"]))
+    prob = PROBLEMS["mdungeon"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng, power, smax, guard) in [(20, 20, 4, 14, 900, 0.3, 0.3), (30, 12, 0, 8, 2500, 0.2, 0.5), (12, 12, 0, 6, 20000, 0.03, 0.95)]:
+        prob._width, prob._height, prob._solver_power = w, h, power
+        maps = random_maps(rs, nrand, h, w, 8, pr) + engineer_mdungeon(rs, h, w, neng, smax, guard)
+        t0 = time.time()
+        res, agents = [], []
+        for m in maps:
+            st = stats_of(prob, m)
+            row = [int(st[k]) for k in STAT_KEYS["mdungeon"]]
+            res.append(row)
+            if st["player"] == 1 and st["exit"] == 1 and st["regions"] == 1:
+                iters, win, dist, sl, gs = run_agents_mdungeon(prob, m)
+                assert dist == row[9] and sl == row[10], (dist, sl, row)
+                agents.append(iters + [win])
+            else:
+                agents.append([0, 0, 0, 0, -2])
+        res = np.array(res, dtype=np.int64); agents = np.array(agents, dtype=np.int64)
+        print("  mdungeon %dx%d power %d: %d maps, solver ran %d, wins by agent %s, cap hits %d, %.1fs" % (
+            h, w, power, len(maps), int((agents[:, 4] > -2).sum()), [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)],
+            int((agents[:, :4] >= power).any(1).sum()), time.time() - t0))
+        save("stats_mdungeon_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+             solver_power=np.array(power), keys=np.array(STAT_KEYS["mdungeon"]))
+    prob = PROBLEMS["ddave"]()
+    pr = [prob._prob[t] for t in prob.get_tile_types()]
+    for (h, w, nrand, neng, power, smax, spk) in [(20, 20, 4, 14, 900, 0.3, 0.1), (12, 30, 0, 8, 2500, 0.15, 0.05), (12, 12, 0, 6, 20000, 0.08, 0.0)]:
+        prob._width, prob._height, prob._solver_power = w, h, power
+        probs7 = np.array(pr + [0.0])
+        maps = [np.minimum(x, 6) for x in random_maps(rs, nrand, h, w, 8, list(probs7))] + engineer_ddave(rs, h, w, neng, smax, spk)
+        t0 = time.time()
+        res, agents = [], []
+        for m in maps:
+            st = stats_of(prob, m)
+            row = [int(st[k]) for k in STAT_KEYS["ddave"]]
+            res.append(row)
+            if st["player"] == 1 and st["exit"] == 1 and st["key"] == 1 and st["regions"] == 1:
+                iters, win, dist, sl, gs = run_agents_ddave(prob, m)
+                assert dist == row[9] and sl == row[10], (dist, sl, row)
+                agents.append(iters + [win])
+            else:
+                agents.append([0, 0, 0, 0, -2])
+        res = np.array(res, dtype=np.int64); agents = np.array(agents, dtype=np.int64)
+        print("  ddave %dx%d power %d: %d maps, solver ran %d, wins by agent %s, cap hits %d, %.1fs" % (
+            h, w, power, len(maps), int((agents[:, 4] > -2).sum()), [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)],
+            int((agents[:, :4] >= power).any(1).sum()), time.time() - t0))
+        save("stats_ddave_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+             solver_power=np.array(power), keys=np.array(STAT_KEYS["ddave"]))
+
+
 def engineer_sokoban(rs, h, w, n, max_k=3, solid_max=0.35):
     maps = []
     for _ in range(n):
@@ -779,6 +879,20 @@ TRAJS = [
     ("smb_turtle_20x7", "smb", "turtle", 4, 160, (dict(width=20, height=7), dict(change_percentage=0.4, probs={"empty": 0.6, "solid": 0.25}))),
     ("smb_narrow", "smb", "narrow", 3, 60, ()),
     ("smb_narrowcast_16x6", "smb", "narrowcast", 4, 120, (dict(width=16, height=6), dict(change_percentage=0.5, probs={"empty": 0.45, "solid": 0.5}))),
+    # round 4: maps beyond 64 x 64 (bigmap.h) -- max_changes follows Q9 (the second adjust_param call sets it)
+    ("binary_narrow_100x100", "binary", "narrow", 3, 90, (dict(width=100, height=100), dict(change_percentage=0.002))),
+    ("binary_wide_70x65", "binary", "wide", 3, 60, (dict(width=70, height=65), dict(change_percentage=0.003))),
+    ("zelda_turtle_66x20", "zelda", "turtle", 3, 120, (dict(width=66, height=20), dict(change_percentage=0.01))),
+    ("binary_turtlecast_30x90", "binary", "turtlecast", 3, 80, (dict(width=30, height=90), dict(change_percentage=0.01))),
+    # round 4: the search problems on levels beyond 256 cells, and a solver_power beyond 16 383 (search_big.h)
+    ("sokoban_narrow_20x20", "sokoban", "narrow", 3, 100, (dict(width=20, height=20), dict(change_percentage=0.02, solver_power=600,
+        probs={"empty": 0.9, "solid": 0.06, "player": 0.004, "crate": 0.004, "target": 0.004}))),
+    ("mdungeon_turtle_18x22", "mdungeon", "turtle", 3, 100, (dict(width=18, height=22), dict(change_percentage=0.02, solver_power=500,
+        probs={"empty": 0.86, "solid": 0.1, "player": 0.004, "exit": 0.004, "potion": 0.01, "treasure": 0.01, "goblin": 0.006, "ogre": 0.006}))),
+    ("ddave_wide_24x16", "ddave", "wide", 3, 100, (dict(width=24, height=16), dict(change_percentage=0.02, solver_power=500,
+        probs={"empty": 0.8, "solid": 0.18, "player": 0.004, "exit": 0.004, "diamond": 0.004, "key": 0.004, "spike": 0.004}))),
+    ("sokoban_wide_p20000", "sokoban", "wide", 4, 60, (dict(solver_power=20000, change_percentage=0.9,
+        probs={"empty": 0.8, "solid": 0.05, "player": 0.05, "crate": 0.05, "target": 0.05}),)),
     ("mdungeon_narrow_monsters", "mdungeon", "narrow", 16, 300, (dict(width=6, height=6), dict(
         change_percentage=0.8, solver_power=250, target_solution=3, target_col_enemies=0.2,
         probs={"empty": 0.45, "solid": 0.03, "player": 0.03, "exit": 0.03, "potion": 0.06, "treasure": 0.05, "goblin": 0.1, "ogre": 0.25}),)),
@@ -846,7 +960,7 @@ def main():
     jobs = {
         "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
         "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "stats_ddave": gen_stats_ddave, "stats_smb": gen_stats_smb, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
-        "wrappers": gen_wrappers,
+        "wrappers": gen_wrappers, "stats_big": gen_stats_big, "stats_big_search": gen_stats_big_search,
     }
     for k, fn in jobs.items():
         if a.only in (None, k):

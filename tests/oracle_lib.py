@@ -46,20 +46,24 @@ INFO_KEYS = {
 }
 NSTATS = {"binary": 2, "zelda": 7, "sokoban": 6, "mdungeon": 11, "ddave": 11, "smb": 8}
 
-_lib = None
+SO_BIG = os.path.join(ORACLE_DIR, "_big", "libpcgrl_oracle.so")
+_libs = {}
 
 
-def build(force=False):
-    if force or not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "pcgrl_oracle.c")):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
-    return SO
+def build(force=False, big=False):
+    so = SO_BIG if big else SO
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ORACLE_DIR, "pcgrl_oracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["big"] if big else []))
+    return so
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(big=False):
+    """The oracle library.  big=True: the same source built with wider limits (oracle/Makefile `big`: up to 256 crates, 4096 things
+    on the floor, 16-bit coordinates) -- for the search problems on levels beyond 256 cells; the default build keeps the small
+    states bench.py's CPU baseline is timed with."""
+    if big not in _libs:
         # PCGRL_ORACLE_SO: another build of the same source (oracle/Makefile `sanitize`: ASan + UBSan, run with LD_PRELOAD=libasan)
-        so = os.environ.get("PCGRL_ORACLE_SO") or build()
+        so = (os.environ.get("PCGRL_ORACLE_BIG_SO") if big else os.environ.get("PCGRL_ORACLE_SO")) or build(big=big)
         L = C.CDLL(so)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int]
@@ -91,8 +95,8 @@ def lib():
         L.orc_rng_key.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_rng_mixed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_build_cdf_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[big] = L
+    return _libs[big]
 
 
 def _p(a):
@@ -103,12 +107,18 @@ def seed_key(seed):
     return np.asarray(seeding.hash_seed_words(seeding.create_seed(seed)), dtype=np.uint32)
 
 
-def get_stats(prob, m, pw=None, ph=None, solver_power=5000, with_iters=False):
+def needs_big(prob, w, h):
+    """The search problems on levels of more than 256 bordered cells take the build with wider limits (see lib())."""
+    return prob in ("sokoban", "mdungeon", "ddave") and (w + 2) * (h + 2) > 256
+
+
+def get_stats(prob, m, pw=None, ph=None, solver_power=5000, with_iters=False, big=None):
     m = np.ascontiguousarray(m, dtype=np.uint8)
     h, w = m.shape
+    big = needs_big(prob, w, h) if big is None else big
     out = np.zeros(12, np.int64)
     it = np.zeros(4, np.int32)
-    lib().orc_get_stats(PROBS[prob], _p(m), w, h, pw or w, ph or h, solver_power, _p(out), _p(it))
+    lib(big).orc_get_stats(PROBS[prob], _p(m), w, h, pw or w, ph or h, solver_power, _p(out), _p(it))
     res = out[:NSTATS[prob]].copy()
     return (res, it) if with_iters else res
 
@@ -116,25 +126,41 @@ def get_stats(prob, m, pw=None, ph=None, solver_power=5000, with_iters=False):
 class OracleEnv:
     """Mirror of the reference PcgrlEnv surface on top of the C oracle (single env)."""
 
-    def __init__(self, prob="binary", rep="narrow"):
-        self.prob, self.rep = prob, rep
-        self._h = lib().orc_create(PROBS[prob], REPS[rep])
+    def __init__(self, prob="binary", rep="narrow", big=False):
+        self.prob, self.rep, self._big = prob, rep, bool(big)
+        self._h = lib(self._big).orc_create(PROBS[prob], REPS[rep])
+        self._calls, self._seed = [], None       # replayed when the environment moves to the build with wider limits
 
     def __del__(self):
         if getattr(self, "_h", None):
             try:
-                lib().orc_destroy(self._h)
+                lib(self._big).orc_destroy(self._h)
             except Exception:        # interpreter shutdown: the module globals are already gone
                 pass
             self._h = None
 
     def seed(self, seed):
+        self._seed = seed
         key = seed_key(seed)
-        lib().orc_seed(self._h, _p(key), len(key))
+        lib(self._big).orc_seed(self._h, _p(key), len(key))
         return [seed]
 
     def adjust_param(self, **kw):
-        L = lib()
+        self._calls.append(dict(kw))
+        w, h = int(kw.get("width", self.width)), int(kw.get("height", self.height))
+        if not self._big and needs_big(self.prob, w, h):
+            # a level beyond 256 bordered cells: the same history again on the build with wider limits
+            calls, seed = self._calls[:-1], self._seed
+            lib(False).orc_destroy(self._h)
+            self._big = True
+            self._h = lib(True).orc_create(PROBS[self.prob], REPS[self.rep])
+            self._calls = []
+            for c in calls:
+                self.adjust_param(**c)
+            self._calls.append(dict(kw))
+            if seed is not None:
+                self.seed(seed)
+        L = lib(self._big)
         L.orc_adjust_begin(self._h)
         for k, v in kw.items():
             if k == "probs":
@@ -149,14 +175,14 @@ class OracleEnv:
                 L.orc_adjust_set(self._h, ADJ_KEYS[k], float(v))
         L.orc_adjust_commit(self._h)
 
-    width = property(lambda s: lib().orc_width(s._h))
-    height = property(lambda s: lib().orc_height(s._h))
-    max_changes = property(lambda s: lib().orc_max_changes(s._h))
-    max_iterations = property(lambda s: lib().orc_max_iterations(s._h))
-    num_tiles = property(lambda s: lib().orc_num_tiles(s._h))
+    width = property(lambda s: lib(s._big).orc_width(s._h))
+    height = property(lambda s: lib(s._big).orc_height(s._h))
+    max_changes = property(lambda s: lib(s._big).orc_max_changes(s._h))
+    max_iterations = property(lambda s: lib(s._big).orc_max_iterations(s._h))
+    num_tiles = property(lambda s: lib(s._big).orc_num_tiles(s._h))
 
     def obs(self):
-        L = lib()
+        L = lib(self._big)
         w, h = L.orc_map_width(self._h), L.orc_map_height(self._h)
         m = np.zeros((h, w), np.uint8)
         L.orc_get_map(self._h, _p(m))
@@ -170,7 +196,7 @@ class OracleEnv:
         return o
 
     def reset(self):
-        lib().orc_reset(self._h)
+        lib(self._big).orc_reset(self._h)
         return self.obs()
 
     def step(self, action):
@@ -179,7 +205,7 @@ class OracleEnv:
         r = C.c_double()
         d = C.c_int()
         info = np.zeros(16, np.int64)
-        lib().orc_step(self._h, _p(a), C.byref(r), C.byref(d), _p(info))
+        lib(self._big).orc_step(self._h, _p(a), C.byref(r), C.byref(d), _p(info))
         keys = INFO_KEYS[self.prob] + ["iterations", "changes"]
         inf = {k: int(info[i]) for i, k in enumerate(keys)}
         inf["max_iterations"] = self.max_iterations
@@ -188,7 +214,7 @@ class OracleEnv:
 
     def rollout(self, actions, want_maps=True, want_heat=True):
         """actions [T,k<=9] int32 -> dict of per-step arrays (auto-reset semantics)."""
-        L = lib()
+        L = lib(self._big)
         actions = np.asarray(actions, dtype=np.int32)
         if actions.ndim == 1:
             actions = actions[:, None]

@@ -30,6 +30,12 @@ def _make(prob, rep, n, calls=(), seed=1000, auto_reset=True):
     return env
 
 
+def _tune(monkeypatch, field, value):
+    """A developer switch of the library (include/pcgrl_hip.h pcgrl_tuning) for the environments made in this test."""
+    from gym_pcgrl_amd import _lib
+    monkeypatch.setitem(_lib.TUNING_OVERRIDES, field, int(value))
+
+
 def _supported(prob):
     return prob in SUPPORTED
 
@@ -102,10 +108,10 @@ def test_golden_trajectory(path):
     _compare_traj(env, d, T)
 
 
-_SWITCH_TRAJ = [("PCGRL_NO_FUSED", p) for p in sorted(glob.glob(os.path.join(G, "traj_binary_*.npz")))
+_SWITCH_TRAJ = [("no_fused", p) for p in sorted(glob.glob(os.path.join(G, "traj_binary_*.npz")))
                 if "64" not in os.path.basename(p) and "40x33" not in os.path.basename(p) and "cast" not in os.path.basename(p)
                 and "multi" not in os.path.basename(p)] + \
-               [("PCGRL_FUSED_ZELDA", p) for p in sorted(glob.glob(os.path.join(G, "traj_zelda_*.npz")))
+               [("fused_zelda", p) for p in sorted(glob.glob(os.path.join(G, "traj_zelda_*.npz")))
                 if "cast" not in os.path.basename(p)]
 
 
@@ -113,9 +119,9 @@ _SWITCH_TRAJ = [("PCGRL_NO_FUSED", p) for p in sorted(glob.glob(os.path.join(G, 
 @pytest.mark.parametrize("switch,path", _SWITCH_TRAJ, ids=lambda v: os.path.basename(v) if v.endswith(".npz") else v)
 def test_golden_trajectory_other_step_pipeline(switch, path, monkeypatch):
     """Binary and zelda maps of at most 16 rows take the fused one-launch step (k_step) by default; the library switches
-    (PCGRL_NO_FUSED=1, PCGRL_FUSED_ZELDA=0) select the two-launch pipeline (k_update + k_stats), which must reproduce the
+    (pcgrl_tuning: no_fused = 1, fused_zelda = 0) select the two-launch pipeline (k_update + k_stats), which must reproduce the
     reference's trajectories just the same."""
-    monkeypatch.setenv(switch, "0" if switch == "PCGRL_FUSED_ZELDA" else "1")
+    _tune(monkeypatch, switch, 0 if switch == "fused_zelda" else 1)
     test_golden_trajectory(path)
 
 
@@ -145,6 +151,25 @@ ORACLE_CASES = [
     ("smb", "turtle", (dict(width=150, height=9), dict(change_percentage=0.05, probs={"empty": 0.55, "solid": 0.3}, min_empty=500, min_jumps=3,
                                                        rewards={"noise": 1.5, "jumps-dist": 0.5})), 32, 80),
     ("smb", "narrow", (dict(width=22, height=7), dict(change_percentage=0.5, probs={"empty": 0.5, "solid": 0.45}, random_tile=False)), 48, 100),
+    # round 4: maps beyond 64 x 64 (bigmap.h: a wavefront per map on multi-word row masks; episodes end often: tiny change budgets)
+    ("binary", "narrow", (dict(width=90, height=70), dict(change_percentage=0.002)), 40, 80),
+    ("binary", "turtle", (dict(width=130, height=12), dict(change_percentage=0.004)), 33, 80),
+    ("binary", "wide", (dict(width=7, height=200), dict(change_percentage=0.004)), 20, 60),
+    ("zelda", "wide", (dict(width=65, height=30), dict(change_percentage=0.003)), 40, 80),
+    ("zelda", "narrow", (dict(width=20, height=66), dict(change_percentage=0.004, probs={"empty": 0.93, "solid": 0.03, "player": 0.002, "key": 0.002,
+                                                                                      "door": 0.002, "bat": 0.01, "scorpion": 0.01, "spider": 0.01})), 40, 120),
+    ("binary", "narrowcast", (dict(width=66, height=66), dict(change_percentage=0.003)), 12, 60),
+    # ... and the search problems beyond the compact searches (search_big.h): levels of more than 256 bordered cells, solver_power > 16 383
+    ("sokoban", "narrow", (dict(width=20, height=20), dict(change_percentage=0.02, solver_power=300,
+                                                           probs={"empty": 0.93, "solid": 0.04, "player": 0.003, "crate": 0.003, "target": 0.003})), 48, 100),
+    ("mdungeon", "wide", (dict(width=22, height=18), dict(change_percentage=0.02, solver_power=250,
+                                                          probs={"empty": 0.9, "solid": 0.05, "player": 0.003, "exit": 0.003, "potion": 0.01, "treasure": 0.01,
+                                                                 "goblin": 0.01, "ogre": 0.01})), 48, 100),
+    ("ddave", "turtle", (dict(width=30, height=12), dict(change_percentage=0.02, solver_power=250,
+                                                         probs={"empty": 0.8, "solid": 0.18, "player": 0.004, "exit": 0.004, "diamond": 0.004, "key": 0.004,
+                                                                "spike": 0.004})), 48, 100),
+    ("sokoban", "wide", (dict(width=70, height=40), dict(change_percentage=0.001, solver_power=100)), 10, 40),
+    ("sokoban", "wide", (dict(solver_power=17000, change_percentage=0.9, probs={"empty": 0.8, "solid": 0.05, "player": 0.05, "crate": 0.05, "target": 0.05}),), 64, 60),
 ]
 
 
@@ -640,10 +665,10 @@ def test_vec_env_monitor_and_rollout_collector():
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz"))), ids=os.path.basename)
 def test_sokoban_generic_search_path(path, monkeypatch):
     """k_sokoban picks the register-resident search for levels with <= 7 crates, which is every fixture level; the
-    generic search (more crates, LDS workspace) must give the same answers: PCGRL_SOK_GENERIC=1 routes every level
+    generic search (more crates, LDS workspace) must give the same answers: the tuning switch sok_generic routes every level
     through it."""
     _torch()
-    monkeypatch.setenv("PCGRL_SOK_GENERIC", "1")
+    _tune(monkeypatch, "sok_generic", "1")
     d = np.load(path)
     maps = d["maps"]
     n, h, w = maps.shape
@@ -659,9 +684,9 @@ def test_sokoban_generic_search_path(path, monkeypatch):
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_mdungeon_*.npz"))), ids=os.path.basename)
 def test_mdungeon_generic_search_path(path, monkeypatch):
     """k_mdungeon picks the compact search (mdungeon_fast.h) for levels with <= 48 things, which is nearly every
-    fixture level; the generic search must give the same answers: PCGRL_SOK_GENERIC=1 routes every level through it."""
+    fixture level; the generic search must give the same answers: the tuning switch sok_generic routes every level through it."""
     _torch()
-    monkeypatch.setenv("PCGRL_SOK_GENERIC", "1")
+    _tune(monkeypatch, "sok_generic", "1")
     d = np.load(path)
     maps = d["maps"]
     n, h, w = maps.shape
@@ -677,9 +702,9 @@ def test_mdungeon_generic_search_path(path, monkeypatch):
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_ddave_*.npz"))), ids=os.path.basename)
 def test_ddave_generic_search_path(path, monkeypatch):
     """k_ddave picks the compact search (ddave_fast.h) for levels with <= 48 diamonds, which is every fixture level; the
-    generic search must give the same answers: PCGRL_SOK_GENERIC=1 routes every level through it."""
+    generic search must give the same answers: the tuning switch sok_generic routes every level through it."""
     _torch()
-    monkeypatch.setenv("PCGRL_SOK_GENERIC", "1")
+    _tune(monkeypatch, "sok_generic", "1")
     d = np.load(path)
     maps = d["maps"]
     n, h, w = maps.shape
@@ -696,9 +721,9 @@ def test_ddave_generic_search_path(path, monkeypatch):
 def test_smb_search_fallback_path(path, monkeypatch):
     """k_smb runs the balance-1 play-through on a two-label heap of at most 4 095 slots in LDS and repeats a search whose
     queue outgrows that with the general search (lanes 0..3, heap continued in global memory) -- which no level of the
-    default size ever needs.  PCGRL_SMB_LDS_HEAP=1024 makes most full-size levels outgrow it: same answers."""
+    default size ever needs.  The tuning switch smb_lds_heap = 1024 makes most full-size levels outgrow it: same answers."""
     _torch()
-    monkeypatch.setenv("PCGRL_SMB_LDS_HEAP", "1024")
+    _tune(monkeypatch, "smb_lds_heap", "1024")
     d = np.load(path)
     maps = d["maps"]
     n, h, w = maps.shape
@@ -733,7 +758,7 @@ def test_smb_search_fallback_rollout_vs_oracle(monkeypatch):
     40 steps against the oracle."""
     _torch()
     import parity_harness as ph
-    monkeypatch.setenv("PCGRL_SMB_LDS_HEAP", "1024")
+    _tune(monkeypatch, "smb_lds_heap", "1024")
     err = ph.run_config("smb", "narrow", [], 24, 40, 77, np.random.RandomState(5), False)
     assert err is None, err
 
@@ -870,7 +895,7 @@ def test_sokoban_hard_list_overflow(cap, monkeypatch):
     that ran the BFS runs them itself.  With the list shrunk to 0 / 1 entries the capped fixture levels take both
     routes at once; the answers must not change."""
     _torch()
-    monkeypatch.setenv("PCGRL_SOK_HARD_CAP", cap)
+    _tune(monkeypatch, "sok_hard_cap", cap)
     d = np.load(os.path.join(G, "stats_sokoban_5x5.npz"))
     maps, n = d["maps"], len(d["maps"])
     env = _make("sokoban", "wide", n, [dict(width=5, height=5), dict(solver_power=int(d["solver_power"]))])
@@ -944,9 +969,9 @@ def test_incremental_routes_soak(prob, rep, calls, E, T):
 ], ids=lambda v: str(v) if isinstance(v, (str, int)) else "cfg")
 def test_paired_certain_resets(prob, rep, calls, E, T, monkeypatch):
     """With thousands of certain resets per launch a wavefront of k_stats takes two of them (four statistics side by
-    side).  PCGRL_PAIR_MIN=1 forces that mode on small batches; the rollout must still equal the oracle's."""
-    monkeypatch.setenv("PCGRL_PAIR_MIN", "1")
-    monkeypatch.setenv("PCGRL_NO_FUSED", "1")      # k_stats is the kernel that pairs (binary would take k_step otherwise)
+    side).  pair_min = 1 forces that mode on small batches; the rollout must still equal the oracle's."""
+    _tune(monkeypatch, "pair_min", "1")
+    _tune(monkeypatch, "no_fused", "1")      # k_stats is the kernel that pairs (binary would take k_step otherwise)
     test_rollout_vs_oracle(prob, rep, calls, E, T)
 
 
@@ -957,10 +982,10 @@ def test_tall_map_resets_split_over_two_blocks(grid, E, few, monkeypatch):
     ended on, and the reset with the statistics of the regenerated map -- that talk through DevBufs::wide_sync.  With
     change_percentage = 0.01 on a 20 x 24 map (max_changes 4) episodes end every few steps, for many environments in the same
     step; tiny grids make every block walk through several rounds of halves (the grid is made even: an odd block only ever waits
-    for its left neighbour).  The full items of maps with few regions go two to a block (PCGRL_WIDE_FEW moves the line)."""
-    monkeypatch.setenv("PCGRL_WIDE_GRID", grid)
+    for its left neighbour).  The full items of maps with few regions go two to a block (the tuning switch wide_few moves the line)."""
+    _tune(monkeypatch, "wide_grid", grid)
     if few is not None:        # which full items go two to a block (maps with at most that many regions): all of them / none
-        monkeypatch.setenv("PCGRL_WIDE_FEW", few)
+        _tune(monkeypatch, "wide_few", few)
     test_rollout_vs_oracle("binary", "turtle", (dict(width=20, height=24), dict(change_percentage=0.01)), E, 60)
     test_rollout_vs_oracle("binary", "wide", (dict(width=40, height=17), dict(change_percentage=0.004)), E, 40)
 
@@ -970,8 +995,8 @@ def test_tall_map_resets_split_over_two_blocks(grid, E, few, monkeypatch):
 def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
     """The binary soak cases on maps of at most 16 rows through k_update + k_stats (PCGRL_NO_FUSED=1) instead of the fused
     k_step -- with two certain resets per wavefront forced as well (PCGRL_PAIR_MIN=1), which only that pipeline has."""
-    monkeypatch.setenv("PCGRL_NO_FUSED", "1")
-    monkeypatch.setenv("PCGRL_PAIR_MIN", "1")
+    _tune(monkeypatch, "no_fused", "1")
+    _tune(monkeypatch, "pair_min", "1")
     test_incremental_routes_soak(*SOAK_CASES[idx])
 
 
@@ -1618,4 +1643,98 @@ def test_observe_into_the_bound_tensor_with_another_window_drops_the_in_place_st
     torch.cuda.synchronize()
     exp = _expected_image(env._bufs["map"].cpu().numpy(), np.zeros((n, 2), np.uint8), 16, 11, 0, 0, 8)
     assert np.array_equal(img.cpu().numpy(), exp)
+    env.close()
+
+
+# ------------------------------------------------------------------ round 4: the reference's behaviours the build used to refuse
+@pytest.mark.gpu
+def test_adjust_param_size_without_reset_steps_the_old_maps():
+    """pcgrl_env.py:106-115 + representation.py:40-45: adjust_param(width, height) changes the problem's size at once but only
+    reset() makes maps of the new size -- the reference goes on stepping the old maps, with the new size in the problem's
+    formulas (zelda's nearest-enemy default W * H, zelda_prob.py:99) and in max_iterations (Q9).  The oracle models exactly that."""
+    torch = _torch()
+    E, T = 32, 40
+    env = _make("zelda", "wide", E, [dict(change_percentage=0.9)], seed=50)
+    orc = []
+    for i in range(E):
+        o = ol.OracleEnv("zelda", "wide")
+        o.adjust_param(change_percentage=0.9)
+        o.seed(50 + i)
+        o.reset()
+        orc.append(o)
+    env.reset()
+    rs = np.random.RandomState(3)
+
+    def steps(n, W, H):
+        for _ in range(n):
+            a = np.stack([rs.randint(0, W, E), rs.randint(0, H, E), rs.randint(0, 8, E)], -1).astype(np.int32)
+            obs, rew, done, info = env.step(a)
+            torch.cuda.synchronize()
+            for i, o in enumerate(orc):
+                eo, er, ed, einf = o.step(a[i])
+                if ed:
+                    eo = o.reset()
+                assert er == rew[i].item() and ed == bool(done[i].item()), (i, er, rew[i].item())
+                assert np.array_equal(eo["map"], obs["map"][i].cpu().numpy()), i
+                assert einf["nearest-enemy"] == info["nearest-enemy"][i].item() and einf["path-length"] == info["path-length"][i].item()
+
+    steps(T, 11, 7)
+    for o in orc:
+        o.adjust_param(width=9, height=12)
+    env.adjust_param(width=9, height=12)            # no reset(): the 11 x 7 maps go on
+    assert env.single_observation_space["map"].shape == (12, 9) and tuple(env._bufs["map"].shape) == (E, 7, 11)
+    steps(T, 9, 7)                                   # (actions inside both the old map and the new action space)
+    obs = env.reset()                                # now the maps are 9 x 12
+    assert tuple(obs["map"].shape) == (E, 12, 9)
+    for i, o in enumerate(orc):
+        assert np.array_equal(o.reset()["map"], obs["map"][i].cpu().numpy())
+    steps(10, 9, 12)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_strict_actions_raise_at_the_offending_call():
+    """wide_rep.py:68-69: the reference raises IndexError on an x / y outside the map.  strict_actions=True does the same at the
+    call (one synchronisation per step); the default clamps and reports through check_status()."""
+    _torch()
+    env = _make("binary", "wide", 16, seed=1)
+    env.strict_actions = True
+    env.reset()
+    ok = np.zeros((16, 3), np.int32)
+    env.step(ok)
+    bad = ok.copy(); bad[5, 0] = 14
+    with pytest.raises(IndexError):
+        env.step(bad)
+    env.step(ok)                                     # the next call is judged on its own actions
+    with pytest.raises(IndexError):
+        env.rollout(np.stack([ok, bad]))
+    env.step(ok)
+    env.close()
+    lax = _make("binary", "wide", 16, seed=1)
+    lax.reset()
+    lax.step(bad); lax.step(ok)
+    with pytest.raises(IndexError):
+        lax.check_status()
+    lax.close()
+
+
+@pytest.mark.gpu
+def test_solver_power_beyond_the_allocated_arena_reallocates():
+    """sokoban_prob.py:60-73: solver_power is an ordinary adjust_param key.  One that the handle's arena cannot take (more than it
+    was allocated for, or beyond 16 383: the general searches) makes the next reset() re-allocate instead of failing."""
+    torch = _torch()
+    d = np.load(os.path.join(G, "stats_sokoban_8x8_p20000.npz"))
+    maps = d["maps"]
+    env = _make("sokoban", "wide", len(maps), [dict(width=8, height=8)], seed=3)
+    env.reset()
+    env.adjust_param(solver_power=20000)
+    with pytest.raises(RuntimeError):
+        env.step(np.zeros((len(maps), 3), np.int32))
+    env.reset()
+    env.set_maps(maps)
+    assert np.array_equal(env.stats.cpu().numpy().astype(np.int64), d["stats"]) and env.check_status() == 0
+    env.adjust_param(solver_power=300)               # shrinking stays in place
+    env.set_maps(maps)
+    exp = np.stack([ol.get_stats("sokoban", m, solver_power=300) for m in maps])
+    assert np.array_equal(env.stats.cpu().numpy().astype(np.int64), exp)
     env.close()

@@ -44,8 +44,25 @@ def sim_stats(L, prob, m, variant=0):
     return out, need.value
 
 
+def _dims(path):
+    """(h, w, solver_power) of a stats fixture, from its name: stats_<prob>_<h>x<w>[_p<power>].npz"""
+    parts = os.path.basename(path)[:-4].split("_")
+    h, w = (int(v) for v in parts[2].split("x"))
+    return h, w, (int(parts[3][1:]) if len(parts) > 3 else 5000)
+
+
+def _row_bitboards(path):          # what the lane-group kernels take: maps of at most 64 x 64 (larger ones: csrc/bigmap.h, GPU tests)
+    h, w, _ = _dims(path)
+    return h <= 64 and w <= 64
+
+
+def _compact_search(path):         # what the compact searches take (larger levels / solver_power: csrc/search_big.h, GPU tests)
+    h, w, power = _dims(path)
+    return (h + 2) * (w + 2) <= 256 and power <= 16383
+
+
 # (smb has no row-bitboard program: its statistics are plain loops over the byte map in kernels_smb.h, covered by the GPU tests)
-@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(G, "stats_*.npz")) if "stats_smb_" not in p), ids=os.path.basename)
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(G, "stats_*.npz")) if "stats_smb_" not in p and _row_bitboards(p)), ids=os.path.basename)
 def test_bitboard_stats_vs_golden(sim, path):
     d = np.load(path)
     prob = os.path.basename(path).split("_")[1]
@@ -85,7 +102,7 @@ def test_device_sokoban_solver_vs_golden(sim, fast):
     exhausted the state space without a win."""
     sim.sim_sokoban_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     n = skipped = 0
-    for path in sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz"))):
+    for path in sorted(p for p in glob.glob(os.path.join(G, "stats_sokoban_*.npz")) if _compact_search(p)):
         d = np.load(path)
         power = int(d["solver_power"])
         for i, m in enumerate(d["maps"]):
@@ -117,7 +134,7 @@ def test_device_mdungeon_solver_vs_golden(sim, fast):
     space -- in which case the reference's own counts show that every agent popped the same number of entries."""
     sim.sim_mdungeon_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     n = skipped = capped = took_fast = 0
-    for path in sorted(glob.glob(os.path.join(G, "stats_mdungeon_*.npz"))):
+    for path in sorted(p for p in glob.glob(os.path.join(G, "stats_mdungeon_*.npz")) if _compact_search(p)):
         d = np.load(path)
         power = int(d["solver_power"])
         for i, m in enumerate(d["maps"]):
@@ -150,7 +167,7 @@ def test_device_ddave_solver_vs_golden(sim, fast):
     results and per-agent iteration counts."""
     sim.sim_ddave_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     n = capped = took_fast = 0
-    for path in sorted(glob.glob(os.path.join(G, "stats_ddave_*.npz"))):
+    for path in sorted(p for p in glob.glob(os.path.join(G, "stats_ddave_*.npz")) if _compact_search(p)):
         d = np.load(path)
         power = int(d["solver_power"])
         for i, m in enumerate(d["maps"]):

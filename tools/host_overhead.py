@@ -1,6 +1,7 @@
 import sys, time, torch
 sys.path.insert(0,'/root/repo')
 from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
 for n in (1024, 65536):
     env = BatchedPcgrlEnv("binary","narrow",num_envs=n,seed=0); env.reset()
     acts = torch.randint(0,3,(300,n),device="cuda",dtype=torch.int32)

@@ -1,6 +1,7 @@
 import sys, torch, numpy as np
 sys.path.insert(0,'/root/repo')
 import gym_pcgrl_amd as gp
+import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
 def run(env_id, n, calls=()):
     env = gp.make_batched(env_id, num_envs=n, seed=0)
     for kw in calls: env.adjust_param(**kw)

@@ -7,6 +7,7 @@ import numpy as np
 ROOT="/root/repo" if os.path.exists("/root/repo/bench.py") else os.environ.get("GRAFT_REPO_ROOT",".")
 sys.path.insert(0, ROOT)
 from gym_pcgrl_amd import _lib
+import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
 so = "/tmp/libpcgrl_hip_mdprof.so"
 subprocess.check_call(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPCGRL_SMB_PROF"] + _lib.SOURCES + ["-o", so])
 _lib.SO = so

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 
 from gym_pcgrl_amd import _lib
+import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
 from gym_pcgrl_amd.envs import BatchedPcgrlEnv
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gym_pcgrl_amd as gp
+import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
 
 copies = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 d = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "stats_sokoban_5x5.npz"))

@@ -7,6 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gym_pcgrl_amd import _lib
+import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
 so = "/tmp/libpcgrl_hip_sokprof.so"
 MIN_POPS = int(sys.argv[1]) if len(sys.argv) > 1 else 0       # only searches of at least that many pops
 PROB = sys.argv[2] if len(sys.argv) > 2 else "sokoban"         # or mdungeon: own work / waiting of the two wavefronts only
