@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list,
                 if (lane == 0) finalize_item<PROB>(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &pre);
             }
             want = 1;
+        } else if (reset_only) {
+            want = 1;                  // (an unchanged environment whose episode ended: k_update finished its step)
         } else {
             const bool ns = big_item_stats<PROB>(P, B, m, G, ar, lane, s);
             if (lane == 0) want = finish_or_park<PROB>(P, B, e, s, ns, MODE_STEP, parity, shard, !inline_reset, park_list) ? 1 : 0;

@@ -17,9 +17,10 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_reset(PcgrlParams P, DevBufs B,
     const int n = wl_load_prefix(B, parity, list, s_pref);
     for (int item = blockIdx.x * 4 + wv; item < n; item += gridDim.x * 4) {
         const int e = wl_get(B, list, s_pref, item);
-        wave_reset_env<PROB>(P, B, e, gen_map, mt, tiles, lane);
+        ResetRows rr;
+        wave_reset_env<PROB>(P, B, e, gen_map, mt, tiles, lane, 0, lane < G ? lane : -1, &rr);
         MaskT b0, b1, b2;
-        planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane < G ? lane : -1, b0, b1, b2);
+        reset_rows_to_planes<MaskT>(P, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * P.group, lane < G ? lane : -1, rr.m0, rr.m1, rr.m2, b0, b1, b2);
         // start stats (pcgrl_env.py:70-71, problem.py:45-46): the rows are already in registers.  With
         // 16-lane groups only the first DPP row holds the map; the other rows see an empty map and idle.
         DevGroup<G, MaskT> g;

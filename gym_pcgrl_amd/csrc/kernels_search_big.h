@@ -54,6 +54,10 @@ __global__ __launch_bounds__(64) void k_search_big(PcgrlParams P, DevBufs B, Big
                 if (ncr > SOKB_MAXC) atomicOr(B.status, PCGRL_STATUS_TOO_MANY_CRATES);
                 sokb_init_deadlocks(C, s_sok, reinterpret_cast<uint16_t*>(C.heap));       // (the heap is not in use yet: scratch for the corner list)
                 s_root.h = (uint16_t)sokb_heuristic(C, s_sok, s_root.crate, used);
+#ifdef PCGRL_DBG_BIG
+                printf("job e=%d nc=%d ncr=%d player=%d h=%d crate0=%d target0=%d w=%d h=%d nwb=%d cap=%d tmask=%d power=%d\n", e, s_sok.nc, ncr, (int)s_root.player, (int)s_root.h,
+                       (int)s_root.crate[0], (int)s_sok.target[0], C.w, C.h, C.nwb, C.nodes_cap, C.table_mask, C.power);
+#endif
             } else if (PROB == PCGRL_PROB_MDUNGEON) {
                 mdb_build_level(C, m, W, s_md, work);
                 mdb_store(C, 0, work);
@@ -78,6 +82,9 @@ __global__ __launch_bounds__(64) void k_search_big(PcgrlParams P, DevBufs B, Big
                 if (PROB == PCGRL_PROB_SOKOBAN) {
                     const int KS[4] = {-1, 2, 1, 0};
                     win = sokb_search(C, s_sok, s_work, s_root, KS[a], used, hh, dd, it, exhausted);
+#ifdef PCGRL_DBG_BIG
+                    printf("  e=%d agent %d win %d hh %d dd %d it %d exh %d\n", e, a, (int)win, hh, dd, it, (int)exhausted);
+#endif
                     // exact shortcut: an exhausted BFS has expanded every reachable state; the A* agents would expand the same states,
                     // find no win and end on a state of minimum heuristic -- which BFS already has (sokoban_solver.h)
                     if (a == 0 && !win && exhausted) stop = 1;

@@ -123,12 +123,13 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
             if (k > 0 && !pair) break;                        // wave-uniform
             if (!__builtin_amdgcn_readlane((int)have, 2 * k * G)) continue;
             const int ek = __builtin_amdgcn_readlane(e, 2 * k * G);
-            // k_step: the draws of this step are still in the draw cache of the environment, not in its ring
-            const int pend = SL ? (int)SL->k[ek - SL->e0] : 0;
+            // k_step, narrow representation: the cursor move of this step has not been drawn (the block's update leaves it to the reset)
+            const int step_draws = (SL && P.rep == PCGRL_REP_NARROW && P.random_tile) ? 1 : 0;
             if (SL && lane64 == 0) SL->dirty[ek - SL->e0] = 1;
-            wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64, pend);
+            ResetRows rr;
+            wave_reset_env<PROB>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, step_draws, gw == 2 * k + 1 ? g.lane : -1, &rr);
             MaskT t0, t1, t2;
-            planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == 2 * k + 1 ? g.lane : -1, t0, t1, t2);
+            reset_rows_to_planes<MaskT>(P, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == 2 * k + 1 ? g.lane : -1, rr.m0, rr.m1, rr.m2, t0, t1, t2);
             if (gw == 2 * k + 1) { b0 = t0; b1 = t1; b2 = t2; }
             __builtin_amdgcn_wave_barrier();
         }
@@ -188,10 +189,10 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
                 if ((want >> (k * G)) & 1ull) {               // wave-uniform
                     const int ek = __builtin_amdgcn_readlane(e, k * G);
                     if (SL && lane64 == 0) SL->dirty[ek - SL->e0] = 1;
-                    wave_reset_env<PROB>(P, B, ek, gen_map, mt, tiles, lane64);
+                    ResetRows rr;
+                    wave_reset_env<PROB>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, 0, gw == k ? g.lane : -1, &rr);
                     MaskT t0, t1, t2;
-                    planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G,
-                                             gw == k ? g.lane : -1, t0, t1, t2);
+                    reset_rows_to_planes<MaskT>(P, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == k ? g.lane : -1, rr.m0, rr.m1, rr.m2, t0, t1, t2);
                     if (gw == k) { b0 = t0; b1 = t1; b2 = t2; mine = true; }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -360,13 +361,28 @@ __device__ __forceinline__ void wave_incremental_item(const PcgrlParams& P, cons
     }
     want = __builtin_amdgcn_readfirstlane(want);
     if (inline_reset && want) {
-        wave_reset_env<PCGRL_PROB_BINARY>(P, B, e, gen_map, mt, tiles, lane);
+        ResetRows rr;
+        wave_reset_env<PCGRL_PROB_BINARY>(P, B, e, gen_map, mt, (uint8_t*)nullptr, lane, 0, lane, &rr);
         MaskT n0, n1, n2;
-        planes_from_tiles<MaskT>(P, tiles, planes_e, lane, n0, n1, n2);
+        reset_rows_to_planes<MaskT>(P, planes_e, lane, rr.m0, rr.m1, rr.m2, n0, n1, n2);
         int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         compute_item_stats<PCGRL_PROB_BINARY>(g, P, n0, n1, n2, rowmask, st, champ);
         champ_e[lane] = champ;
         if (lane == 0) finalize_item<PCGRL_PROB_BINARY>(P, B, e, st, MODE_START, parity, e & (WL_NSHARD - 1));
+    }
+}
+
+// The two blocks of a certain reset (k_stats_wide below) agree on who computes the old map's statistics through one word of
+// DevBufs::wide_sync: the first to swing it to (epoch << 1 | who) has the half.  who = 0: the even block whose item it is, when it
+// gets there; who = 1: the odd block, after waiting DevBufs::wide_spin sleeps (default WIDE_SPIN_LIMIT) for a sign of the even one.  Returns 1 to the winner.
+#define WIDE_SPIN_LIMIT 400          /* x s_sleep(4) + an atomic load each: ~50 us */
+__device__ __forceinline__ int wide_claim(int32_t* word, int epoch, int who) {
+    int cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if ((cur >> 1) == epoch) return 0;                   // claimed in this launch already
+        const int seen = atomicCAS(word, cur, (epoch << 1) | who);
+        if (seen == cur) return 1;
+        cur = seen;
     }
 }
 
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
     __shared__ MaskT s_rest[2][64];
-    __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag, s_flag2[2], s_cur;
+    __shared__ int s_regions[2], s_best[2], s_owner[2], s_flag, s_flag2[2], s_cur, s_claim;
     __shared__ int2 s_pre;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     TL_INIT(); TL(1);
@@ -458,13 +474,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         int32_t* sync_e = B.wide_sync + (size_t)e * 4;
         if (old_half) {
             if (reset_only) continue;                        // (an unchanged map: the step needs no statistics)
+            // claim the half (the other block takes it over when this one has not shown up after a long wait: wide_claim)
+            if (threadIdx.x == 0) s_claim = wide_claim(sync_e + 3, epoch, 0);
+            __syncthreads();
+            if (!s_claim) { __syncthreads(); continue; }
             const MaskT b_old = planes_e[lane];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(sync_e + 0, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // the planes may go
             block_regions_and_path(g, (MaskT)(~b_old & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], (MaskT*)nullptr);
             if (threadIdx.x == 0) {
-                sync_e[2] = s_regions[0]; sync_e[3] = s_best[0];
+                sync_e[2] = s_regions[0] | (s_best[0] << 16);     // (a 64 x 64 map has at most 2 048 regions and no path beyond 4 095)
                 __hip_atomic_store(sync_e + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
@@ -477,8 +497,26 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             __syncthreads();
             TL(24);
             const MaskT n0 = block_reset_env<PCGRL_PROB_BINARY, NWAVES * 64, MaskT>(P, B, e, gen_map, mt, tiles, rst_raw, rst_bits, &s_cur);     // (every wavefront helps: reset_env.h)
+            int own_old = 0;         // this block computed the old map's statistics itself (block-uniform)
             if (!reset_only) {
-                if (threadIdx.x == 0) while (__hip_atomic_load(sync_e + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+                // wait for "planes read" from the block that has the other half -- for a bounded time: the hand-over assumes that block
+                // was dispatched (it is this block's left neighbour of the same round, and workgroups start in index order), which the
+                // programming model does not promise.  After ~50 us without a sign of it this block claims the half for itself.
+                if (threadIdx.x == 0) {
+                    int spins = 0, mine = 0;
+                    while (__hip_atomic_load(sync_e + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins == B.wide_spin && wide_claim(sync_e + 3, epoch, 1)) { mine = 1; break; }
+                    }
+                    s_claim = mine;
+                }
+                __syncthreads();
+                own_old = s_claim;
+                if (own_old) {
+                    const MaskT b_old = planes_e[lane];
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    block_regions_and_path(g, (MaskT)(~b_old & rowmask), wv, NWAVES, lane, H, s_rest[1], &s_regions[1], &s_best[1], &s_owner[1], (MaskT*)nullptr);
+                }
                 __syncthreads();
             }
             if (wv == 0) planes_e[lane] = n0;
@@ -486,9 +524,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
             block_regions_and_path(g, (MaskT)(~n0 & rowmask), wv, NWAVES, lane, H, s_rest[0], &s_regions[0], &s_best[0], &s_owner[0], champ_e);
             if (threadIdx.x == 0) {
                 if (!reset_only) {
-                    while (__hip_atomic_load(sync_e + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
-                    int32_t s[PCGRL_MAX_STATS] = {__hip_atomic_load(sync_e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                                  __hip_atomic_load(sync_e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0, 0, 0, 0, 0, 0};
+                    int32_t s[PCGRL_MAX_STATS] = {s_regions[1], s_best[1], 0, 0, 0, 0, 0, 0};
+                    if (!own_old) {
+                        while (__hip_atomic_load(sync_e + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+                        const int packed = __hip_atomic_load(sync_e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s[0] = packed & 0xFFFF; s[1] = (packed >> 16) & 0xFFFF;
+                    }
                     finalize_item<PCGRL_PROB_BINARY>(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &s_pre);
                 }
                 int32_t st[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};

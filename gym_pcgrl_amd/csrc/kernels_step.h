@@ -227,14 +227,14 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     if (wv < NUPD) {
         const int e = wv * 64 + lane64;                        // block-local index (see B above)
         UpdateOut u = {};
-        if (e < ne) u = update_env<REP, MaskT, true>(P, B, act_lds, e);
+        UpdateMid mid = {};
+        if (e < ne) u = update_env<REP, MaskT, true, true>(P, B, act_lds, e, &mid);      // the decision part: everything the task lists need
         TL(2);
         const bool first = u.rst || u.sure_done;               // reset-only, or certain to end: k_stats' "lone" items
         const bool packed_full = PROB == PCGRL_PROB_ZELDA && B.zelda_inc;
         int dest = -1, v = e;
         if (first) { dest = 0; v = u.rst ? (e | WL_RESET_ONLY) : e; }
         else if (u.chg) { dest = u.cheap ? 2 : 1; v = (u.cheap || packed_full) ? u.inc_item : e; }
-        s_loc.k[e] = (uint8_t)u.k;
         if (u.chg) s_loc.dirty[e] = 1;
         const uint64_t m0 = __ballot(dest == 0), m1 = __ballot(dest == 1), m2 = __ballot(dest == 2);
         const uint64_t below = (1ull << lane64) - 1ull;
@@ -266,7 +266,12 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         // on the LDS copy -- and is waited for below, before refill_done is published.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (has_fifo && e < ne && u.k > 0 && !first) fifo_refill(B, e, u.k, u.cur0);
+        // behind the barrier, while the other wavefronts compute: the cursor move of the step (narrow: the draws, the new cursor, the
+        // heat-map cell it marks), then the consumed draws go into the rings and the draw caches are topped up.  Environments that
+        // are certain to be reset are left alone: their reset consumes the step's draws and rewrites everything.
+        int k_used = 0, cur0 = 0;
+        if (e < ne && !first) update_env_cursor<REP, MaskT>(P, B, e, mid, k_used, cur0);
+        if (has_fifo && e < ne && k_used > 0 && !first) fifo_refill(B, e, k_used, cur0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // ring words, byte-map cells and heatmap increments have landed
         if (lane64 == 0) __hip_atomic_fetch_add(&s_loc.refill_done[sp], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -274,6 +279,10 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     //  loop -- scalar loads of the parameter block, address arithmetic of every task kind: ~2.4 us on the timeline -- then runs
     //  while they would only be waiting for the lists)
     int n0 = 0, n1 = 0, n2 = 0, w_full = 0, w_total = 0;
+    // maps per wavefront task (of the GPW = 4 lane groups): the four maps of a task run their component and sweep loops in lockstep,
+    // so a task lasts as long as its slowest map in every phase, and a block has only about one and a half tasks per wavefront --
+    // fewer maps per task give shorter chains and more units to balance (pcgrl_tuning full_per_wave / inc_per_wave)
+    const int fpw = B.step_fpw, ipw = B.step_ipw;
     const int tiles_bytes = (W * H + 15) & ~15;
     uint32_t* mt = reinterpret_cast<uint32_t*>(reset_scratch + (size_t)wv * (PCGRL_MT_N * 4 + tiles_bytes));
     uint8_t* tiles = reinterpret_cast<uint8_t*>(mt + PCGRL_MT_N);
@@ -291,8 +300,8 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             }
             TL(3);
             n0 = s_n[sp][0]; n1 = s_n[sp][1]; n2 = s_n[sp][2];
-            w_full = (n1 + GPW - 1) / GPW;
-            w_total = n0 + w_full + (n2 + GPW - 1) / GPW;
+            w_full = (n1 + fpw - 1) / fpw;
+            w_total = n0 + w_full + (n2 + ipw - 1) / ipw;
         }
         int wid = 0;
         if (lane64 == 0) wid = atomicAdd(&s_n[sp][3], 1);
@@ -300,8 +309,8 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         TL(18);
         if (wid >= w_total) break;
         const bool lone = wid < n0, inc = wid >= n0 + w_full;
-        const int item = lone ? wid : (inc ? (wid - n0 - w_full) * GPW + gw : (wid - n0) * GPW + gw);
-        const bool have = lone ? gw < 2 : item < (inc ? n2 : n1);
+        const int item = lone ? wid : (inc ? (wid - n0 - w_full) * ipw + gw : (wid - n0) * fpw + gw);
+        const bool have = lone ? gw < 2 : (gw < (inc ? ipw : fpw) && item < (inc ? n2 : n1));
         const int raw = have ? s_items[lone ? 0 : (inc ? 2 : 1)][item] : 0;
         TL(lone ? 4 : (inc ? 6 : 5));
         stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, false, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);

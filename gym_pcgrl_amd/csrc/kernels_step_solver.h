@@ -216,9 +216,10 @@ __global__ __launch_bounds__(SS_THREADS) void k_step_solver(PcgrlParams P, DevBu
                 uint8_t* tiles = reinterpret_cast<uint8_t*>(mt) + PCGRL_MT_N * 4;
                 for (int i = wv; i < nr; i += SS_THREADS / 64) {
                     const int e = e0 + (int)s_lists.items[rst_list][i];
-                    wave_reset_env<PROB>(P, B, e, gen_map, mt, tiles, lane64);
+                    ResetRows rr;
+                    wave_reset_env<PROB>(P, B, e, gen_map, mt, (uint8_t*)nullptr, lane64, 0, lane64 < G ? lane64 : -1, &rr);
                     MaskT b0, b1, b2;
-                    planes_from_tiles<MaskT>(P, tiles, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * G, lane64 < G ? lane64 : -1, b0, b1, b2);
+                    reset_rows_to_planes<MaskT>(P, reinterpret_cast<MaskT*>(B.planes) + (size_t)e * P.nplanes * G, lane64 < G ? lane64 : -1, rr.m0, rr.m1, rr.m2, b0, b1, b2);
                     const MaskT valid = (lane64 < G) ? rowmask : (MaskT)0;
                     int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
                     MaskT champ;

@@ -23,8 +23,13 @@ struct UpdateOut {
 // One environment of k_update (thread per environment; also the first phase of the fused step kernel k_step).
 // FIFO (k_step only): B's per-environment state pointers lead into the block's LDS copy; cursor draws come from the draw
 // cache; an environment that is certain to be reset writes nothing to the byte map and the heatmap (the reset rewrites both).
-template <int REP, class MaskT, bool FIFO = false>
-__device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevBufs& B, const int32_t* __restrict__ actions, int e) {
+// SPLIT (k_step): the decision part only -- the tile write, the counters, what the statistics will have to do, the unchanged
+// environments finished -- so that the block's task lists are complete before the narrow representation's cursor draws (the
+// longest piece of an update: up to eight tempered words and a rejection loop) and the heat-map increment are done; those follow
+// in update_env_cursor, behind the block's list barrier, while the other wavefronts already compute.  `mid` carries what they need.
+struct UpdateMid { int x, y, hx, hy, cur; bool chg, dead; };
+template <int REP, class MaskT, bool FIFO = false, bool SPLIT = false>
+__device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevBufs& B, const int32_t* __restrict__ actions, int e, UpdateMid* mid = nullptr) {
     bool chg = false, rst = false, cheap = false, sure_done = false;
     int bucket = 0, inc_item = 0, k_used = 0, cur0 = 0;
     uint32_t fw[PCGRL_FIFO_N];
@@ -109,7 +114,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
         uint32_t xa[PCGRL_SPEC_DRAWS + 1], xb[PCGRL_SPEC_DRAWS];
         cur0 = cur;
-        if (draws && FIFO) {
+        if (draws && FIFO && !SPLIT) {
             const int tag = B.fifo_tag[e];
             const uint4* fp = reinterpret_cast<const uint4*>(B.fifo + (size_t)e * PCGRL_FIFO_N);
             const uint4 fa = fp[0], fb = fp[1];
@@ -156,7 +161,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
                 pl[2] = (tile & 4) ? (m2 | bit) : (m2 & ~bit);
             }
         }
-        if (REP == PCGRL_REP_NARROW) {   // the cursor moves on every step (narrow_rep.py:104-113)
+        if (REP == PCGRL_REP_NARROW && !SPLIT) {   // the cursor moves on every step (narrow_rep.py:104-113)
             if (draws && FIFO) {
                 // numpy randint(W) then randint(H) (masked rejection) on the words of the draw cache
                 const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
@@ -235,14 +240,17 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
             hx = x; hy = y;   // pcgrl_env.py:137 marks the *new* cursor cell
         }
         // ---- round trip 3
+        bool dead_heat = false;
         if (chg) {
             changes += 1;
             const bool dead_writes = FIFO && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
-            if (!dead_writes) heat_increment(B, B.heat + ((size_t)e * H + hy) * W + hx);
+            dead_heat = dead_writes;
+            if (!dead_writes && !(SPLIT && REP == PCGRL_REP_NARROW)) heat_increment(B, B.heat + ((size_t)e * H + hy) * W + hx);
         }
         reinterpret_cast<int2*>(B.counters)[e] = make_int2(iter, changes);
         if (bad) atomicOr(B.status, PCGRL_STATUS_BAD_ACTION);
-        if (REP != PCGRL_REP_WIDE) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        if (REP != PCGRL_REP_WIDE && !(SPLIT && REP == PCGRL_REP_NARROW)) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+        if (SPLIT && mid) { mid->x = x; mid->y = y; mid->hx = hx; mid->hy = hy; mid->cur = cur; mid->chg = chg; mid->dead = dead_heat; }
         // the episode ends whatever the new statistics are (pcgrl_env.py:143): the reset is certain
         sure_done = chg && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
         if (sure_done) cheap = false;
@@ -269,6 +277,74 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
     return o;
 }
 
+// The second part of a SPLIT update (k_step, narrow representation): the cursor move of the step -- numpy randint(W) then randint(H),
+// masked rejection, on the words of the environment's draw cache (narrow_rep.py:104-113) --, the cursor and the heat-map cell it
+// marks (pcgrl_env.py:137: the NEW cursor cell).  Not called for environments that are certain to be reset: their reset consumes the
+// step's draws itself from the staged ring (wave_reset_env, step_draws) and rewrites cursor and heat map.  Returns the number of
+// cache words consumed (to be written to the ring by fifo_refill; 0 when the draws went to the ring directly) and the cursor before.
+template <int REP, class MaskT>
+__device__ __forceinline__ void update_env_cursor(const PcgrlParams& P, const DevBufs& B, int e, const UpdateMid& mid, int& k_used, int& cur0) {
+    const int W = P.width, H = P.height;
+    int x = mid.x, y = mid.y, cur = mid.cur;
+    k_used = 0; cur0 = cur;
+    if (REP != PCGRL_REP_NARROW) return;
+    if (P.random_tile) {
+        uint32_t* ring = B.rng_rep + (size_t)e * PCGRL_MT_N;
+        uint32_t fw[PCGRL_FIFO_N];
+        const int tag = B.fifo_tag[e];
+        const uint4* fp = reinterpret_cast<const uint4*>(B.fifo + (size_t)e * PCGRL_FIFO_N);
+        const uint4 fa = fp[0], fb = fp[1];
+        fw[0] = fa.x; fw[1] = fa.y; fw[2] = fa.z; fw[3] = fa.w; fw[4] = fb.x; fw[5] = fb.y; fw[6] = fb.z; fw[7] = fb.w;
+        if (tag != cur) {     // not made for this cursor (right after seeding, or another pipeline drew from the ring): make it now
+#pragma unroll
+            for (int i = 0; i < PCGRL_FIFO_N; i++) {
+                fw[i] = mt_twist(ring[mt_wrap(cur + i)], ring[mt_wrap(cur + i + 1)], ring[mt_wrap(mt_wrap(cur + PCGRL_MT_M) + i)]);
+                B.fifo[(size_t)e * PCGRL_FIFO_N + i] = fw[i];
+            }
+        }
+        const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
+        uint32_t mx = rx, my = ry;
+        mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
+        my |= my >> 1; my |= my >> 2; my |= my >> 4; my |= my >> 8; my |= my >> 16;
+        int stage = 0, used = 0;
+        if (rx == 0) { x = 0; stage = 1; }
+        if (stage == 1 && ry == 0) { y = 0; stage = 2; }
+#pragma unroll
+        for (int i = 0; i < PCGRL_FIFO_N; i++) {
+            if (stage < 2) {
+                used = i + 1;
+                const uint32_t v = mt_temper(fw[i]);
+                if (stage == 0) {
+                    if ((v & mx) <= rx) { x = (int)(v & mx); stage = 1; if (ry == 0) { y = 0; stage = 2; } }
+                } else {
+                    if ((v & my) <= ry) { y = (int)(v & my); stage = 2; }
+                }
+            }
+        }
+        if (stage < 2) {
+            // every cached word rejected ((1/8)^k tail): put them into the ring and go on there; the cache is rebuilt by the next step
+#pragma unroll
+            for (int i = 0; i < PCGRL_FIFO_N; i++) ring[mt_wrap(cur + i)] = fw[i];
+            cur = mt_wrap(cur + PCGRL_FIFO_N);
+            if (stage == 0) { x = mt_randint(ring, cur, W); y = mt_randint(ring, cur, H); }
+            else y = mt_randint(ring, cur, H);
+            B.fifo_tag[e] = -1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (a later reset of this environment stages the ring from memory)
+            __threadfence_block();
+            cur0 = cur;
+        } else {
+            cur = mt_wrap(cur + used);
+            k_used = used;
+        }
+        B.rng_cur[2 * e] = cur;
+    } else {
+        x += 1;
+        if (x >= W) { x = 0; y += 1; if (y >= H) y = 0; }
+    }
+    if (mid.chg && !mid.dead) heat_increment(B, B.heat + ((size_t)e * H + y) * W + x);
+    reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
+}
+
 template <int REP, class MaskT>
 __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B, const int32_t* __restrict__ actions, int parity) {
     __shared__ int s_cnt[3][4];
@@ -286,7 +362,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     // in-kernel (every problem but Sokoban, whose resets wait for the solver and go through k_reset)
     const bool inl = rst && B.inline_reset;
     const int val = inl ? (e | WL_RESET_ONLY) : e;
-    if (P.prob == PCGRL_PROB_BINARY && P.group == 16) {
+    if (P.prob == PCGRL_PROB_BINARY && P.group == 16 && !P.big) {
         // bucket 0 = environments that k_stats is certain to reset (k_stats starts those first, a wavefront each)
         bucket = (inl || sure_done) ? 0 : (bucket < 1 ? 1 : bucket);
         block_append_bucketed((chg && !cheap) || inl, bucket, val, B, parity, WL_CHG, s_hist, s_gbase, cheap, inc_item, B.champ != nullptr ? WL_INC : -1);

@@ -393,6 +393,11 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         h->smb_heap = T.smb_lds_heap > 0 ? T.smb_lds_heap : SMB_LDS_HEAP;        // heap words a k_smb search keeps in LDS
         if (h->smb_heap < 256 || h->smb_heap > 4096) h->smb_heap = SMB_LDS_HEAP;
     }
+    {
+        const int f = tun_or(T.full_per_wave, 4), i = tun_or(T.inc_per_wave, 4);
+        h->B.step_fpw = (f == 1 || f == 2) ? f : 4;
+        h->B.step_ipw = (i == 1 || i == 2) ? i : 4;
+    }
     const bool no_inc = tun_or(T.no_inc, 0) != 0;       // every change takes the full statistics (A/B, tests)
     DevBufs& B = h->B;
     B.map = (uint8_t*)b->map; B.old_map = (uint8_t*)b->old_map; B.heat = (uint16_t*)b->heatmap; B.pos = (uint8_t*)b->pos;
@@ -434,6 +439,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     }
     B.wide_sync = nullptr; B.wide_epoch = 0;
     B.wide_few = tun_or(T.wide_few, WL_WIDE_FEW_REGIONS);
+    B.wide_spin = T.wide_spin > 0 ? T.wide_spin : WIDE_SPIN_LIMIT;
     if (wide_sync_bytes(&h->cfg)) {
         B.wide_sync = (int32_t*)(s + scratch_bytes_base(&h->cfg) + champ_bytes(&h->cfg) + fifo_bytes(&h->cfg));
         HIPCHK(hipMemsetAsync(B.wide_sync, 0, wide_sync_bytes(&h->cfg), (hipStream_t)stream));
@@ -681,7 +687,7 @@ static bool fused_step_applies(const pcgrl_env* h, bool rollout = false) {
     //  tasks handed out dynamically and 128 environments per block the fused kernel is ahead of the two-launch pipeline:
     //  34.0 vs 38.2 us/step on C3.  PCGRL_FUSED_ZELDA=0 keeps k_update + k_stats (A/B, tests).)
     const bool prob_ok = P.prob == PCGRL_PROB_BINARY || (P.prob == PCGRL_PROB_ZELDA && (rollout || h->fused_zelda));
-    return prob_ok && P.group == 16 && P.rep <= PCGRL_REP_TURTLE && P.auto_reset &&
+    return prob_ok && P.group == 16 && !P.big && P.rep <= PCGRL_REP_TURTLE && P.auto_reset &&
            h->B.inline_reset && !h->no_fused;
 }
 // Environments per block of k_step: 64 (four wavefronts), 128 (eight) or 256 (sixteen) -- chosen at pcgrl_bind from the batch

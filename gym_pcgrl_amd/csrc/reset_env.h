@@ -28,17 +28,86 @@ __device__ __forceinline__ void planes_from_tiles(const PcgrlParams& P, const ui
     }
 }
 
+// The rows wave_reset_env cut out of its ballots, stored as the environment's plane rows (lanes with row in [0, G)) and handed
+// back in the mask type of the caller.
+template <class MaskT>
+__device__ __forceinline__ void reset_rows_to_planes(const PcgrlParams& P, MaskT* planes_e, int row, const uint64_t r0, const uint64_t r1, const uint64_t r2,
+                                                     MaskT& m0, MaskT& m1, MaskT& m2) {
+    const int G = P.group, NPL = P.nplanes;
+    m0 = (MaskT)r0; m1 = (MaskT)r1; m2 = (MaskT)r2;
+    if (NPL == 0) { m0 = 0; m1 = 0; m2 = 0; return; }
+    if (row >= 0 && row < G) {
+        planes_e[row * NPL] = m0;
+        if (NPL > 1) { planes_e[row * NPL + 1] = m1; planes_e[row * NPL + 2] = m2; }
+    }
+}
+
+// numpy's randint(W) then randint(H) (masked rejection) on the next words of the ring staged in `mt`, by a whole wavefront: eight
+// lanes make the next eight words at once (every operand is an old word), two ballots pick the first accepted x and the first
+// accepted y after it; only if eight words do not hold both (probability < 1e-4 for any W, H) lane 0 goes on one word at a time.
+// The consumed words are written to the staged ring; returns the cursor after them, x / y in every lane.
+__device__ __forceinline__ int wave_draw_xy(uint32_t* mt, int cur, int W, int H, int lane, int& xv, int& yv) {
+    const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
+    uint32_t mx = rx, my = ry;
+    mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
+    my |= my >> 1; my |= my >> 2; my |= my >> 4; my |= my >> 8; my |= my >> 16;
+    const int sl = mt_wrap(cur + (lane & 7));
+    const uint32_t yw = mt_twist(mt[sl], mt[mt_wrap(sl + 1)], mt[mt_wrap(sl + PCGRL_MT_M)]);
+    const uint32_t v = mt_temper(yw);
+    const uint32_t okx = (uint32_t)__ballot(lane < 8 && (v & mx) <= rx) & 0xFFu;
+    const uint32_t oky = (uint32_t)__ballot(lane < 8 && (v & my) <= ry) & 0xFFu;
+    // index of the word that gives x (-1: randint(1) draws nothing), then of the word that gives y
+    const int ix = rx == 0 ? -1 : (okx ? __ffs((int)okx) - 1 : 8);
+    const uint32_t oky_after = ix >= 7 ? 0u : (ix < 0 ? oky : (oky & ~((2u << ix) - 1u)));       // words after ix (all of them when ix = -1)
+    const int iy = ry == 0 ? ix : (ix >= 8 ? 8 : (oky_after ? __ffs((int)oky_after) - 1 : 8));
+    __builtin_amdgcn_wave_barrier();
+    if (iy < 8) {
+        const int used = iy + 1;                                   // words consumed (0 when neither axis draws)
+        if (lane < used) mt[sl] = yw;
+        xv = rx == 0 ? 0 : (int)(__shfl(v, ix < 0 ? 0 : ix, 64) & mx);
+        yv = ry == 0 ? 0 : (int)(__shfl(v, iy < 0 ? 0 : iy, 64) & my);
+        cur = mt_wrap(cur + used);
+    } else {
+        int x = 0, y = 0;
+        if (lane == 0) {
+            x = mt_randint(mt, cur, W);
+            y = mt_randint(mt, cur, H);
+        }
+        cur = __shfl(cur, 0, 64); xv = __shfl(x, 0, 64); yv = __shfl(y, 0, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cur;
+}
+
 // The whole-wavefront part of PcgrlEnv.reset (pcgrl_env.py:66-76) for environment e: new map (or the saved
 // first map), cursor, both MT19937 rings, heatmap, counters, BinaryProblem.reset.  All 64 lanes call it;
 // `mt` (624 words) and `tiles` (H*W bytes) are this wave's LDS scratch; the tile bytes of the new map are
 // left in `tiles` for the caller to turn into row planes.
-// `pend` > 0 (fused step kernel, an environment that was certain to be reset): the environment's cursor already counts
-// `pend` draws of this step whose words are still in its draw cache and not in its ring; they are patched into the staged
-// ring here.  On return the draw cache of the environment is rebuilt for the new cursor.
+// `step_draws` (fused step kernel, narrow representation, an environment that is certain to be reset): the cursor move of the step
+// that ended the episode (narrow_rep.py:104-113: randint(W), randint(H)) has not been drawn yet -- the block's update leaves it to
+// the reset -- so its words are consumed here, from the staged ring, before the map is made (the position itself is not needed: the
+// reset draws a new one).  On return the draw cache of the environment is rebuilt for the new cursor.
+// What a row of the new map gets from 64 consecutive cells [base, base + 64) of the map's cell string, whose bit plane is the
+// ballot q: row bits [0, W) are the cells [o, o + W), o = row * W.  (The caller masks the result to W bits at the end.)
+__device__ __forceinline__ uint64_t reset_row_bits(uint64_t q, int base, int o, int W) {
+    const int sh = o - base;
+    if (sh >= 64 || sh + W <= 0) return 0ull;
+    return sh >= 0 ? (q >> sh) : (q << -sh);
+}
+struct ResetRows { uint64_t m0, m1, m2; };      // bit planes of the tile ids of one row of the regenerated map
+
+// `row` / `rows` (optional): the lanes that pass a row index 0 .. H-1 get that row of the new map as bit planes of the tile ids
+// (bit x of m_b = bit b of the tile of cell (x, row)) -- cut out of the wave ballots of the tiles as they are made, so that no lane
+// has to walk over the bytes of its row afterwards (planes_from_tiles: fourteen dependent LDS reads per row on a 14-column map);
+// lanes with row < 0 or >= H get zeros.  `tiles` may be null when nobody needs the tile bytes in LDS.
 template <int PROB>
 __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt,
-                                               uint8_t* tiles, int lane, int pend = 0) {
+                                               uint8_t* tiles, int lane, int step_draws = 0, int row = -1, ResetRows* rows = nullptr) {
     const int W = P.width, H = P.height, cells = W * H;
+    const bool want_rows = rows != nullptr;
+    const int row_o = (row >= 0 && row < H) ? row * W : -(1 << 20);       // (a start far outside every batch: contributes nothing)
+    uint64_t acc0 = 0ull, acc1 = 0ull, acc2 = 0ull;
+    constexpr bool kThreePlanes = PROB != PCGRL_PROB_BINARY;
     uint32_t* ring_g = B.rng_rep + (size_t)e * PCGRL_MT_N;
     uint8_t* map_g = B.map + (size_t)e * cells;
     uint8_t* old_g = B.old_map + (size_t)e * cells;
@@ -61,15 +130,9 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         int sl = curs.y + off; sl = sl >= PCGRL_MT_N ? sl - PCGRL_MT_N : sl;
         pw = B.rng_prob[(size_t)e * PCGRL_MT_N + sl];
     }
-    if (pend > 0) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < pend) {
-            int sl = cur - pend + lane; sl = sl < 0 ? sl + PCGRL_MT_N : sl;
-            mt[sl] = B.fifo[(size_t)e * PCGRL_FIFO_N + lane];
-        }
-    }
     __builtin_amdgcn_wave_barrier();
     TL(13);
+    if (step_draws) { int sx, sy; cur = wave_draw_xy(mt, cur, W, H, lane, sx, sy); }
     if (gen_map) {
         // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
         // the number of tiles is a property of the problem: constant indices only -- a run-time index into the by-value
@@ -83,67 +146,77 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
 #pragma unroll
             for (int i = 0; i < NT; i++) cdf[i] = P.cdf[i];
         }
-        for (int c0 = 0; c0 < cells; c0 += 64) {
-            // cell c draws ring words 2c, 2c+1 of this episode: 128 new words per round, every
-            // operand is an *old* word (distance 397 > 128), so all reads come before all writes
-            const int c = c0 + lane;
-            int s = cur + 2 * lane; s = s >= PCGRL_MT_N ? s - PCGRL_MT_N : s;
-            const uint32_t x0 = mt[s], x1 = mt[mt_wrap(s + 1)], x2 = mt[mt_wrap(s + 2)];
-            const uint32_t xm0 = mt[mt_wrap(s + PCGRL_MT_M)], xm1 = mt[mt_wrap(s + PCGRL_MT_M + 1)];
-            const uint32_t ya = mt_twist(x0, x1, xm0), yb = mt_twist(x1, x2, xm1);
+        // Cell c draws ring words 2c, 2c + 1 of this episode.  MT19937's recurrence x[k + 624] = f(x[k], x[k + 1], x[k + 397])
+        // reaches back 227 words, so up to 226 consecutive words can be made from old words alone: a round makes the words of 113
+        // cells -- every lane those of cell c0 + lane, lanes 0..48 also those of cell c0 + 64 + lane -- with all reads before all
+        // writes.  (Two rounds for a 14 x 14 map where one cell per lane took four: the rounds are a chain of LDS round trips.)
+        for (int c0 = 0; c0 < cells; c0 += 113) {
+            const int rem = cells - c0;
+            const int nA = rem < 64 ? rem : 64, nB = rem <= 64 ? 0 : (rem - 64 < 49 ? rem - 64 : 49);
+            int sA = cur + 2 * lane; sA = sA >= PCGRL_MT_N ? sA - PCGRL_MT_N : sA;
+            const int sB = mt_wrap(sA + 128);
+            const uint32_t a0 = mt[sA], a1 = mt[mt_wrap(sA + 1)], a2 = mt[mt_wrap(sA + 2)];
+            const uint32_t am0 = mt[mt_wrap(sA + PCGRL_MT_M)], am1 = mt[mt_wrap(sA + PCGRL_MT_M + 1)];
+            uint32_t b0 = 0, b1 = 0, b2 = 0, bm0 = 0, bm1 = 0;
+            if (nB > 0) {      // wave-uniform
+                b0 = mt[sB]; b1 = mt[mt_wrap(sB + 1)]; b2 = mt[mt_wrap(sB + 2)];
+                bm0 = mt[mt_wrap(sB + PCGRL_MT_M)]; bm1 = mt[mt_wrap(sB + PCGRL_MT_M + 1)];
+            }
+            const uint32_t yaA = mt_twist(a0, a1, am0), ybA = mt_twist(a1, a2, am1);
+            const uint32_t yaB = mt_twist(b0, b1, bm0), ybB = mt_twist(b1, b2, bm1);
             __builtin_amdgcn_wave_barrier();
-            if (c < cells) {
-                mt[s] = ya;
-                mt[mt_wrap(s + 1)] = yb;
-                const double u = mt_to_double(mt_temper(ya), mt_temper(yb));
-                const uint8_t t = (uint8_t)pcgrl_pick_tile_c<NT>(cdf, u);
-                if (tiles) tiles[c] = t;              // (k_big passes no staging area: its maps are read back from memory)
-                map_g[c] = t;
-                old_g[c] = t;
+            int tA = 0, tB = 0;
+            if (lane < nA) {
+                mt[sA] = yaA;
+                mt[mt_wrap(sA + 1)] = ybA;
+                tA = pcgrl_pick_tile_c<NT>(cdf, mt_to_double(mt_temper(yaA), mt_temper(ybA)));
+                const int c = c0 + lane;
+                if (tiles) tiles[c] = (uint8_t)tA;          // (k_big passes no staging area: its maps are read back from memory)
+                map_g[c] = (uint8_t)tA;
+                old_g[c] = (uint8_t)tA;
+            }
+            if (lane < nB) {
+                mt[sB] = yaB;
+                mt[mt_wrap(sB + 1)] = ybB;
+                tB = pcgrl_pick_tile_c<NT>(cdf, mt_to_double(mt_temper(yaB), mt_temper(ybB)));
+                const int c = c0 + 64 + lane;
+                if (tiles) tiles[c] = (uint8_t)tB;
+                map_g[c] = (uint8_t)tB;
+                old_g[c] = (uint8_t)tB;
+            }
+            if (want_rows) {
+                acc0 |= reset_row_bits(__ballot(tA & 1), c0, row_o, W);
+                if (kThreePlanes) { acc1 |= reset_row_bits(__ballot(tA & 2), c0, row_o, W); acc2 |= reset_row_bits(__ballot(tA & 4), c0, row_o, W); }
+                if (nB > 0) {
+                    acc0 |= reset_row_bits(__ballot(tB & 1), c0 + 64, row_o, W);
+                    if (kThreePlanes) { acc1 |= reset_row_bits(__ballot(tB & 2), c0 + 64, row_o, W); acc2 |= reset_row_bits(__ballot(tB & 4), c0 + 64, row_o, W); }
+                }
             }
             __builtin_amdgcn_wave_barrier();
-            const int adv = 2 * ((cells - c0) < 64 ? (cells - c0) : 64);
-            cur += adv; cur = cur >= PCGRL_MT_N ? cur - PCGRL_MT_N : cur;
+            cur += 2 * (nA + nB); cur = cur >= PCGRL_MT_N ? cur - PCGRL_MT_N : cur;
         }
     } else {
         // representation.py:44-45: restore the first map of this environment
-        for (int c = lane; c < cells; c += 64) { const uint8_t t = old_g[c]; if (tiles) tiles[c] = t; map_g[c] = t; }
+        for (int c0 = 0; c0 < cells; c0 += 64) {
+            const int c = c0 + lane;
+            int t = 0;
+            if (c < cells) { t = old_g[c]; if (tiles) tiles[c] = (uint8_t)t; map_g[c] = (uint8_t)t; }
+            if (want_rows) {
+                acc0 |= reset_row_bits(__ballot(t & 1), c0, row_o, W);
+                if (kThreePlanes) { acc1 |= reset_row_bits(__ballot(t & 2), c0, row_o, W); acc2 |= reset_row_bits(__ballot(t & 4), c0, row_o, W); }
+            }
+        }
+    }
+    if (want_rows) {
+        const uint64_t wm = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+        rows->m0 = acc0 & wm; rows->m1 = acc1 & wm; rows->m2 = acc2 & wm;
     }
     __builtin_amdgcn_wave_barrier();
     TL(14);
     if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33: x = randint(W), y = randint(H)
-        // numpy's masked rejection on the next words of the stream.  Eight lanes make the next eight words at once (every operand
-        // is an old word), two ballots pick the first accepted x and the first accepted y after it; only if eight words do not
-        // hold both (probability < 1e-4 for any W, H) lane 0 goes on one word at a time.
-        const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
-        uint32_t mx = rx, my = ry;
-        mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
-        my |= my >> 1; my |= my >> 2; my |= my >> 4; my |= my >> 8; my |= my >> 16;
-        const int sl = mt_wrap(cur + (lane & 7));
-        const uint32_t yw = mt_twist(mt[sl], mt[mt_wrap(sl + 1)], mt[mt_wrap(sl + PCGRL_MT_M)]);
-        const uint32_t v = mt_temper(yw);
-        const uint32_t okx = (uint32_t)__ballot(lane < 8 && (v & mx) <= rx) & 0xFFu;
-        const uint32_t oky = (uint32_t)__ballot(lane < 8 && (v & my) <= ry) & 0xFFu;
-        // index of the word that gives x (-1: randint(1) draws nothing), then of the word that gives y
-        const int ix = rx == 0 ? -1 : (okx ? __ffs((int)okx) - 1 : 8);
-        const uint32_t oky_after = ix >= 7 ? 0u : (ix < 0 ? oky : (oky & ~((2u << ix) - 1u)));       // words after ix (all of them when ix = -1)
-        const int iy = ry == 0 ? ix : (ix >= 8 ? 8 : (oky_after ? __ffs((int)oky_after) - 1 : 8));
-        __builtin_amdgcn_wave_barrier();
-        if (iy < 8) {
-            const int used = iy + 1;                                   // words consumed (0 when neither axis draws)
-            if (lane < used) mt[sl] = yw;
-            const int xv = rx == 0 ? 0 : (int)(__shfl(v, ix < 0 ? 0 : ix, 64) & mx);
-            const int yv = ry == 0 ? 0 : (int)(__shfl(v, iy < 0 ? 0 : iy, 64) & my);
-            if (lane == 0) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)xv, (unsigned char)yv);
-            cur = mt_wrap(cur + used);
-        } else {
-            if (lane == 0) {
-                const int x = mt_randint(mt, cur, W);
-                const int y = mt_randint(mt, cur, H);
-                reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)x, (unsigned char)y);
-            }
-            cur = __shfl(cur, 0, 64);
-        }
+        int xv, yv;
+        cur = wave_draw_xy(mt, cur, W, H, lane, xv, yv);
+        if (lane == 0) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)xv, (unsigned char)yv);
     }
     __builtin_amdgcn_wave_barrier();
     TL(15);

@@ -176,8 +176,10 @@ PCGRL_D void sokb_init_deadlocks(const BigSearchCtx& C, SokbLevel& L, uint16_t* 
             }
         }
 }
+// (memcpy of eight bytes at a time: a node is written here as words and read back through its fields -- with plain 64-bit
+//  lvalues the compiler's type-based alias analysis may move the field reads before the copy)
 PCGRL_D void sokb_copy(uint8_t* dst, const uint8_t* src, int stride) {
-    for (int i = 0; i < stride; i += 8) *reinterpret_cast<uint64_t*>(dst + i) = *reinterpret_cast<const uint64_t*>(src + i);
+    for (int i = 0; i < stride; i += 8) { uint64_t v; __builtin_memcpy(&v, src + i, 8); __builtin_memcpy(dst + i, &v, 8); }
 }
 // One agent.  k < 0: BFSAgent, else AStarAgent with integer weight k in {2, 1, 0} (priority 2h + k * depth).  `w`: the node
 // workspace (LDS).  Returns win; out_h / out_depth describe the returned node (winner, or the best node).

@@ -74,7 +74,8 @@ struct ObsSpec { uint8_t* out; int32_t oh, ow, depth, centered, pad;
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
-    int32_t* wide_sync;              // tall binary maps (k_stats_wide): i32 [N][4] = {epoch: planes read, epoch: result there, regions, path} --
+    int32_t* wide_sync;              // tall binary maps (k_stats_wide): i32 [N][4] = {epoch: planes read, epoch: result there, regions | path << 16, claim} --
+    int32_t wide_spin;               //   sleeps the odd block of a certain reset waits for the even one before it takes the old half over (pcgrl_tuning wide_spin)
     int32_t wide_few;                //   (regions up to which a tall map counts as "few regions": WL_WIDE_FEW_REGIONS, PCGRL_WIDE_FEW for experiments)
     int32_t wide_epoch;              //   how the two blocks of a certain reset (old map / new map) talk; the launch's epoch (host counter)
     const uint16_t* heat_end;        // end of the caller's heatmap buffer
@@ -106,6 +107,7 @@ struct DevBufs {
     // pipelines draw from the ring and mark it invalid (-1).
     uint32_t* fifo; int32_t* fifo_tag;
     ObsSpec obs;
+    int32_t step_fpw, step_ipw;      // k_step: full / incremental items per wavefront task (1, 2 or 4)
     uint8_t* big_arena;              // search_big.h: per-block node pool + heap + visited table (levels / solver_power beyond the compact searches)
 };
 #define PCGRL_FIFO_N 8
@@ -116,7 +118,7 @@ struct StepLocal {
     int e0;
     int par, need;              // this step's slot of refill_done; how many update wavefronts have to report
     int refill_done[2];         // update wavefronts that have written the consumed draws back to the rings (release / acquire, workgroup scope)
-    uint8_t k[256];             // draws an environment consumed in this step and that are not in its ring yet (certain resets patch them in)
+    uint8_t k[256];             // (unused since round 4: a certain reset consumes the draws of its step itself, wave_reset_env step_draws)
     uint8_t dirty[256];         // planes / champion / start statistics changed: write them back
 };
 

@@ -128,6 +128,10 @@ typedef struct pcgrl_tuning {
     int32_t sok_spawn;       /* pops after which a Sokoban BFS publishes its level (default 128) */
     int32_t md_only_agent;   /* >= 0: the MiniDungeons planner runs only this agent (timing experiments: results are then wrong) */
     int32_t smb_lds_heap;    /* heap words a k_smb search keeps in LDS (default 2048; tests: the overflow path) */
+    int32_t full_per_wave;   /* k_step: maps of full recomputations per wavefront task: 1, 2 or 4 */
+    int32_t inc_per_wave;    /* k_step: incremental items per wavefront task: 1, 2 or 4 */
+    int32_t wide_spin;       /* k_stats_wide: sleeps a reset's block waits for its partner block before it computes the old map's statistics
+                                itself (default 400, ~50 us; tests: 1 forces the take-over path) */
 } pcgrl_tuning;
 
 int pcgrl_abi_version(void);

@@ -18,6 +18,7 @@ static int g_trace_site[4096], g_trace_rounds[4096], g_trace_n = 0;
 #include "../../gym_pcgrl_amd/csrc/mdungeon_fast.h"
 #include "../../gym_pcgrl_amd/csrc/ddave_solver.h"
 #include "../../gym_pcgrl_amd/csrc/ddave_fast.h"
+#include "../../gym_pcgrl_amd/csrc/search_big.h"
 #include <vector>
 
 template <class T, int G>
@@ -394,30 +395,120 @@ void sim_mt_random(const uint32_t* key624, int count, double* out) {
     uint32_t ring[624]; memcpy(ring, key624, sizeof(ring)); int cur = 0;
     for (int i = 0; i < count; i++) out[i] = mt_random(ring, cur);
 }
-// the reset kernel's 64-cells-per-round parallel generation, emulated lane by lane (reads before writes)
+// the reset kernel's parallel generation (reset_env.h wave_reset_env), emulated lane by lane: a round makes the words of 113 cells --
+// lane l those of cell c0 + l, lanes 0..48 also those of cell c0 + 64 + l -- with every read before every write
 void sim_mt_mapgen(const uint32_t* key624, const double* prob, int ntiles, int w, int h, uint8_t* tiles, int* xy, uint32_t* ring_out, int* cur_out) {
     uint32_t mt[624]; memcpy(mt, key624, sizeof(mt)); int cur = 0;
     double cdf[8]; pcgrl_build_cdf(prob, ntiles, cdf);
     int cells = w * h;
-    for (int c0 = 0; c0 < cells; c0 += 64) {
-        uint32_t ya[64], yb[64]; int ss[64];
-        for (int lane = 0; lane < 64; lane++) {
-            int s = cur + 2 * lane; s = s >= 624 ? s - 624 : s; ss[lane] = s;
-            uint32_t x0 = mt[s], x1 = mt[mt_wrap(s + 1)], x2 = mt[mt_wrap(s + 2)];
-            uint32_t xm0 = mt[mt_wrap(s + 397)], xm1 = mt[mt_wrap(s + 398)];
-            ya[lane] = mt_twist(x0, x1, xm0); yb[lane] = mt_twist(x1, x2, xm1);
-        }
-        for (int lane = 0; lane < 64; lane++) {
-            int c = c0 + lane;
-            if (c < cells) {
-                mt[ss[lane]] = ya[lane]; mt[mt_wrap(ss[lane] + 1)] = yb[lane];
-                tiles[c] = (uint8_t)pcgrl_pick_tile(cdf, ntiles, mt_to_double(mt_temper(ya[lane]), mt_temper(yb[lane])));
+    for (int c0 = 0; c0 < cells; c0 += 113) {
+        const int rem = cells - c0;
+        const int nA = rem < 64 ? rem : 64, nB = rem <= 64 ? 0 : (rem - 64 < 49 ? rem - 64 : 49);
+        uint32_t ya[2][64], yb[2][64]; int ss[2][64];
+        for (int lane = 0; lane < 64; lane++)
+            for (int k = 0; k < 2; k++) {
+                int s = mt_wrap(cur + 2 * lane >= 624 ? cur + 2 * lane - 624 : cur + 2 * lane);
+                if (k) s = mt_wrap(s + 128);
+                ss[k][lane] = s;
+                uint32_t x0 = mt[s], x1 = mt[mt_wrap(s + 1)], x2 = mt[mt_wrap(s + 2)];
+                uint32_t xm0 = mt[mt_wrap(s + 397)], xm1 = mt[mt_wrap(s + 398)];
+                ya[k][lane] = mt_twist(x0, x1, xm0); yb[k][lane] = mt_twist(x1, x2, xm1);
             }
-        }
-        int adv = 2 * ((cells - c0) < 64 ? (cells - c0) : 64);
-        cur += adv; cur = cur >= 624 ? cur - 624 : cur;
+        for (int k = 0; k < 2; k++)
+            for (int lane = 0; lane < (k ? nB : nA); lane++) {
+                int c = c0 + 64 * k + lane;
+                mt[ss[k][lane]] = ya[k][lane]; mt[mt_wrap(ss[k][lane] + 1)] = yb[k][lane];
+                tiles[c] = (uint8_t)pcgrl_pick_tile(cdf, ntiles, mt_to_double(mt_temper(ya[k][lane]), mt_temper(yb[k][lane])));
+            }
+        cur += 2 * (nA + nB); cur = cur >= 624 ? cur - 624 : cur;
     }
     xy[0] = mt_randint(mt, cur, w); xy[1] = mt_randint(mt, cur, h);
     memcpy(ring_out, mt, sizeof(mt)); *cur_out = cur;
+}
+
+// ---- the general searches (search_big.h: levels beyond 256 bordered cells, solver_power beyond 16 383) run on the host, with the
+// arena k_search_big gives them.  shortcut = 0: every agent runs as in the reference (iteration counts comparable).
+struct BigHost {
+    std::vector<uint8_t> pool; std::vector<uint64_t> heap; std::vector<uint32_t> table; std::vector<uint16_t> cx, cy;
+    BigSearchCtx C;
+    BigHost(int w, int h, int power, int stride) {
+        C.w = w + 2; C.h = h + 2; C.cells = C.w * C.h; C.nwb = (C.cells + 63) >> 6;
+        C.nodes_cap = 4 * power + 4; C.power = power;
+        int tsize = 1024; while (tsize < 2 * power) tsize <<= 1;
+        C.table_mask = tsize - 1;
+        pool.resize((size_t)C.nodes_cap * stride); heap.resize(C.nodes_cap); table.resize(tsize); cx.resize(C.cells); cy.resize(C.cells);
+        C.pool = pool.data(); C.heap = heap.data(); C.table = table.data(); C.cx = cx.data(); C.cy = cy.data();
+    }
+    void clear() { for (auto& t : table) t = 0; }
+};
+int sim_big_sokoban(const uint8_t* map, int h, int w, int power, int shortcut, int* dist, int* sol, int* iters) {
+    if ((w + 2) * (h + 2) > BIG_MAX_WORDS * 64) return -1;
+    BigHost H(w, h, power, sokb_stride(SOKB_MAXC));
+    static SokbLevel L; static SokbNode root, work;
+    uint64_t used[SOKB_MAXC / 64];
+    const int ncr = sokb_build_level(H.C, map, w, L, root);
+    if (ncr > SOKB_MAXC) return -2;
+    std::vector<uint16_t> corners(H.C.cells);
+    sokb_init_deadlocks(H.C, L, corners.data());
+    root.h = (uint16_t)sokb_heuristic(H.C, L, root.crate, used);
+    const int KS[4] = {-1, 2, 1, 0};
+    bool win = false;
+    int hh = 0, dd = 0;
+    for (int a = 0; a < 4; a++) iters[a] = 0;
+    for (int a = 0; a < 4 && !win; a++) {
+        H.clear();
+        bool exhausted = false;
+        win = sokb_search(H.C, L, work, root, KS[a], used, hh, dd, iters[a], exhausted);
+        if (a == 0 && !win && exhausted && shortcut) break;
+    }
+    *dist = win ? 0 : hh; *sol = win ? dd : 0;
+    return 0;
+}
+int sim_big_mdungeon(const uint8_t* map, int h, int w, int power, int shortcut, int* out5, int* iters) {
+    if ((w + 2) * (h + 2) > BIG_MAX_WORDS * 64) return -1;
+    BigHost H(w, h, power, mdb_stride(BIG_MAX_WORDS));
+    static MdbLevel L;
+    uint64_t alive[BIG_MAX_WORDS];
+    MdbWork work; work.alive = alive;
+    mdb_build_level(H.C, map, w, L, work);
+    mdb_store(H.C, 0, work);
+    const int KS[4] = {2, 1, 0, -1};
+    bool win = false;
+    for (int a = 0; a < 4; a++) iters[a] = 0;
+    for (int a = 0; a < 4 && !win; a++) {
+        H.clear();
+        bool exhausted = false;
+        win = mdb_search(H.C, L, work, KS[a], iters[a], exhausted);
+        if (a < 3 && !win && exhausted && shortcut) a = 2;
+    }
+    const uint64_t* root_alive = reinterpret_cast<const uint64_t*>(H.C.pool);
+    int pot = 0, ene = 0;
+    for (int i = 0; i < H.C.nwb; i++) {
+        const uint64_t gone = root_alive[i] & ~work.alive[i];
+        pot += md_popcount(gone & L.potion[i]);
+        ene += md_popcount(gone & (L.goblin[i] | L.ogre[i]));
+    }
+    out5[0] = win ? 0 : (int)work.t.h; out5[1] = win ? (int)work.t.depth : 0; out5[2] = pot; out5[3] = work.t.treasures; out5[4] = ene;
+    return 0;
+}
+int sim_big_ddave(const uint8_t* map, int h, int w, int power, int* out4, int* iters) {
+    if ((w + 2) * (h + 2) > BIG_MAX_WORDS * 64) return -1;
+    BigHost H(w, h, power, mdb_stride(BIG_MAX_WORDS));
+    static DdbLevel L;
+    uint64_t alive[BIG_MAX_WORDS];
+    MdbWork work; work.alive = alive;
+    ddb_build_level(H.C, map, w, L, work);
+    mdb_store(H.C, 0, work);
+    const int KS[4] = {2, 1, 0, -1};
+    bool win = false;
+    for (int a = 0; a < 4; a++) iters[a] = 0;
+    for (int a = 0; a < 4 && !win; a++) {
+        H.clear();
+        bool exhausted = false;
+        win = ddb_search(H.C, L, work, KS[a], iters[a], exhausted);
+    }
+    out4[0] = win ? 0 : (int)work.t.h; out4[1] = win ? (int)work.t.depth : 0;
+    out4[2] = (int)work.t.jumps_lo | ((int)work.t.jumps_hi << 8); out4[3] = ddb_diamonds(H.C, L, work.alive);
+    return 0;
 }
 }

@@ -344,3 +344,45 @@ def test_parallel_mapgen_matches_numpy(sim):
     exp = rs.choice([0, 1], size=(64, 64), p=[0.37, 0.63]).astype(np.uint8)
     assert np.array_equal(tiles, exp)
     assert xy[0] == rs.randint(64) and xy[1] == rs.randint(64)
+
+
+def test_general_searches_vs_golden(sim):
+    """gym_pcgrl_amd/csrc/search_big.h (what k_search_big runs: levels of more than 256 bordered cells, solver_power beyond 16 383)
+    compiled for the host.  Without the shortcuts the per-agent iteration counts equal the reference's; with them (what the GPU
+    runs) the results still do.  Every search fixture goes through it -- the general searches take the small levels as well."""
+    for f in ("sim_big_sokoban", "sim_big_mdungeon"):
+        getattr(sim, f).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * (3 if f == "sim_big_sokoban" else 2)
+    sim.sim_big_ddave.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ran = big = 0
+    for path in sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz")) + glob.glob(os.path.join(G, "stats_mdungeon_*.npz")) + glob.glob(os.path.join(G, "stats_ddave_*.npz"))):
+        d = np.load(path)
+        prob = os.path.basename(path).split("_")[1]
+        power = int(d["solver_power"])
+        h, w, _ = _dims(path)
+        large = not _compact_search(path)
+        for i, m in enumerate(d["maps"]):
+            if d["agents"][i, 4] == -2 or (not large and i % 5):      # (every large level, a fifth of the small ones)
+                continue
+            m = np.ascontiguousarray(m)
+            exp = d["stats"][i]
+            for shortcut in (0, 1):
+                it = np.zeros(4, np.int32)
+                if prob == "sokoban":
+                    dist, sol = C.c_int(), C.c_int()
+                    assert sim.sim_big_sokoban(_p(m), h, w, power, shortcut, C.byref(dist), C.byref(sol), _p(it)) == 0
+                    assert (dist.value, sol.value) == (exp[4], exp[5]), (path, i, dist.value, sol.value, exp)
+                elif prob == "mdungeon":
+                    out5 = np.zeros(5, np.int32)
+                    assert sim.sim_big_mdungeon(_p(m), h, w, power, shortcut, _p(out5), _p(it)) == 0
+                    assert list(out5) == [exp[9], exp[10], exp[6], exp[7], exp[8]], (path, i, out5, exp)
+                else:
+                    if shortcut:
+                        continue
+                    out4 = np.zeros(4, np.int32)
+                    assert sim.sim_big_ddave(_p(m), h, w, power, _p(out4), _p(it)) == 0
+                    assert list(out4) == [exp[9], exp[10], exp[7], exp[8]], (path, i, out4, exp)
+                if not shortcut:
+                    assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
+            ran += 1
+            big += int(large)
+    assert ran > 150 and big >= 40, (ran, big)

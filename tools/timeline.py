@@ -77,6 +77,26 @@ for rep_i in range(5):
                     durs.append(tt[j] - tt[i])
         if durs:
             print("%-20s n %5d  %s" % (names[kind], len(durs), pct(np.array(durs))))
+    # inside the certain-reset tasks: time from the task's start to each mark of the chain (ring staged -> map made -> cursor drawn ->
+    # reset stored -> planes (reset done) -> statistics done -> task end)
+    chain = {13: [], 14: [], 15: [], 16: [], 9: [], 10: [], 7: []}
+    fullc = {10: [], 7: []}
+    for b, w in zip(*np.nonzero(((tag == 4) | (tag == 5)).any(axis=2))):
+        tg, tt = tag[b, w], tm[b, w]
+        for i in np.nonzero((tg == 4) | (tg == 5))[0]:
+            dst = chain if tg[i] == 4 else fullc
+            j = i + 1
+            seen = set()
+            while j < SLOTS and tg[j] != 0:
+                g = int(tg[j])
+                if g in dst and g not in seen:
+                    dst[g].append(tt[j] - tt[i]); seen.add(g)
+                if g == 7:
+                    break
+                j += 1
+    print("certain reset chain (us from task start, p50 / p90 / max):", "  ".join(
+        "%s %.1f/%.1f/%.1f" % (names[k], np.percentile(v, 50), np.percentile(v, 90), np.max(v)) for k, v in chain.items() if v))
+    print("full task chain:", "  ".join("%s %.1f/%.1f/%.1f" % (names[k], np.percentile(v, 50), np.percentile(v, 90), np.max(v)) for k, v in fullc.items() if v))
     # the slowest blocks: their marks
     worst = np.argsort(end_b)[-3:]
     for b in worst:
