@@ -189,8 +189,21 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
                 if ((want >> (k * G)) & 1ull) {               // wave-uniform
                     const int ek = __builtin_amdgcn_readlane(e, k * G);
                     if (SL && lane64 == 0) SL->dirty[ek - SL->e0] = 1;
+                    int pend = 0;
+                    if (SL) {
+                        // k_step: the draws of this step may still be in the environment's draw cache, not in its ring -- take them
+                        // (the staged ring is patched), or wait for the update wavefront that already has (StepLocal::pend)
+                        if (lane64 == 0) {
+                            pend = atomicExch(&SL->pend[ek - SL->e0], 0);
+                            if (pend < 0) {
+                                while (__hip_atomic_load(&SL->late_done[(ek - SL->e0) >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+                                pend = 0;
+                            }
+                        }
+                        pend = __builtin_amdgcn_readfirstlane(pend);
+                    }
                     ResetRows rr;
-                    wave_reset_env<PROB>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, 0, gw == k ? g.lane : -1, &rr);
+                    wave_reset_env<PROB>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, 0, gw == k ? g.lane : -1, &rr, pend);
                     MaskT t0, t1, t2;
                     reset_rows_to_planes<MaskT>(P, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == k ? g.lane : -1, rr.m0, rr.m1, rr.m2, t0, t1, t2);
                     if (gw == k) { b0 = t0; b1 = t1; b2 = t2; mine = true; }

@@ -270,9 +270,13 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         // heat-map cell it marks), then the consumed draws go into the rings and the draw caches are topped up.  Environments that
         // are certain to be reset are left alone: their reset consumes the step's draws and rewrites everything.
         int k_used = 0, cur0 = 0;
+        if (lane64 == 0) s_loc.late_done[wv] = 0;
         if (e < ne && !first) update_env_cursor<REP, MaskT>(P, B, e, mid, k_used, cur0);
-        if (has_fifo && e < ne && k_used > 0 && !first) fifo_refill(B, e, k_used, cur0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // ring words, byte-map cells and heatmap increments have landed
+        // the consumed draws stay in the draw cache for now (StepLocal::pend): writing them to the rings and topping the caches up
+        // is ring traffic nothing waits for, and this wavefront is a quarter of the block's capacity for the tasks -- it does that
+        // after the task loop (below)
+        if (e < EPB) s_loc.pend[e] = (has_fifo && e < ne && !first) ? k_used : 0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // byte-map cells and heatmap increments have landed (an episode end nobody saw coming rewrites both)
         if (lane64 == 0) __hip_atomic_fetch_add(&s_loc.refill_done[sp], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // (the other wavefronts take that barrier inside the first round of the task loop below: what the compiler hoists out of the
@@ -315,6 +319,20 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         TL(lone ? 4 : (inc ? 6 : 5));
         stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, false, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
         TL(7);
+    }
+    if (has_fifo && wv < NUPD) {
+        // the draws of the step go into the rings and the draw caches are topped up, for the environments whose words no reset
+        // has taken in the meantime (StepLocal::pend)
+        const int e = wv * 64 + lane64;
+        int k = 0;
+        if (e < ne) k = atomicExch(&s_loc.pend[e], -1);
+        if (k > 0) {
+            int c0 = B.rng_cur[2 * e] - k;                      // the cursor before the step's draws
+            c0 = c0 < 0 ? c0 + PCGRL_MT_N : c0;
+            fifo_refill(B, e, k, c0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane64 == 0) __hip_atomic_store(&s_loc.late_done[wv], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     TL(8);
     if (MULTI && (reward_out || done_out || info_out)) {   // kernel-uniform: the per-step outputs of the block's environments, row t

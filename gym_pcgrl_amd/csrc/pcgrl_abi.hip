@@ -87,7 +87,9 @@
 
 // ------------------------------------------------------------------------------------------
 // Host side of the ABI
+struct BigArenaDims { int nblocks, nodes_cap, tsize, stride; size_t heap_off, table_off, block_bytes; };
 struct pcgrl_env {
+    BigArenaDims big_dims;     // the general searches' arena as it was cut at pcgrl_bind (search_big.h)
     pcgrl_config cfg;
     PcgrlParams P;
     pcgrl_layout L;
@@ -241,7 +243,6 @@ static size_t wide_sync_bytes(const pcgrl_config* c) { return (c->prob == PCGRL_
 static size_t scratch_bytes(const pcgrl_config* c) { return scratch_bytes_base(c) + champ_bytes(c) + fifo_bytes(c) + wide_sync_bytes(c); }
 // The arena of the general searches (search_big.h): per resident block a node pool (4 children per pop), a 64-bit heap and a
 // visited table of 32-bit node indices.  As many blocks as fit a 6 GB budget (at most SOK_BLOCKS, at least 4).
-struct BigArenaDims { int nblocks, nodes_cap, tsize, stride; size_t heap_off, table_off, block_bytes; };
 static BigArenaDims big_arena_of(const pcgrl_config* c) {
     BigArenaDims A;
     const int cells = (c->width + 2) * (c->height + 2), nwb = (cells + 63) / 64, inner = c->width * c->height;
@@ -450,7 +451,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     if (big_search(&h->cfg)) {
         // levels / solver_power beyond the compact searches: the general searches' arena, then the scheduling words
         h->alloc_solver_power = h->cfg.solver_power;
-        const BigArenaDims A = big_arena_of(&h->cfg);
+        const BigArenaDims A = h->big_dims = big_arena_of(&h->cfg);        // (the launches keep using the dimensions the arena was cut with)
         uint8_t* a = s + wl_bytes(&h->cfg);
         B.big_arena = a;
         a += (size_t)A.nblocks * A.block_bytes;
@@ -501,9 +502,13 @@ int pcgrl_configure(pcgrl_env* h, const pcgrl_config* c) {
         c->width != h->cfg.width || c->height != h->cfg.height)
         return PCGRL_EINVAL;
     if (h->bound && solver_prob(c->prob) && c->solver_power > h->alloc_solver_power) return PCGRL_EINVAL;   // arena too small: re-create
-    if (h->bound && big_search(c) != big_search(&h->cfg)) return PCGRL_EINVAL;                              // another search family, another arena: re-create
+    // a handle bound for the general searches keeps them when solver_power shrinks below their threshold (its arena is theirs);
+    // the other direction needs that arena: re-create
+    const bool was_big = h->bound && h->P.big_search;
+    if (h->bound && big_search(c) && !was_big) return PCGRL_EINVAL;
     h->cfg = *c;
     fill_params(c, &h->P);
+    if (was_big) h->P.big_search = 1;
     return PCGRL_OK;
 }
 
@@ -778,7 +783,7 @@ PCGRL_LOCAL int search_device_setup(pcgrl_env* h) {   // the search kernels use 
 }
 template <int PROB>
 static int launch_search_big_p(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st) {
-    const BigArenaDims D = big_arena_of(&h->cfg);
+    const BigArenaDims& D = h->big_dims;
     const BigSearchArena A = {h->B.big_arena, D.block_bytes, D.heap_off, D.table_off, D.nodes_cap, D.tsize};
     const int cells = (h->P.width + 2) * (h->P.height + 2);
     const size_t lds = (((size_t)cells * 4 + 15) & ~(size_t)15) + (size_t)(BIG_MAX_WORDS + SOKB_MAXC / 64) * 8;

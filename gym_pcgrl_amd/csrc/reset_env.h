@@ -102,7 +102,7 @@ struct ResetRows { uint64_t m0, m1, m2; };      // bit planes of the tile ids of
 // lanes with row < 0 or >= H get zeros.  `tiles` may be null when nobody needs the tile bytes in LDS.
 template <int PROB>
 __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt,
-                                               uint8_t* tiles, int lane, int step_draws = 0, int row = -1, ResetRows* rows = nullptr) {
+                                               uint8_t* tiles, int lane, int step_draws = 0, int row = -1, ResetRows* rows = nullptr, int pend = 0) {
     const int W = P.width, H = P.height, cells = W * H;
     const bool want_rows = rows != nullptr;
     const int row_o = (row >= 0 && row < H) ? row * W : -(1 << 20);       // (a start far outside every batch: contributes nothing)
@@ -129,6 +129,15 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         const int off = lane < 3 ? lane : PCGRL_MT_M + (lane - 3);
         int sl = curs.y + off; sl = sl >= PCGRL_MT_N ? sl - PCGRL_MT_N : sl;
         pw = B.rng_prob[(size_t)e * PCGRL_MT_N + sl];
+    }
+    if (pend > 0) {
+        // (fused step kernel, an episode end nobody saw coming: the environment's cursor already counts `pend` draws of this step whose
+        //  words are still in its draw cache and not in its ring -- they are patched into the staged ring)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < pend) {
+            int sl = cur - pend + lane; sl = sl < 0 ? sl + PCGRL_MT_N : sl;
+            mt[sl] = B.fifo[(size_t)e * PCGRL_FIFO_N + lane];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     TL(13);

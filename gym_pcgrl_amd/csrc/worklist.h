@@ -117,8 +117,13 @@ struct DevBufs {
 struct StepLocal {
     int e0;
     int par, need;              // this step's slot of refill_done; how many update wavefronts have to report
-    int refill_done[2];         // update wavefronts that have written the consumed draws back to the rings (release / acquire, workgroup scope)
-    uint8_t k[256];             // (unused since round 4: a certain reset consumes the draws of its step itself, wave_reset_env step_draws)
+    int refill_done[2];         // update wavefronts that are through with the cursor moves of the step (their byte-map / heat-map writes have landed)
+    // Draw-cache words an environment consumed in this step that are not in its ring yet.  The update wavefronts write them to the
+    // rings and top the caches up only after the block's tasks (ring traffic nobody waits for); an episode end nobody saw coming
+    // needs the ring earlier, so the two sides claim the words with an atomic exchange: k > 0 = that many pending, 0 = none,
+    // -1 = the update wavefront has taken them (late_done[its index] says when they have landed).
+    int pend[256];
+    int late_done[4];
     uint8_t dirty[256];         // planes / champion / start statistics changed: write them back
 };
 

@@ -417,6 +417,8 @@ class BatchedPcgrlEnv:
 
     def set_maps(self, maps):
         """Overwrite every map (uint8 [N,H,W]) and recompute the current stats on the device."""
+        if self._needs_reset:
+            raise RuntimeError("reset() must be called before set_maps()")
         torch = self._torch
         m = torch.as_tensor(maps, device=self.device).to(torch.uint8).contiguous()
         assert tuple(m.shape) == tuple(self._bufs["map"].shape)
