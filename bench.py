@@ -48,6 +48,9 @@ WORKLOADS = {
     "M1": ("mdungeon", "narrow", (), 65536, "mdungeon-narrow-v0 7x11, 65536 envs/GPU"),
     "D1": ("ddave", "narrow", (), 65536, "ddave-narrow-v0 11x7, 65536 envs/GPU"),
     "S1": ("smb", "narrow", (), 16384, "smb-narrow-v0 114x14, 16384 envs/GPU"),
+    # round 4, not BASELINE configs: the general paths beyond the tuned kernels' sizes (csrc/bigmap.h, csrc/search_big.h)
+    "B1": ("binary", "narrow", (dict(width=100, height=100), dict(change_percentage=0.2)), 4096, "binary-narrow-v0 100x100 (adjust_param; general path k_big), 4096 envs/GPU"),
+    "K1": ("sokoban", "narrow", (dict(width=20, height=20),), 16384, "sokoban-narrow-v0 20x20 (adjust_param; general searches k_search_big), 16384 envs/GPU"),
     # the trainer-shaped step (utils.make_vec_envs :60-71): the same batches behind the reference's composite
     # wrappers -- the step also leaves the policy's image (crop 28 centred on the cursor / one-hot map) in a device tensor
     "C2w": ("binary", "narrow", (), 65536, "binary-narrow-v0 14x14 behind CroppedImagePCGRLWrapper(crop 28): step + [N,28,28,1] image, 65536 envs/GPU"),
@@ -57,7 +60,7 @@ WRAPPED = {"C2w": ("cropped", 28), "C3w": ("actionmap", None)}
 # legs of the default run besides the headline workload: every BASELINE.json config (and smb, and the wrapped steps) gets a
 # driver-timed figure.  (steps, warmup, steady warm-up) are sized so that the whole default run stays well under a minute of GPU time.
 LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 45), "C2w": (20, 5, 800), "C3w": (20, 5, 800)}
-DOMINANT = {"C2": "k_step", "C3": "k_step", "C3d": "k_step", "C4": "k_sokoban", "C5": "k_stats_wide", "C5b": "k_stats_wide", "M1": "k_mdungeon",
+DOMINANT = {"B1": "k_big", "K1": "k_search_big", "C2": "k_step", "C3": "k_step", "C3d": "k_step", "C4": "k_sokoban", "C5": "k_stats_wide", "C5b": "k_stats_wide", "M1": "k_mdungeon",
             "D1": "k_ddave", "S1": "k_smb", "C2w": "k_step (writes the image)", "C3w": "k_step (writes the image)"}
 
 

@@ -389,6 +389,9 @@ PCGRL_D int count_regions(B& g, typename B::mask_t pass) {
 // bit of the last frontier, second sweep; returns the second eccentricity (or 0 when it provably cannot exceed `best`).
 template <class B>
 PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
+#ifdef PCGRL_EXP_NOSWEEP      /* timing experiment (tools/timeline.py with PCGRL_TL_FLAGS): what a task costs without its sweeps; results are wrong */
+    return g.popcount_sum(comp) / 4 + 1;
+#endif
     typename B::mask_t last, unused;
     const int e1 = bfs_levels(g, g.first_bit(comp), comp, last);
     // the second sweep measures an eccentricity, which cannot exceed the diameter <= 2 * e1

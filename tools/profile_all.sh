@@ -17,7 +17,9 @@ timeout 400 tools/profile_gpu.sh C4 rtrace
 timeout 400 tools/profile_gpu.sh M1 trace
 timeout 400 tools/profile_gpu.sh D1 trace
 timeout 400 tools/profile_gpu.sh S1 trace
-for w in C2 C3 C3d C4 C5 C5b M1 D1 S1 C2w C3w; do
+timeout 300 tools/profile_gpu.sh B1 trace
+timeout 300 tools/profile_gpu.sh K1 trace
+for w in C2 C3 C3d C4 C5 C5b M1 D1 S1 C2w C3w B1 K1; do
   timeout 500 python bench.py --workload $w --no-legs > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
   tail -c 300 gpurun_out/bench_$w.json
 done

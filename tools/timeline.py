@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from gym_pcgrl_amd import _lib
 import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
 so = "/tmp/libpcgrl_hip_tl.so"
-subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + _lib.HIPCC_FLAGS + ["-DPCGRL_TIMELINE"] + _lib.SOURCES + ["-o", so])
+subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + _lib.HIPCC_FLAGS + ["-DPCGRL_TIMELINE"] + os.environ.get("PCGRL_TL_FLAGS", "").split() + _lib.SOURCES + ["-o", so])
 _lib.SO = so
 import torch
 import bench
