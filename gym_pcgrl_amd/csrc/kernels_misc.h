@@ -64,10 +64,3 @@ __global__ void k_init_by_array(uint32_t* __restrict__ rng_rep, uint32_t* __rest
 }
 
 
-// pcgrl_rollout, configurations without the fused step kernel: row t of the per-step outputs
-__global__ __launch_bounds__(256) void k_copy_step_outputs(DevBufs B, int n, double* reward_row, uint8_t* done_row, int32_t* info_row) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (reward_row && i < n) reward_row[i] = B.reward[i];
-    if (done_row && i < n) done_row[i] = B.done[i];
-    if (info_row) for (int k = i; k < n * 10; k += gridDim.x * 256) info_row[k] = B.info[k];
-}

@@ -94,6 +94,10 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
                                                 bool inc, bool pair, bool zinc, bool have, int raw, int shard, int mode, int parity,
                                                 int inline_reset, int gen_map, uint32_t* mt, uint8_t* tiles, MaskT rowmask,
                                                 StepLocal* SL = nullptr) {
+    // (the problems with a search kernel never reset inside the statistics kernel -- their resets wait for the search -- so the reset
+    //  code is not compiled into their instantiations: it cost k_stats<sokoban> its registers, 68 bytes of scratch per lane)
+    constexpr bool kCanReset = PROB == PCGRL_PROB_BINARY || PROB == PCGRL_PROB_ZELDA;
+    if (!kCanReset) inline_reset = 0;
     constexpr int GPW = 64 / G;
     constexpr bool kInc = PROB == PCGRL_PROB_BINARY;
     constexpr bool kZinc = PROB == PCGRL_PROB_ZELDA && G == 16 && sizeof(MaskT) == 4;
@@ -227,7 +231,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
 // The item loop is therefore wave-uniform: all groups of a wavefront iterate together, a group without
 // an item computes on an empty map.
 template <int PROB, int G, class MaskT>
-__global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
+__global__ __launch_bounds__(PCGRL_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_stats(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity,
                                                         int inline_reset, int gen_map, int lone0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // inline_reset: per wave MT ring + tile bytes
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1];

@@ -1079,17 +1079,26 @@ int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* r
         return rc;
     }
     h->obs_hold = 1;            // one image at the end of the tape, not one per step
-    for (int t = 0; t < steps; t++) {
-        int rc = pcgrl_step(h, actions + (size_t)t * stride, stream);
-        if (rc) { h->obs_hold = 0; return rc; }
-        if (reward_out || done_out || info_out) {
-            hipLaunchKernelGGL(k_copy_step_outputs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->B, (int)n,
-                               reward_out ? reward_out + (size_t)t * n : nullptr, done_out ? done_out + (size_t)t * n : nullptr,
-                               info_out ? info_out + (size_t)t * n * 10 : nullptr);
-            if (hipGetLastError() != hipSuccess) { h->obs_hold = 0; return PCGRL_EHIP; }
-        }
+    // The step kernels write reward / done / info through the handle's pointers and never read an earlier step's: step t of the tape
+    // writes its rows of the caller's [steps, N] outputs directly (no copy launch per step); the bound buffers get the last step's
+    // values at the end, so that the state is what `steps` calls of pcgrl_step leave.
+    double* const reward0 = h->B.reward; uint8_t* const done0 = h->B.done; int32_t* const info0 = h->B.info;
+    int rc = PCGRL_OK;
+    for (int t = 0; t < steps && rc == PCGRL_OK; t++) {
+        if (reward_out) h->B.reward = reward_out + (size_t)t * n;
+        if (done_out) h->B.done = done_out + (size_t)t * n;
+        if (info_out) h->B.info = info_out + (size_t)t * n * 10;
+        rc = pcgrl_step(h, actions + (size_t)t * stride, stream);
     }
+    h->B.reward = reward0; h->B.done = done0; h->B.info = info0;
     h->obs_hold = 0;
+    if (rc) return rc;
+    {
+        const size_t last = (size_t)(steps - 1);
+        if (reward_out) HIPCHK(hipMemcpyAsync(reward0, reward_out + last * n, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (done_out) HIPCHK(hipMemcpyAsync(done0, done_out + last * n, n, hipMemcpyDeviceToDevice, st));
+        if (info_out) HIPCHK(hipMemcpyAsync(info0, info_out + last * n * 10, n * 10 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
     if (h->B.obs.out) return launch_obs(h, h->B.obs, st);
     return PCGRL_OK;
 }
