@@ -15,6 +15,52 @@ REPS = ["narrow", "wide", "turtle", "narrowcast", "narrowmulti", "turtlecast"]
 PROB_MIX = ["binary", "binary", "zelda", "zelda", "sokoban", "mdungeon", "mdungeon", "ddave", "ddave", "smb"]
 
 
+def draw_config_extra(rs, mode, only=None):
+    """The fuzz modes of round 4 (tools/fuzz_parity.py ... big|goal; their own draw stream, so that the seeded slice of draw_config
+    that test_fuzz_slice runs stays what it was):
+      big   sizes beyond the tuned kernels: maps with a side of 65..130 (csrc/bigmap.h), search levels of 257..1 200 bordered cells
+            and now and then a solver_power beyond 16 383 (csrc/search_big.h);
+      goal  binary / zelda on the fused step kernel with goals that are met all the time (target_path 1..3, a near enemy allowed):
+            episodes end where nobody saw it coming, which is what the draw-cache hand-over between the update wavefronts and the
+            in-kernel reset is for (StepLocal::pend)."""
+    if mode == "goal":
+        prob = only or ("binary", "zelda")[rs.randint(2)]
+        rep = ("narrow", "narrow", "turtle", "wide")[rs.randint(4)]
+        w, h = int(rs.randint(3, 33)), int(rs.randint(3, 17))
+        calls = [dict(width=w, height=h), dict(change_percentage=float(rs.choice([0.2, 0.5, 1.0])), target_path=int(rs.randint(1, 4)))]
+        if prob == "zelda":
+            calls.append(dict(target_enemy_dist=int(rs.randint(1, 3)), probs={"empty": 0.8, "solid": 0.1, "player": 0.02, "key": 0.02, "door": 0.02,
+                                                                              "bat": 0.01, "scorpion": 0.01, "spider": 0.01}))
+        return prob, rep, (w, h), calls, int(rs.choice([96, 300, 1000])), 150, int(rs.randint(1, 10 ** 6))
+    prob = only or ("binary", "zelda", "sokoban", "mdungeon", "ddave")[rs.randint(5)]
+    rep = REPS[rs.randint(6)]
+    if prob in ("binary", "zelda"):
+        w, h = int(rs.randint(65, 131)), int(rs.randint(1, 131))
+        if rs.rand() < 0.5:
+            w, h = h, w
+        calls = [dict(width=w, height=h), dict(change_percentage=float(rs.choice([0.001, 0.003, 0.01])))]
+        E, T = int(rs.choice([5, 16, 40])), 60
+    else:
+        while True:
+            w, h = int(rs.randint(3, 41)), int(rs.randint(3, 41))
+            if 256 < (w + 2) * (h + 2) <= 1200:
+                break
+        power = int(rs.choice([60, 300, 1000])) if rs.rand() < 0.85 else 17000
+        calls = [dict(width=w, height=h), dict(change_percentage=float(rs.choice([0.01, 0.03, 0.1])), solver_power=power)]
+        if rs.rand() < 0.7:     # open maps with few of the things a level must have exactly one of: the planner runs
+            few = float(rs.choice([0.002, 0.004]))
+            if prob == "sokoban":
+                calls.append(dict(probs={"empty": 0.93, "solid": 0.04, "player": few, "crate": few, "target": few}))
+            elif prob == "mdungeon":
+                calls.append(dict(probs={"empty": 0.9, "solid": 0.05, "player": few, "exit": few, "potion": 0.01, "treasure": 0.01, "goblin": 0.01, "ogre": 0.01}))
+            else:
+                calls.append(dict(probs={"empty": 0.8, "solid": 0.17, "player": few, "exit": few, "diamond": 0.004, "key": few, "spike": 0.004}))
+        E, T = int(rs.choice([16, 48])), 80
+    if rep in ("turtle", "turtlecast") and rs.rand() < 0.5:
+        calls.append(dict(warp=True))
+    return prob, rep, (w, h), calls, E, T, int(rs.randint(1, 10 ** 6))
+
+
 def draw_config(rs, only=None):
     """-> (prob, rep, (w, h), calls, E, T, seed0, use_rollout): everything random about one fuzz configuration."""
     prob = only or PROB_MIX[rs.randint(len(PROB_MIX))]
@@ -146,9 +192,9 @@ def run_config(prob, rep, calls, E, T, seed0, rs, use_rollout, mixed=False, step
     return None
 
 
-def fuzz_case(rs, only=None, rollout_share=0.4, mixed_share=0.0, steps_scale=1.0):
+def fuzz_case(rs, only=None, rollout_share=0.4, mixed_share=0.0, steps_scale=1.0, mode=None):
     """Draw one configuration from `rs` and run it.  -> (description, error or None)."""
-    prob, rep, wh, calls, E, T, seed0 = draw_config(rs, only)
+    prob, rep, wh, calls, E, T, seed0 = draw_config(rs, only) if mode is None else draw_config_extra(rs, mode, only)
     u = rs.rand()
     use_rollout = u < rollout_share
     mixed = (not use_rollout) and u < rollout_share + mixed_share

@@ -1303,6 +1303,20 @@ def test_fuzz_slice(chunk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,seed,n", [("big", 9100, 8), ("big", 9101, 8), ("goal", 9200, 10), ("goal", 9201, 10)])
+def test_fuzz_slice_round4_modes(mode, seed, n):
+    """Seeded slices of the two fuzz modes of round 4 (parity_harness.draw_config_extra): sizes beyond the tuned kernels (maps with
+    a side of 65..130, search levels of 257..1 200 bordered cells, solver_power 17 000), and goals that are met all the time
+    (episodes ending where the update did not see it coming: the draw-cache hand-over of the fused step kernel)."""
+    _torch()
+    import parity_harness as ph
+    rs = np.random.RandomState(seed)
+    for _ in range(n):
+        desc, err = ph.fuzz_case(rs, None, rollout_share=0.4, mixed_share=0.15, steps_scale=0.6, mode=mode)
+        assert err is None, (desc, err)
+
+
+@pytest.mark.gpu
 def test_hypothesis_configurations():
     """property-style search over the configuration space with hypothesis -- (problem, representation,
     width, height, change_percentage, flags, batch size, seed) drawn by its strategies (and shrunk to a minimal failing
