@@ -9,8 +9,8 @@
 // on word arrays (lane l takes words l, l + 64, ...):
 //   big_fill          the 4-connected component of a seed: in-place sweeps (monotone, so any order of the words is right) with
 //                     an O(1) run fill inside a word, confined to the rows the component has reached so far
-//   big_bfs_levels    helper.py:222-237 run_dikjstra as level-synchronous set expansion inside one component (three rotating
-//                     buffers: the last frontier is C & ~P when a level adds nothing); eccentricity = number of levels
+//   big_bfs_levels    helper.py:222-237 run_dikjstra as level-synchronous set expansion inside one component (visited set + two
+//                     frontier buffers; a level only touches the rows next to the frontier); eccentricity = number of levels
 //   big_regions_path  helper.py:197-207 + :250-264: components in row-major order of their first cell, double sweep from that
 //                     cell, np.argmax = first cell of the last frontier; a component of k cells is only swept while k - 1 can
 //                     still raise the maximum (and the second sweep only while 2 * e1 can)
@@ -114,58 +114,111 @@ __device__ __forceinline__ void big_fill(uint64_t* f, const uint64_t* pass, cons
     }
 }
 
-// BFS inside `comp` (rows [r0, r1]) from the single cell (word i0, bit b0).  Returns the eccentricity; the last frontier is C & ~P
-// (for an eccentricity of 0 the source itself: P is then empty).  P, C, N: three scratch masks, rotated; the caller gets the
-// final roles back through the pointers.
-__device__ __forceinline__ int big_bfs_levels(const uint64_t* comp, int i0, int b0, const BigGeom& G, int r0, int r1, uint64_t*& P, uint64_t*& C,
-                                              uint64_t*& N, int lane) {
+__device__ __forceinline__ int big_wave_min(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// the four neighbours of the cells of s (not s itself), at word i
+__device__ __forceinline__ uint64_t big_neighbours_word(const uint64_t* s, int i, int r, int k, const BigGeom& G) {
+    const uint64_t c = s[i];
+    uint64_t n = (c << 1) | (c >> 1);
+    if (k > 0) n |= s[i - 1] >> 63;
+    if (k < G.KW - 1) n |= s[i + 1] << 63;
+    if (r > 0) n |= s[i - G.KW];
+    if (r < G.H - 1) n |= s[i + G.KW];
+    return n;
+}
+
+// BFS inside `comp` (rows [r0, r1]) from the single cell (word i0, bit b0): helper.py:222-237 as level-synchronous set expansion.
+// V: the visited set, F / Fn: this level's and the next level's frontier (scratch masks; F and Fn are swapped, the caller gets the
+// final roles back).  A level only looks at the rows next to the current frontier, [fa - 1, fb + 1] -- a corridor's frontier is a
+// cell or two, and a level then costs a handful of words instead of the whole component's rows.  (Frontier bits of earlier levels
+// may be left in the two buffers outside that window: harmless, every neighbour of an earlier frontier cell is visited already.)
+// Returns the eccentricity; the last frontier is F within the rows [fa, fb].
+__device__ __forceinline__ int big_bfs_levels(const uint64_t* comp, int i0, int b0, const BigGeom& G, int r0, int r1, uint64_t* V, uint64_t*& F,
+                                              uint64_t*& Fn, int lane, int& fa, int& fb) {
     const int lo = r0 * G.KW, hi = (r1 + 1) * G.KW;
-    big_zero(P, lo, hi, lane); big_zero(C, lo, hi, lane); big_zero(N, lo, hi, lane);
+    big_zero(V, lo, hi, lane); big_zero(F, lo, hi, lane); big_zero(Fn, lo, hi, lane);
     big_sync();
-    if (lane == 0) C[i0] = 1ull << b0;
+    if (lane == 0) { F[i0] = 1ull << b0; V[i0] = 1ull << b0; }
     big_sync();
+    fa = fb = big_row(G, i0);
     int ecc = 0;
     for (;;) {
-        bool changed = false;
-        for (int i = lo + lane; i < hi; i += 64) {
+        const int a = fa - 1 > r0 ? fa - 1 : r0, b = fb + 1 < r1 ? fb + 1 : r1;
+        int mn = 1 << 20, mx = 1 << 20;                       // (mx holds -row: one kind of reduction)
+        for (int i = a * G.KW + lane; i < (b + 1) * G.KW; i += 64) {
             const int r = big_row(G, i), k = i - r * G.KW;
-            // (rows outside [r0, r1] hold nothing of the component: the neighbours read across the range's edge are masked by comp)
-            uint64_t n = C[i] | (C[i] << 1) | (C[i] >> 1);
-            if (k > 0) n |= C[i - 1] >> 63;
-            if (k < G.KW - 1) n |= C[i + 1] << 63;
-            if (r > r0) n |= C[i - G.KW];
-            if (r < r1) n |= C[i + G.KW];
-            n &= comp[i];
-            N[i] = n;
-            changed = changed || n != C[i];
+            const uint64_t c = F[i];
+            uint64_t n = (c << 1) | (c >> 1);
+            if (k > 0) n |= F[i - 1] >> 63;
+            if (k < G.KW - 1) n |= F[i + 1] << 63;
+            if (r > r0) n |= F[i - G.KW];
+            if (r < r1) n |= F[i + G.KW];
+            const uint64_t v = V[i], nw = n & comp[i] & ~v;
+            Fn[i] = nw;
+            if (nw) { V[i] = v | nw; mn = r < mn ? r : mn; mx = -r < mx ? -r : mx; }
         }
         big_sync();
-        if (!big_any(changed)) return ecc;
+        mn = big_wave_min(mn); mx = big_wave_min(mx);
+        if (mn == (1 << 20)) return ecc;                      // nothing new: F holds the last frontier
         ++ecc;
-        uint64_t* t = P; P = C; C = N; N = t;
+        uint64_t* t = F; F = Fn; Fn = t;
+        fa = mn; fb = -mx;
     }
 }
 
 // helper.py:197-207 calc_num_regions + :250-264 calc_longest_path over `pass`.  rest, comp, X, Y, Z: scratch masks (comp must be
-// all zero on entry and is on return).  want_path = false: regions only (zelda and the search problems).
+// all zero on entry and is on return; Y, Z only for want_path).  want_path = false: regions only (zelda and the search problems).
 __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t* rest, uint64_t* comp, uint64_t* X, uint64_t* Y, uint64_t* Z,
                                                  const BigGeom& G, int lane, bool want_path, int& regions, int& path) {
     regions = 0; path = 0;
-    // isolated cells: components of one cell, counted without a fill (path 0)
-    int n_iso = 0;
+    // Components of one, two and three cells in closed form, from bit-sliced neighbour counts (pcg_tiny_components in pcgrl_algos.h:
+    // most components of a random map): an isolated cell; two cells of degree 1 next to each other; a cell of degree 2 whose two
+    // neighbours both have degree 1.  deg1 goes to `comp`, deg2 -- then the cells of the 2- and 3-cell components found from
+    // them -- to X.
+    int n_iso = 0, n_dom = 0, n_tri = 0;
     for (int i = lane; i < G.NW; i += 64) {
         const int r = big_row(G, i), k = i - r * G.KW;
         const uint64_t p = pass[i];
-        uint64_t nb = (p << 1) | (p >> 1);
-        if (k > 0) nb |= pass[i - 1] >> 63;
-        if (k < G.KW - 1) nb |= pass[i + 1] << 63;
-        if (r > 0) nb |= pass[i - G.KW];
-        if (r < G.H - 1) nb |= pass[i + G.KW];
-        const uint64_t iso = p & ~nb;
+        uint64_t lf = p << 1, rt = p >> 1;
+        if (k > 0) lf |= pass[i - 1] >> 63;
+        if (k < G.KW - 1) rt |= pass[i + 1] << 63;
+        const uint64_t a = lf & p, b = rt & p, c = (r > 0 ? pass[i - G.KW] : 0ull) & p, d = (r < G.H - 1 ? pass[i + G.KW] : 0ull) & p;
+        const uint64_t s0 = a ^ b, c0 = a & b, s1 = c ^ d, c1 = c & d, n0 = s0 ^ s1, kk = s0 & s1, two = c0 | c1 | kk;
+        const uint64_t iso = p & ~(a | b | c | d);
+        comp[i] = n0 & ~two;                                   // degree 1
+        X[i] = ~n0 & (c0 ^ c1 ^ kk) & ~(c0 & c1);              // degree 2
         n_iso += __popcll(iso);
         rest[i] = p & ~iso;
     }
-    regions = big_wave_sum(n_iso);
+    big_sync();
+    for (int i = lane; i < G.NW; i += 64) {
+        const int r = big_row(G, i), k = i - r * G.KW;
+        const uint64_t d1 = comp[i];
+        uint64_t e1 = d1 << 1, e2 = d1 >> 1;
+        if (k > 0) e1 |= comp[i - 1] >> 63;
+        if (k < G.KW - 1) e2 |= comp[i + 1] << 63;
+        const uint64_t e3 = r > 0 ? comp[i - G.KW] : 0ull, e4 = r < G.H - 1 ? comp[i + G.KW] : 0ull;
+        const uint64_t dom = d1 & (e1 | e2 | e3 | e4);
+        const uint64_t centre = X[i] & ((e1 & e2) | (e3 & e4) | ((e1 | e2) & (e3 | e4)));
+        n_dom += __popcll(dom); n_tri += __popcll(centre);
+        X[i] = dom | centre;
+    }
+    big_sync();
+    for (int i = lane; i < G.NW; i += 64) {
+        const int r = big_row(G, i), k = i - r * G.KW;
+        // the ends of the 3-cell components: degree-1 cells next to a centre (next to a cell of a 2-cell component there is only its partner)
+        const uint64_t t = X[i] | (comp[i] & big_neighbours_word(X, i, r, k, G));
+        rest[i] &= ~t;
+        comp[i] = 0ull;
+    }
+    n_iso = big_wave_sum(n_iso); n_dom = big_wave_sum(n_dom); n_tri = big_wave_sum(n_tri);
+    regions = n_iso + (n_dom >> 1) + n_tri;
+    path = n_tri > 0 ? 2 : (n_dom > 0 ? 1 : 0);
     big_sync();
     int from = 0;
     for (;;) {
@@ -183,12 +236,12 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
             const int size = big_popcount(comp, lo, hi, lane);
             if (size - 1 > path) {
                 // the first cell of the component in row-major order is the seed itself (rest only ever loses whole components)
-                const int e1 = big_bfs_levels(comp, i0, b0, G, r0, r1, X, Y, Z, lane);
+                int fa, fb;
+                const int e1 = big_bfs_levels(comp, i0, b0, G, r0, r1, X, Y, Z, lane, fa, fb);
                 if (2 * e1 > path) {
                     int b1 = 0;
-                    const int i1 = e1 == 0 ? i0 : big_first(Y, X, lo, hi, lane, b1);       // np.argmax: first cell of the last frontier
-                    if (e1 == 0) b1 = b0;
-                    const int e2 = big_bfs_levels(comp, i1, b1, G, r0, r1, X, Y, Z, lane);
+                    const int i1 = big_first(Y, nullptr, fa * G.KW, (fb + 1) * G.KW, lane, b1);       // np.argmax: first cell of the last frontier
+                    const int e2 = big_bfs_levels(comp, i1, b1, G, r0, r1, X, Y, Z, lane, fa, fb);
                     path = e2 > path ? e2 : path;
                 }
             }
@@ -326,7 +379,7 @@ __device__ __forceinline__ bool big_item_stats(const PcgrlParams& P, const DevBu
 #pragma unroll
     for (int q = 0; q < 5; q++) cnt[q] = big_wave_sum(cnt[q]);
     int regions, unused;
-    big_regions_path(a3, a4, a5, nullptr, nullptr, nullptr, G, lane, false, regions, unused);
+    big_regions_path(a3, a4, a5, a6, nullptr, nullptr, G, lane, false, regions, unused);
     if (PROB == PCGRL_PROB_ZELDA) {                // zelda_prob.py:80-112
         const int player = cnt[0], key = cnt[1], door = cnt[2], enemies = cnt[3];
         int nearest = 0, path = 0;
