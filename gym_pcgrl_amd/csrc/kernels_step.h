@@ -108,6 +108,16 @@ __device__ __forceinline__ void fifo_refill(const DevBufs& B, int e, int k, int 
     B.fifo_tag[e] = mt_wrap(cur0 + k);
 }
 
+// s_setprio with a wave-uniform level (the instruction takes an immediate).  A wavefront that works through a long dependent
+// chain -- a certain reset, the dearest full tasks -- issues an instruction every ~9 cycles when it has its SIMD to itself and a
+// fraction of that next to three others; with a higher level the arbiter serves it first and the short tasks fill the gaps.
+__device__ __forceinline__ void step_set_prio(int p) {
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 // MULTI: the pcgrl_rollout form (loop over the tape); the single-step form is compiled without the loop so that it pays
 // nothing for it.  EPB: environments per block, 64 (four wavefronts) or 128 (eight): a block of 128 pools the tasks of twice
 // as many environments over twice as many wavefronts, which evens out the spread between blocks -- a block that happens to
@@ -224,7 +234,10 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     }
     __syncthreads();                        // the state copy is complete; everything the previous step wrote is visible to the whole block
     TL(17);
+    const int prio = B.step_prio, prio_nfull = (prio >> 8) & 15;
+    int prio_now = 0;                       // the level this wavefront is at: s_setprio only when it changes (the instruction is not free)
     if (wv < NUPD) {
+        if ((prio >> 6) & 3) { prio_now = (prio >> 6) & 3; step_set_prio(prio_now); }
         const int e = wv * 64 + lane64;                        // block-local index (see B above)
         UpdateOut u = {};
         UpdateMid mid = {};
@@ -317,9 +330,14 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         const bool have = lone ? gw < 2 : (gw < (inc ? ipw : fpw) && item < (inc ? n2 : n1));
         const int raw = have ? s_items[lone ? 0 : (inc ? 2 : 1)][item] : 0;
         TL(lone ? 4 : (inc ? 6 : 5));
+        if (prio) {
+            const int want = lone ? (prio & 3) : (inc ? ((prio >> 4) & 3) : ((prio_nfull == 0 || wid - n0 < prio_nfull) ? ((prio >> 2) & 3) : 0));
+            if (want != prio_now) { prio_now = want; step_set_prio(want); }
+        }
         stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, false, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
         TL(7);
     }
+    if (prio_now) { prio_now = 0; step_set_prio(0); }
     if (has_fifo && wv < NUPD) {
         // the draws of the step go into the rings and the draw caches are topped up, for the environments whose words no reset
         // has taken in the meantime (StepLocal::pend)

@@ -397,6 +397,10 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     {
         const int f = tun_or(T.full_per_wave, 4), i = tun_or(T.inc_per_wave, 4);
         h->B.step_fpw = (f == 1 || f == 2) ? f : 4;
+        // wavefront priorities in k_step: certain resets and full recomputations of the binary problem at level 3, its incremental
+        // updates at 0 (C2: 30.4 -> 28.9 us first window, 29.4 -> 28.7 steady).  Zelda's tasks are all of one kind and about one
+        // length; every setting measured there was 0.3-0.7 us slower than none.
+        h->B.step_prio = tun_or(T.step_prio, h->cfg.prob == PCGRL_BINARY ? 15 : 0) & 0xFFF;
         h->B.step_ipw = (i == 1 || i == 2) ? i : 4;
     }
     const bool no_inc = tun_or(T.no_inc, 0) != 0;       // every change takes the full statistics (A/B, tests)

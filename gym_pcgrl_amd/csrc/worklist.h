@@ -108,6 +108,7 @@ struct DevBufs {
     uint32_t* fifo; int32_t* fifo_tag;
     ObsSpec obs;
     int32_t step_fpw, step_ipw;      // k_step: full / incremental items per wavefront task (1, 2 or 4)
+    int32_t step_prio;               // k_step: s_setprio levels by kind of work (pcgrl_tuning step_prio)
     uint8_t* big_arena;              // search_big.h: per-block node pool + heap + visited table (levels / solver_power beyond the compact searches)
 };
 #define PCGRL_FIFO_N 8

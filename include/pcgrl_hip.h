@@ -132,6 +132,9 @@ typedef struct pcgrl_tuning {
     int32_t inc_per_wave;    /* k_step: incremental items per wavefront task: 1, 2 or 4 */
     int32_t wide_spin;       /* k_stats_wide: sleeps a reset's block waits for its partner block before it computes the old map's statistics
                                 itself (default 400, ~50 us; tests: 1 forces the take-over path) */
+    int32_t step_prio;       /* k_step: s_setprio levels of the wavefronts by what they do, two bits each: bits 0-1 a certain reset, 2-3 a full
+                                recomputation, 4-5 an incremental update, 6-7 the update wavefronts; bits 8-11: how many of the leading
+                                (dearest) full tasks of a block get the level of bits 2-3 (0 = all of them) */
 } pcgrl_tuning;
 
 int pcgrl_abi_version(void);
