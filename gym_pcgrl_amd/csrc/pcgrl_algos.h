@@ -33,6 +33,11 @@
 #include "pcgrl_common.h"
 
 // Cost-model hook for the CPU lane-group simulator (tests/hostsim); compiles to nothing in the product.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define PCGRL_NO_IFCVT() asm volatile("" ::: "memory")
+#else
+#define PCGRL_NO_IFCVT() do {} while (0)
+#endif
 #ifndef PCGRL_TRACE
 #define PCGRL_TRACE(g, site)
 #endif
@@ -316,10 +321,28 @@ PCGRL_D typename B::mask_t pcg_tiny_components(B& g, typename B::mask_t p, int& 
 
 // BFS from `src` through `pass` until nothing new is reached.  Returns the number of levels
 // (eccentricity of src); `last` = cells at maximum distance.  Levels are tracked per lane.
-template <class B>
+//
+// Backends with kHistBfs (16-row groups of 32-bit masks on the device; the simulator) keep the per-lane bookkeeping of a level
+// in ONE instruction: the "changed" bit of the level's compare is shifted into a per-lane history word through the carry
+// (hist = hist + hist + carry), and the level of a lane's last change is read out of the word (count of trailing zeros) every 32
+// levels.  WANT_LAST = false (the second sweep of a double sweep) also drops the copy of the set before a lane's last change.
+template <bool WANT_LAST = true, class B>
 PCGRL_D int bfs_levels(B& g, typename B::mask_t src, typename B::mask_t pass, typename B::mask_t& last) {
     typedef typename B::mask_t M;
     typedef typename B::ivec_t I;
+    if constexpr (B::kHistBfs != 0) {
+        M n = src, prev = src ^ src;
+        I hist = g.izero(), last_it = g.izero();
+        int it = 0;
+        PCGRL_TRACE(g, 2);
+        // bfs_run: pairs of levels (a level after the last one changes nothing) until nothing changes any more or `it` reaches a
+        // multiple of 32 -- a history word holds 32 levels
+        while (g.template bfs_run<WANT_LAST>(n, pass, hist, prev, it)) { last_it = g.hist_fold(hist, it, last_it); hist = g.izero(); }
+        last_it = g.hist_fold(hist, it, last_it);          // hist != 0 ? it - ctz(hist) : last_it
+        const int ecc = g.imax(last_it);
+        if (WANT_LAST) last = g.keep_where_eq(last_it, ecc, n & ~prev);
+        return ecc;
+    }
     M f = src, prev = src ^ src;
     I last_it = g.izero();
     int it = 0;
@@ -396,7 +419,7 @@ PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
     const int e1 = bfs_levels(g, g.first_bit(comp), comp, last);
     // the second sweep measures an eccentricity, which cannot exceed the diameter <= 2 * e1
     if (2 * e1 <= best) return 0;
-    return bfs_levels(g, g.first_bit(last), comp, unused);
+    return bfs_levels<false>(g, g.first_bit(last), comp, unused);
 }
 
 // binary_prob.py:81-86: regions + helper.py:250-264 double-sweep longest path.

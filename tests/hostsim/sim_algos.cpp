@@ -43,7 +43,43 @@ template <int G, class T>
 struct SimGroup {
     typedef SimVec<T, G> mask_t;
     typedef SimVec<int, G> ivec_t;
-    enum { kGroup = G, kLog2Group = 4 };
+    enum { kGroup = G, kLog2Group = 4, kHistBfs = 1 };
+    // two BFS levels with the carry-history bookkeeping (lanegroup_dev.h has the device form)
+    template <bool WANT_LAST>
+    bool bfs_run(mask_t& n, const mask_t& pass, ivec_t& hist, mask_t& prev, int& it) const {
+        for (;;) {
+            const bool more = bfs_pair<WANT_LAST>(n, pass, hist, prev);
+            it += 2;
+            if (!more) return false;
+            if ((it & 31) == 0) return true;
+        }
+    }
+    template <bool WANT_LAST>
+    bool bfs_pair(mask_t& n, const mask_t& pass, ivec_t& hist, mask_t& prev) const {
+        bool more = false;
+        for (int lv = 0; lv < 2; lv++) {
+            mask_t nn;
+            for (int i = 0; i < G; i++) {
+                T e = n.v[i] | (T)(n.v[i] << 1) | (T)(n.v[i] >> 1);
+                if (i > 0) e |= n.v[i - 1];
+                if (i + 1 < G) e |= n.v[i + 1];
+                nn.v[i] = e & pass.v[i];
+            }
+            mask_t diff;
+            for (int i = 0; i < G; i++) {
+                const bool ch = nn.v[i] != n.v[i];
+                diff.v[i] = nn.v[i] ^ n.v[i];
+                if (WANT_LAST && ch) prev.v[i] = n.v[i];
+                hist.v[i] = (int)(((unsigned)hist.v[i] << 1) | (ch ? 1u : 0u));
+            }
+            if (lv == 1) more = wave_any(diff);
+            n = nn;
+        }
+        return more;
+    }
+    ivec_t hist_fold(const ivec_t& hist, int it, const ivec_t& last_it) const {
+        ivec_t r; for (int i = 0; i < G; i++) r.v[i] = hist.v[i] != 0 ? it - __builtin_ctz((unsigned)hist.v[i]) : last_it.v[i]; return r;
+    }
     // like the device: the doubling moves never cross an aligned block of 16 rows (one DPP row)
     mask_t rows_down(const mask_t& m, int k) const { mask_t r; int n = 1 << k; for (int i = 0; i < G; i++) if ((i & 15) >= n) r.v[i] = m.v[i - n]; return r; }
     mask_t rows_up(const mask_t& m, int k) const { mask_t r; int n = 1 << k; for (int i = 0; i < G; i++) if ((i & 15) + n < 16) r.v[i] = m.v[i + n]; return r; }
