@@ -32,7 +32,7 @@ __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBuf
         episode_account(B, e, r, d);
         int32_t* inf = B.info + (size_t)e * 10;
         for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
-        if (prob == PCGRL_PROB_BINARY) inf[2] = s[1] - sv[1];      // path-imp (binary_prob.py:137)
+        if (prob == PCGRL_PROB_BINARY) { inf[2] = s[1] - sv[1]; inf[3] = 0; }      // path-imp (binary_prob.py:137); slots 2, 3 of the stats row are the library's own
         inf[8] = c.x; inf[9] = c.y;
         if (d && P.auto_reset && push_reset) wl_push(B, parity, rst_list, shard, e);
         return d && P.auto_reset;
@@ -50,12 +50,13 @@ __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBuf
 // a slot of the stats row the binary problem does not use otherwise; k_update reads it to route the next change.
 template <int PROB, class G, class MaskT>
 __device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, MaskT b0, MaskT b1, MaskT b2, MaskT valid, int32_t* s,
-                                                   MaskT& champ) {
+                                                   MaskT& champ, bool tight = true) {
     champ = 0;
     if (PROB == PCGRL_PROB_BINARY) {
-        int regions, path;
-        regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path, champ);
+        int regions, path, ub2;
+        regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path, champ, ub2, tight);
         s[0] = regions; s[1] = path; s[2] = g.any(champ) ? 1 : 0;
+        s[3] = ub2 + 1;          // bound on the components other than the champion, + 1 (0 = not known): binary_touch
         return false;
     }
     if (PROB == PCGRL_PROB_ZELDA) { zelda_stats(g, P, b0, b1, b2, valid, s); return false; }
@@ -103,7 +104,9 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
     constexpr bool kZinc = PROB == PCGRL_PROB_ZELDA && G == 16 && sizeof(MaskT) == 4;
     constexpr int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
     MaskT* champ_base = reinterpret_cast<MaskT*>(B.champ);
-    const bool packed = inc || (kZinc && zinc && !lone);        // (environment, cell, passability change) in one word
+    // (binary, full list: a negative item is a packed one too -- a change in or next to the champion, k_step)
+    const bool tch = kInc && G == 16 && !inc && !lone && have && raw < 0;
+    const bool packed = inc || (kZinc && zinc && !lone) || tch;        // (environment, cell, passability change) in one word
     const bool reset_only = have && !packed && (raw & WL_RESET_ONLY) != 0;
     const bool compute = have && !reset_only && !(lone && (gw & 1));
     const int e = packed ? wl_inc_env<G>(raw) : (raw & ~WL_RESET_ONLY);
@@ -142,7 +145,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
         int32_t sl[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
         MaskT champ_l = 0;
         bool ns = false;
-        if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l);
+        if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l, (B.step_tight & 2) != 0);
         TL(10);
         if (g.lane == 0 && role == 0 && act) finalize_item<PROB>(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
         __builtin_amdgcn_wave_barrier();
@@ -159,18 +162,32 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
         if (compute) {      // one cell changed away from the champion: update the previous answer
             const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
             const MaskT champ_old = champ_base[(size_t)e * G + g.lane];
-            const int2 old = *reinterpret_cast<const int2*>(B.stats + (size_t)e * 8);
-            int regions, path;
-            binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, wl_inc_code<G>(raw) != 0, old.x, old.y, champ_old, regions, path, champ);
-            s[0] = regions; s[1] = path; s[2] = 1;
+            const int4 old = *reinterpret_cast<const int4*>(B.stats + (size_t)e * 8);
+            int regions, path, ub2;
+            binary_incremental(g, (MaskT)(~b0 & rowmask), cbit, wl_inc_code<G>(raw) != 0, old.x, old.y, champ_old, old.w - 1, regions, path, champ, ub2);
+            s[0] = regions; s[1] = path; s[2] = 1; s[3] = ub2 + 1;
         }
     } else if (kZinc && packed) {
         if (compute) {      // zelda: one cell was written; keep or update the region count
             const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
             zelda_stats(g, P, b0, b1, b2, rowmask, s, (int)wl_inc_code<G>(raw), cbit, B.stats[(size_t)e * 8 + 4]);
         }
-    } else if (compute) {
-        need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ);
+    } else {
+        bool full = compute;
+        if (kInc && G == 16) {
+            const bool t = compute && tch;
+            if (t) {       // the change is in the champion or next to it: its pieces / its union with the cell, one double sweep
+                const MaskT cbit = (g.lane == wl_inc_row<G>(raw)) ? (MaskT)1 << wl_inc_col<G>(raw) : (MaskT)0;
+                const MaskT champ_old = champ_base[(size_t)e * G + g.lane];
+                const int4 old = *reinterpret_cast<const int4*>(B.stats + (size_t)e * 8);
+                int regions, path, ub2;
+                if (binary_touch(g, (MaskT)(~b0 & rowmask), cbit, (wl_inc_code<G>(raw) & 1u) != 0, old.x, champ_old, old.w - 1, regions, path, champ, ub2)) {
+                    s[0] = regions; s[1] = path; s[2] = 1; s[3] = ub2 + 1;
+                    full = false;
+                }
+            }
+        }
+        if (full) need_solver = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, s, champ, (B.step_tight & 1) != 0);      // (also what binary_touch gave up on)
     }
     if (kInc && compute && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
     TL(10);
@@ -217,7 +234,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
             // start stats of the regenerated maps (pcgrl_env.py:70-71, problem.py:45-46)
             if (mine) {
                 int32_t st[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
-                const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st, champ);
+                const bool ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, st, champ, (B.step_tight & 2) != 0);
                 if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
                 if (g.lane == 0) finish_or_park<PROB>(P, B, e, st, ns, MODE_START, parity, shard);
             }

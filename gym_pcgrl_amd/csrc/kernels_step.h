@@ -247,7 +247,8 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         const bool packed_full = PROB == PCGRL_PROB_ZELDA && B.zelda_inc;
         int dest = -1, v = e;
         if (first) { dest = 0; v = u.rst ? (e | WL_RESET_ONLY) : e; }
-        else if (u.chg) { dest = u.cheap ? 2 : 1; v = (u.cheap || packed_full) ? u.inc_item : e; }
+        // (binary: a change in or next to the champion goes to the full list as a packed item with bit 31 set: binary_touch first)
+        else if (u.chg) { dest = u.cheap ? 2 : 1; v = (u.cheap || packed_full) ? u.inc_item : ((u.touch && B.step_touch) ? (u.inc_item | (int)0x80000000) : e); }
         if (u.chg) s_loc.dirty[e] = 1;
         const uint64_t m0 = __ballot(dest == 0), m1 = __ballot(dest == 1), m2 = __ballot(dest == 2);
         const uint64_t below = (1ull << lane64) - 1ull;

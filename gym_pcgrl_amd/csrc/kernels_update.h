@@ -13,6 +13,7 @@ struct UpdateOut {
     bool chg;          // a tile changed: the statistics have to be recomputed (or updated)
     bool rst;          // nothing changed and the episode ended (auto_reset): reset only
     bool cheap;        // binary: incremental update possible; zelda: the cell's passability did not change
+    bool touch;        // binary: the change is in or next to the champion and the bound on the other components is known (binary_touch)
     bool sure_done;    // a tile changed and the episode ends whatever the new statistics are
     int bucket;        // difficulty bucket (binary)
     int inc_item;      // packed (environment, cell, passability change) for the incremental routes
@@ -30,7 +31,7 @@ struct UpdateOut {
 struct UpdateMid { int x, y, hx, hy, cur; bool chg, dead; };
 template <int REP, class MaskT, bool FIFO = false, bool SPLIT = false>
 __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevBufs& B, const int32_t* __restrict__ actions, int e, UpdateMid* mid = nullptr) {
-    bool chg = false, rst = false, cheap = false, sure_done = false;
+    bool chg = false, rst = false, cheap = false, sure_done = false, touch_item = false;
     int bucket = 0, inc_item = 0, k_used = 0, cur0 = 0;
     uint32_t fw[PCGRL_FIFO_N];
 #pragma unroll
@@ -141,6 +142,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
                 const MaskT bit = (MaskT)1 << wx;
                 const MaskT touch = ((ch0 | chu | chd) & bit) | (ch0 & ((bit << 1) | (bit >> 1)));
                 cheap = touch == 0;
+                touch_item = touch != 0 && s0.w != 0;         // s0.w = bound on the other components + 1, 0 = not known
                 inc_item = wl_inc_pack(G, e, wy, wx, tile == 0 ? 1u : 0u);
             }
             if (B.zelda_inc) {
@@ -253,7 +255,7 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         if (SPLIT && mid) { mid->x = x; mid->y = y; mid->hx = hx; mid->hy = hy; mid->cur = cur; mid->chg = chg; mid->dead = dead_heat; }
         // the episode ends whatever the new statistics are (pcgrl_env.py:143): the reset is certain
         sure_done = chg && P.auto_reset && B.inline_reset && (changes >= P.max_changes || iter >= P.max_iterations);
-        if (sure_done) cheap = false;
+        if (sure_done) { cheap = false; touch_item = false; }
         if (!chg) {
             // new_stats is old_stats (pcgrl_env.py:132-142): reward 0, done/info from the current stats
             int32_t s[PCGRL_MAX_STATS], st[PCGRL_MAX_STATS];
@@ -266,13 +268,13 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
             int32_t* inf = B.info + (size_t)e * 10;
             inf[0] = s0.x; inf[1] = s0.y; inf[2] = s0.z; inf[3] = s0.w;
             inf[4] = s1.x; inf[5] = s1.y; inf[6] = s1.z; inf[7] = s1.w;
-            if (P.prob == PCGRL_PROB_BINARY) inf[2] = s0.y - t0.y;   // path-imp (binary_prob.py:137)
+            if (P.prob == PCGRL_PROB_BINARY) { inf[2] = s0.y - t0.y; inf[3] = 0; }   // path-imp (binary_prob.py:137); slots 2 and 3 of the stats row are the library's own
             inf[8] = iter; inf[9] = changes;
             rst = d && P.auto_reset;
         }
     }
     UpdateOut o;
-    o.chg = chg; o.rst = rst; o.cheap = cheap; o.sure_done = sure_done; o.bucket = bucket; o.inc_item = inc_item;
+    o.chg = chg; o.rst = rst; o.cheap = cheap; o.touch = touch_item; o.sure_done = sure_done; o.bucket = bucket; o.inc_item = inc_item;
     o.k = k_used; o.cur0 = cur0;
     return o;
 }

@@ -402,6 +402,8 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         // length; every setting measured there was 0.3-0.7 us slower than none.
         h->B.step_prio = tun_or(T.step_prio, h->cfg.prob == PCGRL_BINARY ? 15 : 0) & 0xFFF;
         h->B.step_ipw = (i == 1 || i == 2) ? i : 4;
+        h->B.step_touch = tun_or(T.no_touch, 0) ? 0 : 1;
+        h->B.step_tight = h->B.step_touch ? tun_or(T.touch_tight, 1) : 0;
     }
     const bool no_inc = tun_or(T.no_inc, 0) != 0;       // every change takes the full statistics (A/B, tests)
     DevBufs& B = h->B;

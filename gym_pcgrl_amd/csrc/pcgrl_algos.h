@@ -410,16 +410,22 @@ PCGRL_D int count_regions(B& g, typename B::mask_t pass) {
 
 // helper.py:250-264 for one component: sweep from its first cell in row-major order, np.argmax == first
 // bit of the last frontier, second sweep; returns the second eccentricity (or 0 when it provably cannot exceed `best`).
+// `bound`: what is then known of the component's value -- the value itself, or 2 * e1 (<= best) when the second sweep was not needed.
 template <class B>
-PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
+PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best, int& bound) {
 #ifdef PCGRL_EXP_NOSWEEP      /* timing experiment (tools/timeline.py with PCGRL_TL_FLAGS): what a task costs without its sweeps; results are wrong */
-    return g.popcount_sum(comp) / 4 + 1;
+    return bound = g.popcount_sum(comp) / 4 + 1;
 #endif
     typename B::mask_t last, unused;
     const int e1 = bfs_levels(g, g.first_bit(comp), comp, last);
     // the second sweep measures an eccentricity, which cannot exceed the diameter <= 2 * e1
-    if (2 * e1 <= best) return 0;
-    return bfs_levels<false>(g, g.first_bit(last), comp, unused);
+    if (2 * e1 <= best) { bound = 2 * e1; return 0; }
+    return bound = bfs_levels<false>(g, g.first_bit(last), comp, unused);
+}
+template <class B>
+PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
+    int bound;
+    return pcg_double_sweep(g, comp, best, bound);
 }
 
 // binary_prob.py:81-86: regions + helper.py:250-264 double-sweep longest path.
@@ -431,11 +437,15 @@ PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
 // cannot hold a shortest path longer than k-1).  Whole-wave groups sweep as they go.
 // `champ` receives a component whose sweep produced the returned path (the "champion"), or an empty mask when the
 // path comes from the closed-form tiny components: binary_incremental below builds on it.
+// `ub2` (16-lane groups; -1 = not known): an upper bound of the double-sweep value of every component OTHER than the champion --
+// the exact value where a component was swept, else min(size - 1, path).  binary_touch below needs it: when a change to the champion
+// leaves its new value at or above that bound, no other component has to be looked at.
 template <class B>
-PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path, typename B::mask_t& champ) {
+PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path, typename B::mask_t& champ, int& ub2, bool tight = true) {
     typedef typename B::mask_t M;
     regions = 0;
     path = 0;
+    ub2 = -1;
     champ = pass ^ pass;
     const M nontiny = pass & ~pcg_tiny_components(g, pass, regions, path);
     if (!g.any(nontiny)) return;
@@ -467,16 +477,33 @@ PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& region
         else if (size > size2) { size3 = size2; size2 = size; big2 = comp; }
         else if (size > size3) size3 = size;
     }
-    if (size1 - 1 > path) { const int e = pcg_double_sweep(g, big1, path); if (e > path) { path = e; champ = big1; } }
-    if (size2 - 1 > path) { const int e = pcg_double_sweep(g, big2, path); if (e > path) { path = e; champ = big2; } }
+    const int tiny_path = path;
+    int bd1 = size1 - 1, bd2 = size2 - 1, who = 0;      // what is known of the two largest; which one is the champion (3: another one)
+    if (size1 - 1 > path) { const int e = pcg_double_sweep(g, big1, path, bd1); if (e > path) { path = e; champ = big1; who = 1; } }
+    // (the second largest is also swept when its size alone would set ub2: a tight bound keeps binary_touch from giving up)
+    {
+        const int rest_b = size3 - 1 > tiny_path ? size3 - 1 : tiny_path;
+        if (size2 - 1 > path) { const int e = pcg_double_sweep(g, big2, path, bd2); if (e > path) { path = e; champ = big2; who = 2; } }
+        else if (tight && size2 - 1 > rest_b) pcg_double_sweep(g, big2, rest_b, bd2);
+    }
     if (size3 - 1 > path) {   // rare: a third component is still large enough to matter
         rest = nontiny & ~big1 & ~big2;
         while (g.any(rest)) {
             const M comp = pcg_component(g, g.first_bit(rest), ctx);
             rest = rest & ~comp;
-            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); if (e > path) { path = e; champ = comp; } }
+            if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); if (e > path) { path = e; champ = comp; who = 3; } }
         }
     }
+    // every component but the champion: the tiny ones, the two largest by what is known of them, the rest by their size
+    const int b1 = who == 1 ? 0 : bd1, b2 = who == 2 ? 0 : bd2, b3 = size3 - 1;
+    ub2 = tiny_path;
+    ub2 = b1 > ub2 ? b1 : ub2; ub2 = b2 > ub2 ? b2 : ub2; ub2 = b3 > ub2 ? b3 : ub2;
+    ub2 = ub2 > path ? path : ub2;                   // (no component has a value above the maximum)
+}
+template <class B>
+PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path, typename B::mask_t& champ) {
+    int ub2;
+    regions_and_longest_path(g, pass, regions, path, champ, ub2);
 }
 template <class B>
 PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& regions, int& path) {
@@ -495,15 +522,17 @@ PCGRL_D void regions_and_longest_path(B& g, typename B::mask_t pass, int& region
 //   * c became impassable: its old component fell into those k pieces -- regions + k - 1, each piece swept if its
 //     size allows (removing a cell can lengthen the shortest paths around it).
 // `cbit` has the bit of c in the lane of its row and is zero elsewhere; pass_new is the new passable mask.
+// ub2_old -> ub2: the bound on the other components (regions_and_longest_path) carried along: it only grows here -- by the bound of
+// every component this update makes, and by the old path when the champion is replaced (a negative ub2_old, "not known", stays).
 template <class B>
 PCGRL_D void binary_incremental(B& g, typename B::mask_t pass_new, typename B::mask_t cbit, bool added, int regions_old, int path_old,
-                                typename B::mask_t champ_old, int& regions, int& path, typename B::mask_t& champ) {
+                                typename B::mask_t champ_old, int ub2_old, int& regions, int& path, typename B::mask_t& champ, int& ub2) {
     typedef typename B::mask_t M;
     const M base = pass_new & ~cbit;                 // the new map with c impassable
     M rest = pcg_neighbours(g, cbit) & base;
     path = path_old;
     champ = champ_old;
-    int k = 0;
+    int k = 0, ub = ub2_old < 0 ? 0 : ub2_old;
     M uni = cbit;
     if (g.any(rest)) {
         const PcgFillCtx<B> ctx = pcg_fill_ctx(g, base);
@@ -512,15 +541,93 @@ PCGRL_D void binary_incremental(B& g, typename B::mask_t pass_new, typename B::m
             rest = rest & ~comp;
             ++k;
             if (added) uni = uni | comp;
-            else if (g.popcount_sum(comp) - 1 > path) { const int e = pcg_double_sweep(g, comp, path); if (e > path) { path = e; champ = comp; } }
+            else {
+                // swept when it could beat the champion -- or, with a bound to keep, when its size alone would raise it
+                int bd = g.popcount_sum(comp) - 1, e = 0;
+                const int thr = ub2_old < 0 ? path : ub;
+                if (bd > thr) e = pcg_double_sweep(g, comp, thr, bd);
+                if (e > path) { ub = path > ub ? path : ub; path = e; champ = comp; }
+                else ub = bd > ub ? bd : ub;
+            }
         }
     }
     if (added) {
         regions = regions_old + 1 - k;
-        if (g.popcount_sum(uni) - 1 > path) { const int e = pcg_double_sweep(g, uni, path); if (e > path) { path = e; champ = uni; } }
+        int bd = g.popcount_sum(uni) - 1, e = 0;
+        const int thr = ub2_old < 0 ? path : ub;
+        if (bd > thr) e = pcg_double_sweep(g, uni, thr, bd);
+        if (e > path) { ub = path > ub ? path : ub; path = e; champ = uni; }
+        else ub = bd > ub ? bd : ub;
     } else {
         regions = regions_old + k - 1;
     }
+    ub2 = ub2_old < 0 ? -1 : ub;
+}
+template <class B>
+PCGRL_D void binary_incremental(B& g, typename B::mask_t pass_new, typename B::mask_t cbit, bool added, int regions_old, int path_old,
+                                typename B::mask_t champ_old, int& regions, int& path, typename B::mask_t& champ) {
+    int ub2;
+    binary_incremental(g, pass_new, cbit, added, regions_old, path_old, champ_old, -1, regions, path, champ, ub2);
+}
+
+// The same two statistics after ONE cell `c` changed that IS in the champion (it became impassable) or next to it (it became
+// passable) -- exact whenever it returns true.  Every component that does not touch c is unchanged, and none of them has a double-sweep
+// value above ub2 (regions_and_longest_path), so:
+//   * c became passable: the champion, c and the other components around c (k of them, looked for outside the champion) are one
+//     component now -- regions - k; its double sweep is the new path if it is at least ub2;
+//   * c became impassable: the champion fell into k pieces around c (fills inside the old champion only) -- regions + k - 1; the
+//     largest is swept, a second one if its size allows; the maximum is the new path if it is at least ub2.  The other pieces join
+//     "the others": ub2 grows by their bounds.
+// false (the new value is below the bound, the champion is gone, three pieces that matter): the caller computes from scratch.
+// One double sweep serves both cases, so the lane groups of a wavefront stay in lockstep whatever their changes were.
+template <class B>
+PCGRL_D bool binary_touch(B& g, typename B::mask_t pass_new, typename B::mask_t cbit, bool added, int regions_old,
+                          typename B::mask_t champ_old, int ub2_old, int& regions, int& path, typename B::mask_t& champ, int& ub2) {
+    typedef typename B::mask_t M;
+    const M base = pass_new & ~cbit;
+    const M dom = added ? (base & ~champ_old) : (champ_old & ~cbit);      // where the fills may go
+    M rest = pcg_neighbours(g, cbit) & dom;
+    int k = 0, size1 = 0, size2 = 0, size3 = 0;
+    M uni = cbit ^ cbit, big1 = uni, big2 = uni;
+    if (g.any(rest)) {
+        const PcgFillCtx<B> ctx = pcg_fill_ctx(g, dom);
+        while (g.any(rest)) {
+            const M comp = pcg_component(g, g.first_bit(rest), ctx);
+            rest = rest & ~comp;
+            ++k;
+            uni = uni | comp;
+            const int size = g.popcount_sum(comp);
+            if (size > size1) { size3 = size2; size2 = size1; big2 = big1; size1 = size; big1 = comp; }
+            else if (size > size2) { size3 = size2; size2 = size; big2 = comp; }
+            else if (size > size3) size3 = size;
+        }
+    }
+    const M target = added ? (champ_old | cbit | uni) : big1;
+    // (added: a sweep that cannot reach ub2 may give up -- the answer is then "false" anyway)
+    int e = pcg_double_sweep(g, target, added ? ub2_old - 1 : -1);
+    bool ok = true;
+    int ub = ub2_old;
+    champ = target;
+    if (added) {
+        regions = regions_old - k;
+    } else {
+        regions = regions_old + k - 1;
+        ok = k > 0;
+        if (size2 > 0) {          // the second piece: swept when it could be the new champion or when its size alone would raise the bound
+            int bd = size2 - 1, e2 = 0;
+            const int thr = e < ub ? e : ub;
+            if (bd > thr) e2 = pcg_double_sweep(g, big2, thr, bd);
+            if (e2 > e) { ub = e > ub ? e : ub; e = e2; champ = big2; }
+            else ub = bd > ub ? bd : ub;
+        }
+        if (size3 > 0) {
+            if (size3 - 1 > e) ok = false;
+            else ub = size3 - 1 > ub ? size3 - 1 : ub;
+        }
+    }
+    path = e;
+    ub2 = ub;
+    return ok && e >= ub2_old;
 }
 
 // ---------------------------------------------------------------- one map, several cooperating lane groups

@@ -135,6 +135,10 @@ typedef struct pcgrl_tuning {
     int32_t step_prio;       /* k_step: s_setprio levels of the wavefronts by what they do, two bits each: bits 0-1 a certain reset, 2-3 a full
                                 recomputation, 4-5 an incremental update, 6-7 the update wavefronts; bits 8-11: how many of the leading
                                 (dearest) full tasks of a block get the level of bits 2-3 (0 = all of them) */
+    int32_t no_touch;        /* 1: k_step recomputes the binary statistics in full when a change is in or next to the champion component
+                                (default 0: binary_touch first -- the champion's pieces / its union with the cell and one double sweep) */
+    int32_t touch_tight;     /* where a full computation also sweeps the second largest component, for a tight bound on "the others": bit 0 the
+                                recomputations of a step, bit 1 the resets (default 1) */
 } pcgrl_tuning;
 
 int pcgrl_abi_version(void);

@@ -4,6 +4,8 @@
 // group" is a plain array of G row masks, so the algorithm logic (not the DPP plumbing) can be
 // checked against the oracle and the golden fixtures without a GPU.  Never loaded by the product.
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 // trace of loop entries: site 1 = component fill, site 2 = BFS sweep; the counts of wave_any() calls that
@@ -198,8 +200,10 @@ static long run_shared(const uint8_t* map, int h, int w, int ngroups, int32_t* o
 // computation when there is no champion or the change touches it, binary_incremental otherwise.
 // flips: cell indices (y * w + x) toggled one after the other; out: [nflips + 1][2] (regions, path); returns the
 // number of incremental updates.
+// counts (optional): [0] incremental updates, [1] updates through the champion (binary_touch), [2] of those given up and computed in
+// full, [3] full computations for want of a champion.
 template <int G, class T>
-static int run_incremental(const uint8_t* map0, int h, int w, const int* flips, int nflips, int32_t* out) {
+static int run_incremental(const uint8_t* map0, int h, int w, const int* flips, int nflips, int32_t* out, int* counts = nullptr) {
     typedef SimGroup<G, T> Gp;
     typedef typename Gp::mask_t M;
     Gp g;
@@ -208,9 +212,9 @@ static int run_incremental(const uint8_t* map0, int h, int w, const int* flips, 
         valid.v[y] = (w >= (int)(8 * sizeof(T))) ? ~(T)0 : (((T)1 << w) - 1);
         for (int x = 0; x < w; x++) if (!(map0[y * w + x] & 1)) pass.v[y] |= (T)1 << x;
     }
-    int regions, path, ninc = 0;
+    int regions, path, ninc = 0, ub2 = -1, ntouch = 0, ngiveup = 0, nfull = 0;
     M champ;
-    regions_and_longest_path(g, pass, regions, path, champ);
+    regions_and_longest_path(g, pass, regions, path, champ, ub2);
     out[0] = regions; out[1] = path;
     for (int f = 0; f < nflips; f++) {
         const int y = flips[f] / w, x = flips[f] % w;
@@ -218,16 +222,25 @@ static int run_incremental(const uint8_t* map0, int h, int w, const int* flips, 
         const bool added = !(pass.v[y] >> x & 1);
         pass.v[y] ^= (T)1 << x;
         M touch = (pcg_expand(g, cbit)) & champ;
-        if (!g.any(champ) || g.any(touch)) {
-            regions_and_longest_path(g, pass, regions, path, champ);
+        if (!g.any(champ) || ub2 < 0) {
+            regions_and_longest_path(g, pass, regions, path, champ, ub2);
+            nfull++;
+        } else if (g.any(touch)) {
+            int r2, p2, u2; M c2;
+            ntouch++;
+            if (binary_touch(g, pass, cbit, added, regions, champ, ub2, r2, p2, c2, u2)) { regions = r2; path = p2; champ = c2; ub2 = u2; }
+            else {
+                regions_and_longest_path(g, pass, regions, path, champ, ub2); ngiveup++;
+            }
         } else {
-            int r2, p2; M c2;
-            binary_incremental(g, pass, cbit, added, regions, path, champ, r2, p2, c2);
-            regions = r2; path = p2; champ = c2;
+            int r2, p2, u2; M c2;
+            binary_incremental(g, pass, cbit, added, regions, path, champ, ub2, r2, p2, c2, u2);
+            regions = r2; path = p2; champ = c2; ub2 = u2;
             ninc++;
         }
         out[2 * (f + 1)] = regions; out[2 * (f + 1) + 1] = path;
     }
+    if (counts) { counts[0] = ninc; counts[1] = ntouch; counts[2] = ngiveup; counts[3] = nfull; }
     return ninc;
 }
 
@@ -273,6 +286,10 @@ void sim_zelda_incremental(const uint8_t* map0, int h, int w, const int* writes,
 int sim_binary_incremental(const uint8_t* map0, int h, int w, const int* flips, int nflips, int32_t* out) {
     if (w > 32) return run_incremental<16, uint64_t>(map0, h, w, flips, nflips, out);
     return run_incremental<16, uint32_t>(map0, h, w, flips, nflips, out);
+}
+int sim_binary_incremental2(const uint8_t* map0, int h, int w, const int* flips, int nflips, int32_t* out, int* counts) {
+    if (w > 32) return run_incremental<16, uint64_t>(map0, h, w, flips, nflips, out, counts);
+    return run_incremental<16, uint32_t>(map0, h, w, flips, nflips, out, counts);
 }
 long sim_stats_shared(const uint8_t* map, int h, int w, int ngroups, int32_t* out) {
     if (w > 32) return run_shared<64, uint64_t>(map, h, w, ngroups, out);

@@ -230,10 +230,12 @@ def test_binary_incremental_update(sim):
     """binary_incremental (pcgrl_algos.h): regions and path after single-cell changes from the previous answer and
     the cached champion component, against the oracle on the full map after every change -- long random walks
     at several shapes and densities, with spurious wave rounds injected."""
-    sim.sim_binary_incremental.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    sim.sim_binary_incremental2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     sim.sim_set_spurious.argtypes = [C.c_int]
     rs = np.random.RandomState(17)
     total = ninc = 0
+    counts = np.zeros(4, np.int32)
+    tot = np.zeros(4, np.int64)
     for (h, w) in ((14, 14), (16, 11), (5, 5), (9, 32), (3, 7), (16, 40), (1, 9)):
         for dens in (0.3, 0.5, 0.65):
             for rep in range(3):
@@ -242,7 +244,8 @@ def test_binary_incremental_update(sim):
                 flips = rs.randint(0, h * w, size=T).astype(np.int32)
                 out = np.zeros((T + 1, 2), np.int32)
                 sim.sim_set_spurious(int(rs.randint(0, 30)))
-                ninc += sim.sim_binary_incremental(_p(m), h, w, _p(flips), T, _p(out))
+                ninc += sim.sim_binary_incremental2(_p(m), h, w, _p(flips), T, _p(out), _p(counts))
+                tot += counts
                 sim.sim_set_spurious(0)
                 cur = m.copy()
                 assert np.array_equal(out[0], ol.get_stats("binary", cur))
@@ -251,6 +254,9 @@ def test_binary_incremental_update(sim):
                     assert np.array_equal(out[t + 1], ol.get_stats("binary", cur)), ((h, w), dens, t, out[t + 1], ol.get_stats("binary", cur))
                 total += T
     assert ninc > total // 3          # the incremental route is the common one
+    # changes in or next to the champion (binary_touch): the rest of the changes; given up (recomputed in full) only now and then
+    assert tot[1] > total // 4 and tot[2] * 5 < tot[1], tot
+    print("incremental / touch / given up / full:", tot)
 
 
 def test_zelda_incremental_regions(sim):
