@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pcgrl_common.h"
+#include "bfs_asm.h"
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov0(uint32_t v) {
@@ -46,58 +47,10 @@ struct DevGroup;
 template <class MaskT>
 struct DevGroup<16, MaskT> : DevLaneOps<MaskT> {
     typedef MaskT mask_t;
-    enum { kGroup = 16, kLog2Group = 4, kHistBfs = sizeof(MaskT) == 4 ? 1 : 0 };
-    // BFS levels (bfs_levels in pcgrl_algos.h, the kHistBfs form) for 32-bit masks, written out -- the loop included: pairs of
-    // levels until no lane of the WAVEFRONT changes any more or the history word is full (`it`, counted up by 2 per pair, reaches
-    // a multiple of 32).  A level is 5 instructions for n' = (n | n<<1 | n>>1 | up(n) | down(n)) & pass, the compare, [the copy of
-    // the set before the lane's last change,] the carry into the history word: 16 (14) vector and 4 scalar instructions a pair,
-    // where the compiler's rendering of the plain form has 22 and 3.  Returns whether the last pair still changed something.
-    // (The DPP reads of a register come at least two instructions after the VALU write of it, as gfx9 requires: the compiler
-    // cannot see inside the block.)
+    enum { kGroup = 16, kLog2Group = 4, kHistBfs = 1 };
+    // the level loop of bfs_levels (pcgrl_algos.h, the kHistBfs form), written out: bfs_asm.h
     template <bool WANT_LAST>
-    __device__ __forceinline__ bool bfs_run(uint32_t& n, uint32_t pass, int& hist, uint32_t& prev, int& it) const {
-        uint32_t t, u, a;
-        uint64_t m, c;
-        int tmp;
-#define PCGRL_BFS_LEVEL(SRC, DST) \
-        "v_lshl_or_b32 %[t], " SRC ", 1, " SRC "\n\t" \
-        "v_lshrrev_b32 %[u], 1, " SRC "\n\t" \
-        "v_or_b32_dpp %[t], " SRC ", %[t] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "v_or_b32_dpp %[t], " SRC ", %[t] row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "v_bitop3_b32 " DST ", %[t], %[p], %[u] bitop3:0xc8\n\t" \
-        "v_cmp_ne_u32 vcc, " DST ", " SRC "\n\t"
-#define PCGRL_BFS_TAIL \
-        "v_addc_co_u32_e64 %[h], %[c], %[h], %[h], vcc\n\t" \
-        "s_add_i32 %[it], %[it], 2\n\t" \
-        "s_cbranch_vccz 2f\n\t" \
-        "s_and_b32 %[tmp], %[it], 31\n\t" \
-        "s_cbranch_scc1 1b\n" \
-        "2:\n\t" \
-        "s_mov_b64 %[m], vcc"
-        if (WANT_LAST)
-            asm volatile("1:\n\t"
-                         PCGRL_BFS_LEVEL("%[n]", "%[a]")
-                         "v_cndmask_b32 %[prev], %[prev], %[n], vcc\n\t"
-                         "v_addc_co_u32 %[h], vcc, %[h], %[h], vcc\n\t"
-                         PCGRL_BFS_LEVEL("%[a]", "%[n]")
-                         "v_cndmask_b32 %[prev], %[prev], %[a], vcc\n\t"
-                         PCGRL_BFS_TAIL
-                         : [n] "+v"(n), [h] "+v"(hist), [prev] "+v"(prev), [it] "+s"(it), [t] "=&v"(t), [u] "=&v"(u), [a] "=&v"(a), [m] "=s"(m), [c] "=&s"(c), [tmp] "=&s"(tmp)
-                         : [p] "v"(pass) : "vcc", "scc");
-        else
-            asm volatile("1:\n\t"
-                         PCGRL_BFS_LEVEL("%[n]", "%[a]")
-                         "v_addc_co_u32 %[h], vcc, %[h], %[h], vcc\n\t"
-                         PCGRL_BFS_LEVEL("%[a]", "%[n]")
-                         PCGRL_BFS_TAIL
-                         : [n] "+v"(n), [h] "+v"(hist), [it] "+s"(it), [t] "=&v"(t), [u] "=&v"(u), [a] "=&v"(a), [m] "=s"(m), [c] "=&s"(c), [tmp] "=&s"(tmp)
-                         : [p] "v"(pass) : "vcc", "scc");
-#undef PCGRL_BFS_LEVEL
-#undef PCGRL_BFS_TAIL
-        return m != 0;
-    }
-    template <bool WANT_LAST>
-    __device__ __forceinline__ bool bfs_run(uint64_t&, uint64_t, int&, uint64_t&, int&) const { return false; }      // (kHistBfs = 0: never called)
+    __device__ __forceinline__ bool bfs_run(MaskT& n, MaskT pass, int& hist, MaskT& prev, int& it) const { return pcg_bfs_run<WANT_LAST, false>(n, pass, hist, prev, it); }
     __device__ __forceinline__ int hist_fold(int hist, int it, int last_it) const { return hist != 0 ? it - (int)__builtin_ctz((unsigned)hist) : last_it; }
     // row r receives row r - 2^k (rows_down) / r + 2^k (rows_up); k is a compile-time constant after unrolling
     __device__ __forceinline__ mask_t rows_down(mask_t m, int k) const {
@@ -153,8 +106,8 @@ struct DevGroup<64, MaskT> : DevLaneOps<MaskT> {
     // whole-wave hop per round to cross row-block boundaries (pcg_fill_cols).
     enum { kGroup = 64, kLog2Group = 4, kHistBfs = 0 };
     template <bool WANT_LAST>
-    __device__ __forceinline__ bool bfs_run(MaskT&, MaskT, int&, MaskT&, int&) const { return false; }      // (never called)
-    __device__ __forceinline__ int hist_fold(int, int, int last_it) const { return last_it; }
+    __device__ __forceinline__ bool bfs_run(MaskT& n, MaskT pass, int& hist, MaskT& prev, int& it) const { return pcg_bfs_run<WANT_LAST, true>(n, pass, hist, prev, it); }
+    __device__ __forceinline__ int hist_fold(int hist, int it, int last_it) const { return hist != 0 ? it - (int)__builtin_ctz((unsigned)hist) : last_it; }
     int lane;
     __device__ __forceinline__ DevGroup() { lane = (int)(threadIdx.x & 63); }
     __device__ __forceinline__ mask_t up(mask_t m) const { return dpp_mov0<0x138>(m); }    // wave_shr:1
