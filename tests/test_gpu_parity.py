@@ -1003,6 +1003,19 @@ def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 1, 2])
+@pytest.mark.parametrize("switches", [dict(no_touch=1), dict(touch_tight=0), dict(touch_tight=3), dict(step_prio=0), dict(step_prio=0xE4 | (3 << 8)),
+                                      dict(no_touch=1, no_inc=1)], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_soak_fused_step_alternatives(idx, switches, monkeypatch):
+    """The binary soak cases through k_step with the round-4 switches set the other way: no binary_touch (every change in or next to
+    the champion recomputes), the bound on the other components loose / tight everywhere, no wavefront priorities / other
+    priorities -- every alternative must reproduce the oracle step for step."""
+    for k, v in switches.items():
+        _tune(monkeypatch, k, v)
+    test_incremental_routes_soak(*SOAK_CASES[idx])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env_id,calls,N,T", [
     ("binary-narrow-v0", (), 1000, 150),                              # one launch for the whole tape (k_step); 1000: a partial last block
     ("binary-turtle-v0", (dict(change_percentage=0.1),), 300, 120),
