@@ -31,8 +31,14 @@ __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBuf
         B.done[e] = d ? 1 : 0;
         episode_account(B, e, r, d);
         int32_t* inf = B.info + (size_t)e * 10;
-        for (int k = 0; k < 8; k++) { st[k] = s[k]; inf[k] = s[k]; }
-        if (prob == PCGRL_PROB_BINARY) { inf[2] = s[1] - sv[1]; inf[3] = 0; }      // path-imp (binary_prob.py:137); slots 2, 3 of the stats row are the library's own
+        // (binary: slots 2 and 3 of the stats row are the library's own -- champion flag, bound on the other components; the info row has
+        //  path-imp (binary_prob.py:137) and zero there.  One store per slot: an extra one cost k_stats_wide three registers and with
+        //  them its second block per CU)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            st[k] = s[k];
+            inf[k] = (prob == PCGRL_PROB_BINARY && k == 2) ? s[1] - sv[1] : ((prob == PCGRL_PROB_BINARY && k == 3) ? 0 : s[k]);
+        }
         inf[8] = c.x; inf[9] = c.y;
         if (d && P.auto_reset && push_reset) wl_push(B, parity, rst_list, shard, e);
         return d && P.auto_reset;
@@ -53,10 +59,15 @@ __device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, M
                                                    MaskT& champ, bool tight = true) {
     champ = 0;
     if (PROB == PCGRL_PROB_BINARY) {
-        int regions, path, ub2;
-        regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path, champ, ub2, tight);
+        int regions, path;
+        if (G::kGroup == 16) {
+            int ub2;
+            regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path, champ, ub2, tight);
+            s[3] = ub2 + 1;      // bound on the components other than the champion, + 1 (0 = not known): binary_touch
+        } else {
+            regions_and_longest_path(g, (MaskT)(~b0 & valid), regions, path, champ);
+        }
         s[0] = regions; s[1] = path; s[2] = g.any(champ) ? 1 : 0;
-        s[3] = ub2 + 1;          // bound on the components other than the champion, + 1 (0 = not known): binary_touch
         return false;
     }
     if (PROB == PCGRL_PROB_ZELDA) { zelda_stats(g, P, b0, b1, b2, valid, s); return false; }

@@ -424,8 +424,13 @@ PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best, int& bound
 }
 template <class B>
 PCGRL_D int pcg_double_sweep(B& g, typename B::mask_t comp, int best) {
-    int bound;
-    return pcg_double_sweep(g, comp, best, bound);
+#ifdef PCGRL_EXP_NOSWEEP
+    return g.popcount_sum(comp) / 4 + 1;
+#endif
+    typename B::mask_t last, unused;
+    const int e1 = bfs_levels(g, g.first_bit(comp), comp, last);
+    if (2 * e1 <= best) return 0;
+    return bfs_levels<false>(g, g.first_bit(last), comp, unused);
 }
 
 // binary_prob.py:81-86: regions + helper.py:250-264 double-sweep longest path.
@@ -532,7 +537,11 @@ PCGRL_D void binary_incremental(B& g, typename B::mask_t pass_new, typename B::m
     M rest = pcg_neighbours(g, cbit) & base;
     path = path_old;
     champ = champ_old;
-    int k = 0, ub = ub2_old < 0 ? 0 : ub2_old;
+    // (the bound is only kept where binary_touch runs: 16-row groups.  Whole-wavefront groups compile to the plain form -- three more
+    //  registers took k_stats_wide from two blocks per CU to one: C5 steady 49.5 -> 58 us)
+    constexpr bool kTrack = B::kGroup == 16;
+    const bool track = kTrack && ub2_old >= 0;
+    int k = 0, ub = track ? ub2_old : 0;
     M uni = cbit;
     if (g.any(rest)) {
         const PcgFillCtx<B> ctx = pcg_fill_ctx(g, base);
@@ -544,24 +553,24 @@ PCGRL_D void binary_incremental(B& g, typename B::mask_t pass_new, typename B::m
             else {
                 // swept when it could beat the champion -- or, with a bound to keep, when its size alone would raise it
                 int bd = g.popcount_sum(comp) - 1, e = 0;
-                const int thr = ub2_old < 0 ? path : ub;
+                const int thr = track ? ub : path;
                 if (bd > thr) e = pcg_double_sweep(g, comp, thr, bd);
-                if (e > path) { ub = path > ub ? path : ub; path = e; champ = comp; }
-                else ub = bd > ub ? bd : ub;
+                if (e > path) { if (kTrack) ub = path > ub ? path : ub; path = e; champ = comp; }
+                else if (kTrack) ub = bd > ub ? bd : ub;
             }
         }
     }
     if (added) {
         regions = regions_old + 1 - k;
         int bd = g.popcount_sum(uni) - 1, e = 0;
-        const int thr = ub2_old < 0 ? path : ub;
+        const int thr = track ? ub : path;
         if (bd > thr) e = pcg_double_sweep(g, uni, thr, bd);
-        if (e > path) { ub = path > ub ? path : ub; path = e; champ = uni; }
-        else ub = bd > ub ? bd : ub;
+        if (e > path) { if (kTrack) ub = path > ub ? path : ub; path = e; champ = uni; }
+        else if (kTrack) ub = bd > ub ? bd : ub;
     } else {
         regions = regions_old + k - 1;
     }
-    ub2 = ub2_old < 0 ? -1 : ub;
+    ub2 = track ? ub : -1;
 }
 template <class B>
 PCGRL_D void binary_incremental(B& g, typename B::mask_t pass_new, typename B::mask_t cbit, bool added, int regions_old, int path_old,
