@@ -296,7 +296,8 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     // (the other wavefronts take that barrier inside the first round of the task loop below: what the compiler hoists out of the
     //  loop -- scalar loads of the parameter block, address arithmetic of every task kind: ~2.4 us on the timeline -- then runs
     //  while they would only be waiting for the lists)
-    int n0 = 0, n1 = 0, n2 = 0, w_full = 0, w_total = 0;
+    int n0 = 0, n1 = 0, n2 = 0, w_full = 0, w_total = 0, w_lone = 0;
+    bool pair = false;      // two certain resets per wavefront task (four statistics side by side) from DevBufs::step_pair of them on
     // maps per wavefront task (of the GPW = 4 lane groups): the four maps of a task run their component and sweep loops in lockstep,
     // so a task lasts as long as its slowest map in every phase, and a block has only about one and a half tasks per wavefront --
     // fewer maps per task give shorter chains and more units to balance (pcgrl_tuning full_per_wave / inc_per_wave)
@@ -319,23 +320,25 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             TL(3);
             n0 = s_n[sp][0]; n1 = s_n[sp][1]; n2 = s_n[sp][2];
             w_full = (n1 + fpw - 1) / fpw;
-            w_total = n0 + w_full + (n2 + ipw - 1) / ipw;
+            pair = B.step_pair > 0 && n0 >= B.step_pair;
+            w_lone = pair ? (n0 + 1) >> 1 : n0;
+            w_total = w_lone + w_full + (n2 + ipw - 1) / ipw;
         }
         int wid = 0;
         if (lane64 == 0) wid = atomicAdd(&s_n[sp][3], 1);
         wid = __builtin_amdgcn_readfirstlane(wid);
         TL(18);
         if (wid >= w_total) break;
-        const bool lone = wid < n0, inc = wid >= n0 + w_full;
-        const int item = lone ? wid : (inc ? (wid - n0 - w_full) * ipw + gw : (wid - n0) * fpw + gw);
-        const bool have = lone ? gw < 2 : (gw < (inc ? ipw : fpw) && item < (inc ? n2 : n1));
+        const bool lone = wid < w_lone, inc = wid >= w_lone + w_full;
+        const int item = lone ? (pair ? 2 * wid + (gw >> 1) : wid) : (inc ? (wid - w_lone - w_full) * ipw + gw : (wid - w_lone) * fpw + gw);
+        const bool have = lone ? (item < n0 && (pair || gw < 2)) : (gw < (inc ? ipw : fpw) && item < (inc ? n2 : n1));
         const int raw = have ? s_items[lone ? 0 : (inc ? 2 : 1)][item] : 0;
         TL(lone ? 4 : (inc ? 6 : 5));
         if (prio) {
-            const int want = lone ? (prio & 3) : (inc ? ((prio >> 4) & 3) : ((prio_nfull == 0 || wid - n0 < prio_nfull) ? ((prio >> 2) & 3) : 0));
+            const int want = lone ? (prio & 3) : (inc ? ((prio >> 4) & 3) : ((prio_nfull == 0 || wid - w_lone < prio_nfull) ? ((prio >> 2) & 3) : 0));
             if (want != prio_now) { prio_now = want; step_set_prio(want); }
         }
-        stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, false, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
+        stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, pair, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
         TL(7);
     }
     if (prio_now) { prio_now = 0; step_set_prio(0); }

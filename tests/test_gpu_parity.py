@@ -1003,6 +1003,16 @@ def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 2, 7, 8])
+@pytest.mark.parametrize("pair", [0, 1])
+def test_soak_fused_step_reset_pairs(idx, pair, monkeypatch):
+    """k_step with two certain resets per wavefront task from the first one on (step_pair = 1; the default pairs from six a block)
+    and never (0): binary and zelda soak cases, short episodes included (5 x 5 / 5 x 4 maps: resets all the time)."""
+    _tune(monkeypatch, "step_pair", pair)
+    test_incremental_routes_soak(*SOAK_CASES[idx])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("idx", [0, 1, 2])
 @pytest.mark.parametrize("switches", [dict(no_touch=1), dict(touch_tight=0), dict(touch_tight=3), dict(step_prio=0), dict(step_prio=0xE4 | (3 << 8)),
                                       dict(no_touch=1, no_inc=1)], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))

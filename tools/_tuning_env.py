@@ -13,7 +13,7 @@ ENV_TO_FIELD = {
     "PCGRL_INLINE_RESET": "inline_reset", "PCGRL_PAIR_MIN": "pair_min", "PCGRL_NO_WIDE": "no_wide", "PCGRL_WIDE_WAVES": "wide_waves",
     "PCGRL_WIDE_GRID": "wide_grid", "PCGRL_WIDE_PAIRS": "wide_pairs", "PCGRL_WIDE_FEW": "wide_few", "PCGRL_SOK_GENERIC": "sok_generic",
     "PCGRL_SOK_HARD_CAP": "sok_hard_cap", "PCGRL_SOK_SPAWN": "sok_spawn", "PCGRL_MD_ONLY_AGENT": "md_only_agent",
-    "PCGRL_SMB_LDS_HEAP": "smb_lds_heap", "PCGRL_STEP_FPW": "full_per_wave", "PCGRL_STEP_IPW": "inc_per_wave", "PCGRL_WIDE_SPIN": "wide_spin", "PCGRL_STEP_PRIO": "step_prio", "PCGRL_NO_TOUCH": "no_touch", "PCGRL_TOUCH_TIGHT": "touch_tight",
+    "PCGRL_SMB_LDS_HEAP": "smb_lds_heap", "PCGRL_STEP_FPW": "full_per_wave", "PCGRL_STEP_IPW": "inc_per_wave", "PCGRL_WIDE_SPIN": "wide_spin", "PCGRL_STEP_PRIO": "step_prio", "PCGRL_NO_TOUCH": "no_touch", "PCGRL_TOUCH_TIGHT": "touch_tight", "PCGRL_STEP_PAIR": "step_pair",
 }
 
 
