@@ -17,7 +17,7 @@ __device__ __forceinline__ MaskT row_valid(int lane, int W, int H) {
 template <int PROB = -1>
 __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s,
                                               int mode, int parity, int shard, bool push_reset = true, int rst_list = WL_RST,
-                                              const int2* pre = nullptr) {
+                                              const int2* pre = nullptr, const double* reward_pre = nullptr) {
     const int prob = PROB >= 0 ? PROB : P.prob;
     int32_t* st = B.stats + (size_t)e * 8;
     int32_t* start = B.start_stats + (size_t)e * 8;
@@ -25,7 +25,7 @@ __device__ __forceinline__ bool finalize_item(const PcgrlParams& P, const DevBuf
         int32_t old[PCGRL_MAX_STATS], sv[PCGRL_MAX_STATS];
         for (int k = 0; k < 8; k++) { old[k] = st[k]; sv[k] = start[k]; }
         const int2 c = pre ? *pre : reinterpret_cast<const int2*>(B.counters)[e];
-        const double r = compute_reward(P, s, old, prob);
+        const double r = reward_pre ? *reward_pre : compute_reward(P, s, old, prob);      // (reward_pre: zelda_reward_lanes below)
         const bool d = episode_over(P, s, sv, prob) || c.y >= P.max_changes || c.x >= P.max_iterations;
         B.reward[e] = r;
         B.done[e] = d ? 1 : 0;
@@ -85,7 +85,8 @@ __device__ __forceinline__ bool compute_item_stats(G& g, const PcgrlParams& P, M
 // Lane 0 of the group: hand the item to the solver or finish it.
 template <int PROB = -1>
 __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBufs& B, int e, const int32_t* s, bool need_solver,
-                                               int mode, int parity, int shard, bool push_reset = true, int park_list = -1) {
+                                               int mode, int parity, int shard, bool push_reset = true, int park_list = -1,
+                                               const double* reward_pre = nullptr) {
     if (need_solver) {
         // park the partial stats and hand the environment to the solver kernel.  STEP: in the info
         // row (the old stats are still needed for the reward); otherwise in the stats row itself
@@ -95,7 +96,40 @@ __device__ __forceinline__ bool finish_or_park(const PcgrlParams& P, const DevBu
         wl_push(B, parity, park_list >= 0 ? park_list : (mode == MODE_STEP ? WL_SOL : WL_SOL2), shard, e);
         return false;
     }
-    return finalize_item<PROB>(P, B, e, s, mode, parity, shard, push_reset);
+    return finalize_item<PROB>(P, B, e, s, mode, parity, shard, push_reset, WL_RST, nullptr, reward_pre);
+}
+
+// The zelda reward (zelda_prob.py:124-142: seven range rewards times their weights, summed left to right in fp64) by the sixteen lanes
+// of a group instead of its lane 0: lane k evaluates term k -- one range_reward_i and one product for all seven at once where lane 0
+// alone went through them one after the other (a third of k_step's vector instructions on C3) -- and the products are added up in the
+// reference's order as they are moved down to lane 0.  Every lane of the group calls it; lane 0 has the result.  `old`: the previous
+// statistics row (B.stats + e * 8: read by lanes 0..6); s: the new one (the same in every lane).
+template <int J>
+__device__ __forceinline__ double dpp_down(double v) {      // lane i receives lane i + J of its row (row_shl:J)
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x100 + J, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 + J, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// (the weights and bands come from a table in LDS, zelda_reward_tab: selecting them per lane from the by-value parameter block would be a
+//  run-time index into it, which puts a copy of it into scratch memory)
+__device__ __forceinline__ void zelda_reward_tab(const PcgrlParams& P, ZeldaRewardTab* T) {      // one thread
+    // term k of get_reward: player, key, door, enemies (weight 4), regions (weight 3), nearest-enemy, path-length
+    T->w[0] = P.rewards[0]; T->w[1] = P.rewards[1]; T->w[2] = P.rewards[2]; T->w[3] = P.rewards[4]; T->w[4] = P.rewards[3];
+    T->w[5] = P.rewards[5]; T->w[6] = P.rewards[6]; T->w[7] = 0.0;
+    T->lo[0] = 1; T->lo[1] = 1; T->lo[2] = 1; T->lo[3] = 2; T->lo[4] = 1; T->lo[5] = P.target_enemy_dist; T->lo[6] = PCGRL_IPOS; T->lo[7] = 0;
+    T->hi[0] = 1; T->hi[1] = 1; T->hi[2] = 1; T->hi[3] = P.max_enemies; T->hi[4] = 1; T->hi[5] = PCGRL_IPOS; T->hi[6] = PCGRL_IPOS; T->hi[7] = 0;
+}
+__device__ __forceinline__ double zelda_reward_lanes(const ZeldaRewardTab* T, const int32_t* old, const int32_t* s, int k) {
+    const int s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
+    int n = s6;
+    n = k == 5 ? s5 : n; n = k == 4 ? s4 : n; n = k == 3 ? s3 : n; n = k == 2 ? s2 : n; n = k == 1 ? s1 : n; n = k == 0 ? s0 : n;
+    const int kk = k & 7;
+    const int o = old[kk];
+    const double t = k < 7 ? (double)range_reward_i(n, o, T->lo[kk], T->hi[kk]) * T->w[kk] : 0.0;
+    double r = t;
+    r = r + dpp_down<1>(t); r = r + dpp_down<2>(t); r = r + dpp_down<3>(t);
+    r = r + dpp_down<4>(t); r = r + dpp_down<5>(t); r = r + dpp_down<6>(t);
+    return r;
 }
 
 // What one wavefront does with its share of the work of a launch (k_stats, and the fused step kernel k_step): `lone` -- a
@@ -158,7 +192,10 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
         bool ns = false;
         if (act) ns = compute_item_stats<PROB>(g, P, b0, b1, b2, rowmask, sl, champ_l, (B.step_tight & 2) != 0);
         TL(10);
-        if (g.lane == 0 && role == 0 && act) finalize_item<PROB>(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre);
+        constexpr bool kLaneReward = PROB == PCGRL_PROB_ZELDA && G == 16;
+        double rpre = 0.0;
+        if (kLaneReward && SL && role == 0 && act) rpre = zelda_reward_lanes(&SL->zr, B.stats + (size_t)e * 8, sl, g.lane);
+        if (g.lane == 0 && role == 0 && act) finalize_item<PROB>(P, B, e, sl, MODE_STEP, parity, shard, false, WL_RST, &pre, (kLaneReward && SL) ? &rpre : nullptr);
         __builtin_amdgcn_wave_barrier();
         if (role == 1 && have) {
             if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ_l;
@@ -203,9 +240,13 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
     if (kInc && compute && champ_base) champ_base[(size_t)e * G + g.lane] = champ;
     TL(10);
     int want_reset = 0;
+    constexpr bool kLaneReward = PROB == PCGRL_PROB_ZELDA && G == 16;
+    double rpre = 0.0;
+    const bool lane_reward = kLaneReward && SL != nullptr && mode == MODE_STEP;      // (k_step: the table is in its StepLocal)
+    if (lane_reward && have && !reset_only) rpre = zelda_reward_lanes(&SL->zr, B.stats + (size_t)e * 8, s, g.lane);
     if (g.lane == 0 && have) {
         if (reset_only) want_reset = 1;
-        else want_reset = finish_or_park<PROB>(P, B, e, s, need_solver, mode, parity, shard, !inline_reset) ? 1 : 0;
+        else want_reset = finish_or_park<PROB>(P, B, e, s, need_solver, mode, parity, shard, !inline_reset, -1, lane_reward ? &rpre : nullptr) ? 1 : 0;
     }
     if (inline_reset) {
         const uint64_t want = __ballot(want_reset != 0);     // one bit per group, at its lane 0

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     if (threadIdx.x < EPB) s_loc.dirty[threadIdx.x] = 0;
     if (threadIdx.x < 8) s_n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
     if (threadIdx.x == 0) { s_loc.e0 = 0; s_loc.need = NUPD; s_loc.refill_done[0] = 0; s_loc.refill_done[1] = 0; }
+    if (PROB == PCGRL_PROB_ZELDA && threadIdx.x == 64) zelda_reward_tab(P, &s_loc.zr);
     uint8_t* reset_scratch = smem + L.total;
     // steps > 1 (pcgrl_rollout): the environments of a block do not depend on any other block, so the block simply goes on
     // with the next row of the action tape -- no launch, no grid-wide barrier between steps, blocks run ahead of each other

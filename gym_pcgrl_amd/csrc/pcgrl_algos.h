@@ -116,6 +116,9 @@ PCGRL_HD void dd_pack(int32_t* s, const int* out4) {   // out4 = dist-win, sol-l
 // binary_prob.py:98-106 | zelda_prob.py:124-142 | sokoban_prob.py:157-175 (same summation order; the
 // products and sums are done in fp64 exactly as Python does them with int * weight)
 PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int32_t* o, int prob) {
+#ifdef PCGRL_EXP_NOREWARD     /* timing experiment (tools/exp_build_bench.py): what the reward arithmetic costs; results are wrong */
+    return (double)(n[0] - o[0]);
+#endif
     const double* w = P.rewards;
     if (prob == PCGRL_PROB_BINARY) {
         return (double)range_reward_i(n[0], o[0], 1, 1) * w[0] + (double)range_reward_i(n[1], o[1], PCGRL_IPOS, PCGRL_IPOS) * w[1];

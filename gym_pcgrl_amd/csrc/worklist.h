@@ -118,6 +118,8 @@ struct DevBufs {
 
 // Block-local state of the fused step kernel (k_step) that the shared device functions have to know about: the block keeps
 // the per-environment state of its 64 environments in LDS (DevBufs pointers rebased into it) for the whole launch.
+// zelda's reward by lanes (zelda_reward_lanes, kernels_stats.h): weight and band of term k, in the order get_reward sums them
+struct ZeldaRewardTab { double w[8]; int lo[8]; int hi[8]; };
 struct StepLocal {
     int e0;
     int par, need;              // this step's slot of refill_done; how many update wavefronts have to report
@@ -129,6 +131,7 @@ struct StepLocal {
     int pend[256];
     int late_done[4];
     uint8_t dirty[256];         // planes / champion / start statistics changed: write them back
+    ZeldaRewardTab zr;          // (zelda; written once by thread 0 at the start of k_step: constant indices into the parameter block only)
 };
 
 __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {
