@@ -96,6 +96,17 @@ struct DevGroup<16, MaskT> : DevLaneOps<MaskT> {
         return v;
     }
     __device__ __forceinline__ int popcount_sum(mask_t m) const { return sum(pcg_popc(m)); }
+    // several counts through ONE reduction: packed into a word (a group of sixteen 32-bit rows has at most 512 cells, of 64-bit rows 1 024)
+    __device__ __forceinline__ void popcount_sum2(mask_t a, mask_t b, int& x, int& y) const {
+        const int v = sum(pcg_popc(a) | (pcg_popc(b) << 16));
+        x = v & 0xFFFF; y = (int)((unsigned)v >> 16);
+    }
+    __device__ __forceinline__ void popcount_sum3(mask_t a, mask_t b, mask_t c, int& x, int& y, int& z) const {
+        if (sizeof(MaskT) == 4) {
+            const int v = sum(pcg_popc(a) | (pcg_popc(b) << 10) | (pcg_popc(c) << 20));
+            x = v & 1023; y = (v >> 10) & 1023; z = (int)((unsigned)v >> 20);
+        } else { popcount_sum2(a, b, x, y); z = popcount_sum(c); }
+    }
 };
 
 template <class MaskT>
@@ -145,4 +156,9 @@ struct DevGroup<64, MaskT> : DevLaneOps<MaskT> {
                    max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
     }
     __device__ __forceinline__ int popcount_sum(mask_t m) const { return sum(pcg_popc(m)); }
+    __device__ __forceinline__ void popcount_sum2(mask_t a, mask_t b, int& x, int& y) const {       // (at most 4 096 cells: sixteen bits each)
+        const int v = sum(pcg_popc(a) | (pcg_popc(b) << 16));
+        x = v & 0xFFFF; y = (int)((unsigned)v >> 16);
+    }
+    __device__ __forceinline__ void popcount_sum3(mask_t a, mask_t b, mask_t c, int& x, int& y, int& z) const { popcount_sum2(a, b, x, y); z = popcount_sum(c); }
 };

@@ -21,7 +21,7 @@
 //   wave_any(m)          true if m != 0 in any lane of the wavefront (>= any(m); only used where an
 //                        extra loop round is harmless)
 //   first_bit(m)         m with only its first set bit in row-major order kept (whole group)
-//   popcount_sum(m)      group-uniform total popcount;  popc_lanes(m) per-lane popcount
+//   popcount_sum(m)      group-uniform total popcount;  popc_lanes(m) per-lane popcount;  popcount_sum2 / 3: several counts at once
 //   imax(v)              group-uniform max of a per-lane int
 //   isel_ne / msel_ne    per lane: a != b ? x : y;   keep_where_eq(v, x, m): v == x ? m : 0
 //   bitrev(m)            reverse the bits of the mask word
@@ -315,7 +315,8 @@ PCGRL_D typename B::mask_t pcg_tiny_components(B& g, typename B::mask_t p, int& 
     const M e1 = deg1 << 1, e2 = deg1 >> 1, e3 = g.up(deg1), e4 = g.down(deg1);
     const M centre = deg2 & ((e1 & e2) | (e3 & e4) | ((e1 | e2) & (e3 | e4)));
     const M ends = deg1 & pcg_neighbours(g, centre);
-    const int n_iso = g.popcount_sum(iso), n_dom = g.popcount_sum(dom), n_tri = g.popcount_sum(centre);
+    int n_iso, n_dom, n_tri;
+    g.popcount_sum3(iso, dom, centre, n_iso, n_dom, n_tri);          // (one reduction for the three counts)
     regions += n_iso + (n_dom >> 1) + n_tri;
     const int tiny_path = n_tri > 0 ? 2 : (n_dom > 0 ? 1 : 0);
     path = tiny_path > path ? tiny_path : path;
@@ -741,7 +742,8 @@ PCGRL_D void zelda_stats(B& g, const PcgrlParams& P, typename B::mask_t b0, type
                          int pass_change = -1, typename B::mask_t cbit = typename B::mask_t(), int regions_old = 0) {
     typedef typename B::mask_t M;
     ZeldaMasks<M> z = zelda_masks(b0, b1, b2, valid);
-    int player = g.popcount_sum(z.player), key = g.popcount_sum(z.key), door = g.popcount_sum(z.door);
+    int player, key, door;
+    g.popcount_sum3(z.player, z.key, z.door, player, key, door);
     int enemies = g.popcount_sum(z.enemy);
     M walk = z.empty | z.player | z.key | z.enemy;          // regions / player->key passable set
     int regions;

@@ -94,6 +94,8 @@ struct SimGroup {
         if (g_spurious > 0 && (g_rng >> 16) % 3 != 0) { g_spurious--; return true; }   // another group of the wave is not done yet
         return false;
     }
+    void popcount_sum2(const mask_t& a, const mask_t& b, int& x, int& y) const { x = popcount_sum(a); y = popcount_sum(b); }
+    void popcount_sum3(const mask_t& a, const mask_t& b, const mask_t& c, int& x, int& y, int& z) const { x = popcount_sum(a); y = popcount_sum(b); z = popcount_sum(c); }
     ivec_t popc_lanes(const mask_t& m) const { ivec_t r; for (int i = 0; i < G; i++) r.v[i] = __builtin_popcountll((unsigned long long)m.v[i]); return r; }
     int imax(const ivec_t& v) const { int m = v.v[0]; for (int i = 1; i < G; i++) m = v.v[i] > m ? v.v[i] : m; return m; }
     ivec_t isel_ne(const mask_t& a, const mask_t& b, int x, const ivec_t& y) const { ivec_t r; for (int i = 0; i < G; i++) r.v[i] = a.v[i] != b.v[i] ? x : y.v[i]; return r; }
