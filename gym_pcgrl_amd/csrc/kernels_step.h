@@ -321,7 +321,9 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             TL(3);
             n0 = s_n[sp][0]; n1 = s_n[sp][1]; n2 = s_n[sp][2];
             w_full = (n1 + fpw - 1) / fpw;
-            pair = B.step_pair > 0 && n0 >= B.step_pair;
+            // (zelda only, at compile time: a step of the binary problem has two or three certain resets a block, and a second inlined
+            //  copy of the reset cost its kernel 1 400 instructions and half again as many scalar-register spills: + 4 % vector instructions)
+            pair = PROB == PCGRL_PROB_ZELDA && B.step_pair > 0 && n0 >= B.step_pair;
             w_lone = pair ? (n0 + 1) >> 1 : n0;
             w_total = w_lone + w_full + (n2 + ipw - 1) / ipw;
         }
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             const int want = lone ? (prio & 3) : (inc ? ((prio >> 4) & 3) : ((prio_nfull == 0 || wid - w_lone < prio_nfull) ? ((prio >> 2) & 3) : 0));
             if (want != prio_now) { prio_now = want; step_set_prio(want); }
         }
-        stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, pair, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
+        stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, PROB == PCGRL_PROB_ZELDA && pair, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
         TL(7);
     }
     if (prio_now) { prio_now = 0; step_set_prio(0); }

@@ -139,7 +139,7 @@ typedef struct pcgrl_tuning {
                                 (default 0: binary_touch first -- the champion's pieces / its union with the cell and one double sweep) */
     int32_t touch_tight;     /* where a full computation also sweeps the second largest component, for a tight bound on "the others": bit 0 the
                                 recomputations of a step, bit 1 the resets (default 1) */
-    int32_t step_pair;       /* k_step: from this many certain resets in a block's step on, a wavefront takes two of them (default 6; 0: never) */
+    int32_t step_pair;       /* k_step, zelda: from this many certain resets in a block's step on, a wavefront takes two of them (default 6; 0: never) */
 } pcgrl_tuning;
 
 int pcgrl_abi_version(void);
