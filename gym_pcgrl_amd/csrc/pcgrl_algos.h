@@ -121,7 +121,8 @@ PCGRL_HD double compute_reward(const PcgrlParams& P, const int32_t* n, const int
 #endif
     const double* w = P.rewards;
     if (prob == PCGRL_PROB_BINARY) {
-        return (double)range_reward_i(n[0], o[0], 1, 1) * w[0] + (double)range_reward_i(n[1], o[1], PCGRL_IPOS, PCGRL_IPOS) * w[1];
+        // (a band at +inf -- "the longer the better" -- is the second case of get_range_reward for every finite value: new - old)
+        return (double)range_reward_i(n[0], o[0], 1, 1) * w[0] + (double)(n[1] - o[1]) * w[1];
     } else if (prob == PCGRL_PROB_ZELDA) {
         double r = (double)range_reward_i(n[0], o[0], 1, 1) * w[0];
         r = r + (double)range_reward_i(n[1], o[1], 1, 1) * w[1];
@@ -747,9 +748,13 @@ PCGRL_D void zelda_stats(B& g, const PcgrlParams& P, typename B::mask_t b0, type
     int enemies = g.popcount_sum(z.enemy);
     M walk = z.empty | z.player | z.key | z.enemy;          // regions / player->key passable set
     int regions;
+#ifdef PCGRL_EXP_NOREGIONS    /* timing experiment (tools/exp_build_local.py): zelda without its region counts; results are wrong */
+    regions = regions_old + g.popcount_sum(cbit);
+#else
     if (pass_change < 0) regions = count_regions(g, walk);
     else if (pass_change == 0) regions = regions_old;
     else regions = regions_incremental(g, walk, cbit, pass_change == 1, regions_old);
+#endif
     int nearest = 0, path = 0;
     if (player == 1 && regions == 1) {
         if (enemies > 0) {
