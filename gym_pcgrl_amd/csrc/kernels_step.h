@@ -29,7 +29,7 @@
 // bytes for a full block of 64 environments), then the ones that are only produced.  Sizes depend on the kernel's template
 // parameters only (the champion rows of the binary problem and the draw cache of the narrow representation keep their room
 // even when the feature is off), so that the prefetch can be laid out at compile time.
-struct StepLds { int planes, champ, stats, start, cnt, cur, fifo, tag, pos, act, in_total, info, rew, done, total; };
+struct StepLds { int planes, champ, stats, start, cnt, cur, fifo, tag, pos, act, flat, in_total, info, rew, done, total; };
 __host__ __device__ constexpr StepLds step_lds_layout(int plane_row_bytes, int champ_row_bytes, bool fifo, int action_width, int epb) {
     StepLds L = {};
     int o = 0;
@@ -43,6 +43,7 @@ __host__ __device__ constexpr StepLds step_lds_layout(int plane_row_bytes, int c
     L.tag = o; o += fifo ? epb * 4 : 0;
     L.pos = o; o += epb * 2;
     L.act = o; o += epb * 4 * action_width;
+    L.flat = o; o += action_width == 3 ? epb * 4 : 0;       // wide representation: the ActionMap wrapper's flat indices (pcgrl_step_flat), decoded into `act` by the update
     L.in_total = o;
     L.info = o; o += epb * 40;
     L.rew = o; o += epb * 8;
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             PCGRL_SEG_LOAD(L.tag / 16, EPB / 4, has_fifo ? Bg.fifo_tag + e0 : nullptr, has_fifo);
         }
         PCGRL_SEG_LOAD(L.pos / 16, EPB / 8, Bg.pos + (size_t)e0 * 2, true);
-        PCGRL_SEG_LOAD(L.act / 16, EPB / 4 * AW, actions + (size_t)e0 * AW, true);
+        PCGRL_SEG_LOAD(L.act / 16, EPB / 4 * AW, actions + (size_t)e0 * AW, !(AW == 3 && Bg.flat));
+        if (AW == 3) PCGRL_SEG_LOAD(L.flat / 16, (AW == 3 ? EPB / 4 : 1), Bg.flat ? Bg.flat + e0 : nullptr, Bg.flat != nullptr);
         asm volatile("" ::: "memory");      // every load above is issued before the first LDS store below waits for its data
         constexpr int TOT = L.in_total / 16;
         seg_store_c<TPB, 0, TOT>(smem, r0, tid0); seg_store_c<TPB, 1, TOT>(smem, r1, tid0); seg_store_c<TPB, 2, TOT>(smem, r2, tid0);
@@ -210,7 +212,8 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             blk_copy<TPB>(smem + L.fifo, reinterpret_cast<const uint8_t*>(Bg.fifo + (size_t)e0 * PCGRL_FIFO_N), ne * PCGRL_FIFO_N * 4);
             blk_copy<TPB>(smem + L.tag, reinterpret_cast<const uint8_t*>(Bg.fifo_tag + e0), ne * 4);
         }
-        blk_copy<TPB>(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)e0 * AW), ne * 4 * AW);
+        if (AW == 3 && Bg.flat) blk_copy<TPB>(smem + L.flat, reinterpret_cast<const uint8_t*>(Bg.flat + e0), ne * 4);
+        else blk_copy<TPB>(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)e0 * AW), ne * 4 * AW);
     }
     if (threadIdx.x < EPB) s_loc.dirty[threadIdx.x] = 0;
     if (threadIdx.x < 8) s_n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
@@ -242,6 +245,16 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         const int e = wv * 64 + lane64;                        // block-local index (see B above)
         UpdateOut u = {};
         UpdateMid mid = {};
+        if (REP == PCGRL_REP_WIDE && !MULTI && Bg.flat && e < ne) {
+            // ActionMap.step (wrappers.py:139-154) folded in: flat index into (H, W, tiles) -> (x, y, tile), clamped and reported like k_action_map
+            const int dim = P.ntiles, total = W * H * dim;
+            int a = reinterpret_cast<const int32_t*>(smem + L.flat)[e];
+            if (a < 0 || a >= total) atomicOr(B.status, PCGRL_STATUS_BAD_ACTION);
+            a = a < 0 ? 0 : (a >= total ? total - 1 : a);
+            int32_t* t3 = reinterpret_cast<int32_t*>(smem + L.act) + 3 * e;
+            const int q = a / dim;
+            t3[0] = q % W; t3[1] = q / W; t3[2] = a - q * dim;
+        }
         if (e < ne) u = update_env<REP, MaskT, true, true>(P, B, act_lds, e, &mid);      // the decision part: everything the task lists need
         TL(2);
         const bool first = u.rst || u.sure_done;               // reset-only, or certain to end: k_stats' "lone" items

@@ -454,6 +454,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     }
     // inline_reset = 0 routes resets through the reset list + k_reset instead (A/B measurements)
     B.inline_reset = (!solver_prob(h->cfg.prob) && tun_or(T.inline_reset, 1) != 0) ? 1 : 0;
+    B.flat = nullptr;
     B.big_arena = nullptr;
     if (big_search(&h->cfg)) {
         // levels / solver_power beyond the compact searches: the general searches' arena, then the scheduling words
@@ -1059,6 +1060,21 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     // the wrapped observation: the fused step kernel wrote it; every other pipeline gets one more launch
     if ((used_lists || !h->B.obs.fused) && h->B.obs.out && !h->obs_hold && (rc = launch_obs(h, h->B.obs, (hipStream_t)stream))) return rc;
     return PCGRL_OK;
+}
+
+// ActionMap.step + PcgrlEnv.step: where the fused step kernel applies the flat indices are decoded by its update wavefronts (one launch
+// less: the decode kernel was 4-5 us of a 35 us step with the image); elsewhere k_action_map fills xyv and the step takes that.
+int pcgrl_step_flat(pcgrl_env* h, const int32_t* flat, int32_t* xyv, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!flat || !xyv || h->cfg.rep != PCGRL_REP_WIDE) return PCGRL_EINVAL;
+    if (fused_step_applies(h, false)) {
+        h->B.flat = flat;
+        const int rc = pcgrl_step(h, xyv, stream);        // (xyv is not read: the action segment of the kernel's prefetch is off)
+        h->B.flat = nullptr;
+        return rc;
+    }
+    const int rc = pcgrl_action_map(h, flat, xyv, stream);
+    return rc ? rc : pcgrl_step(h, xyv, stream);
 }
 
 // `steps` consecutive pcgrl_step calls on a tape of actions.  Where the fused step kernel applies this is ONE launch: a block

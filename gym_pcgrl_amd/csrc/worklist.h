@@ -110,6 +110,7 @@ struct DevBufs {
     int32_t step_fpw, step_ipw;      // k_step: full / incremental items per wavefront task (1, 2 or 4)
     int32_t step_prio;               // k_step: s_setprio levels by kind of work (pcgrl_tuning step_prio)
     int32_t step_tight;              //   bit 0: a full recomputation of the step sweeps the second largest component for a tight bound, bit 1: a reset does
+    const int32_t* flat;             // k_step, wide representation: this step's actions as the ActionMap wrapper's flat indices (pcgrl_step_flat), else null
     int32_t step_pair;               // k_step: certain resets per block and step from which a wavefront takes two of them (0: never; pcgrl_tuning step_pair)
     int32_t step_touch;              // k_step, binary: changes in or next to the champion try binary_touch before a full recomputation (pcgrl_tuning no_touch)
     uint8_t* big_arena;              // search_big.h: per-block node pool + heap + visited table (levels / solver_power beyond the compact searches)

@@ -292,6 +292,20 @@ class BatchedPcgrlEnv:
         info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
         return self._obs(), b["reward"], b["done"].view(self._torch.bool), info
 
+    def step_flat(self, flat, xyv):
+        """ActionMap.step + step() for the wide representation in one call of the library (pcgrl_step_flat): `flat` int32 [N] device
+        tensor of indices into (H, W, tiles), `xyv` int32 [N, 3] device scratch.  Same return value as step()."""
+        if self._needs_reset:
+            raise RuntimeError("reset() must be called before step()")
+        self._last_actions = (flat, xyv)
+        _lib.check(self._lib.pcgrl_step_flat(self._handle, C.c_void_p(flat.data_ptr()), C.c_void_p(xyv.data_ptr()), self._stream()), "pcgrl_step_flat")
+        if self.strict_actions:
+            self.check_status()
+        b = self._bufs
+        decode = self._prob.decode_rows if self._prob.packed_rows else None
+        info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
+        return self._obs(), b["reward"], b["done"].view(self._torch.bool), info
+
     def rollout(self, actions, want_info=True, out=None):
         """`T` consecutive steps on a tape of actions: int tensor [T, N] (narrow, turtle), [T, N, 3] (wide), [T, N, 2] /
         [T, N, 9] (cast / multi).  Returns (reward f64 [T, N], done bool [T, N], info) with `info` an InfoBatch over the

@@ -120,8 +120,7 @@ class ActionMapImagePCGRLWrapper(_ImageWrapper):
         a = a.to(device=e.device, dtype=torch.int32).reshape(self.num_envs).contiguous()
         if self._xyv is None:
             self._xyv = torch.empty((self.num_envs, 3), dtype=torch.int32, device=e.device)
-        _lib.check(e._lib.pcgrl_action_map(e._handle, C.c_void_p(a.data_ptr()), C.c_void_p(self._xyv.data_ptr()), e._stream()), "pcgrl_action_map")
-        _, reward, done, info = e.step(self._xyv)
+        _, reward, done, info = e.step_flat(a, self._xyv)          # decode + step: one call, one launch where the step is fused
         return self._obs, reward, done, info
 
 

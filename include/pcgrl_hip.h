@@ -202,6 +202,10 @@ int pcgrl_bind_observation(pcgrl_env* env, uint8_t* out, int32_t out_h, int32_t 
 /* ActionMap.step for the wide representation (wrappers.py:139-154): flat DEVICE i32 [N] index into
  * (H, W, tiles) -> xyv DEVICE i32 [N,3] = (x, y, tile), the action pcgrl_step takes. */
 int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* stream);
+/* ActionMap.step followed by PcgrlEnv.step (wrappers.py:139-154 + pcgrl_env.py:129-150) for the wide representation in one call:
+ * flat DEVICE i32 [N]; xyv DEVICE i32 [N,3] scratch of the caller (filled where the decode is a kernel of its own; the fused step
+ * kernel decodes inside and leaves it alone).  PCGRL_EINVAL for another representation. */
+int pcgrl_step_flat(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* stream);
 /* Episode statistics kept by the step kernels -- what stable-baselines' Monitor keeps around the reference env in
  * utils.make_env / make_vec_envs (utils.py:13-29, 60-71).  ep_return f64 [N], ep_length i32 [N]: reward sum (in step
  * order) and step count of the running episode; last_return / last_length: the same, latched when an episode ends

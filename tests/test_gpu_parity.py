@@ -1003,6 +1003,40 @@ def test_soak_two_launch_binary_pipeline(idx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prob,calls,n", [("zelda", (dict(width=11, height=16),), 300),           # fused: decoded inside k_step
+                                          ("binary", (), 130),                                    # fused, binary
+                                          ("binary", (dict(width=20, height=30),), 70),           # tall map: k_action_map + the pipeline
+                                          ("sokoban", (), 64)], ids=lambda v: v if isinstance(v, str) else "")
+def test_step_flat_equals_action_map_plus_step(prob, calls, n):
+    """pcgrl_step_flat (ActionMap.step + PcgrlEnv.step in one call; the fused step kernel decodes the flat indices itself) against
+    pcgrl_action_map followed by pcgrl_step on a twin batch: every step's reward / done / info and the maps, out-of-range indices
+    (clamped and reported) included."""
+    torch = _torch()
+    import ctypes as C
+    from gym_pcgrl_amd import _lib
+    a_env, b_env = _make(prob, "wide", n, list(calls), seed=4321), _make(prob, "wide", n, list(calls), seed=4321)
+    a_env.reset(); b_env.reset()
+    W, H, nt = a_env._prob._width, a_env._prob._height, a_env.get_num_tiles()
+    rs = np.random.RandomState(99)
+    xa = torch.empty((n, 3), dtype=torch.int32, device=a_env.device)
+    xb = torch.empty((n, 3), dtype=torch.int32, device=a_env.device)
+    for t in range(60):
+        flat = rs.randint(0, W * H * nt, size=n).astype(np.int32)
+        if t % 7 == 3:
+            flat[rs.randint(0, n, size=3)] = [-5, W * H * nt, W * H * nt + 1000]      # out of range: clamped, PCGRL_STATUS_BAD_ACTION
+        f = torch.as_tensor(flat, device=a_env.device)
+        _, ra, da, ia = a_env.step_flat(f, xa)
+        _lib.check(b_env._lib.pcgrl_action_map(b_env._handle, C.c_void_p(f.data_ptr()), C.c_void_p(xb.data_ptr()), b_env._stream()), "pcgrl_action_map")
+        _, rb, db, ib = b_env.step(xb)
+        assert torch.equal(ra, rb) and torch.equal(da, db), (prob, t)
+        assert torch.equal(a_env._bufs["info"], b_env._bufs["info"]), (prob, t)
+        assert torch.equal(a_env._bufs["map"], b_env._bufs["map"]), (prob, t)
+    for env in (a_env, b_env):
+        with pytest.raises(IndexError):
+            env.check_status()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("idx", [0, 2, 7, 8])
 @pytest.mark.parametrize("pair", [0, 1])
 def test_soak_fused_step_reset_pairs(idx, pair, monkeypatch):
