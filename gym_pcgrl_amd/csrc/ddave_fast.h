@@ -79,35 +79,49 @@ struct DdKidsSerial {     // one lane makes the four children one after the othe
 };
 
 // One search.  `table` (64-bit slots) must be all zeros; `cache` is room for four nodes.  ret_* describe the returned node.
-template <class HP, class TP, class Hook, class Kids>
+template <class HP, class TP, class Hook, class Kids, class RSP = SokNoResume>
 PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* pool, HP heap, TP table, int table_mask, DdFastNode* cache,
                             const DdNode& root, int k, int power, uint64_t& ret_key, int& ret_h, int& ret_depth, int& ret_jumps, int& out_iters,
-                            bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr) {
+                            bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr, RSP rsp = RSP()) {
+    constexpr bool RS = SokRs<RSP>::on;          // suspend / resume: sokoban_fast.h SokResume
+    SokResume* const rst = sok_rs_state(rsp);
+    const int rs_limit = sok_rs_limit(rsp);
+    const bool resumed = RS && rst->iterations > 0;
+    bool suspended = false;
     int npool = 0, head = 0, heapn = 0, iterations = 0, best_h = 0, best_depth = 0, best_aj = 0;
     bool have_best = false, aborted = false, win = false;
     uint64_t best_key = 0;
     DdFastNode n0;
     n0.key = F.alive0 | ((uint64_t)root.player << 48) | ((root.flags & DD_F_KEY_THERE) ? DDF_KEY_THERE : 0ull);
     n0.hd = (uint32_t)(root.h + DD_PRIO_BIAS); n0.aj = 0;
-    pool[0] = n0;
-    npool = 1;
-    heap[0] = (k >= 0) ? ((uint32_t)(2 * root.h + DD_PRIO_BIAS) << 16) : 0u;
-    heapn = 1;                                 // BFS: entries [head, heapn) of the same array are the queue
     DdFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;
+    if (!resumed) {
+        pool[0] = n0;
+        npool = 1;
+        heap[0] = (k >= 0) ? ((uint32_t)(2 * root.h + DD_PRIO_BIAS) << 16) : 0u;
+        heapn = 1;                                 // BFS: entries [head, heapn) of the same array are the queue
+    } else {
+        npool = rst->npool; head = rst->head; heapn = rst->heapn; iterations = rst->iterations;
+        best_h = rst->best_h; best_depth = rst->best_depth; have_best = rst->have_best != 0; best_key = rst->best_key; best_aj = rst->best_aux;
+        ahead_idx = -1;
+    }
     ret_key = n0.key; ret_h = root.h; ret_depth = 0; ret_jumps = 0;
 #if defined(__HIPCC__)
     if (duo && k >= 0) {
         // the search wavefront of a two-wavefront A* search (sokoban_fast.h, SokDuoBox; the same split as in mdungeon_fast.h):
         // the block's heap server owns the heap.  Same operations in the same order as the loop below.
-        duo->session = 1;
+        uint32_t cur_word = (uint32_t)(2 * root.h + DD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
+        int hn = 0;                                      // (RS) the heap's entries after the server's removal for the pending pop
+        if (resumed) { cur_word = rst->cur_word; hn = heapn; duo->resume_n = heapn; duo->resume_aw = rst->aw; }
+        duo->session = resumed ? 2 : 1;
         sok_duo_sync();                                  // (0)
         bool empty = false;
         int turn = 1;                                    // the pop the coming barrier (A) belongs to (SokDuoBox: its parity selects the set)
-        uint32_t cur_word = (uint32_t)(2 * root.h + DD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
         for (;;) {
             if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
+            if (RS && iterations >= rs_limit) { suspended = true; break; }
             iterations++;
             if ((iterations & SOK_POLL_MASK) == 0 && SOK_UNI(hook(iterations))) { aborted = true; break; }     // (the A* hooks poll at that rate)
             const uint32_t ent = cur_word & 0xFFFFu;
@@ -153,6 +167,7 @@ PCGRL_D bool dd_search_fast(const DdLevel& L, const DdFastLevel& F, DdFastNode* 
                 }
             }
             duo->npush[turn & 1] = npush;
+            if (RS) { hn += npush; hn -= hn > 0 ? 1 : 0; }
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
             const uint32_t aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
             turn++;
@@ -164,6 +179,12 @@ if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cm
         }
         duo->npush[turn & 1] = -1;                       // the server leaves the search
         sok_duo_sync();                                  // (A)
+        if (RS) {
+            rst->suspended = suspended ? 1 : 0;
+            rst->iterations = iterations; rst->npool = npool; rst->head = 0; rst->heapn = hn;
+            rst->cur_word = cur_word; rst->aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
+            rst->best_h = best_h; rst->best_depth = best_depth; rst->have_best = have_best ? 1 : 0; rst->best_key = best_key; rst->best_aux = best_aj;
+        }
         if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; ret_jumps = best_aj >> 2; }
         out_iters = iterations;
         out_exhausted = !win && !aborted && empty;
@@ -171,6 +192,7 @@ if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cm
     }
 #endif
     while (iterations < power && (k >= 0 ? heapn > 0 : head < heapn)) {
+        if (RS && iterations >= rs_limit) { suspended = true; break; }
         iterations++;
         if (hook(iterations)) { aborted = true; break; }
         uint32_t ent;
@@ -238,9 +260,14 @@ if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cm
             }
         }
     }
+    if (RS) {
+        rst->suspended = suspended ? 1 : 0;
+        rst->iterations = iterations; rst->npool = npool; rst->head = head; rst->heapn = heapn;
+        rst->best_h = best_h; rst->best_depth = best_depth; rst->have_best = have_best ? 1 : 0; rst->best_key = best_key; rst->best_aux = best_aj;
+    }
     if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; ret_jumps = best_aj >> 2; }
     out_iters = iterations;
-    out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < heapn);
+    out_exhausted = !win && !aborted && !suspended && !(k >= 0 ? heapn > 0 : head < heapn);
     return win;
 }
 

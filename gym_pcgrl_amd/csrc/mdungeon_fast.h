@@ -130,37 +130,51 @@ extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer bu
 // the four children of a pop (serially, or one per lane on the device: the search then runs on four lanes in lockstep,
 // uniform except for that step).
 // ret_key / ret_h / ret_depth describe the returned node (winner, or best node).
-template <class HP, class TP, class Hook, class Kids>
+template <class HP, class TP, class Hook, class Kids, class RSP = SokNoResume>
 PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* pool, HP heap, TP table, int table_mask, MdFastNode* cache,
                             const MdNode& root, int k, int power, uint64_t& ret_key, int& ret_h, int& ret_depth, int& out_iters,
-                            bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr) {
+                            bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr, RSP rsp = RSP()) {
+    constexpr bool RS = SokRs<RSP>::on;          // suspend / resume: sokoban_fast.h SokResume
+    SokResume* const rst = sok_rs_state(rsp);
+    const int rs_limit = sok_rs_limit(rsp);
+    const bool resumed = RS && rst->iterations > 0;
+    bool suspended = false;
     int npool = 0, head = 0, heapn = 0, iterations = 0, best_h = 0, best_depth = 0;
     bool have_best = false, aborted = false, win = false;
     uint64_t best_key = 0;
     MdFastNode n0;
     n0.key = F.alive0 | ((uint64_t)root.player << 48) | ((uint64_t)root.health << 56);
     n0.hd = (uint32_t)(root.h + MD_PRIO_BIAS); n0.pad = 0;
-    pool[0] = n0;
-    npool = 1;
-    heap[0] = (k >= 0) ? ((uint32_t)(2 * root.h + MD_PRIO_BIAS) << 16) : 0u;
-    heapn = 1;                                 // BFS: entries [head, heapn) of the same array are the queue
     MdFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;   // cache[j] = pool[cache_base + j], j < cache_n
+    if (!resumed) {
+        pool[0] = n0;
+        npool = 1;
+        heap[0] = (k >= 0) ? ((uint32_t)(2 * root.h + MD_PRIO_BIAS) << 16) : 0u;
+        heapn = 1;                                 // BFS: entries [head, heapn) of the same array are the queue
+    } else {
+        npool = rst->npool; head = rst->head; heapn = rst->heapn; iterations = rst->iterations;
+        best_h = rst->best_h; best_depth = rst->best_depth; have_best = rst->have_best != 0; best_key = rst->best_key;
+        ahead_idx = -1;
+    }
     ret_key = n0.key; ret_h = root.h; ret_depth = 0;
 #if defined(__HIPCC__)
     if (duo && k >= 0) {
         // the search wavefront of a two-wavefront A* search (sokoban_fast.h, SokDuoBox): the heap belongs to the block's heap
         // server, which appends the children of a pop, publishes the new top and removes / repairs for it while this
         // wavefront expands it.  Same operations in the same order as the loop below.
-        duo->session = 1;
+        uint32_t cur_word = (uint32_t)(2 * root.h + MD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
+        int hn = 0;                                      // (RS) the heap's entries after the server's removal for the pending pop
+        if (resumed) { cur_word = rst->cur_word; hn = heapn; duo->resume_n = heapn; duo->resume_aw = rst->aw; }
+        duo->session = resumed ? 2 : 1;
         sok_duo_sync();                                  // (0)
         SKD_DECL;
         bool empty = false;
         int turn = 1;                                    // the pop the coming barrier (A) belongs to (SokDuoBox: its parity selects the set)
-        uint32_t cur_word = (uint32_t)(2 * root.h + MD_PRIO_BIAS) << 16;      // the root's word: pool index 0, not flagged
         for (;;) {
             if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
+            if (RS && iterations >= rs_limit) { suspended = true; break; }
             iterations++;
             if ((iterations & SOK_POLL_MASK) == 0 && SOK_UNI(hook(iterations))) { aborted = true; break; }     // (the A* hooks poll at that rate)
             const uint32_t ent = cur_word & 0xFFFFu;
@@ -204,6 +218,7 @@ PCGRL_D bool md_search_fast(const MdLevel& L, const MdFastLevel& F, MdFastNode* 
                 }
             }
             duo->npush[turn & 1] = npush;
+            if (RS) { hn += npush; hn -= hn > 0 ? 1 : 0; }
             SKD_MARK(0);
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
             SKD_MARK(1);
@@ -218,6 +233,12 @@ if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cm
         duo->npush[turn & 1] = -1;                       // the server leaves the search
         sok_duo_sync();                                  // (A)
         SKD_FLUSH(32, iterations);
+        if (RS) {
+            rst->suspended = suspended ? 1 : 0;
+            rst->iterations = iterations; rst->npool = npool; rst->head = 0; rst->heapn = hn;
+            rst->cur_word = cur_word; rst->aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
+            rst->best_h = best_h; rst->best_depth = best_depth; rst->have_best = have_best ? 1 : 0; rst->best_key = best_key;
+        }
         if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; }
         out_iters = iterations;
         out_exhausted = !win && !aborted && empty;
@@ -226,6 +247,7 @@ if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cm
 #endif
     MDP_DECL;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < heapn)) {
+        if (RS && iterations >= rs_limit) { suspended = true; break; }
         iterations++;
         MDP(4);
         if (hook(iterations)) { aborted = true; break; }
@@ -298,9 +320,14 @@ if (cmin != SOK_DUO_NONE && (nxt == SOK_DUO_NONE || sok_lt(cmin, nxt))) nxt = cm
         MDP(3);
     }
     MDP_FLUSH(iterations);
+    if (RS) {
+        rst->suspended = suspended ? 1 : 0;
+        rst->iterations = iterations; rst->npool = npool; rst->head = head; rst->heapn = heapn;
+        rst->best_h = best_h; rst->best_depth = best_depth; rst->have_best = have_best ? 1 : 0; rst->best_key = best_key;
+    }
     if (!win && have_best) { ret_key = best_key; ret_h = best_h; ret_depth = best_depth; }
     out_iters = iterations;
-    out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < heapn);
+    out_exhausted = !win && !aborted && !suspended && !(k >= 0 ? heapn > 0 : head < heapn);
     return win;
 }
 

@@ -229,6 +229,9 @@ struct SokDuoBox {
     int npush[2];            // (A) search -> server: children of this pop (0..4), or -1 = the search is over
     uint32_t push[2][4];
     uint32_t ahead_word[2];  // (A) server -> search: the packed word of the top the repair left (SOK_DUO_NONE: the heap is empty)
+    // session == 2: a suspended search goes on (SokResume).  Its heap has resume_n entries, the pending pop's entry is out of it
+    // already and resume_aw is the top that removal left: the server's first turn skips its removal.
+    int resume_n; uint32_t resume_aw;
 };
 #define SOK_DUO_NONE 0xFFFFFFFFu
 #if defined(__HIPCC__)
@@ -287,12 +290,40 @@ extern __device__ unsigned long long* g_tl_buf;      // worklist.h (developer bu
 #define SKP(i) do {} while (0)
 #define SKP_FLUSH(it) do {} while (0)
 #endif
+// ---- Searches that can be suspended and resumed (round 5: pcgrl_step_async, kernels_search_async.h).  A search is handed
+// `SokResumeArg{state, limit}`: it stops *before* the pop that would take `iterations` past `limit`, leaves everything the next
+// call needs in `state` (the scalars below; the caller keeps the pool, the visited table and the heap array as they are) and
+// sets state->suspended.  A call with state->iterations > 0 continues that search instead of starting one: same pops in the
+// same order as the uninterrupted search, so same result and same iteration count (tests/test_hostsim_algos.py holds the
+// one-wavefront loops against themselves in one piece; the two-wavefront form is held against the oracle on the GPU).
+// SokNoResume (the default) compiles every trace of this away: the lockstep kernels are the code they were.
+struct SokResume {
+    int32_t iterations, npool, head, heapn;       // heapn: the heap's entries (two-wavefront A*: after the removal for the pending pop)
+    uint32_t cur_word, aw;                        // two-wavefront A*: the pending pop's word and the top its removal left (SokDuoBox)
+    int32_t best_h, best_depth, have_best, suspended;
+    uint64_t best_key;                            // (mdungeon, ddave: the key of the best node)
+    int32_t best_aux, pad;                        // (ddave: the best node's air time / jumps word)
+};
+struct SokResumeArg { SokResume* st; int limit; };
+struct SokNoResume {};
+template <class RSP> struct SokRs { static constexpr bool on = false; };
+template <> struct SokRs<SokResumeArg> { static constexpr bool on = true; };
+PCGRL_D SokResume* sok_rs_state(const SokResumeArg& a) { return a.st; }
+PCGRL_D SokResume* sok_rs_state(const SokNoResume&) { return nullptr; }
+PCGRL_D int sok_rs_limit(const SokResumeArg& a) { return a.limit; }
+PCGRL_D int sok_rs_limit(const SokNoResume&) { return 0x7FFFFFFF; }
+
 // One search.  `table` must be all zeros; `cache`
 // is room for four nodes (LDS on the device).  Same contract as sok_search otherwise.
-template <int NW, class HP, class TP, class Hook, class Kids>
+template <int NW, class HP, class TP, class Hook, class Kids, class RSP = SokNoResume>
 PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP table, int table_mask,
                              SokFastNode* cache, const SokNode& root, int k, int power, int& out_h, int& out_depth, int& out_iters,
-                             bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr) {
+                             bool& out_exhausted, Hook hook, Kids kids, SokDuoBox* duo = nullptr, RSP rsp = RSP()) {
+    constexpr bool RS = SokRs<RSP>::on;
+    SokResume* const rst = sok_rs_state(rsp);
+    const int rs_limit = sok_rs_limit(rsp);
+    const bool resumed = RS && rst->iterations > 0;
+    bool suspended = false;
     SokFastLevel<NW> F;
     sokf_level(L, F);
     const int nc = F.nc;
@@ -303,24 +334,33 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
     for (int i = 0; i < nc; i++) n0.cr |= (uint64_t)root.crate[i] << (8 * i);
     n0.ph = (uint32_t)root.player | ((uint32_t)root.h << 16);
     n0.depth = 0;
-    pool[0] = n0;
-    npool = 1;
-    if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth) << 16) | 0u; heapn = 1; }
     SokFastNode ahead = n0;
     int ahead_idx = 0, cache_base = 0, cache_n = 0;   // cache[j] = pool[cache_base + j], j < cache_n
+    if (!resumed) {
+        pool[0] = n0;
+        npool = 1;
+        if (k >= 0) { heap[0] = ((uint32_t)(2 * root.h + k * root.depth) << 16) | 0u; heapn = 1; }
+    } else {      // pool, table and heap are the ones the suspended search left
+        npool = rst->npool; head = rst->head; heapn = rst->heapn; iterations = rst->iterations;
+        best_h = rst->best_h; best_depth = rst->best_depth; have_best = rst->have_best != 0;
+        ahead_idx = -1;
+    }
     int result_h = root.h, result_depth = 0;
 #if defined(__HIPCC__)
     if (duo && k >= 0) {
         // the search wavefront of a two-wavefront A* search: see SokDuoBox.  (heap[0] = the root's word is in place.)
-        duo->session = 1;
+        uint32_t cur_word = (uint32_t)(2 * root.h + k * root.depth) << 16;     // the root's word: pool index 0
+        int hn = 0;                                      // (RS) the heap's entries after the server's removal for the pending pop
+        if (resumed) { cur_word = rst->cur_word; hn = heapn; duo->resume_n = heapn; duo->resume_aw = rst->aw; }
+        duo->session = resumed ? 2 : 1;
         sok_duo_sync();                                  // (0) wakes the heap server of this block
         SKD_DECL;
         bool empty = false;
         int turn = 1;                                    // the pop the coming barrier (A) belongs to: its parity selects the set
-        uint32_t cur_word = (uint32_t)(2 * root.h + k * root.depth) << 16;     // the root's word: pool index 0
         for (;;) {
             if (SOK_UNI(cur_word == SOK_DUO_NONE)) { empty = true; break; }
             if (iterations >= power) break;
+            if (RS && iterations >= rs_limit) { suspended = true; break; }
             iterations++;
             if ((iterations & SOK_POLL_MASK) == 0 && SOK_UNI(hook(iterations))) { aborted = true; break; }     // (the hooks of the A* agents poll at that rate)
             const int cur = (int)(cur_word & 0xFFFFu);
@@ -374,6 +414,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
                 cmin = sok_duo_first_smallest(mine.ok != 0, word, kids.lane);
             }
             duo->npush[turn & 1] = npush;
+            if (RS) { hn += npush; hn -= hn > 0 ? 1 : 0; }         // the server appends the children, then removes the top for the next pop
             SKD_MARK(0);
             sok_duo_sync();                              // (A) children one way, the top the repair left the other
             SKD_MARK(1);
@@ -390,6 +431,14 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
                                                          // set of the coming barrier is written: the server may still be reading the other)
         sok_duo_sync();                                  // (A)
         SKD_FLUSH(32, iterations);
+        if (RS) {
+            // suspended in front of the pop of `cur_word`: the server has taken that entry out of the heap already and repaired;
+            // the top it left is in this turn's set.  The heap array stays as it is.
+            rst->suspended = suspended ? 1 : 0;
+            rst->iterations = iterations; rst->npool = npool; rst->head = 0; rst->heapn = hn;
+            rst->cur_word = cur_word; rst->aw = SOK_SCALAR(duo->ahead_word[turn & 1]);
+            rst->best_h = best_h; rst->best_depth = best_depth; rst->have_best = have_best ? 1 : 0;
+        }
         if (!win) { result_h = best_h; result_depth = best_depth; }
         out_h = result_h; out_depth = result_depth; out_iters = iterations;
         out_exhausted = !win && !aborted && empty;
@@ -398,6 +447,7 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
 #endif
     SKP_DECL;
     while (iterations < power && (k >= 0 ? heapn > 0 : head < npool)) {
+        if (RS && iterations >= rs_limit) { suspended = true; break; }
         iterations++;
         if (hook(iterations)) { aborted = true; break; }
         SKP(0);
@@ -465,9 +515,14 @@ PCGRL_D bool sok_search_fast(const SokLevel& L, SokFastNode* pool, HP heap, TP t
         SKP(4);
     }
     SKP_FLUSH(iterations);
+    if (RS) {
+        rst->suspended = suspended ? 1 : 0;
+        rst->iterations = iterations; rst->npool = npool; rst->head = head; rst->heapn = heapn;
+        rst->best_h = best_h; rst->best_depth = best_depth; rst->have_best = have_best ? 1 : 0;
+    }
     if (!win) { result_h = best_h; result_depth = best_depth; }
     out_h = result_h; out_depth = result_depth; out_iters = iterations;
-    out_exhausted = !win && !aborted && !(k >= 0 ? heapn > 0 : head < npool);
+    out_exhausted = !win && !aborted && !suspended && !(k >= 0 ? heapn > 0 : head < npool);
     return win;
 }
 
@@ -547,6 +602,7 @@ __device__ __forceinline__ void sok_duo_append(uint32_t* heap, int p, uint32_t i
 // The heap server: the second wavefront of a k_sokoban / k_mdungeon / k_ddave block (see SokDuoBox).  Waits for searches (barrier 0),
 // owns their heap -- removes the top the search wavefront is expanding and repairs (sok_duo_repair), hands over the top that left,
 // appends the children (sok_duo_append) -- and leaves when the block does.  All 64 lanes take part; the barriers are the wavefront's.
+template <bool RS = false>
 __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, int lane) {
     // (the appends: every lane runs the same chain on the same addresses -- the values are wave-uniform, so the compiler keeps
     //  the index arithmetic and the comparisons on the scalar unit; the repair after a removal: sok_duo_repair)
@@ -555,11 +611,15 @@ __device__ __forceinline__ void sok_duo_server(uint32_t* heap, SokDuoBox* box, i
         sok_duo_sync();                                 // (0) a search starts, or the block is done
         if (box->session == 0) return;
         int n = 1;                                      // the root's word is in heap[0]
+        bool skip = false;
+        uint32_t aw0 = SOK_DUO_NONE;
+        if (RS && box->session == 2) { n = box->resume_n; aw0 = box->resume_aw; skip = true; }
         SKD_DECL;
         int pop = 1;
         for (;; pop++) {                     // (the search wavefront's `iterations`: the parity selects the set)
             uint32_t aw = SOK_DUO_NONE;
-            if (n > 0) {                                // heappop of the entry the search wavefront is expanding: the last entry goes
+            if (RS && skip) { aw = aw0; skip = false; }
+            else if (n > 0) {                           // heappop of the entry the search wavefront is expanding: the last entry goes
                 const uint32_t last = heap[--n];        // to the root and sinks (CPython _siftup)
                 if (n > 0) aw = sok_duo_repair(heap, n, last, lane, T);
             }

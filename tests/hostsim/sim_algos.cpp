@@ -300,6 +300,10 @@ long sim_stats_shared(const uint8_t* map, int h, int w, int ngroups, int32_t* ou
 // the device solver (sokoban_solver.h / sokoban_fast.h) run on the host: same pool/heap/table layout as k_sokoban.
 // fast = 1 takes the register-resident search for levels with at most SOKF_MAXC crates (what the kernel does),
 // fast = 0 forces the generic one.
+static int g_chunk = 0;       // > 0: the compact searches run in pieces of that many pops (sim_set_chunk)
+static long g_pieces = 0;
+void sim_set_chunk(int n) { g_chunk = n; }
+long sim_pieces_reset() { long v = g_pieces; g_pieces = 0; return v; }
 int sim_sokoban_solve2(const uint8_t* map, int h, int w, int power, int shortcut, int fast, int* dist, int* sol, int* iters) {
     SokLevel L; SokNode root;
     int ncr = sok_build_level(map, w, h, L, root);
@@ -329,7 +333,17 @@ int sim_sokoban_solve2(const uint8_t* map, int h, int w, int power, int shortcut
         bool exhausted = false;
         SokFastNode* fp = reinterpret_cast<SokFastNode*>(pool.data());
         SokFastNode cache[4];
-        if (L.cells <= 64)
+        if (g_chunk > 0) {       // the same search in pieces of g_chunk pops (SokResume: what pcgrl_step_async does across launches)
+            SokResume st; memset(&st, 0, sizeof(st));
+            do {
+                const SokResumeArg ra = {&st, st.iterations + g_chunk};
+                if (L.cells <= 64)
+                    win = sok_search_fast<1>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook(), SokKidsSerial(), nullptr, ra);
+                else
+                    win = sok_search_fast<4>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook(), SokKidsSerial(), nullptr, ra);
+                g_pieces++;
+            } while (st.suspended);
+        } else if (L.cells <= 64)
             win = sok_search_fast<1>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook(), SokKidsSerial());
         else
             win = sok_search_fast<4>(L, fp, heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, hh, dd, iters[a], exhausted, SokNoHook(), SokKidsSerial());
@@ -378,6 +392,14 @@ int sim_mdungeon_solve2(const uint8_t* map, int h, int w, int power, int shortcu
         for (int i = 0; i < tsize; i++) table[i] = 0;
         bool exhausted = false;
         MdFastNode cache[4];
+        if (g_chunk > 0) {
+            SokResume st; memset(&st, 0, sizeof(st));
+            do {
+                const SokResumeArg ra = {&st, st.iterations + g_chunk};
+                win = md_search_fast(L, F, pool.data(), heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, key, hh, dd, iters[a], exhausted, SokNoHook(), MdKidsSerial(), nullptr, ra);
+                g_pieces++;
+            } while (st.suspended);
+        } else
         win = md_search_fast(L, F, pool.data(), heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, key, hh, dd, iters[a], exhausted, SokNoHook(), MdKidsSerial());
         if (a < 3 && !win && exhausted && shortcut) a = 2;
     }
@@ -418,6 +440,15 @@ int sim_ddave_solve2(const uint8_t* map, int h, int w, int power, int fast, int*
         for (int i = 0; i < tsize; i++) table[i] = 0;
         bool exhausted = false;
         DdFastNode cache[4];
+        if (g_chunk > 0) {
+            SokResume st; memset(&st, 0, sizeof(st));
+            do {
+                const SokResumeArg ra = {&st, st.iterations + g_chunk};
+                win = dd_search_fast(L, F, pool.data(), heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, key, hh, dd, jj, iters[a], exhausted,
+                                     SokNoHook(), DdKidsSerial(), nullptr, ra);
+                g_pieces++;
+            } while (st.suspended);
+        } else
         win = dd_search_fast(L, F, pool.data(), heap.data(), table.data(), tsize - 1, cache, root, KS[a], power, key, hh, dd, jj, iters[a], exhausted,
                              SokNoHook(), DdKidsSerial());
     }

@@ -187,6 +187,54 @@ def test_device_ddave_solver_vs_golden(sim, fast):
     assert (took_fast > 0.9 * n) if fast else took_fast == 0
 
 
+@pytest.mark.parametrize("chunk", [1, 37, 1000])
+def test_compact_searches_suspend_and_resume(sim, chunk):
+    """SokResume (csrc/sokoban_fast.h; round 5, pcgrl_step_async): the compact searches of the three search problems run in
+    pieces of `chunk` pops -- suspended in front of a pop, continued by the next call from the saved scalars with pool, heap
+    and visited table left as they were -- must give the reference's results AND its per-agent iteration counts, exactly like
+    the search in one piece (the one-wavefront loops, which is what the host simulator can run; the two-wavefront form of the
+    GPU is held against the oracle by tests/test_gpu_async.py)."""
+    sim.sim_sokoban_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    sim.sim_mdungeon_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    sim.sim_ddave_solve2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    sim.sim_pieces_reset.restype = C.c_long
+    sim.sim_set_chunk(chunk)
+    sim.sim_pieces_reset()
+    stride = 1 if chunk > 1 else 7          # (one pop a piece is slow: every seventh map)
+    n = agents = 0
+    try:
+        for prob in ("sokoban", "mdungeon", "ddave"):
+            for path in sorted(p for p in glob.glob(os.path.join(G, "stats_%s_*.npz" % prob)) if _compact_search(p)):
+                d = np.load(path)
+                power = int(d["solver_power"])
+                for i in range(0, len(d["maps"]), stride):
+                    if d["agents"][i, 4] == -2:
+                        continue
+                    m = np.ascontiguousarray(d["maps"][i])
+                    it = np.zeros(4, np.int32)
+                    if prob == "sokoban":
+                        dist, sol = C.c_int(), C.c_int()
+                        assert sim.sim_sokoban_solve2(_p(m), m.shape[0], m.shape[1], power, 0, 1, C.byref(dist), C.byref(sol), _p(it)) == 0
+                        got, exp = [dist.value, sol.value], [d["stats"][i, 4], d["stats"][i, 5]]
+                    elif prob == "mdungeon":
+                        out = np.zeros(5, np.int32)
+                        assert sim.sim_mdungeon_solve2(_p(m), m.shape[0], m.shape[1], power, 0, 1, _p(out), _p(it)) in (0, 1)
+                        got, exp = list(out), [d["stats"][i, 9], d["stats"][i, 10], d["stats"][i, 6], d["stats"][i, 7], d["stats"][i, 8]]
+                    else:
+                        out = np.zeros(4, np.int32)
+                        assert sim.sim_ddave_solve2(_p(m), m.shape[0], m.shape[1], power, 1, _p(out), _p(it)) in (0, 1)
+                        got, exp = list(out), [d["stats"][i, 9], d["stats"][i, 10], d["stats"][i, 7], d["stats"][i, 8]]
+                    assert got == exp, (path, i, got, exp)
+                    assert np.array_equal(it, d["agents"][i, :4]), (path, i, it, d["agents"][i])
+                    n += 1
+                    agents += int((it > 0).sum())
+    finally:
+        sim.sim_set_chunk(0)
+    pieces = sim.sim_pieces_reset()
+    assert n > (150 if chunk == 1 else 1000)
+    assert pieces > agents          # searches really were cut into more than one piece
+
+
 def test_bitboard_stats_vs_oracle_random(sim):
     rs = np.random.RandomState(99)
     for prob, nt in (("binary", 2), ("zelda", 8)):
