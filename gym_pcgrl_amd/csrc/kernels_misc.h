@@ -18,6 +18,12 @@ __global__ void k_fill_all(DevBufs B, int n, int parity, int list) {
     if (i < n) B.wl_items[list][(size_t)(i & (WL_NSHARD - 1)) * B.wl_cap[list] + (i >> 6)] = i;
     if (i < WL_NSHARD) wl_counters(B, parity, list)[i * WL_CSTRIDE] = (n - i + WL_NSHARD - 1) / WL_NSHARD;
 }
+// pcgrl_async_flush: the environments whose search ended their episode in the last tick (kernels_search_async.h ASYNC_PEND_RESET)
+// go on `list` -- a tick's k_update would have done it
+__global__ void k_async_collect(DevBufs B, uint8_t* pending, int n, int parity, int list) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && pending[e] == 2) { pending[e] = 0; wl_push(B, parity, list, e & (WL_NSHARD - 1), e); }
+}
 __global__ void k_bcast_tile_p(double* tile_p, int n, double p0, double p1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { tile_p[2 * i] = p0; tile_p[2 * i + 1] = p1; }

@@ -354,7 +354,18 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
     __shared__ int s_hist[WL_NSHARD + 1], s_gbase[WL_NSHARD + 1];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
     UpdateOut u = {};
-    if (e < P.num_envs) u = update_env<REP, MaskT>(P, B, actions, e);
+    bool live = e < P.num_envs;
+    if (B.pending) {
+        // a tick of pcgrl_step_async: an environment whose step is still in flight sits this one out; one whose search ended its
+        // episode in the last tick (kernels_search_async.h ASYNC_PEND_RESET) is reset now: it goes on the reset list like an
+        // environment whose episode the update itself ends, and takes no action
+        const int pv = live ? (int)B.pending[e] : 1;
+        live = pv == 0;
+        const int cnt = __popcll(__ballot(live));
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(B.async_stats + 8 + 8 * (blockIdx.x & 15), (unsigned long long)cnt);
+        if (pv == 2) { u.rst = true; B.pending[e] = 0; }      // (a search of the new map that is cut short marks it pending again)
+    }
+    if (live) u = update_env<REP, MaskT>(P, B, actions, e);
     const bool chg = u.chg, rst = u.rst, cheap = u.cheap, sure_done = u.sure_done;
     int bucket = u.bucket;
     const int inc_item = u.inc_item;
@@ -399,8 +410,15 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
     __shared__ int s_cnt[2][4];
     __shared__ int s_base[2];
     const int e = blockIdx.x * PCGRL_BLOCK + threadIdx.x;
-    const bool act = e < P.num_envs;
+    bool act = e < P.num_envs;
     bool chg = false, rst = false, sure_done = false;
+    if (B.pending) {            // (see k_update)
+        const int pv = act ? (int)B.pending[e] : 1;
+        act = pv == 0;
+        const int cnt = __popcll(__ballot(act));
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(B.async_stats + 8 + 8 * (blockIdx.x & 15), (unsigned long long)cnt);
+        if (pv == 2) { rst = true; B.pending[e] = 0; }
+    }
     if (act) {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes, NT = P.ntiles;
         const int2 c = reinterpret_cast<const int2*>(B.counters)[e];

@@ -79,6 +79,8 @@
 #include "kernels_ddave.h"
 #include "kernels_smb.h"
 #include "kernels_step_solver.h"
+#include "level_build_wave.h"
+#include "kernels_search_async.h"
 #include "search_big.h"
 #include "kernels_search_big.h"
 #if PCGRL_IN_PART(PART_CORE)
@@ -108,6 +110,9 @@ struct pcgrl_env {
     int obs_incremental;       // pcgrl_bind_observation(incremental): the bound target is the library's to update in place
     const uint8_t* obs_synced; // the buffer that holds the image of the current state (written by the last step / reset), or NULL
     int obs_hold;     // inside pcgrl_rollout's loop of steps: the bound observation is written once, at the end
+    // pcgrl_step_async (kernels_search_async.h): the caller's arena, whether any step may be pending, the tick counter
+    AsyncCtl async;
+    int async_on, async_dirty;
     std::vector<hipEvent_t> events;
     size_t ev_used;
     int prof_steps;
@@ -333,6 +338,7 @@ int pcgrl_create(const pcgrl_config* c, pcgrl_env** out) {
     pcgrl_env* h = new pcgrl_env();
     h->bound = h->has_old = h->was_reset = h->parity = h->device = 0;
     h->profiling = 0; h->ev_used = 0; h->prof_steps = 0; h->obs_hold = 0; h->obs_incremental = 0; h->obs_synced = nullptr;
+    memset(&h->async, 0, sizeof(h->async)); h->async_on = h->async_dirty = 0;
     memset(&h->B, 0, sizeof(h->B));
     pcgrl_tuning_defaults(&h->tun);
     h->cfg = *c;
@@ -499,6 +505,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         }
     }
     h->bound = 1; h->has_old = 0; h->was_reset = 0; h->parity = 0;
+    h->async_on = h->async_dirty = 0;      // (pcgrl_bind_async follows a bind)
     return PCGRL_OK;   // tile_p is caller state: call pcgrl_set_tile_probs once after the first bind
 }
 
@@ -574,6 +581,7 @@ PCGRL_LOCAL int launch_step_zelda(pcgrl_env* h, const int32_t* actions, int pari
 PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st);
 PCGRL_LOCAL int launch_smb(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st, int inline_reset);
 PCGRL_LOCAL int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb);
+PCGRL_LOCAL int launch_search_async(pcgrl_env* h, int32_t* tickets, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, int budget, int resume, hipStream_t st);
 static int grid_for(int items, int per_block, int cap) {
     int g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -787,6 +795,21 @@ PCGRL_LOCAL int search_device_setup(pcgrl_env* h) {   // the search kernels use 
     const void* f = h->cfg.prob == PCGRL_SOKOBAN ? reinterpret_cast<const void*>(k_sokoban<0>)
                   : h->cfg.prob == PCGRL_MDUNGEON ? reinterpret_cast<const void*>(k_mdungeon<0>) : reinterpret_cast<const void*>(k_ddave<0>);
     HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const void* fa = h->cfg.prob == PCGRL_SOKOBAN ? reinterpret_cast<const void*>(k_search_async<PCGRL_PROB_SOKOBAN>)
+                   : h->cfg.prob == PCGRL_MDUNGEON ? reinterpret_cast<const void*>(k_search_async<PCGRL_PROB_MDUNGEON>) : reinterpret_cast<const void*>(k_search_async<PCGRL_PROB_DDAVE>);
+    HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    return PCGRL_OK;
+}
+// one launch of a tick of pcgrl_step_async (kernels_search_async.h): `tickets` = two zeroed words
+PCGRL_LOCAL int launch_search_async(pcgrl_env* h, int32_t* tickets, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, int budget, int resume, hipStream_t st) {
+    const size_t lds = (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4;
+    if (h->P.prob == PCGRL_PROB_DDAVE)
+        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_DDAVE>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume);
+    else if (h->P.prob == PCGRL_PROB_MDUNGEON)
+        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_MDUNGEON>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume);
+    else
+        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_SOKOBAN>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume);
+    HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
 template <int PROB>
@@ -1035,10 +1058,109 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream, bool* us
     return PCGRL_OK;
 }
 
+// ---- pcgrl_step_async (kernels_search_async.h) ------------------------------------------------
+static bool async_applies(const pcgrl_config* c) {
+    return solver_prob(c->prob) && c->prob != PCGRL_SMB && !big_search(c) && !big_map(c) && c->solver_power <= SOK_LDS_POWER;
+}
+static size_t async_head_bytes(const pcgrl_config* c) { return align_up((size_t)c->num_envs, 256) + 64 + ASYNC_NSHARD * 64; }      // pending, counters, shards of the first counter
+static size_t async_slot_bytes(const pcgrl_config* c) {
+    return align_up((size_t)ASYNC_SLOT_HDR + (size_t)(4 * c->solver_power + 4) * 16 + (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4, 256);
+}
+size_t pcgrl_async_bytes(const pcgrl_config* c, int32_t nslots) {
+    if (validate_config(c) != PCGRL_OK || nslots < 1 || !async_applies(c)) return 0;
+    return async_head_bytes(c) + (size_t)nslots * async_slot_bytes(c);
+}
+int pcgrl_bind_async(pcgrl_env* h, void* arena, size_t bytes, int32_t nslots, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!arena) { h->async_on = h->async_dirty = 0; return PCGRL_OK; }
+    if (!async_applies(&h->cfg) || nslots < 1 || ((uintptr_t)arena & 255) != 0 || bytes < pcgrl_async_bytes(&h->cfg, nslots)) return PCGRL_EINVAL;
+    if (h->alloc_solver_power != h->cfg.solver_power) return PCGRL_EINVAL;         // (the slots are cut for the bound solver_power)
+    DeviceGuard guard(h->device);
+    uint8_t* a = (uint8_t*)arena;
+    AsyncCtl& A = h->async;
+    A.pending = a;
+    A.stats = (unsigned long long*)(a + align_up((size_t)h->cfg.num_envs, 256));
+    A.slots = a + async_head_bytes(&h->cfg);
+    A.slot_bytes = async_slot_bytes(&h->cfg);
+    A.nslots = nslots; A.nodes_cap = 4 * h->cfg.solver_power + 4; A.tick = 0; A.pad = 0;
+    HIPCHK(hipMemsetAsync(a, 0, async_head_bytes(&h->cfg), (hipStream_t)stream));
+    HIPCHK(hipMemset2DAsync(A.slots, A.slot_bytes, 0, ASYNC_SLOT_HDR, (size_t)nslots, (hipStream_t)stream));
+    h->async_on = 1; h->async_dirty = 0;
+    return PCGRL_OK;
+}
+// the pending steps are dropped (pcgrl_reset: every environment starts over)
+static int async_drop(pcgrl_env* h, hipStream_t st) {
+    if (!h->async_on || !h->async_dirty) return PCGRL_OK;
+    HIPCHK(hipMemsetAsync(h->async.pending, 0, (size_t)h->cfg.num_envs, st));
+    HIPCHK(hipMemset2DAsync(h->async.slots, h->async.slot_bytes, 0, ASYNC_SLOT_HDR, (size_t)h->async.nslots, st));
+    h->async_dirty = 0;
+    return PCGRL_OK;
+}
+// the searches of a tick: the suspended ones and the jobs of the step's lists, one launch (an episode a search ends is reset by the next tick)
+static int async_tick_searches(pcgrl_env* h, int budget, hipStream_t st) {
+    const int par = h->parity;
+    const bool ar = h->P.auto_reset != 0;
+    h->async.tick = (h->async.tick + 1) & 0x3FFFFFFF;
+    HIPCHK(hipMemsetAsync(h->B.sok_sync, 0, 2 * sizeof(int32_t), st));
+    return launch_search_async(h, h->B.sok_sync, WL_SOL, MODE_STEP, ar ? (int)WL_SOL2 : -1, MODE_START, par, -1, par ^ 1, budget, 1, st);
+}
+// everything that is pending, to its end: the suspended searches, then the resets and searches of the episodes they ended
+static int async_finish_all(pcgrl_env* h, hipStream_t st) {
+    const int par = h->parity, n = h->P.num_envs, budget = 0x3FFFFFFF;
+    const bool ar = h->P.auto_reset != 0;
+    int rc;
+    h->async.tick = (h->async.tick + 1) & 0x3FFFFFFF;
+    int32_t* sync0 = h->B.sok_sync, *sync1 = h->B.sok_sync + (SOK_SY_WORDS + SOK_HARD_CAP);
+    hipLaunchKernelGGL(k_async_collect, dim3((n + 255) / 256), dim3(256), 0, st, h->B, h->async.pending, n, par, (int)WL_RST2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(sync0, 0, 2 * sizeof(int32_t), st));
+    if ((rc = launch_search_async(h, sync0, -1, MODE_STEP, -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), budget, 1, st))) return rc;
+    if (ar) {
+        if ((rc = launch_reset(h, WL_RST2, WL_SOL3, par, -1, st))) return rc;
+        HIPCHK(hipMemsetAsync(sync1, 0, 2 * sizeof(int32_t), st));
+        if ((rc = launch_search_async(h, sync1, WL_SOL3, MODE_START, -1, 0, par, WL_RST2, par ^ 1, budget, 0, st))) return rc;
+    }
+    return PCGRL_OK;
+}
+int pcgrl_async_flush(pcgrl_env* h, void* stream) {
+    if (!h || !h->bound) return PCGRL_ESTATE;
+    if (!h->async_on || !h->async_dirty) return PCGRL_OK;
+    DeviceGuard guard(h->device);
+    int rc = async_finish_all(h, (hipStream_t)stream);
+    if (rc) return rc;
+    h->parity ^= 1;
+    h->async_dirty = 0;
+    if (h->B.obs.out && (rc = launch_obs(h, h->B.obs, (hipStream_t)stream))) return rc;
+    return PCGRL_OK;
+}
+int pcgrl_step_async(pcgrl_env* h, const int32_t* actions, int32_t pop_budget, void* stream) {
+    if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
+    if (!actions || pop_budget < 1) return PCGRL_EINVAL;
+    if (!h->async_on) return PCGRL_ESTATE;          // pcgrl_bind_async first
+    DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int par = h->parity;
+    const bool ar = h->P.auto_reset != 0;
+    int rc;
+    h->B.pending = h->async.pending; h->B.async_stats = h->async.stats;
+    rc = launch_update(h, actions, par, st);
+    h->B.pending = nullptr; h->B.async_stats = nullptr;
+    if (rc) return rc;
+    if ((rc = launch_stats(h, WL_CHG, par, MODE_STEP, -1, 0, st))) return rc;
+    if (ar && (rc = launch_reset(h, WL_RST, WL_SOL2, par, -1, st))) return rc;
+    if ((rc = async_tick_searches(h, pop_budget, st))) return rc;
+    h->parity ^= 1;
+    h->async_dirty = 1;
+    if (h->B.obs.out) { h->B.obs.delta = 0; if ((rc = launch_obs(h, h->B.obs, st))) return rc; }
+    return PCGRL_OK;
+}
+
 int pcgrl_reset(pcgrl_env* h, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
     DeviceGuard guard(h->device);
-    int rc = reset_one(h, stream);
+    int rc = async_drop(h, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = reset_one(h, stream);
     if (rc) return rc;
     h->parity ^= 1;
     h->has_old = 1;
@@ -1049,6 +1171,7 @@ int pcgrl_reset(pcgrl_env* h, void* stream) {
 int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!actions) return PCGRL_EINVAL;
+    if (h->async_dirty) { const int rf = pcgrl_async_flush(h, stream); if (rf) return rf; }
     DeviceGuard guard(h->device);
     bool used_lists = true;
     h->B.obs.delta = (h->B.obs.out && h->B.obs.fused && h->obs_incremental && !h->obs_hold && h->obs_synced == h->B.obs.out) ? 1 : 0;
@@ -1082,6 +1205,7 @@ int pcgrl_step_flat(pcgrl_env* h, const int32_t* flat, int32_t* xyv, void* strea
 int pcgrl_rollout(pcgrl_env* h, const int32_t* actions, int32_t steps, double* reward_out, uint8_t* done_out, int32_t* info_out, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!actions || steps < 1) return PCGRL_EINVAL;
+    if (h->async_dirty) { const int rf = pcgrl_async_flush(h, stream); if (rf) return rf; }
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->P.num_envs, stride = n * action_width(h->P.rep);
@@ -1251,7 +1375,9 @@ int pcgrl_set_maps(pcgrl_env* h, const uint8_t* maps, void* stream) {
     if (!h || !h->bound || !h->was_reset) return PCGRL_ESTATE;
     if (!maps) return PCGRL_EINVAL;
     DeviceGuard guard(h->device);
-    int rc = set_maps_one(h, maps, stream);
+    int rc = async_drop(h, (hipStream_t)stream);          // (every map is replaced: what was in flight is void)
+    if (rc) return rc;
+    rc = set_maps_one(h, maps, stream);
     if (rc) return rc;
     h->parity ^= 1;
     return PCGRL_OK;

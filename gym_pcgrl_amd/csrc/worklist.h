@@ -114,6 +114,9 @@ struct DevBufs {
     int32_t step_pair;               // k_step: certain resets per block and step from which a wavefront takes two of them (0: never; pcgrl_tuning step_pair)
     int32_t step_touch;              // k_step, binary: changes in or next to the champion try binary_touch before a full recomputation (pcgrl_tuning no_touch)
     uint8_t* big_arena;              // search_big.h: per-block node pool + heap + visited table (levels / solver_power beyond the compact searches)
+    // pcgrl_step_async (kernels_search_async.h): non-null only inside a tick -- pending[e] != 0: environment e's step is in flight
+    // (a suspended search), it takes no action; async_stats[0] counts the actions that were taken
+    uint8_t* pending; unsigned long long* async_stats;
 };
 #define PCGRL_FIFO_N 8
 

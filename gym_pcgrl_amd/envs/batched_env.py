@@ -87,6 +87,8 @@ class BatchedPcgrlEnv:
         self._alloc_dims = None
         self._probs_dirty = False
         self._obs_spec = None          # bind_observation(): (out tensor, h, w, centered, pad, onehot)
+        self._async = None             # enable_async(): arena tensor + views (pending, counters)
+        self._async_nslots = 0
         self._update_spaces()
         self.seed(seed)
 
@@ -188,6 +190,9 @@ class BatchedPcgrlEnv:
         if self._episode is not None:      # rebinding after a reallocation keeps the running episodes' sums
             self._bind_episode_stats()
         self._apply_observation()
+        self._async = None
+        if self._async_nslots:
+            self._bind_async()
 
     def _upload_seeds(self):
         words = np.ascontiguousarray(self._seed_keys, dtype=np.uint32)      # [N, 3]: the MT19937 states are made on the device
@@ -393,6 +398,72 @@ class BatchedPcgrlEnv:
 
     def step_wait(self):
         return self._pending
+
+    # ---- asynchronous stepping of the search problems (pcgrl_step_async, csrc/kernels_search_async.h)
+    def enable_async(self, nslots=1024):
+        """Prepare tick(): room for `nslots` suspended searches (about 0.46 MB each at solver_power 5000).  Returns False when
+        this configuration has no asynchronous form (binary, zelda, smb; levels or solver_power beyond the compact searches) --
+        tick() is then step() with nothing ever pending."""
+        self._async_nslots = int(nslots)
+        if self._handle is None:
+            self._allocate()
+        elif self._async is None:
+            self._bind_async()
+        return self._async is not None
+
+    def _bind_async(self):
+        torch = self._torch
+        cfg = self._config(self._alloc_dims)
+        need = int(self._lib.pcgrl_async_bytes(C.byref(cfg), self._async_nslots))
+        if need == 0:
+            self._async = None
+            return
+        arena = torch.empty((need,), dtype=torch.uint8, device=self.device)          # (zeroed by the call)
+        _lib.check(self._lib.pcgrl_bind_async(self._handle, C.c_void_p(arena.data_ptr()), need, self._async_nslots, self._stream()), "pcgrl_bind_async")
+        n = self.num_envs
+        off = (n + 255) // 256 * 256
+        self._async = dict(arena=arena, pending=arena[:n], counters=arena[off:off + 64 + 16 * 64].view(torch.int64))
+
+    def tick(self, actions, pop_budget=256):
+        """One tick of asynchronous stepping (include/pcgrl_hip.h pcgrl_step_async): every environment whose previous step is
+        complete takes its action and steps; every search gets at most `pop_budget` pops, an environment whose search is not
+        finished by then stays *pending* -- it ignores the actions of the following ticks until one of them completes its step.
+        Returns (obs, reward, done, info, pending): the usual live views plus pending uint8 [N] (a live view too) -- where it is
+        0 the outputs are those of the environment's last taken action and it takes the next one; elsewhere (1: a search is
+        suspended, 2: its search ended the episode and the next tick resets it) the environment's rows are to be ignored.  Per environment the sequence of (taken action -> outputs) is bitwise that of
+        step().  step() / rollout() / set_maps() finish what is pending first (flush()); reset() drops it."""
+        if self._needs_reset:
+            raise RuntimeError("reset() must be called before tick()")
+        if self._async is None:
+            if self._async_nslots == 0:
+                self.enable_async()
+            if self._async is None:            # no asynchronous form: a lockstep step, nothing pending
+                o, r, d, i = self.step(actions)
+                if getattr(self, "_never_pending", None) is None:
+                    self._never_pending = self._torch.zeros(self.num_envs, dtype=self._torch.uint8, device=self.device)
+                return o, r, d, i, self._never_pending
+        a = self._as_actions(actions)
+        self._last_actions = a
+        _lib.check(self._lib.pcgrl_step_async(self._handle, C.c_void_p(a.data_ptr()), int(pop_budget), self._stream()), "pcgrl_step_async")
+        if self.strict_actions:
+            self.check_status()
+        b = self._bufs
+        decode = self._prob.decode_rows if self._prob.packed_rows else None
+        info = InfoBatch(self._prob.info_keys, b["info"], self._max_iterations, self._max_changes, decode)
+        return self._obs(), b["reward"], b["done"].view(self._torch.bool), info, self._async["pending"]
+
+    def flush(self):
+        """Finish every pending step (searches with an unbounded budget)."""
+        if self._handle is not None:
+            _lib.check(self._lib.pcgrl_async_flush(self._handle, self._stream()), "pcgrl_async_flush")
+
+    def async_counters(self):
+        """{actions taken, searches suspended, jobs finished from a slot, slot overflows, pops of the resumable searches} since
+        enable_async() (synchronises)."""
+        if self._async is None:
+            return None
+        c = self._async["counters"].cpu().numpy()
+        return dict(consumed=int(c[8::8].sum()), suspended=int(c[1]), late=int(c[2]), overflow=int(c[3]), pops=int(c[4]))
 
     # ---- episode statistics (stable-baselines Monitor as wrapped around the reference env, utils.py:13-29)
     def enable_episode_stats(self, enable=True):

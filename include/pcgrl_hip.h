@@ -38,7 +38,7 @@ extern "C" {
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
  *    clamped actions.  10: + pcgrl_tuning / pcgrl_set_tuning (the library reads no environment variables any more); pcgrl_config
  *    grew (prob_width, prob_height); maps up to 255 x 255, search levels up to 4096 bordered cells, solver_power up to 1 000 000. */
-#define PCGRL_ABI_VERSION 10
+#define PCGRL_ABI_VERSION 11
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -206,6 +206,30 @@ int pcgrl_action_map(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* st
  * flat DEVICE i32 [N]; xyv DEVICE i32 [N,3] scratch of the caller (filled where the decode is a kernel of its own; the fused step
  * kernel decodes inside and leaves it alone).  PCGRL_EINVAL for another representation. */
 int pcgrl_step_flat(pcgrl_env* env, const int32_t* flat, int32_t* xyv, void* stream);
+/* ---- Asynchronous stepping of the search problems (sokoban, mdungeon, ddave; csrc/kernels_search_async.h).  No reference
+ * counterpart as such: it is what the reference gets from running every environment in a process of its own behind
+ * SubprocVecEnv (utils.py:60-71) -- no environment waits for another environment's solver (sokoban_prob.py:85-122,
+ * mdungeon_prob.py:110-126, ddave_prob.py) -- on one GPU and one stream.
+ * pcgrl_step_async is one *tick*: every environment whose previous step is complete takes its action from `actions` (laid out
+ * as for pcgrl_step) and steps; every search gets at most `pop_budget` pops; an environment whose search is not finished by then
+ * is marked pending (its search is suspended and goes on in the following ticks) and takes no further action -- the entries of
+ * `actions` for pending environments are ignored -- until a tick completes its step.  After a tick, pending[e] == 0 means: the
+ * observation / reward / done / info of environment e are those of its last taken action, and it takes the next one.  Per
+ * environment, the sequence of (taken action -> outputs) is bitwise what pcgrl_step gives for the same actions.
+ *   pcgrl_async_bytes      DEVICE bytes the caller provides for `nslots` suspended searches (0: the configuration has no
+ *                          asynchronous form -- another problem, levels or solver_power beyond the compact searches).
+ *   pcgrl_bind_async       after pcgrl_bind; arena DEVICE, 256-byte aligned, zeroed by the call.  Its head is the caller's to
+ *                          read: pending u8 [N] at offset 0 (0: complete; 1: a search is suspended; 2: the search ended the episode,
+ *                          the next tick resets the environment), then (256-byte aligned) eight u64 counters: -, searches suspended,
+ *                          jobs finished from a slot, slot overflows (no free slot: that search ran to its end inside its tick), pops
+ *                          of the resumable searches; then sixteen u64 words 64 bytes apart whose sum is the number of actions taken.
+ *   pcgrl_async_flush      finishes every pending step (unbounded budget) -- pcgrl_step, pcgrl_rollout, pcgrl_set_maps and
+ *                          pcgrl_reset do it themselves (pcgrl_reset drops the pending steps instead).
+ * pop_budget < 1: PCGRL_EINVAL. */
+size_t pcgrl_async_bytes(const pcgrl_config* cfg, int32_t nslots);
+int pcgrl_bind_async(pcgrl_env* env, void* arena, size_t bytes, int32_t nslots, void* stream);
+int pcgrl_step_async(pcgrl_env* env, const int32_t* actions, int32_t pop_budget, void* stream);
+int pcgrl_async_flush(pcgrl_env* env, void* stream);
 /* Episode statistics kept by the step kernels -- what stable-baselines' Monitor keeps around the reference env in
  * utils.make_env / make_vec_envs (utils.py:13-29, 60-71).  ep_return f64 [N], ep_length i32 [N]: reward sum (in step
  * order) and step count of the running episode; last_return / last_length: the same, latched when an episode ends

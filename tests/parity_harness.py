@@ -263,3 +263,98 @@ def fullsize_case(name, use_rollout, max_steps=None):
     finally:
         env.close()
     return len(idx)
+
+
+def async_case(prob, rep, calls, E, ticks, seed0, rs, pop_budget, nslots, sample=None, flush_every=0):
+    """Asynchronous stepping (BatchedPcgrlEnv.tick, pcgrl_step_async) against the oracle: `ticks` ticks of random actions; per
+    environment the actions it *took* (the ticks it was not pending at) and the outputs of every step it completed are recorded,
+    and afterwards the oracle is stepped through exactly the taken actions -- reward, done, info, cursor, heat map and map of
+    every completed step must be equal, bit for bit.  `sample`: indices of the environments compared (default: all).
+    flush_every > 0: every that many ticks the pending steps are finished by flush() and a lockstep step() is taken in between
+    (the two kinds of stepping on one handle).  Returns a dict of counters; raises AssertionError on a mismatch."""
+    import torch
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=E, seed=seed0)
+    try:
+        for kw in calls:
+            env.adjust_param(**kw)
+        env.reset()
+        assert env.enable_async(nslots), "no asynchronous form for this configuration"
+        sp = env.single_action_space
+        if hasattr(sp, "n"):
+            acts = rs.randint(0, sp.n, size=(ticks, E, 1)).astype(np.int32)
+        else:
+            acts = np.stack([rs.randint(0, int(k), size=(ticks, E)) for k in sp.nvec], -1).astype(np.int32)
+        idx = np.arange(E) if sample is None else np.asarray(sample)
+        ti = torch.as_tensor(idx, device="cuda")
+        keys = list(env._prob.info_keys) + ["iterations", "changes"]
+        taken = [[] for _ in idx]
+        got = [[] for _ in idx]
+        pending = np.zeros(len(idx), bool)
+        in_flight = [None] * len(idx)
+        n_pending_ticks = 0
+        for t in range(ticks):
+            lock = flush_every and t % flush_every == flush_every - 1
+            a = acts[t] if acts.shape[2] > 1 else acts[t, :, 0]
+            if lock:
+                # lockstep step on the same handle: finishes what is pending first (those steps complete with their own actions),
+                # then every environment takes a[t]
+                env.flush()
+                assert not env._async["pending"][ti].any()
+                rows_f = _async_rows(env, ti, keys)
+                for j in np.nonzero(pending)[0]:
+                    got[j].append(tuple(x[j] for x in rows_f))
+                pending[:] = False
+                obs, rew, done, info = env.step(a)
+                after = np.zeros(len(idx), bool)
+            else:
+                obs, rew, done, info, pend = env.tick(a, pop_budget=pop_budget)
+                after = pend[ti].cpu().numpy() != 0
+            rows = None
+            for j in range(len(idx)):
+                if not pending[j]:
+                    taken[j].append(acts[t, idx[j]])
+                if not after[j]:
+                    if rows is None:
+                        rows = _async_rows(env, ti, keys)
+                    got[j].append(tuple(x[j] for x in rows))
+            pending = after
+            n_pending_ticks += int(after.sum())
+        env.flush()
+        rows = _async_rows(env, ti, keys)
+        for j in np.nonzero(pending)[0]:
+            got[j].append(tuple(x[j] for x in rows))
+        cnt = env.async_counters()
+        exp = _oracle_rollouts(prob, rep, calls, [seed0 + int(i) for i in idx], [np.asarray(tk) for tk in taken])
+        for j, x in enumerate(exp):
+            assert len(got[j]) == len(taken[j]), ("steps completed vs actions taken", prob, idx[j], len(got[j]), len(taken[j]))
+            for k, (rew_k, done_k, info_k, pos_k, heat_k, map_k) in enumerate(got[j]):
+                where = (prob, rep, "env", int(idx[j]), "its step", k)
+                assert rew_k == x["reward"][k] and bool(done_k) == bool(x["done"][k]), ("reward/done",) + where + (rew_k, x["reward"][k], done_k, x["done"][k])
+                assert np.array_equal(info_k, x["info"][k]), ("info",) + where + (info_k, x["info"][k])
+                if env._rep.has_pos:
+                    assert np.array_equal(pos_k, x["pos"][k]), ("pos",) + where
+                assert np.array_equal(heat_k, x["heatmap"][k].astype(np.int64)), ("heatmap",) + where
+                assert np.array_equal(map_k, x["maps"][k]), ("map",) + where
+        env.check_status()
+        cnt["pending_env_ticks"] = n_pending_ticks
+        cnt["steps"] = sum(len(tk) for tk in taken)
+        return cnt
+    finally:
+        env.close()
+
+
+def _async_rows(env, ti, keys):
+    b = env._bufs
+    info = env._prob.decode_rows(b["info"]) if env._prob.packed_rows else None
+    tab = b["info"][ti].cpu().numpy().astype(np.int64)
+    if info is not None:
+        from gym_pcgrl_amd.envs.batched_env import InfoBatch
+        ib = InfoBatch(env._prob.info_keys, b["info"], env._max_iterations, env._max_changes, env._prob.decode_rows)
+        inf = np.stack([ib[k][ti].cpu().numpy() for k in keys], 1).astype(np.int64)
+    else:
+        nk = len(env._prob.info_keys)
+        inf = np.concatenate([tab[:, :nk], tab[:, 8:10]], 1)
+    return (b["reward"][ti].cpu().numpy(), b["done"][ti].cpu().numpy(), inf, b["pos"][ti].cpu().numpy().astype(np.int64),
+            b["heatmap"][ti].cpu().numpy().astype(np.int64), b["map"][ti].cpu().numpy())
+

@@ -1,0 +1,59 @@
+"""pcgrl_step_async (include/pcgrl_hip.h; csrc/kernels_search_async.h) against the CPU oracle: asynchronous ticks with pop
+budgets small enough that most searches are suspended -- several times -- before they finish, slots running out, ticks mixed
+with lockstep steps on one handle.  Per environment the taken actions and the outputs of the completed steps must be the
+oracle's, bit for bit (tests/parity_harness.py async_case).  GPU only."""
+import numpy as np
+import pytest
+
+import parity_harness as ph
+
+pytestmark = pytest.mark.gpu
+
+FEW_SOK = dict(probs={"empty": 0.75, "solid": 0.1, "player": 0.02, "crate": 0.07, "target": 0.06})
+
+
+@pytest.mark.parametrize("prob,rep,calls,E,ticks,budget,nslots", [
+    ("sokoban", "narrow", (), 512, 120, 24, 256),                                        # the BASELINE shape (C4), tiny budget
+    ("sokoban", "narrow", (dict(width=7, height=6), FEW_SOK), 256, 120, 16, 256),         # levels of 72 bordered cells (four-word sets), open maps: long searches
+    ("sokoban", "wide", (dict(width=6, height=6), dict(solver_power=700), FEW_SOK), 200, 100, 40, 64),
+    ("sokoban", "turtle", (), 300, 150, 7, 256),
+    ("mdungeon", "narrow", (), 256, 100, 24, 256),
+    ("mdungeon", "wide", (dict(solver_power=900),), 128, 100, 4, 64),
+    ("ddave", "narrow", (), 256, 100, 5, 256),
+    ("ddave", "turtle", (dict(solver_power=1200),), 128, 100, 3, 64),
+])
+def test_async_ticks_vs_oracle(prob, rep, calls, E, ticks, budget, nslots):
+    rs = np.random.RandomState(hash((prob, rep, E)) % 2 ** 31)
+    cnt = ph.async_case(prob, rep, list(calls), E, ticks, 4242, rs, budget, nslots)
+    few = prob != "sokoban" and rep != "narrow"       # (planners that usually win within a few pops: little to cut even with a budget of 3)
+    assert cnt["suspended"] > (3 if few else 10), cnt     # searches really were cut
+    assert cnt["late"] >= (1 if few else 3) and cnt["pending_env_ticks"] > (3 if few else 10), cnt
+    assert cnt["consumed"] == cnt["steps"], cnt       # the library's count of taken actions is the harness's
+
+
+def test_async_slot_overflow_and_lockstep_mix():
+    """Two slots for hundreds of environments: most suspensions find no slot and run to their end inside the tick (still exact);
+    every seventh tick is a flush + lockstep step on the same handle."""
+    rs = np.random.RandomState(11)
+    cnt = ph.async_case("sokoban", "narrow", [dict(width=6, height=6), FEW_SOK], 384, 90, 77, rs, 12, 2, flush_every=7)
+    assert cnt["overflow"] > 3 and cnt["suspended"] > 3, cnt
+
+
+def test_async_budget_invariance():
+    """The same actions, taken by every environment in the same order, whatever the budget: a huge budget is lockstep."""
+    rs = np.random.RandomState(5)
+    cnt = ph.async_case("sokoban", "narrow", [], 256, 60, 99, rs, 10 ** 6, 16)
+    assert cnt["suspended"] == 0 and cnt["overflow"] == 0, cnt
+    # (the only environments that ever sit a tick out are those whose search ended their episode: they are reset by the next tick)
+    assert cnt["steps"] + cnt["pending_env_ticks"] == 256 * 60, cnt
+
+
+def test_async_no_form_falls_back_to_step():
+    import torch
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    env = BatchedPcgrlEnv(prob="binary", rep="narrow", num_envs=64, seed=1)
+    env.reset()
+    assert env.enable_async() is False
+    o, r, d, i, pend = env.tick(torch.zeros(64, dtype=torch.int32, device="cuda"))
+    assert not pend.any()
+    env.close()
