@@ -60,6 +60,9 @@ WRAPPED = {"C2w": ("cropped", 28), "C3w": ("actionmap", None)}
 # legs of the default run besides the headline workload: every BASELINE.json config (and smb, and the wrapped steps) gets a
 # driver-timed figure.  (steps, warmup, steady warm-up) are sized so that the whole default run stays well under a minute of GPU time.
 LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 45), "C2w": (20, 5, 800), "C3w": (20, 5, 800)}
+# asynchronous ticks of the search problems (pcgrl_step_async): (workload, ticks, warm-up ticks, pop budget per search and tick)
+ASYNC_LEGS = {"C4_async": ("C4", 300, 60, 128), "M1_async": ("M1", 300, 60, 64), "D1_async": ("D1", 300, 60, 64)}
+GPU_CLOCK_HZ = 2.4e9     # MI355X engine clock (MI355X_MICROARCH.md), for the cycles-per-pop figures
 DOMINANT = {"B1": "k_big", "K1": "k_search_big", "C2": "k_step", "C3": "k_step", "C3d": "k_step", "C4": "k_sokoban", "C5": "k_stats_wide", "C5b": "k_stats_wide", "M1": "k_mdungeon",
             "D1": "k_ddave", "S1": "k_smb", "C2w": "k_step (writes the image)", "C3w": "k_step (writes the image)"}
 
@@ -191,6 +194,101 @@ def collector_leg(torch, device, n=65536, n_steps=8, warm_steps=2):
             "direct_rows": bool(col.direct)}
 
 
+def async_leg(torch, device, workload, ticks, warm, budget, nslots=2048, seed=0):
+    """Asynchronous stepping of a search problem (BatchedPcgrlEnv.tick = pcgrl_step_async; csrc/kernels_search_async.h): `ticks`
+    ticks of random actions on the workload's full batch.  value = actions TAKEN per second = environment steps completed per second
+    in the long run (an environment whose search is suspended sits ticks out; the library counts the taken actions).  Every tick
+    leaves observation / reward / done / info of every non-pending environment in the live tensors, as a step does."""
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    prob, rep, calls, n, desc = WORKLOADS[workload]
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, device=device, seed=seed)
+    for kw in calls:
+        env.adjust_param(**kw)
+    env.reset()
+    if not env.enable_async(nslots):
+        env.close()
+        return {"error": "no asynchronous form for " + workload}
+    W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
+    acts = make_actions(torch, rep, ticks + warm, n, W, H, nt, device, 1234)
+    for t in range(warm):
+        env.tick(acts[t], pop_budget=budget)
+    torch.cuda.synchronize(device)
+    c0 = env.async_counters()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
+    torch.cuda.synchronize(device)
+    w0 = time.perf_counter()
+    e0.record()
+    for t in range(warm, warm + ticks):
+        env.tick(acts[t], pop_budget=budget)
+    e1.record()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - w0
+    gms = e0.elapsed_time(e1) / ticks
+    c1 = env.async_counters()
+    pend = int((env._async["pending"] != 0).sum())
+    taken = c1["consumed"] - c0["consumed"]
+    pops = c1["pops"] - c0["pops"]
+    b_alg = 2 * H * W + 64
+    leg = {"workload": desc + " -- asynchronous ticks (pcgrl_step_async), pop budget %d per search and tick, %d slots" % (budget, nslots),
+           "envs": n, "ticks": ticks, "warmup_ticks": warm, "pop_budget": budget,
+           "value": taken / wall, "unit": "env-steps/s", "ms_per_tick": wall / ticks * 1e3, "gpu_ms_per_tick": gms,
+           "actions_taken_of_offered": taken / float(n * ticks), "pending_environments_at_the_end": pend,
+           "searches_suspended_per_tick": (c1["suspended"] - c0["suspended"]) / ticks, "slot_overflows": c1["overflow"] - c0["overflow"],
+           "search_pops_per_tick": pops / ticks, "search_pops_per_s": pops / wall,
+           "algorithmic_bytes_per_env_step": b_alg, "roofline_frac": taken / wall * b_alg / 1e9 / HBM_PEAK_GBPS,
+           "dominant_kernel": "k_search_async"}
+    env.close()
+    return leg
+
+
+def search_chain(torch, env, step, acts, t0, k=8):
+    """Lockstep step of a search problem: the step waits for its longest search.  GPU time of the solver phase per step (HIP events
+    of pcgrl_profile around the search kernel) and what that is per pop if the longest search ran into the cap of solver_power
+    pops -- at the benchmark's batch sizes nearly every step holds one that does."""
+    env.profile(True)
+    for t in range(t0, t0 + k):
+        step(acts[t % acts.shape[0]])
+    ph, n = env.profile_read()
+    env.profile(False)
+    n = max(n, 1)
+    ev = min(ph.values()) / n * 1e3
+    us = max(ph.get("solver_or_reset", 0.0) / n * 1e3 - ev, 0.0)
+    power = int(getattr(env._prob, "_solver_power", 5000))
+    return {"solver_phase_us": us, "solver_power": power, "us_per_pop_if_capped": us / power, "cycles_per_pop_if_capped": us * 1e-6 * GPU_CLOCK_HZ / power,
+            "pops_per_s_of_the_longest_search": power / (us * 1e-6) if us > 0 else None}
+
+
+def node_driver_leg(torch, device, G=8, n_per=256, calls=300):
+    """Host cost of stepping a whole node from ONE process (node.MultiGpuPcgrlEnv; SURVEY 8e: at 28 us per C2 step per GPU the host
+    must issue the step of all eight GPUs in less than one kernel's time or it is the bottleneck).  G handles with a stream each --
+    all on this one GPU: the driver's box has one -- and tiny batches, so that what is timed is the host: microseconds per step()
+    call of all G handles, nothing waited for, (a) through pcgrl_step_multi (gather="list": one call of the library per step) and
+    (b) shard by shard (G calls of pcgrl_step inside torch stream contexts: the round-4 path)."""
+    from gym_pcgrl_amd.node import MultiGpuPcgrlEnv
+    out = {"handles": G, "envs_per_handle": n_per, "calls": calls, "workload": "binary-narrow-v0 14x14"}
+    for name, sync_streams in (("host_us_per_call", False), ("host_us_per_call_with_stream_ordering", True)):
+        env = MultiGpuPcgrlEnv(prob="binary", rep="narrow", num_envs=G * n_per, devices=[str(device)] * G, seed=0, sync_streams=sync_streams)
+        env.reset()
+        parts = [torch.zeros(n_per, dtype=torch.int32, device=device) for _ in range(G)]
+        for _ in range(20):
+            env.step(parts)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            env.step(parts)
+        out[name] = (time.perf_counter() - t0) / calls * 1e6
+        torch.cuda.synchronize(device)
+        if sync_streams:
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                env._each(lambda g, sh: sh.step(parts[g]))
+            out["host_us_per_call_shard_by_shard"] = (time.perf_counter() - t0) / calls * 1e6
+            torch.cuda.synchronize(device)
+        env.close()
+    return out
+
+
 def run_leg(torch, device, workload, steps, warmup, steady_warmup, seed=0):
     """One short driver-timed measurement of another workload (rank 0, one GPU): first window after a reset + steady state."""
     prob, rep, calls, n, desc = WORKLOADS[workload]
@@ -220,6 +318,8 @@ def run_leg(torch, device, workload, steps, warmup, steady_warmup, seed=0):
                                "roofline_frac": n * (b_alg + obs_bytes) / (sgms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     if obs_bytes:
         leg["image_bytes_per_env_step"] = obs_bytes
+    if prob in ("sokoban", "mdungeon", "ddave"):
+        leg["search"] = search_chain(torch, env, step, acts, warmup + steps)
     env.close()
     return leg
 
@@ -371,7 +471,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="process plumbing only (launcher, rendezvous, barrier, max-over-ranks reduction over gloo); "
                                                           "no GPU, no environment: the line carries value null and dry_run true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short legs of the other configs (the `configs` object of the default line)")
-    ap.add_argument("--legs", default="C3,C4,C5,S1,C2w,C3w,n1_facade,collector", help="which legs the default line carries")
+    ap.add_argument("--legs", default="C3,C4,C4_async,M1_async,C5,S1,C2w,C3w,n1_facade,collector,node_driver", help="which legs the default line carries")
     ap.add_argument("--tuning", default="", help="developer switches of the library for A/B runs: field=value[,field=value...] "
                                                  "(include/pcgrl_hip.h pcgrl_tuning, e.g. no_fused=1,step_epb=128)")
     ap.add_argument("--steady-warmup", type=int, default=800, help="steps before the steady_state measurement (0: skip it)")
@@ -583,6 +683,11 @@ def main():
             out["steady_state"] = steady
         if rollout is not None:
             out["rollout"] = rollout
+        if solver and prob != "smb" and not wrapped:
+            out["search"] = search_chain(torch, env, step, acts, 0)
+            if n == n_default and (a.workload + "_async") in ASYNC_LEGS:
+                env.close()
+                out["async"] = async_leg(torch, device, *ASYNC_LEGS[a.workload + "_async"])
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, rep, calls)
         if world == 1 and not a.no_legs and a.workload == "C2" and n == n_default:
@@ -592,9 +697,13 @@ def main():
             for name in a.legs.split(","):
                 if name in LEGS:
                     legs[name] = run_leg(torch, device, name, *LEGS[name])
+                if name in ASYNC_LEGS:
+                    legs[name] = async_leg(torch, device, *ASYNC_LEGS[name])
             # what a user of the reference's surfaces gets: the single environment (C1's counterpart) and the trainer's loop
             if "n1_facade" in a.legs.split(","):
                 legs["n1_facade"] = n1_facade_leg()
+            if "node_driver" in a.legs.split(","):
+                legs["node_driver"] = node_driver_leg(torch, device)
             if "collector" in a.legs.split(","):
                 try:
                     legs["collector"] = collector_leg(torch, device)

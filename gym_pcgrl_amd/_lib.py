@@ -71,7 +71,7 @@ EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "p
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
            "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout", "pcgrl_bind_observation", "pcgrl_selftest_heap",
            "pcgrl_tuning_defaults", "pcgrl_set_tuning", "pcgrl_clear_status", "pcgrl_step_flat",
-           "pcgrl_async_bytes", "pcgrl_bind_async", "pcgrl_step_async", "pcgrl_async_flush")
+           "pcgrl_async_bytes", "pcgrl_bind_async", "pcgrl_step_async", "pcgrl_async_flush", "pcgrl_step_multi")
 NPHASE = 6
 # the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
 # other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
@@ -192,6 +192,7 @@ def load():
     L.pcgrl_bind_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
     L.pcgrl_step_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.pcgrl_async_flush.argtypes = [C.c_void_p, C.c_void_p]
+    L.pcgrl_step_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32]
     _lib = L
     return L
 

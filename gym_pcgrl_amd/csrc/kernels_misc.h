@@ -23,6 +23,7 @@ __global__ void k_fill_all(DevBufs B, int n, int parity, int list) {
 __global__ void k_async_collect(DevBufs B, uint8_t* pending, int n, int parity, int list) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n && pending[e] == 2) { pending[e] = 0; wl_push(B, parity, list, e & (WL_NSHARD - 1), e); }
+    async_list_runnable(B, e);
 }
 __global__ void k_bcast_tile_p(double* tile_p, int n, double p0, double p1) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

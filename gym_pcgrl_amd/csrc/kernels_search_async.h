@@ -45,6 +45,7 @@ struct AsyncCtl {
     uint8_t* slots;                          // [nslots][slot_bytes]: header | pool | heap | visited table
     size_t slot_bytes;
     int32_t nslots, nodes_cap, tick, pad;
+    int32_t* runlist;                        // [nslots] the runnable slots of this tick (written by k_update / k_async_collect; count in tickets[2])
 };
 __device__ __forceinline__ AsyncSlotHdr* async_hdr(const AsyncCtl& A, int s) { return reinterpret_cast<AsyncSlotHdr*>(A.slots + (size_t)s * A.slot_bytes); }
 __device__ __forceinline__ uint8_t* async_pool(const AsyncCtl& A, int s) { return A.slots + (size_t)s * A.slot_bytes + ASYNC_SLOT_HDR; }
@@ -140,8 +141,8 @@ struct AsyncGame<PCGRL_PROB_DDAVE> {
 #define AP(i) do {} while (0)
 #define AP_COUNT(i) do {} while (0)
 #endif
-// Jobs: the suspended slots (resume != 0), then list_a (mode_a) and list_b (mode_b; < 0: none).  `tickets`: two words the host
-// zeroed.  budget: pops per job and launch.  An environment whose episode a finished job ends goes to rst_list (pcgrl_async_flush:
+// Jobs: the suspended slots (resume != 0), then list_a (mode_a) and list_b (mode_b; < 0: none).  `tickets`: [0], [1] two counters the
+// host zeroed, [2] the number of runnable slots in A.runlist.  budget: pops per job and launch.  An environment whose episode a finished job ends goes to rst_list (pcgrl_async_flush:
 // reset and searched again behind this launch) or, rst_list < 0 (a tick), is marked ASYNC_PEND_RESET: the next tick's k_update
 // puts it on its reset list instead of giving it an action -- one launch sequence per tick, not two.
 template <int PROB>
@@ -168,25 +169,23 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
     for (;;) {
         // ---- a ticket: a suspended slot, else a fresh job, else leave
         int slot = -1, e = 0, mode = 0, a0 = 0, kind = 0;
-        if (lane == 0) {
-            if (resume) {
-                while (sok_ld(tickets + 1) < A.nslots) {
-                    const int t = atomicAdd(tickets + 1, 1);
-                    if (t >= A.nslots) break;
-                    AsyncSlotHdr* hd = async_hdr(A, t);
-                    if (sok_ld(&hd->state) == 1 && sok_ld(&hd->stamp) != A.tick) { hd->state = 2; slot = t; kind = 1; break; }
-                }
+        // suspended slots: the update kernel listed the runnable ones (async_list_runnable, worklist.h); a ticket is an entry of that list
+        if (lane == 0 && resume) {
+            const int nrun = sok_ld(tickets + 2);
+            if (sok_ld(tickets + 1) < nrun) {
+                const int t = atomicAdd(tickets + 1, 1);
+                if (t < nrun) { slot = A.runlist[t]; kind = 1; async_hdr(A, slot)->state = 2; }
             }
-            if (kind == 0 && sok_ld(tickets) < n) {
-                const int t = atomicAdd(tickets, 1);
-                if (t < n) { kind = 2; e = t; }
-            }
+        }
+        slot = __shfl(slot, 0, 64);
+        if (lane == 0 && kind == 0 && sok_ld(tickets) < n) {
+            const int t = atomicAdd(tickets, 1);
+            if (t < n) { kind = 2; e = t; }
         }
         kind = __shfl(kind, 0, 64);
         AP(1);
         if (kind == 0) break;
         AP_COUNT(8 + kind);
-        slot = __shfl(slot, 0, 64);
         e = __shfl(e, 0, 64);
         if (kind == 2) {
             const int t = e;

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
         const int cnt = __popcll(__ballot(live));
         if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(B.async_stats + 8 + 8 * (blockIdx.x & 15), (unsigned long long)cnt);
         if (pv == 2) { u.rst = true; B.pending[e] = 0; }      // (a search of the new map that is cut short marks it pending again)
+        async_list_runnable(B, e);
     }
     if (live) u = update_env<REP, MaskT>(P, B, actions, e);
     const bool chg = u.chg, rst = u.rst, cheap = u.cheap, sure_done = u.sure_done;
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update_block(PcgrlParams P, Dev
         const int cnt = __popcll(__ballot(act));
         if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(B.async_stats + 8 + 8 * (blockIdx.x & 15), (unsigned long long)cnt);
         if (pv == 2) { rst = true; B.pending[e] = 0; }
+        async_list_runnable(B, e);
     }
     if (act) {
         const int W = P.width, H = P.height, G = P.group, NPL = P.nplanes, NT = P.ntiles;

@@ -254,6 +254,9 @@ static BigArenaDims big_arena_of(const pcgrl_config* c) {
     A.nodes_cap = 4 * c->solver_power + 4;
     A.tsize = 1024;
     while (A.tsize < 2 * c->solver_power) A.tsize <<= 1;
+    // sokb_init_deadlocks keeps its corner list (16-bit cells, fewer than `cells` of them) in the block's heap before the search
+    // starts: heap + visited table must hold it even for a tiny solver_power, so that it never reaches the next block's node pool
+    while (align_up((size_t)A.nodes_cap * 8, 256) + (size_t)A.tsize * 4 < (size_t)2 * cells) A.tsize <<= 1;
     A.stride = c->prob == PCGRL_SOKOBAN ? sokb_stride(inner < SOKB_MAXC ? inner : SOKB_MAXC) : mdb_stride(nwb);
     A.heap_off = align_up((size_t)A.nodes_cap * A.stride, 256);
     A.table_off = A.heap_off + align_up((size_t)A.nodes_cap * 8, 256);
@@ -676,7 +679,9 @@ PCGRL_LOCAL int launch_stats(pcgrl_env* h, int list, int parity, int mode, int c
 template <class MaskT>
 static int launch_update_m(pcgrl_env* h, const int32_t* actions, int parity, hipStream_t st) {
     const PcgrlParams& P = h->P;
-    const int grid = (P.num_envs + PCGRL_BLOCK - 1) / PCGRL_BLOCK;
+    // (a tick of pcgrl_step_async: the kernel's threads also look through the slots of the suspended searches, one each)
+    const int nthreads = P.num_envs > h->B.async_nslots ? P.num_envs : h->B.async_nslots;
+    const int grid = (nthreads + PCGRL_BLOCK - 1) / PCGRL_BLOCK;
     switch (P.rep) {
         case PCGRL_REP_NARROW:
             hipLaunchKernelGGL((k_update<PCGRL_REP_NARROW, MaskT>), dim3(grid), dim3(PCGRL_BLOCK), 0, st, P, h->B, actions, parity); break;
@@ -911,7 +916,9 @@ PCGRL_LOCAL int launch_planes_from_map(pcgrl_env* h, const uint8_t* maps, hipStr
 // pcgrl_rollout for the search problems: persistent blocks that own their environments for the whole tape (kernels_step_solver.h)
 static bool solver_rollout_applies(const pcgrl_env* h, int* envs_per_block) {
     const PcgrlParams& P = h->P;
-    if (!solver_prob(P.prob) || P.prob == PCGRL_PROB_SMB || P.rep > PCGRL_REP_TURTLE || !P.auto_reset || !h->B.sok_use_lds || P.group != 16 || h->no_fused) return false;
+    // (P.big: maps wider than 64 cells take the general map path and keep no bit planes; P.big_search: the general searches)
+    if (!solver_prob(P.prob) || P.prob == PCGRL_PROB_SMB || P.rep > PCGRL_REP_TURTLE || !P.auto_reset || !h->B.sok_use_lds || P.group != 16 || h->no_fused || P.big ||
+        P.big_search) return false;
     int epb = 64 * ((P.num_envs + SOK_BLOCKS * 64 - 1) / (SOK_BLOCKS * 64));      // one block per compute unit when the batch is large enough
     epb = epb < 64 ? 64 : epb;
     if (epb > WL_LOCAL_CAP) return false;                                            // more than 256 x 512 environments: the sequence of steps
@@ -1062,13 +1069,15 @@ static int step_one(pcgrl_env* h, const int32_t* actions, void* stream, bool* us
 static bool async_applies(const pcgrl_config* c) {
     return solver_prob(c->prob) && c->prob != PCGRL_SMB && !big_search(c) && !big_map(c) && c->solver_power <= SOK_LDS_POWER;
 }
-static size_t async_head_bytes(const pcgrl_config* c) { return align_up((size_t)c->num_envs, 256) + 64 + ASYNC_NSHARD * 64; }      // pending, counters, shards of the first counter
+// head of the arena: pending [N] | counters + the shards of the first one | the tick's list of runnable slots
+static size_t async_stats_bytes() { return 64 + ASYNC_NSHARD * 64; }
+static size_t async_head_bytes(const pcgrl_config* c, int nslots) { return align_up((size_t)c->num_envs, 256) + async_stats_bytes() + align_up((size_t)nslots * 4, 256); }
 static size_t async_slot_bytes(const pcgrl_config* c) {
     return align_up((size_t)ASYNC_SLOT_HDR + (size_t)(4 * c->solver_power + 4) * 16 + (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4, 256);
 }
 size_t pcgrl_async_bytes(const pcgrl_config* c, int32_t nslots) {
     if (validate_config(c) != PCGRL_OK || nslots < 1 || !async_applies(c)) return 0;
-    return async_head_bytes(c) + (size_t)nslots * async_slot_bytes(c);
+    return async_head_bytes(c, nslots) + (size_t)nslots * async_slot_bytes(c);
 }
 int pcgrl_bind_async(pcgrl_env* h, void* arena, size_t bytes, int32_t nslots, void* stream) {
     if (!h || !h->bound) return PCGRL_ESTATE;
@@ -1080,10 +1089,11 @@ int pcgrl_bind_async(pcgrl_env* h, void* arena, size_t bytes, int32_t nslots, vo
     AsyncCtl& A = h->async;
     A.pending = a;
     A.stats = (unsigned long long*)(a + align_up((size_t)h->cfg.num_envs, 256));
-    A.slots = a + async_head_bytes(&h->cfg);
+    A.runlist = (int32_t*)(a + align_up((size_t)h->cfg.num_envs, 256) + async_stats_bytes());
+    A.slots = a + async_head_bytes(&h->cfg, nslots);
     A.slot_bytes = async_slot_bytes(&h->cfg);
     A.nslots = nslots; A.nodes_cap = 4 * h->cfg.solver_power + 4; A.tick = 0; A.pad = 0;
-    HIPCHK(hipMemsetAsync(a, 0, async_head_bytes(&h->cfg), (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(a, 0, async_head_bytes(&h->cfg, nslots), (hipStream_t)stream));
     HIPCHK(hipMemset2DAsync(A.slots, A.slot_bytes, 0, ASYNC_SLOT_HDR, (size_t)nslots, (hipStream_t)stream));
     h->async_on = 1; h->async_dirty = 0;
     return PCGRL_OK;
@@ -1096,12 +1106,19 @@ static int async_drop(pcgrl_env* h, hipStream_t st) {
     h->async_dirty = 0;
     return PCGRL_OK;
 }
+// what the update kernel of a tick (and the collect kernel of a flush) needs of the arena: set for that one launch
+static void async_devbufs(pcgrl_env* h, bool on) {
+    DevBufs& B = h->B;
+    const AsyncCtl& A = h->async;
+    B.pending = on ? A.pending : nullptr; B.async_stats = on ? A.stats : nullptr;
+    B.async_slots = on ? A.slots : nullptr; B.async_slot_bytes = A.slot_bytes; B.async_nslots = on ? A.nslots : 0;
+    B.async_run = on ? A.runlist : nullptr; B.async_run_n = on ? h->B.sok_sync + 2 : nullptr;
+}
 // the searches of a tick: the suspended ones and the jobs of the step's lists, one launch (an episode a search ends is reset by the next tick)
 static int async_tick_searches(pcgrl_env* h, int budget, hipStream_t st) {
     const int par = h->parity;
     const bool ar = h->P.auto_reset != 0;
     h->async.tick = (h->async.tick + 1) & 0x3FFFFFFF;
-    HIPCHK(hipMemsetAsync(h->B.sok_sync, 0, 2 * sizeof(int32_t), st));
     return launch_search_async(h, h->B.sok_sync, WL_SOL, MODE_STEP, ar ? (int)WL_SOL2 : -1, MODE_START, par, -1, par ^ 1, budget, 1, st);
 }
 // everything that is pending, to its end: the suspended searches, then the resets and searches of the episodes they ended
@@ -1111,9 +1128,14 @@ static int async_finish_all(pcgrl_env* h, hipStream_t st) {
     int rc;
     h->async.tick = (h->async.tick + 1) & 0x3FFFFFFF;
     int32_t* sync0 = h->B.sok_sync, *sync1 = h->B.sok_sync + (SOK_SY_WORDS + SOK_HARD_CAP);
-    hipLaunchKernelGGL(k_async_collect, dim3((n + 255) / 256), dim3(256), 0, st, h->B, h->async.pending, n, par, (int)WL_RST2);
+    HIPCHK(hipMemsetAsync(sync0, 0, 3 * sizeof(int32_t), st));
+    async_devbufs(h, true);
+    {
+        const int nn = n > h->async.nslots ? n : h->async.nslots;
+        hipLaunchKernelGGL(k_async_collect, dim3((nn + 255) / 256), dim3(256), 0, st, h->B, h->async.pending, n, par, (int)WL_RST2);
+    }
+    async_devbufs(h, false);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(sync0, 0, 2 * sizeof(int32_t), st));
     if ((rc = launch_search_async(h, sync0, -1, MODE_STEP, -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), budget, 1, st))) return rc;
     if (ar) {
         if ((rc = launch_reset(h, WL_RST2, WL_SOL3, par, -1, st))) return rc;
@@ -1142,9 +1164,10 @@ int pcgrl_step_async(pcgrl_env* h, const int32_t* actions, int32_t pop_budget, v
     const int par = h->parity;
     const bool ar = h->P.auto_reset != 0;
     int rc;
-    h->B.pending = h->async.pending; h->B.async_stats = h->async.stats;
-    rc = launch_update(h, actions, par, st);
-    h->B.pending = nullptr; h->B.async_stats = nullptr;
+    HIPCHK(hipMemsetAsync(h->B.sok_sync, 0, 3 * sizeof(int32_t), st));       // the search launch's tickets and the count of runnable slots
+    async_devbufs(h, true);
+    rc = launch_update(h, actions, par, st);        // (also lists the runnable slots)
+    async_devbufs(h, false);
     if (rc) return rc;
     if ((rc = launch_stats(h, WL_CHG, par, MODE_STEP, -1, 0, st))) return rc;
     if (ar && (rc = launch_reset(h, WL_RST, WL_SOL2, par, -1, st))) return rc;
@@ -1182,6 +1205,19 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
     if (h->profiling) h->prof_steps++;
     // the wrapped observation: the fused step kernel wrote it; every other pipeline gets one more launch
     if ((used_lists || !h->B.obs.fused) && h->B.obs.out && !h->obs_hold && (rc = launch_obs(h, h->B.obs, (hipStream_t)stream))) return rc;
+    return PCGRL_OK;
+}
+
+// pcgrl_step on `count` handles (the shards of one batch: one per GPU of a node, or several on one GPU) in ONE call: step k is issued
+// on every handle -- its device made current, on its own stream -- before the call returns; nothing is waited for.  A host thread
+// that drives eight GPUs pays one foreign-function call per step instead of eight (node.MultiGpuPcgrlEnv; SURVEY 8e: the scaling
+// risk of a 28 us step is host launch latency).  Returns the first error (the handles before it have been stepped).
+int pcgrl_step_multi(pcgrl_env* const* envs, const int32_t* const* actions, void* const* streams, int32_t count) {
+    if (!envs || !actions || !streams || count < 1) return PCGRL_EINVAL;
+    for (int i = 0; i < count; i++) {
+        const int rc = pcgrl_step(envs[i], actions[i], streams[i]);
+        if (rc) return rc;
+    }
     return PCGRL_OK;
 }
 

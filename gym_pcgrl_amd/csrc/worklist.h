@@ -117,6 +117,9 @@ struct DevBufs {
     // pcgrl_step_async (kernels_search_async.h): non-null only inside a tick -- pending[e] != 0: environment e's step is in flight
     // (a suspended search), it takes no action; async_stats[0] counts the actions that were taken
     uint8_t* pending; unsigned long long* async_stats;
+    // ... and the slots of the suspended searches, for the update kernel's side job: the threads of its first blocks list the
+    // runnable slots (async_run[0 .. *async_run_n)) for the search kernel that follows
+    const uint8_t* async_slots; size_t async_slot_bytes; int32_t async_nslots; int32_t* async_run; int32_t* async_run_n;
 };
 #define PCGRL_FIFO_N 8
 
@@ -138,6 +141,11 @@ struct StepLocal {
     ZeldaRewardTab zr;          // (zelda; written once by thread 0 at the start of k_step: constant indices into the parameter block only)
 };
 
+// thread gi of a launch looks at slot gi of the suspended searches (header word 0 = state, 1 = runnable: kernels_search_async.h)
+__device__ __forceinline__ void async_list_runnable(const DevBufs& B, int gi) {
+    if (gi < B.async_nslots && __hip_atomic_load(reinterpret_cast<const int32_t*>(B.async_slots + (size_t)gi * B.async_slot_bytes), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+        B.async_run[atomicAdd(B.async_run_n, 1)] = gi;
+}
 __device__ __forceinline__ int32_t* wl_counters(const DevBufs& B, int parity, int list) {
     return B.wl_cnt + (size_t)(parity * WL_NLIST + list) * WL_NSHARD * WL_CSTRIDE;
 }

@@ -115,7 +115,10 @@ class BatchedPcgrlEnv:
         c.prob, c.rep, c.num_envs = PROB_IDS[self._prob.name], REP_IDS[self._rep.name], self.num_envs
         c.width, c.height = (int(self._prob._width), int(self._prob._height)) if map_dims is None else (int(map_dims[0]), int(map_dims[1]))
         c.prob_width, c.prob_height = int(self._prob._width), int(self._prob._height)
-        c.max_changes, c.max_iterations = int(self._max_changes), int(self._max_iterations)
+        # (pcgrl_env.py:33-34 computes max_iterations = max_changes * W * H with Python integers; the device field and the iteration
+        #  counter it is compared with are 32-bit: beyond 2^31 - 1 -- e.g. 255 x 255 with change_percentage above 0.5 -- the limit is
+        #  one no episode can reach either way, and the info dict keeps reporting the exact value from the host side)
+        c.max_changes, c.max_iterations = int(self._max_changes), min(int(self._max_iterations), 2 ** 31 - 1)
         c.random_start, c.random_tile, c.warp, c.random_probs = 1, 1, 0, 0
         c.auto_reset = int(self.auto_reset)
         for k, v in list(self._prob.device_params().items()) + list(self._rep.device_params().items()):
@@ -238,12 +241,21 @@ class BatchedPcgrlEnv:
             # the reference does.  Everything else is applied to the live handle.
             stale = (self._prob._width, self._prob._height) != self._alloc_dims
             cfg = self._config(self._alloc_dims if stale else None)
+            # a value the library refuses outright (solver_power < 1 or beyond 10^6, a size beyond its limits ...) is reported here, at
+            # the call that passed it -- the layout query validates a configuration without touching the handle
+            lay = _lib.Layout()
+            if self._lib.pcgrl_query_layout(C.byref(self._config()), C.byref(lay)) != 0:
+                raise ValueError("adjust_param(%s): outside what the library takes (include/pcgrl_hip.h: map side <= 255, search levels of at most "
+                                 "4096 bordered cells, 1 <= solver_power <= 10^6; smb: width <= 250, height 3..32, solver_power <= 16383)" %
+                                 ", ".join("%s=%r" % kv for kv in kwargs.items()))
             rc = self._lib.pcgrl_configure(self._handle, C.byref(cfg))
             if rc == _lib.PCGRL_EINVAL and not self._needs_reset:
-                # the handle cannot take the change in place (a solver_power beyond what its arena was sized for, or one that moves the
-                # searches to the other kernel family): the buffers are re-allocated by the next reset(), which has to come first
+                # a valid configuration the handle cannot take in place: a solver_power beyond what its search arena was sized for, or one
+                # that moves the searches to the other kernel family.  The buffers are re-allocated by the next reset(), which has to
+                # come first (the reference would let the new solver_power take effect in the middle of the episode)
                 self._realloc = True
                 self._needs_reset = True
+                self._reset_reason = "adjust_param(%s) needs another search arena" % ", ".join("%s=%r" % kv for kv in kwargs.items())
             elif rc != _lib.PCGRL_EINVAL:
                 _lib.check(rc, "pcgrl_configure")
             if rc == 0 and self._prob._probs_touched:
@@ -267,6 +279,7 @@ class BatchedPcgrlEnv:
             self._realloc = False
         _lib.check(self._lib.pcgrl_reset(self._handle, self._stream()), "pcgrl_reset")
         self._needs_reset = False
+        self._reset_reason = None
         return self._obs()
 
     def _as_actions(self, actions):
@@ -286,7 +299,7 @@ class BatchedPcgrlEnv:
         (wide: x, y, tile).  Returns (obs, reward f64[N], done bool[N], InfoBatch); tensors are views
         of the live state and are overwritten by the next step."""
         if self._needs_reset:
-            raise RuntimeError("reset() must be called before step()")
+            raise RuntimeError("reset() must be called before step()" + (": " + self._reset_reason if getattr(self, "_reset_reason", None) else ""))
         a = self._as_actions(actions)
         self._last_actions = a   # keep the buffer alive until the launches are done
         _lib.check(self._lib.pcgrl_step(self._handle, C.c_void_p(a.data_ptr()), self._stream()), "pcgrl_step")

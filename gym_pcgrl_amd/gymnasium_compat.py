@@ -121,6 +121,13 @@ class NewApiPcgrlVectorEnv(_vector_base()):
 
     def __init__(self, env_id_or_env, num_envs=None, seed=None, device=None, to_numpy=True, **adjust):
         from .vector import PcgrlVectorEnv
+        # the batch resets a finished environment inside the step that finished it (the observation returned with done is the first
+        # one of the next episode): gymnasium >= 1.0 wants that declared
+        g = find_gymnasium()
+        mode = getattr(getattr(getattr(g, "vector", None), "AutoresetMode", None), "SAME_STEP", None) if g is not None else None
+        self.metadata = dict(getattr(type(self), "metadata", None) or {})
+        if mode is not None:
+            self.metadata["autoreset_mode"] = mode
         self._v = PcgrlVectorEnv(env_id_or_env, num_envs=num_envs, seed=seed, device=device, to_numpy=to_numpy, **adjust)
         self.num_envs = self._v.num_envs
         self.to_numpy = self._v.to_numpy

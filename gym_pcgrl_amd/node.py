@@ -46,10 +46,17 @@ class ShardedTensor:
 
 
 class MultiGpuPcgrlEnv:
-    def __init__(self, prob="binary", rep="narrow", num_envs=1, devices=None, seed=0, auto_reset=True, gather="list"):
+    def __init__(self, prob="binary", rep="narrow", num_envs=1, devices=None, seed=0, auto_reset=True, gather="list", sync_streams=True):
         """gather: what reset()/step() return per output -- "list": a ShardedTensor of live per-device views (zero copy, no
         host sync: the default); "host": one pinned host tensor (the copies are issued per stream, then every stream is
-        waited for -- the shape a central numpy/CPU consumer wants); a device string: one tensor on that device."""
+        waited for -- the shape a central numpy/CPU consumer wants); a device string: one tensor on that device.
+        With "host" the returned tensors are the driver's own pinned buffers, two sets used alternately: what step k returned
+        stays valid through step k + 1 (observation and next observation of a transition can be held side by side) and is
+        overwritten by step k + 2 -- copy what has to live longer.  ("list" views are live state: overwritten by the next step.)
+        sync_streams: every step() makes each shard's stream wait (on the device) for what the caller's current stream of that
+        device has queued -- the action tensors -- and the caller's stream wait for the shard's afterwards, so that the outputs
+        can be consumed on the current stream like those of a single BatchedPcgrlEnv.  False: the caller orders the streams itself
+        (per-shard policies that run on `streams[g]`): step() then issues nothing but the step."""
         import torch
 
         from .envs import BatchedPcgrlEnv
@@ -77,7 +84,10 @@ class MultiGpuPcgrlEnv:
             s = (self.base_seed + lo) if self.base_seed is not None else [int(v) for v in seed[lo:hi]]
             self.shards.append(BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=hi - lo, device=self.devices[g], seed=s, auto_reset=auto_reset))
             self.streams.append(torch.cuda.Stream(device=self.devices[g]))
+        self.sync_streams = bool(sync_streams)
+        self._multi = None             # step() through pcgrl_step_multi: ctypes arrays + the cached live views (built by reset())
         self._pinned = {}
+        self._flip = 0                 # which of the two pinned sets the current call fills (gather="host")
         self._pending = None
 
     # ------------------------------------------------------------------ the surface of BatchedPcgrlEnv
@@ -115,6 +125,7 @@ class MultiGpuPcgrlEnv:
     def adjust_param(self, **kwargs):
         for sh in self.shards:
             sh.adjust_param(**kwargs)
+        self._multi = None             # (the cached info views carry max_changes / max_iterations)
 
     def split(self, actions):
         """[N(, k)] actions -> the per-shard pieces, each on its shard's device (a list is taken as already split)."""
@@ -132,7 +143,7 @@ class MultiGpuPcgrlEnv:
         if self.gather == "list":
             return ShardedTensor(parts)
         if self.gather == "host":
-            key = (name, tuple(parts[0].shape[1:]), parts[0].dtype)
+            key = (name, tuple(parts[0].shape[1:]), parts[0].dtype, self._flip)
             buf = self._pinned.get(key)
             if buf is None:
                 buf = torch.empty((self.num_envs,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype).pin_memory()
@@ -155,15 +166,53 @@ class MultiGpuPcgrlEnv:
         return o
 
     def reset(self):
+        self._flip ^= 1
         obs = self._each(lambda g, sh: sh.reset())
         out = self._obs(obs)
         self._finish()
+        self._multi = None             # (a reset may have re-allocated a shard: new handles, new views)
         return out
+
+    def _prepare_multi(self):
+        """What step() needs to go through ONE call of the library (pcgrl_step_multi): the handles and streams as C arrays, and the
+        outputs -- the shards' live views never move between resets, so the returned structures are built once."""
+        import ctypes as C
+        from .envs.batched_env import InfoBatch
+        G = len(self.shards)
+        VP = C.c_void_p * G
+        res = []
+        for sh in self.shards:
+            b = sh._bufs
+            decode = sh._prob.decode_rows if sh._prob.packed_rows else None
+            res.append((sh._obs(), b["reward"], b["done"].view(self._torch.bool), InfoBatch(sh._prob.info_keys, b["info"], sh._max_iterations, sh._max_changes, decode)))
+        self._multi = dict(lib=self.shards[0]._lib, n=G, handles=VP(*[sh._handle.value for sh in self.shards]), actions=VP(),
+                           streams=VP(*[st.cuda_stream for st in self.streams]), res=res,
+                           out=(self._obs([r[0] for r in res]), ShardedTensor([r[1] for r in res]), ShardedTensor([r[2] for r in res]), [r[3] for r in res]))
 
     def step(self, actions):
         """pcgrl_env.py:129-150 for every environment of every shard.  Returns (obs, reward, done, infos): obs / reward / done in
-        the `gather` form, infos the list of the shards' InfoBatch objects (live device tables)."""
+        the `gather` form, infos the list of the shards' InfoBatch objects (live device tables).  With gather="list" the whole
+        node is stepped by one call of the library (pcgrl_step_multi) and the call performs no host synchronisation."""
+        self._flip ^= 1
         parts = self.split(actions)
+        if self.gather == "list" and not any(sh.strict_actions or sh._needs_reset for sh in self.shards):
+            if self._multi is None:
+                self._prepare_multi()
+            M = self._multi
+            torch = self._torch
+            acts = [sh._as_actions(p) for sh, p in zip(self.shards, parts)]
+            self._last_actions = acts          # keep the buffers alive until the launches are done
+            for g, a in enumerate(acts):
+                M["actions"][g] = a.data_ptr()
+            if self.sync_streams:
+                for g, st in enumerate(self.streams):
+                    st.wait_stream(torch.cuda.current_stream(self.devices[g]))
+            from . import _lib
+            _lib.check(M["lib"].pcgrl_step_multi(M["handles"], M["actions"], M["streams"], M["n"]), "pcgrl_step_multi")
+            if self.sync_streams:
+                for g, st in enumerate(self.streams):
+                    torch.cuda.current_stream(self.devices[g]).wait_stream(st)
+            return M["out"]
         res = self._each(lambda g, sh: sh.step(parts[g]))
         out = (self._obs([r[0] for r in res]), self._collect("reward", [r[1] for r in res]),
                self._collect("done", [r[2] for r in res]), [r[3] for r in res])

@@ -167,6 +167,11 @@ int pcgrl_reset(pcgrl_env* env, void* stream);
 /* actions: DEVICE pointer, i32 [N] (narrow, turtle), [N,3] = (x, y, tile) (wide), [N,2] = (type, tile)
  * (narrowcast, turtlecast) or [N,9] (narrowmulti: tile+1 per cell of the 3x3 block, 0 = keep). */
 int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
+/* pcgrl_step on `count` handles in one call -- the shards of one batch of environments, one handle per GPU of a node (or several
+ * on one GPU), each with its own stream: envs / actions / streams are HOST arrays of `count` entries.  Step k is issued on every
+ * handle before the call returns and nothing is waited for; what SubprocVecEnv.step_async does for the reference's worker
+ * processes (utils.py:60-71), as one foreign-function call per step of the whole node.  Returns the first error. */
+int pcgrl_step_multi(pcgrl_env* const* envs, const int32_t* const* actions, void* const* streams, int32_t count);
 /* `steps` consecutive pcgrl_step calls on a tape of actions (a random-action rollout as in the reference's README
  * loop `env.step(env.action_space.sample())`, a recorded episode, an evaluation run): actions DEVICE i32
  * [steps, N(, k)] laid out like `steps` action arrays of pcgrl_step one after the other.  Optional DEVICE outputs, one

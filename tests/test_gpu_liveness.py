@@ -1,0 +1,147 @@
+"""Liveness of the kernels that wait for each other: the fused step kernel's LDS ticket / claim protocol with
+unforeseen resets (k_step), the two-block hand-over of a tall map's certain reset with its bounded spin (k_stats_wide).  Each case is
+run >= 50 times under RANDOMISED developer switches (pcgrl_tuning: block size, wavefront priorities, items per task, pairing,
+champion shortcuts; grid size / spin limit / pairing of the tall-map kernel), every result is compared with the reference fixture or
+the oracle, and every step is watched by a HOST WATCHDOG: the test records an event behind the step and polls it with a deadline
+-- a kernel that never ends fails the test with the step index and the switches instead of hanging the run (the process exits at
+once: a hung GPU cannot be waited for).  GPU only."""
+import ast
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEADLINE_S = 20.0            # a step of these batches takes well under a millisecond
+REPEATS = int(os.environ.get("PCGRL_LIVENESS_REPEATS", "50"))
+
+
+def _watch(torch, context):
+    """Wait for everything queued on the current stream -- but not for ever."""
+    ev = torch.cuda.Event()
+    ev.record()
+    t0 = time.perf_counter()
+    while not ev.query():
+        if time.perf_counter() - t0 > DEADLINE_S:
+            sys.stderr.write("\nWATCHDOG: the GPU did not finish within %.0f s -- %s\n" % (DEADLINE_S, context))
+            sys.stderr.flush()
+            os._exit(86)           # no teardown: every further HIP call would wait for the hung kernel
+        time.sleep(0.0005)
+
+
+def _random_tuning(rs, tall):
+    t = {}
+    if tall:
+        t["wide_grid"] = int(rs.choice([2, 6, 64, 512, 2048]))
+        t["wide_waves"] = int(rs.choice([4, 8]))
+        t["wide_pairs"] = int(rs.randint(2))
+        t["wide_few"] = int(rs.choice([0, 32, 1000]))
+        if rs.rand() < 0.6:
+            t["wide_spin"] = 1                      # the block with the reset gives up waiting at once
+    else:
+        t["step_epb"] = int(rs.choice([64, 128, 256]))
+        t["step_prio"] = int(rs.choice([0, 3, 15, 31, 0xFFF]))
+        t["full_per_wave"] = int(rs.choice([1, 2, 4]))
+        t["inc_per_wave"] = int(rs.choice([1, 2, 4]))
+        t["step_pair"] = int(rs.choice([0, 2, 6]))
+        t["no_touch"] = int(rs.randint(2))
+        t["touch_tight"] = int(rs.randint(2))
+    return t
+
+
+def _make(prob, rep, n, calls, seed, tuning):
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, seed=seed, tuning=tuning)
+    for kw in calls:
+        env.adjust_param(**kw)
+    return env
+
+
+@pytest.mark.parametrize("name", ["traj_binary_narrow", "traj_zelda_wide_11x16"])
+def test_fused_step_kernel_trajectories_under_random_switches(name):
+    import torch
+    d = np.load(os.path.join(G, name + ".npz"))
+    prob, rep = str(d["prob"]), str(d["rep"])
+    calls = ast.literal_eval(str(d["calls"]))
+    seed0 = int(d["cfg"][4])
+    acts = d["actions"]
+    T, E = acts.shape[:2]
+    keys = [str(k) for k in d["info_keys"]]
+    for it in range(REPEATS):
+        rs = np.random.RandomState(1000 + it)
+        tuning = _random_tuning(rs, False)
+        env = _make(prob, rep, E, calls, seed0, tuning)
+        obs = env.reset()
+        _watch(torch, "%s reset, iteration %d, tuning %s" % (name, it, tuning))
+        assert np.array_equal(obs["map"].cpu().numpy(), d["map0"]), (it, tuning)
+        for t in range(T):
+            obs, rew, done, info = env.step(acts[t] if acts.shape[2] > 1 else acts[t, :, 0])
+            _watch(torch, "%s step %d, iteration %d, tuning %s" % (name, t, it, tuning))
+            assert np.array_equal(rew.cpu().numpy(), d["reward"][t]) and np.array_equal(done.cpu().numpy(), d["done"][t]), ("reward/done", t, it, tuning)
+            if t % 8 == 0 or t == T - 1:
+                got = np.stack([info[k].cpu().numpy() for k in keys], 1).astype(np.int64)
+                assert np.array_equal(got, d["info"][t]) and np.array_equal(obs["map"].cpu().numpy(), d["maps"][t]), ("info/map", t, it, tuning)
+        env.close()
+
+
+def test_tall_map_split_resets_under_random_switches():
+    """C5's shape of trouble at a small size: binary-turtle 20 x 24 with max_changes 4 -- many certain resets per step, each split
+    over two blocks of k_stats_wide that talk through DevBufs::wide_sync."""
+    import torch
+    prob, rep, calls, E, T, seed0 = "binary", "turtle", [dict(width=20, height=24), dict(change_percentage=0.01)], 160, 60, 777
+    rs0 = np.random.RandomState(11)
+    acts = rs0.randint(0, 2 + 4, size=(T, E)).astype(np.int32)
+    exp = []
+    for i in range(E):
+        o = ol.OracleEnv(prob, rep)
+        for kw in calls:
+            o.adjust_param(**kw)
+        o.seed(seed0 + i)
+        o.reset()
+        exp.append(o.rollout(acts[:, i]))
+    e_rew = np.stack([x["reward"] for x in exp], 1)
+    e_done = np.stack([x["done"] for x in exp], 1)
+    e_map = np.stack([x["maps"][-1] for x in exp])
+    for it in range(REPEATS):
+        rs = np.random.RandomState(5000 + it)
+        tuning = _random_tuning(rs, True)
+        env = _make(prob, rep, E, calls, seed0, tuning)
+        env.reset()
+        for t in range(T):
+            obs, rew, done, info = env.step(acts[t])
+            _watch(torch, "tall map step %d, iteration %d, tuning %s" % (t, it, tuning))
+            assert np.array_equal(rew.cpu().numpy(), e_rew[t]) and np.array_equal(done.cpu().numpy(), e_done[t]), (t, it, tuning)
+        assert np.array_equal(obs["map"].cpu().numpy(), e_map), (it, tuning)
+        env.close()
+
+
+def test_large_batches_never_hang_under_random_switches():
+    """Pure liveness at sizes where many blocks run at once (no oracle: the parity suites hold these paths; here every step only has
+    to END): C2's and C3's shapes at 16 384 environments, C5's at 2 048, 150 steps each, ten random switch settings apiece."""
+    import torch
+    for prob, rep, calls, n, tall in (("binary", "narrow", [], 16384, False), ("zelda", "wide", [dict(width=11, height=16)], 16384, False),
+                                      ("binary", "turtle", [dict(width=64, height=64)], 2048, True)):
+        for it in range(max(REPEATS // 5, 2)):
+            rs = np.random.RandomState(9000 + it)
+            tuning = _random_tuning(rs, tall)
+            env = _make(prob, rep, n, calls, 0, tuning)
+            env.reset()
+            W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
+            g = torch.Generator(device="cuda").manual_seed(it)
+            for t in range(150):
+                if rep == "wide":
+                    a = torch.stack([torch.randint(0, W, (n,), device="cuda", generator=g), torch.randint(0, H, (n,), device="cuda", generator=g),
+                                     torch.randint(0, nt, (n,), device="cuda", generator=g)], -1).to(torch.int32)
+                else:
+                    a = torch.randint(0, nt + (1 if rep == "narrow" else 4), (n,), device="cuda", generator=g, dtype=torch.int32)
+                env.step(a)
+                if t % 10 == 9:
+                    _watch(torch, "%s-%s x %d step %d, iteration %d, tuning %s" % (prob, rep, n, t, it, tuning))
+            _watch(torch, "%s-%s x %d end, iteration %d, tuning %s" % (prob, rep, n, it, tuning))
+            assert env.check_status() == 0
+            env.close()
