@@ -21,7 +21,7 @@
 
 struct BigGeom {
     int W, H, KW, NW;          // words per row, words per mask
-    uint32_t magic;            // floor(i / KW) = (i * magic) >> 16 for i < 1024 (KW <= 4)
+    uint32_t magic;            // floor(i / KW) = (i * magic) >> 16 for i * KW < 65536 (validate_config keeps NW * KW below that)
     uint64_t last;             // valid bits of the last word of a row
 };
 __device__ __forceinline__ BigGeom big_geom(int W, int H) {

@@ -161,6 +161,8 @@ static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGR
 //     search_big.h (big_search below);
 //   * smb: its own limits (kernels_smb.h).
 #define PCGRL_MAX_DIM 255
+#define PCGRL_MAX_DIM_WIDE 4096
+#define PCGRL_BIG_LDS_BUDGET ((size_t)150 * 1024)      /* k_big: LDS of one wavefront's masks (launch_big_p) */
 #define PCGRL_MAX_LEVEL_CELLS 4096
 #define PCGRL_MAX_SOLVER_POWER 1000000
 static bool big_map(const pcgrl_config* c) { return c->prob != PCGRL_SMB && (c->width > 64 || c->height > 64); }
@@ -173,8 +175,18 @@ static int validate_config(const pcgrl_config* c) {
     if (c->num_envs < 1) return PCGRL_EINVAL;
     if (c->prob == PCGRL_SMB) {   // the platformer's grid is (width + 6) x height cells, a column index fits a byte (kernels_smb.h)
         if (c->width < 1 || c->width > 250 || c->height < 3 || c->height > SMB_MAX_H) return PCGRL_EINVAL;
-    } else if (c->width < 1 || c->width > PCGRL_MAX_DIM || c->height < 1 || c->height > PCGRL_MAX_DIM) return PCGRL_EINVAL;
+    } else {
+        // a representation with a cursor reports it as uint8 `pos` (narrow_rep.py:60-64, turtle_rep.py:73-77): 255 per side.  The wide
+        // representation has none (wide_rep.py:42-45, 67-70): any size one wavefront's LDS holds as multi-word row masks (bigmap.h)
+        const int max_dim = c->rep == PCGRL_REP_WIDE ? PCGRL_MAX_DIM_WIDE : PCGRL_MAX_DIM;
+        if (c->width < 1 || c->width > max_dim || c->height < 1 || c->height > max_dim) return PCGRL_EINVAL;
+        if (big_map(c)) {
+            const int kw = (c->width + 63) >> 6;
+            if (big_wave_lds(c->width, c->height) > PCGRL_BIG_LDS_BUDGET || (long long)big_words(c->width, c->height) * kw >= 65536) return PCGRL_EINVAL;
+        }
+    }
     if (c->max_changes < 1 || c->max_iterations < 1) return PCGRL_EINVAL;
+    if (c->max_changes > 65535) return PCGRL_EINVAL;          // the heat map counts changes per cell in 16 bits (a cell's count <= the episode's changes)
     if (solver_prob(c->prob)) {
         if (c->prob != PCGRL_SMB && (c->width + 2) * (c->height + 2) > PCGRL_MAX_LEVEL_CELLS) return PCGRL_EINVAL;
         if (c->solver_power < 1 || c->solver_power > (c->prob == PCGRL_SMB ? 16383 : PCGRL_MAX_SOLVER_POWER)) return PCGRL_EINVAL;
@@ -642,7 +654,7 @@ template <int PROB>
 static int launch_big_p(pcgrl_env* h, int list, int parity, int mode, int clr, int inline_reset, int park_list, hipStream_t st) {
     const PcgrlParams& P = h->P;
     const size_t per_wave = big_wave_lds(P.width, P.height);
-    int nw = (int)((size_t)(150 * 1024) / per_wave);
+    int nw = (int)(PCGRL_BIG_LDS_BUDGET / per_wave);
     nw = nw > 4 ? 4 : nw;
     if (nw < 1) return PCGRL_EINVAL;
     const size_t lds = (size_t)nw * per_wave;

@@ -227,6 +227,8 @@ class BatchedPcgrlEnv:
     def adjust_param(self, **kwargs):
         """pcgrl_env.py:106-115, including the ordering quirk: max_changes is recomputed only when
         change_percentage is passed, and both limits use the width/height from *before* this call."""
+        import copy
+        before = (copy.deepcopy(self._prob.__dict__), copy.deepcopy(self._rep.__dict__), self._max_changes, self._max_iterations)
         if "change_percentage" in kwargs:
             percentage = min(1, max(0, kwargs.get("change_percentage")))
             self._max_changes = max(int(percentage * self._prob._width * self._prob._height), 1)
@@ -245,7 +247,10 @@ class BatchedPcgrlEnv:
             # the call that passed it -- the layout query validates a configuration without touching the handle
             lay = _lib.Layout()
             if self._lib.pcgrl_query_layout(C.byref(self._config()), C.byref(lay)) != 0:
-                raise ValueError("adjust_param(%s): outside what the library takes (include/pcgrl_hip.h: map side <= 255, search levels of at most "
+                self._prob.__dict__, self._rep.__dict__, self._max_changes, self._max_iterations = before      # nothing of the call sticks
+                self._update_spaces()
+                raise ValueError("adjust_param(%s): outside what the library takes (include/pcgrl_hip.h: map side <= 255 -- the wide representation, which "
+                                 "has no cursor: any size whose row masks fit a compute unit's LDS --, max_changes <= 65535, search levels of at most "
                                  "4096 bordered cells, 1 <= solver_power <= 10^6; smb: width <= 250, height 3..32, solver_power <= 16383)" %
                                  ", ".join("%s=%r" % kv for kv in kwargs.items()))
             rc = self._lib.pcgrl_configure(self._handle, C.byref(cfg))
@@ -269,7 +274,10 @@ class BatchedPcgrlEnv:
         if self._rep.has_pos:
             o["pos"] = b["pos"]
         o["map"] = b["map"]
-        o["heatmap"] = b["heatmap"]
+        # the device counts changes per cell in 16 bits (pcgrl_env.py:35,137 keeps a float64): the view is int16 while a count cannot
+        # pass 32 767 (max_changes, which bounds it, does not: every configuration of the reference's defaults) -- full operator
+        # support in torch -- and uint16 beyond (maps of more than 32 767 cells with a change_percentage to match)
+        o["heatmap"] = b["heatmap"] if self._max_changes <= 32767 else b["heatmap"].view(self._torch.uint16)
         return o
 
     def reset(self):

@@ -893,6 +893,9 @@ TRAJS = [
         probs={"empty": 0.8, "solid": 0.18, "player": 0.004, "exit": 0.004, "diamond": 0.004, "key": 0.004, "spike": 0.004}))),
     ("sokoban_wide_p20000", "sokoban", "wide", 4, 60, (dict(solver_power=20000, change_percentage=0.9,
         probs={"empty": 0.8, "solid": 0.05, "player": 0.05, "crate": 0.05, "target": 0.05}),)),
+    # round 5: the wide representation has no cursor, so no uint8 `pos` caps its map: sides beyond 255 (wide_rep.py:42-45, 67-70)
+    ("binary_wide_300x40", "binary", "wide", 2, 36, (dict(width=300, height=40), dict(change_percentage=0.001))),
+    ("zelda_wide_12x270", "zelda", "wide", 2, 36, (dict(width=12, height=270), dict(change_percentage=0.003))),
     ("mdungeon_narrow_monsters", "mdungeon", "narrow", 16, 300, (dict(width=6, height=6), dict(
         change_percentage=0.8, solver_power=250, target_solution=3, target_col_enemies=0.2,
         probs={"empty": 0.45, "solid": 0.03, "player": 0.03, "exit": 0.03, "potion": 0.06, "treasure": 0.05, "goblin": 0.1, "ogre": 0.25}),)),
@@ -953,6 +956,36 @@ def gen_wrappers():
         print("    %s obs %s" % (name, obs.shape))
 
 
+def gen_heat_boundary():
+    """The heat map beyond 32 767 (pcgrl_env.py:35,137: a float64 count per cell; the build keeps 16 bits).  binary-wide on a
+    182 x 182 map that starts all solid, change_percentage 1.0 -> max_changes 33 124; ONE cell is rewritten with alternating tiles
+    32 900 times, every write a change: its count passes 2^15.  Stored: the per-step reward / done / info of the first and last 200
+    steps and of every 100th one, the final map's empty cells and the final heat map as (cell, count) pairs."""
+    t0 = time.time()
+    W = H = 182
+    T = 32900
+    env = gym.make("binary-wide-v0")
+    env.seed(7)
+    env.adjust_param(width=W, height=H, probs={"empty": 0.0, "solid": 1.0})
+    env.adjust_param(change_percentage=1.0)
+    obs = env.reset()
+    assert int(obs["map"].sum()) == W * H
+    keep = sorted(set(list(range(200)) + list(range(0, T, 100)) + list(range(T - 200, T))))
+    rew, done, info = [], [], []
+    for t in range(T):
+        obs, r, d, inf = env.step([5, 7, t % 2])
+        assert not d
+        if t in keep:
+            rew.append(r); done.append(d); info.append([inf[k] for k in INFO_KEYS["binary"]] + [inf["iterations"], inf["changes"]])
+    heat = np.asarray(obs["heatmap"])
+    cells = np.argwhere(heat != 0)
+    save("heat_boundary", cfg=np.array([W, H, env._max_changes, env._max_iterations, 7, T], np.int64), cell=np.array([5, 7, 0], np.int64),
+         steps=np.array(keep, np.int64), reward=np.array(rew, np.float64), done=np.array(done, np.bool_), info=np.array(info, np.int64),
+         heat_cells=cells.astype(np.int64), heat_counts=np.array([heat[y, x] for y, x in cells], np.int64),
+         empty_cells=np.argwhere(np.asarray(obs["map"]) == 0).astype(np.int64))
+    print("heat_boundary", heat.max(), "%.0f s" % (time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -960,7 +993,7 @@ def main():
     jobs = {
         "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
         "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "stats_ddave": gen_stats_ddave, "stats_smb": gen_stats_smb, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
-        "wrappers": gen_wrappers, "stats_big": gen_stats_big, "stats_big_search": gen_stats_big_search,
+        "wrappers": gen_wrappers, "stats_big": gen_stats_big, "stats_big_search": gen_stats_big_search, "heat_boundary": gen_heat_boundary,
     }
     for k, fn in jobs.items():
         if a.only in (None, k):

@@ -175,3 +175,27 @@ def test_oracle_under_sanitizers():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "replayed %d" % len(picks) in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_heat_map_beyond_int16_matches_reference():
+    """heat_boundary.npz (tests/golden/make_golden.py gen_heat_boundary): the reference's float64 heat map (pcgrl_env.py:35,137) counts
+    one cell of a 182 x 182 binary-wide map past 32 767; the oracle's uint16 must hold the same counts."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "heat_boundary.npz"))
+    W, H, max_changes, max_iter, seed, T = [int(v) for v in d["cfg"]]
+    x, y, _ = [int(v) for v in d["cell"]]
+    o = ol.OracleEnv("binary", "wide")
+    o.adjust_param(width=W, height=H, probs={"empty": 0.0, "solid": 1.0})
+    o.adjust_param(change_percentage=1.0)
+    o.seed(seed)
+    o.reset()
+    assert (o.max_changes, o.max_iterations) == (max_changes, max_iter)
+    acts = np.zeros((T, 3), np.int32)
+    acts[:, 0], acts[:, 1], acts[:, 2] = x, y, np.arange(T) % 2
+    r = o.rollout(acts, want_maps=False, want_heat=False)
+    steps = d["steps"]
+    assert np.array_equal(r["reward"][steps], d["reward"]) and np.array_equal(r["done"][steps], d["done"]) and np.array_equal(r["info"][steps], d["info"])
+    heat = o.obs()["heatmap"]
+    got = np.argwhere(heat != 0)
+    assert np.array_equal(got, d["heat_cells"]) and np.array_equal(heat[got[:, 0], got[:, 1]].astype(np.int64), d["heat_counts"])
+    assert int(d["heat_counts"].max()) == T > 32767
+    assert np.array_equal(np.argwhere(o.obs()["map"] == 0), d["empty_cells"])
