@@ -103,7 +103,7 @@ def test_sizes_the_library_takes_and_refuses():
     env.close()
     env = BatchedPcgrlEnv(prob="binary", rep="wide", num_envs=2, seed=1)
     env.reset()
-    env.adjust_param(width=600, height=300)
+    env.adjust_param(width=1000, height=80)
     with pytest.raises(ValueError):
-        env.adjust_param(change_percentage=0.9)           # max_changes 162 000 > 65 535
+        env.adjust_param(change_percentage=0.9)           # max_changes 72 000 > 65 535
     env.close()
