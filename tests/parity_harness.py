@@ -358,3 +358,75 @@ def _async_rows(env, ti, keys):
     return (b["reward"][ti].cpu().numpy(), b["done"][ti].cpu().numpy(), inf, b["pos"][ti].cpu().numpy().astype(np.int64),
             b["heatmap"][ti].cpu().numpy().astype(np.int64), b["map"][ti].cpu().numpy())
 
+
+
+def expected_image(m, pos, oh, ow, centered, pad, depth):
+    """wrappers.py restated with numpy: Cropped.transform :197-206 (np.pad with the border tile, window at the cursor),
+    OneHotEncoding.transform :101-104 (np.eye(dim)[map]), ToImage.transform :53-60.  m [N,H,W], pos [N,2] = (x, y)."""
+    n, H, W = m.shape
+    out = np.full((n, oh, ow), pad, dtype=np.int64)
+    for i in range(n):
+        if centered:
+            ph_, pw_ = oh // 2 + oh, ow // 2 + ow
+            padded = np.pad(m[i].astype(np.int64), ((ph_, ph_), (pw_, pw_)), constant_values=pad)
+            x, y = int(pos[i, 0]), int(pos[i, 1])
+            out[i] = padded[y + ph_ - oh // 2: y + ph_ - oh // 2 + oh, x + pw_ - ow // 2: x + pw_ - ow // 2 + ow]
+        else:
+            hh, ww = min(oh, H), min(ow, W)
+            out[i, :hh, :ww] = m[i, :hh, :ww]
+    if depth == 1:
+        return out[..., None].astype(np.uint8)
+    return np.eye(depth, dtype=np.uint8)[out]
+
+
+def fullsize_wrapped_case(name, max_steps=40):
+    """The trainer-shaped configurations of bench.py at their real batch size against the ORACLE (not against another call of the
+    library): C2w = binary-narrow behind CroppedImagePCGRLWrapper(28) -- the fused step writes the [N, 28, 28, 1] image --, C3w =
+    zelda-wide 11 x 16 behind ActionMapImagePCGRLWrapper -- flat ActionMap indices decoded inside the step (pcgrl_step_flat), one-hot
+    [N, 16, 11, 8] image.  294 sampled environments: the oracle is stepped with the decoded actions (wrappers.py:139-154: index into
+    (H, W, tiles)); reward, done, info and the IMAGE (the wrappers' transform of the oracle's map and cursor) of every step."""
+    import torch
+    from gym_pcgrl_amd import wrappers
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    N = 65536
+    if name == "C2w":
+        prob, rep, calls = "binary", "narrow", []
+    else:
+        prob, rep, calls = "zelda", "wide", [dict(width=11, height=16)]
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=N, seed=0)
+    for kw in calls:
+        env.adjust_param(**kw)
+    w = wrappers.CroppedImagePCGRLWrapper(env, 28) if name == "C2w" else wrappers.ActionMapImagePCGRLWrapper(env)
+    try:
+        img = w.reset()
+        W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
+        T = max_steps
+        g = torch.Generator(device="cuda"); g.manual_seed(6)
+        if name == "C2w":
+            acts = torch.randint(0, nt + 1, (T, N), device="cuda", dtype=torch.int32, generator=g)
+        else:
+            acts = torch.randint(0, W * H * nt, (T, N), device="cuda", dtype=torch.int32, generator=g)
+        idx = np.unique(np.concatenate([np.arange(0, 64), np.linspace(0, N - 1, 200).astype(int), np.arange(N - 32, N)]))
+        ti = torch.as_tensor(idx, device="cuda")
+        a_host = acts[:, ti].cpu().numpy()
+        if name == "C2w":
+            dec = a_host[:, :, None]
+        else:       # ActionMap: flat -> (x, y, tile)
+            dec = np.stack([(a_host // nt) % W, a_host // (nt * W), a_host % nt], -1)
+        exp = _oracle_rollouts(prob, rep, calls, idx, [dec[:, j] for j in range(len(idx))])
+        keys = list(env._prob.info_keys) + ["iterations", "changes"]
+        oh, ow, centered, pad = w._window()
+        depth = nt if w.one_hot else 1
+        for t in range(T):
+            img, rew, done, info = w.step(acts[t])
+            assert np.array_equal(done[ti].cpu().numpy(), np.array([x["done"][t] for x in exp])), ("done", name, t)
+            assert np.array_equal(rew[ti].cpu().numpy(), np.array([x["reward"][t] for x in exp])), ("reward", name, t)
+            assert np.array_equal(np.stack([info[k][ti].cpu().numpy() for k in keys], 1).astype(np.int64), np.stack([x["info"][t] for x in exp])), ("info", name, t)
+            e_img = expected_image(np.stack([x["maps"][t] for x in exp]), np.stack([x["pos"][t] for x in exp]), oh, ow, centered, pad, depth)
+            got = img[ti].cpu().numpy()
+            bad = np.nonzero((got != e_img).reshape(len(idx), -1).any(1))[0]
+            assert bad.size == 0, ("image", name, t, idx[bad[:5]])
+        env.check_status()
+    finally:
+        env.close()
+    return len(idx)

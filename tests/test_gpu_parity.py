@@ -1429,6 +1429,17 @@ def test_full_size_vs_oracle(name, use_rollout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["C2w", "C3w"])
+def test_full_size_wrapped_vs_oracle(name):
+    """bench.py's trainer-shaped configurations at 65 536 environments against the oracle: the image the fused step writes and --
+    C3w -- pcgrl_step_flat's decode of the ActionMap indices, held against the oracle stepped with the decoded actions and the
+    wrappers' transform of its maps (not against pcgrl_action_map + pcgrl_step of the library itself)."""
+    _torch()
+    import parity_harness as ph
+    assert ph.fullsize_wrapped_case(name) >= 290
+
+
+@pytest.mark.gpu
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (torch.distributed.run inside) and
     prints ONE line with n_gpus == 2 -- both ranks on cuda:0 over gloo here (PCGRL_BENCH_SAME_GPU=1: a one-GPU box)."""

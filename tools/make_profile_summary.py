@@ -50,7 +50,7 @@ for W in workloads:
         out.append("HBM traffic per step (sum over the step's kernels; rocprofv3 KB): FETCH_SIZE %.1f MB + WRITE_SIZE %.1f MB as reported.  Calibrated "
                    "on this GPU (`traffic_calibration.md`, `tools/traffic_calib.hip`): FETCH_SIZE is half of the bytes of the 128-byte lines read -- for wide "
                    "coalesced and narrow scattered reads alike -- and WRITE_SIZE is exact for coalesced writes and counts a 32-byte sector per scattered "
-                   "narrow write, so the step moves **%.1f MB** (2 x fetch + write; what `roofline.traffic` reports).\n" % (tot_f / 1024, tot_w / 1024, (2 * tot_f + tot_w) / 1024))
+                   "narrow write, so the step moves **%.1f MB** (2 x fetch + write; what `roofline.traffic` reports).\n" % (tot_f * 1024 / 1e6, tot_w * 1024 / 1e6, (2 * tot_f + tot_w) * 1024 / 1e6))
         hp = os.path.join(G, "srchash_%s.txt" % W)
         src_hash = open(hp).read().strip() if os.path.exists(hp) else None      # _lib.source_hash() of the tree the passes ran on
         json.dump({"workload": W, "fetch_bytes_per_step": tot_f * 1024, "write_bytes_per_step": tot_w * 1024, "csrc_hash": src_hash},
