@@ -105,13 +105,14 @@ __global__ __launch_bounds__(128) void k_ddave(PcgrlParams P, DevBufs B, int lis
         if (lane == 0) {
             const DdPollHook hook = {B.sok_stop + e, a};
             skip = hook(0) ? 1 : 0;                                  // already decided before this agent started
-            if (!skip) {
-                dd_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
-                // the compact search (ddave_fast.h) for levels with few diamonds; PCGRL_SOK_GENERIC=1 switches it off (tests)
-                s_fast = (ddf_level(s_L, s_F) <= DDF_MAXD && B.sok_use_lds && B.sok_fast_maxc >= 0) ? 1 : 0;
-            }
         }
         skip = __shfl(skip, 0, 64);
+        if (!skip) {
+            // the level by all 64 lanes (level_build_wave.h); the compact search (ddave_fast.h) for levels with few diamonds;
+            // PCGRL_SOK_GENERIC=1 switches it off (tests)
+            const int nd = dd_build_level_wave(B.map + (size_t)e * W * H, W, H, s_L, s_root, s_F, lane);
+            if (lane == 0) s_fast = (nd <= DDF_MAXD && B.sok_use_lds && B.sok_fast_maxc >= 0) ? 1 : 0;
+        }
         __threadfence_block();
         const int fast = skip ? 0 : s_fast;
         if (!skip) {

@@ -68,7 +68,7 @@ struct AsyncGame<PCGRL_PROB_SOKOBAN> {
     // the 64 lanes of the search wavefront (level_build_wave.h); m: the map; scratch: 64 bytes of LDS
     static __device__ __forceinline__ void build(const PcgrlParams& P, const DevBufs& B, const uint8_t* m, Shared& S, uint8_t* scratch, int lane) {
         const int ncr = sok_build_level_wave(m, P.width, P.height, S.L, S.root, lane);
-        sok_init_deadlocks_wave(S.L, scratch, lane);
+        sok_init_deadlocks_wave(S.L, S.scratch, lane);
         if (lane == 0) {
             if (ncr > SOK_MAXC) atomicOr(B.status, 1);
             S.root.h = (uint16_t)sok_heuristic(S.L, S.root.crate);

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(128) void k_sokoban(PcgrlParams P, DevBufs B, int l
     __shared__ SokLevel s_L;             // level + node workspace in LDS: they are indexed dynamically
     __shared__ SokNode s_root, s_work;
     __shared__ int s_spawned, s_fast;
+    __shared__ uint8_t s_scr[64];
     __shared__ SokFastNode s_cache[4];
     SokNode* pool = B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride;
     uint32_t* g_heap = B.sok_use_lds ? nullptr : B.sok_heap + (size_t)blockIdx.x * B.sok_heap_stride;
@@ -212,13 +213,15 @@ __global__ __launch_bounds__(128) void k_sokoban(PcgrlParams P, DevBufs B, int l
             mode = (tag >> 28) & 3;
             first = last = 1 + t % 3;
         }
-        if (lane == 0) {
-            const int ncr = sok_build_level(B.map + (size_t)e * W * H, W, H, s_L, s_root);
-            if (ncr > SOK_MAXC) atomicOr(B.status, 1);
-            sok_init_deadlocks(s_L);
-            s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
-            s_spawned = 0;
-            s_fast = (B.sok_use_lds && s_L.nc <= B.sok_fast_maxc) ? 1 : 0;
+        {   // the level by all 64 lanes (level_build_wave.h: ~40 us on one lane, a few on the wavefront)
+            const int ncr = sok_build_level_wave(B.map + (size_t)e * W * H, W, H, s_L, s_root, lane);
+            sok_init_deadlocks_wave(s_L, s_scr, lane);
+            if (lane == 0) {
+                if (ncr > SOK_MAXC) atomicOr(B.status, 1);
+                s_root.h = (uint16_t)sok_heuristic(s_L, s_root.crate);
+                s_spawned = 0;
+                s_fast = (B.sok_use_lds && s_L.nc <= B.sok_fast_maxc) ? 1 : 0;
+            }
         }
         __threadfence_block();
         const int fast = s_fast;

@@ -35,15 +35,17 @@ struct SolverGame;
 
 template <>
 struct SolverGame<PCGRL_PROB_SOKOBAN> {
-    struct Shared { SokLevel L; SokNode root, work; SokFastNode cache[4]; int fast; };
+    struct Shared { SokLevel L; SokNode root, work; SokFastNode cache[4]; int fast; uint8_t scratch[64]; };
     static __device__ __forceinline__ bool run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* heap, int table_off, int tsize, int power,
                                                SokNode* pool, int lane, int32_t* s) {
-        if (lane == 0) {
-            const int ncr = sok_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
-            if (ncr > SOK_MAXC) atomicOr(B.status, 1);
-            sok_init_deadlocks(S.L);
-            S.root.h = (uint16_t)sok_heuristic(S.L, S.root.crate);
-            S.fast = (S.L.nc <= B.sok_fast_maxc) ? 1 : 0;
+        {   // the level by all 64 lanes (level_build_wave.h)
+            const int ncr = sok_build_level_wave(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root, lane);
+            sok_init_deadlocks_wave(S.L, S.scratch, lane);
+            if (lane == 0) {
+                if (ncr > SOK_MAXC) atomicOr(B.status, 1);
+                S.root.h = (uint16_t)sok_heuristic(S.L, S.root.crate);
+                S.fast = (S.L.nc <= B.sok_fast_maxc) ? 1 : 0;
+            }
         }
         __threadfence_block();
         const int fast = S.fast;
@@ -74,9 +76,9 @@ struct SolverGame<PCGRL_PROB_MDUNGEON> {
     struct Shared { MdLevel L; MdNode root, work; MdFastLevel F; MdFastNode cache[4]; int fast; };
     static __device__ __forceinline__ bool run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* heap, int table_off, int tsize, int power,
                                                SokNode* pool, int lane, int32_t* s) {
-        if (lane == 0) {
-            md_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
-            S.fast = (mdf_level(S.L, S.root, S.F) <= MDF_MAXI && B.sok_fast_maxc >= 0) ? 1 : 0;
+        {
+            const int nthings = md_build_level_wave(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root, S.F, lane);
+            if (lane == 0) S.fast = (nthings <= MDF_MAXI && B.sok_fast_maxc >= 0) ? 1 : 0;
         }
         __threadfence_block();
         const int fast = S.fast;
@@ -115,9 +117,9 @@ struct SolverGame<PCGRL_PROB_DDAVE> {
     struct Shared { DdLevel L; DdNode root, work; DdFastLevel F; DdFastNode cache[4]; int fast; };
     static __device__ __forceinline__ bool run(const PcgrlParams& P, const DevBufs& B, int e, Shared& S, uint32_t* heap, int table_off, int tsize, int power,
                                                SokNode* pool, int lane, int32_t* s) {
-        if (lane == 0) {
-            dd_build_level(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root);
-            S.fast = (ddf_level(S.L, S.F) <= DDF_MAXD && B.sok_fast_maxc >= 0) ? 1 : 0;
+        {
+            const int nd = dd_build_level_wave(B.map + (size_t)e * P.width * P.height, P.width, P.height, S.L, S.root, S.F, lane);
+            if (lane == 0) S.fast = (nd <= DDF_MAXD && B.sok_fast_maxc >= 0) ? 1 : 0;
         }
         __threadfence_block();
         const int fast = S.fast;

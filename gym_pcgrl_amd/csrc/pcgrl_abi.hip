@@ -64,6 +64,7 @@
 #include "mdungeon_fast.h"
 #include "ddave_solver.h"
 #include "ddave_fast.h"
+#include "level_build_wave.h"
 
 #include "worklist.h"
 #include "kernels_update.h"
@@ -79,7 +80,6 @@
 #include "kernels_ddave.h"
 #include "kernels_smb.h"
 #include "kernels_step_solver.h"
-#include "level_build_wave.h"
 #include "kernels_search_async.h"
 #include "search_big.h"
 #include "kernels_search_big.h"

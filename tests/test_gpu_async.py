@@ -23,9 +23,10 @@ FEW_SOK = dict(probs={"empty": 0.75, "solid": 0.1, "player": 0.02, "crate": 0.07
     ("ddave", "turtle", (dict(solver_power=1200),), 128, 100, 3, 64),
 ])
 def test_async_ticks_vs_oracle(prob, rep, calls, E, ticks, budget, nslots):
-    rs = np.random.RandomState(hash((prob, rep, E)) % 2 ** 31)
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(("%s %s %d" % (prob, rep, E)).encode()))
     cnt = ph.async_case(prob, rep, list(calls), E, ticks, 4242, rs, budget, nslots)
-    few = prob != "sokoban" and rep != "narrow"       # (planners that usually win within a few pops: little to cut even with a budget of 3)
+    few = prob != "sokoban"       # (planners that usually win within a few pops: little to cut even with a budget of 3)
     assert cnt["suspended"] > (3 if few else 10), cnt     # searches really were cut
     assert cnt["late"] >= (1 if few else 3) and cnt["pending_env_ticks"] > (3 if few else 10), cnt
     assert cnt["consumed"] == cnt["steps"], cnt       # the library's count of taken actions is the harness's
