@@ -61,7 +61,7 @@ WRAPPED = {"C2w": ("cropped", 28), "C3w": ("actionmap", None)}
 # driver-timed figure.  (steps, warmup, steady warm-up) are sized so that the whole default run stays well under a minute of GPU time.
 LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 45), "C2w": (20, 5, 800), "C3w": (20, 5, 800)}
 # asynchronous ticks of the search problems (pcgrl_step_async): (workload, ticks, warm-up ticks, pop budget per search and tick)
-ASYNC_LEGS = {"C4_async": ("C4", 300, 60, 128), "M1_async": ("M1", 300, 60, 64), "D1_async": ("D1", 300, 60, 64)}
+ASYNC_LEGS = {"C4_async": ("C4", 300, 60, 64), "M1_async": ("M1", 300, 60, 64), "D1_async": ("D1", 300, 60, 64)}
 GPU_CLOCK_HZ = 2.4e9     # MI355X engine clock (MI355X_MICROARCH.md), for the cycles-per-pop figures
 DOMINANT = {"B1": "k_big", "K1": "k_search_big", "C2": "k_step", "C3": "k_step", "C3d": "k_step", "C4": "k_sokoban", "C5": "k_stats_wide", "C5b": "k_stats_wide", "M1": "k_mdungeon",
             "D1": "k_ddave", "S1": "k_smb", "C2w": "k_step (writes the image)", "C3w": "k_step (writes the image)"}

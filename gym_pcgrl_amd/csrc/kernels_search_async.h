@@ -25,7 +25,8 @@ struct AsyncSlotHdr {
     int32_t state;                           // 0 free, 1 suspended (runnable), 2 taken (being run or written)
     int32_t env, mode, agent;                // the job: environment, MODE_*, index of the agent that goes on
     int32_t stamp;                           // the tick that suspended it last (a slot is not continued in the launch that wrote it)
-    int32_t pad[3];
+    int32_t tsmall;                          // != 0: the saved visited table is the small launch's (that many slots): re-hashed into the full one
+    int32_t pad[2];
     SokResume rs;                            // iterations == 0: agent `agent` starts from the root
 };
 static_assert(sizeof(AsyncSlotHdr) <= ASYNC_SLOT_HDR, "slot header");
@@ -46,7 +47,16 @@ struct AsyncCtl {
     size_t slot_bytes;
     int32_t nslots, nodes_cap, tick, pad;
     int32_t* runlist;                        // [nslots] the runnable slots of this tick (written by k_update / k_async_collect; count in tickets[2])
+    // the tick's two launches: the FRESH jobs of the step's lists run in blocks with a small heap and table (a piece is at most
+    // ASYNC_SMALL_POPS pops: a few KB of LDS, several blocks per compute unit), the suspended ones in blocks with the full ones
+    uint8_t* small_pool;                     // [ASYNC_SMALL_BLOCKS][ASYNC_SMALL_NODES * 16] node pools of the small launch's blocks
+    int32_t* overflow;                       // [num_envs] jobs the small launch hands to the full one (count in tickets[3]): env | mode << 28 | reason << 30
 };
+#define ASYNC_SMALL_POPS 128
+#define ASYNC_SMALL_NODES (4 * ASYNC_SMALL_POPS + 8)
+#define ASYNC_SMALL_HEAP (4 * ASYNC_SMALL_POPS + 8)          /* words; the table follows */
+#define ASYNC_SMALL_TABLE 512                                /* slots (64-bit keys) */
+#define ASYNC_SMALL_BLOCKS 1024
 __device__ __forceinline__ AsyncSlotHdr* async_hdr(const AsyncCtl& A, int s) { return reinterpret_cast<AsyncSlotHdr*>(A.slots + (size_t)s * A.slot_bytes); }
 __device__ __forceinline__ uint8_t* async_pool(const AsyncCtl& A, int s) { return A.slots + (size_t)s * A.slot_bytes + ASYNC_SLOT_HDR; }
 __device__ __forceinline__ uint32_t* async_heap(const AsyncCtl& A, int s) { return reinterpret_cast<uint32_t*>(async_pool(A, s) + (size_t)A.nodes_cap * 16); }
@@ -75,11 +85,11 @@ struct AsyncGame<PCGRL_PROB_SOKOBAN> {
             S.fast = (S.L.nc <= B.sok_fast_maxc) ? 1 : 0;
         }
     }
-    static __device__ __forceinline__ bool agent(Shared& S, int a, void* pool, uint32_t* lds, int tsize, SokDuoBox* duo, int power, const SokResumeArg& ra,
+    static __device__ __forceinline__ bool agent(Shared& S, int a, void* pool, uint32_t* lds, int toff, int tsize, SokDuoBox* duo, int power, const SokResumeArg& ra,
                                                  int lane, int* res, bool& exhausted) {
         const int KS[4] = {-1, 2, 1, 0};                                            // BFS, A*(1), A*(0.5), A*(0): sokoban_prob.py:104-122
         const SokKidsLanes kids = {lane, sokf_dir(lane & 3, S.L.w)};
-        uint64_t* tab = reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP);
+        uint64_t* tab = reinterpret_cast<uint64_t*>(lds + toff);
         int hh = 0, dd = 0, it = 0;
         bool w;
         if (S.L.cells <= 64) w = sok_search_fast<1>(S.L, reinterpret_cast<SokFastNode*>(pool), lds, tab, tsize - 1, S.cache, S.root, KS[a], power, hh, dd, it, exhausted, SokNoHook(), kids, duo, ra);
@@ -97,12 +107,12 @@ struct AsyncGame<PCGRL_PROB_MDUNGEON> {
         const int n = md_build_level_wave(m, P.width, P.height, S.L, S.root, S.F, lane);
         if (lane == 0) S.fast = (n <= MDF_MAXI && B.sok_fast_maxc >= 0) ? 1 : 0;
     }
-    static __device__ __forceinline__ bool agent(Shared& S, int a, void* pool, uint32_t* lds, int tsize, SokDuoBox* duo, int power, const SokResumeArg& ra,
+    static __device__ __forceinline__ bool agent(Shared& S, int a, void* pool, uint32_t* lds, int toff, int tsize, SokDuoBox* duo, int power, const SokResumeArg& ra,
                                                  int lane, int* res, bool& exhausted) {
         const int KS[4] = {2, 1, 0, -1};                                            // mdungeon_prob.py:110-126
         const MdKidsLanes kids = {lane};
         uint64_t key = 0; int hh = 0, dd = 0, it = 0;
-        const bool w = md_search_fast(S.L, S.F, reinterpret_cast<MdFastNode*>(pool), lds, reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP), tsize - 1, S.cache,
+        const bool w = md_search_fast(S.L, S.F, reinterpret_cast<MdFastNode*>(pool), lds, reinterpret_cast<uint64_t*>(lds + toff), tsize - 1, S.cache,
                                       S.root, KS[a], power, key, hh, dd, it, exhausted, SokNoHook(), kids, duo, ra);
         mdf_result(S.F, key, hh, dd, w, res);
         return w;
@@ -117,12 +127,12 @@ struct AsyncGame<PCGRL_PROB_DDAVE> {
         const int n = dd_build_level_wave(m, P.width, P.height, S.L, S.root, S.F, lane);
         if (lane == 0) S.fast = (n <= DDF_MAXD && B.sok_fast_maxc >= 0) ? 1 : 0;
     }
-    static __device__ __forceinline__ bool agent(Shared& S, int a, void* pool, uint32_t* lds, int tsize, SokDuoBox* duo, int power, const SokResumeArg& ra,
+    static __device__ __forceinline__ bool agent(Shared& S, int a, void* pool, uint32_t* lds, int toff, int tsize, SokDuoBox* duo, int power, const SokResumeArg& ra,
                                                  int lane, int* res, bool& exhausted) {
         const int KS[4] = {2, 1, 0, -1};
         const DdKidsLanes kids = {lane};
         uint64_t key = 0; int hh = 0, dd = 0, jj = 0, it = 0;
-        const bool w = dd_search_fast(S.L, S.F, reinterpret_cast<DdFastNode*>(pool), lds, reinterpret_cast<uint64_t*>(lds + SOK_LDS_HEAP), tsize - 1, S.cache,
+        const bool w = dd_search_fast(S.L, S.F, reinterpret_cast<DdFastNode*>(pool), lds, reinterpret_cast<uint64_t*>(lds + toff), tsize - 1, S.cache,
                                       S.root, KS[a], power, key, hh, dd, jj, it, exhausted, SokNoHook(), kids, duo, ra);
         ddf_result(S.F, key, hh, dd, jj, w, res);
         return w;
@@ -141,13 +151,17 @@ struct AsyncGame<PCGRL_PROB_DDAVE> {
 #define AP(i) do {} while (0)
 #define AP_COUNT(i) do {} while (0)
 #endif
-// Jobs: the suspended slots (resume != 0), then list_a (mode_a) and list_b (mode_b; < 0: none).  `tickets`: [0], [1] two counters the
-// host zeroed, [2] the number of runnable slots in A.runlist.  budget: pops per job and launch.  An environment whose episode a finished job ends goes to rst_list (pcgrl_async_flush:
+// Jobs: the suspended slots (resume != 0), the jobs the small launch handed over (resume != 0), then list_a (mode_a) and list_b (mode_b;
+// < 0: none).  `tickets`: [0], [1], [4] counters the host zeroed, [2] the number of runnable slots in A.runlist (k_update), [3] the number
+// of handed-over jobs in A.overflow.  budget: pops per job and launch.  toff / tsize: where the visited table starts in the block's
+// LDS (words) and its slots -- the full search region of k_sokoban, or (small != 0) the small one of the launch that takes the fresh
+// jobs: what does not fit there (a level for the generic search, a suspension that finds no free slot) goes to A.overflow and is run
+// to its end by the full launch behind it.  An environment whose episode a finished job ends goes to rst_list (pcgrl_async_flush:
 // reset and searched again behind this launch) or, rst_list < 0 (a tick), is marked ASYNC_PEND_RESET: the next tick's k_update
 // puts it on its reset list instead of giving it an action -- one launch sequence per tick, not two.
 template <int PROB>
 __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, AsyncCtl A, int list_a, int mode_a, int list_b, int mode_b, int parity,
-                                                     int rst_list, int32_t* tickets, int clear_parity, int budget, int resume) {
+                                                     int rst_list, int32_t* tickets, int clear_parity, int budget, int resume, int toff, int tsize, int small) {
     typedef AsyncGame<PROB> Game;
     extern __shared__ __attribute__((aligned(16))) uint32_t as_lds[];       // heap | visited table, as in k_sokoban
     __shared__ int s_pref_a[WL_NSHARD + 1], s_pref_b[WL_NSHARD + 1];
@@ -162,19 +176,27 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
     const int n_b = list_b >= 0 ? wl_load_prefix(B, parity, list_b, s_pref_b) : 0;
     const int n = n_a + n_b;
     if (threadIdx.x >= 64) { sok_duo_server<true>(as_lds, &s_box, lane); return; }
-    const int tsize = SOK_LDS_TABLE;
-    uint8_t* const block_pool = reinterpret_cast<uint8_t*>(B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride);
+    if (small && budget > ASYNC_SMALL_POPS) budget = ASYNC_SMALL_POPS;
+    uint8_t* const block_pool = small ? A.small_pool + (size_t)blockIdx.x * ASYNC_SMALL_NODES * 16
+                                      : reinterpret_cast<uint8_t*>(B.sok_pool + (size_t)blockIdx.x * B.sok_pool_stride);
     AP_DECL;
     AP(0);
     for (;;) {
-        // ---- a ticket: a suspended slot, else a fresh job, else leave
-        int slot = -1, e = 0, mode = 0, a0 = 0, kind = 0;
+        // ---- a ticket: a suspended slot, a handed-over job, a fresh job -- or leave
+        int slot = -1, e = 0, mode = 0, a0 = 0, kind = 0, unbounded = 0;
         // suspended slots: the update kernel listed the runnable ones (async_list_runnable, worklist.h); a ticket is an entry of that list
         if (lane == 0 && resume) {
             const int nrun = sok_ld(tickets + 2);
             if (sok_ld(tickets + 1) < nrun) {
                 const int t = atomicAdd(tickets + 1, 1);
                 if (t < nrun) { slot = A.runlist[t]; kind = 1; async_hdr(A, slot)->state = 2; }
+            }
+            if (kind == 0) {
+                const int novf = sok_ld(tickets + 3);
+                if (sok_ld(tickets + 4) < novf) {
+                    const int t = atomicAdd(tickets + 4, 1);
+                    if (t < novf) { kind = 3; e = __hip_atomic_load(A.overflow + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                }
             }
         }
         slot = __shfl(slot, 0, 64);
@@ -185,27 +207,39 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
         kind = __shfl(kind, 0, 64);
         AP(1);
         if (kind == 0) break;
-        AP_COUNT(8 + kind);
+        AP_COUNT(8 + (kind == 3 ? 2 : kind));
         e = __shfl(e, 0, 64);
+        int tsm = 0;
         if (kind == 2) {
             const int t = e;
             if (t < n_a) { e = wl_get(B, list_a, s_pref_a, t); mode = mode_a; }
             else { e = wl_get(B, list_b, s_pref_b, t - n_a); mode = mode_b; }
             if (lane == 0) { s_rs = SokResume{}; }
+        } else if (kind == 3) {                 // from the small launch: from the root, to the end (the budget was spent there)
+            mode = (e >> 28) & 3;
+            if (lane == 0) { s_rs = SokResume{}; if (e & (1 << 30)) atomicAdd(A.stats + ASYNC_ST_OVERFLOW, 1ull); }
+            e &= 0x0FFFFFFF;
+            unbounded = 1;
         } else {
             const AsyncSlotHdr* hd = async_hdr(A, slot);
-            e = hd->env; mode = hd->mode; a0 = hd->agent;
+            e = hd->env; mode = hd->mode; a0 = hd->agent; tsm = hd->tsmall;
             if (lane == 0) s_rs = hd->rs;
         }
         Game::build(P, B, B.map + (size_t)e * P.width * P.height, s_game, s_scratch, lane);
         __threadfence_block();
         AP(2);
         if (!s_game.fast) {
-            // a level the compact searches do not take (more than SOKF_MAXC crates ...): the generic search, in one piece (rare)
+            // a level the compact searches do not take (more than SOKF_MAXC crates ...): the generic search, in one piece (rare) -- in
+            // the full search region
+            if (small) {
+                if (lane == 0) { A.overflow[atomicAdd(tickets + 3, 1)] = e | (mode << 28); A.pending[e] = ASYNC_PEND_SEARCH; }
+                __threadfence_block();
+                continue;
+            }
             int32_t s[PCGRL_MAX_STATS];
             const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
             if (lane == 0) for (int k = 0; k < 8; k++) s[k] = park[k];
-            SolverGame<PROB>::run(P, B, e, s_game, as_lds, SOK_LDS_HEAP, tsize, P.solver_power, reinterpret_cast<SokNode*>(block_pool), lane, s);
+            SolverGame<PROB>::run(P, B, e, s_game, as_lds, toff, tsize, P.solver_power, reinterpret_cast<SokNode*>(block_pool), lane, s);
             if (lane == 0) {
                 const bool ended = finalize_item<PROB>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), rst_list >= 0, rst_list);
                 A.pending[e] = (ended && rst_list < 0) ? ASYNC_PEND_RESET : 0;
@@ -216,16 +250,33 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
         }
         // ---- the agents one after the other, at most `budget` pops in this launch
         void* pool = slot >= 0 ? (void*)async_pool(A, slot) : (void*)block_pool;
-        int a = a0, remaining = budget, done = 0;
+        int a = a0, remaining = unbounded ? 0x3FFFFFFF : budget, done = 0, handed = 0;
         int how = (slot >= 0 && s_rs.iterations > 0) ? 1 : 0;          // 0: the agent starts (clear the table), 1: restore from the slot, 2: go on in place
         int res[5] = {0, 0, 0, 0, 0};
         for (;;) {
             for (;;) {
                 if (how == 1) {
                     async_copy(as_lds, async_heap(A, slot), s_rs.heapn, lane);
-                    async_copy(as_lds + SOK_LDS_HEAP, async_table(A, slot), 2 * tsize, lane);
+                    if (tsm == 0) {
+                        async_copy(as_lds + toff, async_table(A, slot), 2 * tsize, lane);
+                    } else {
+                        // suspended by the small launch: its few keys go into the (cleared) full table -- which slot a key sits in
+                        // depends on the order of insertion, what the table answers does not
+                        uint4* t4 = reinterpret_cast<uint4*>(as_lds + toff);
+                        for (int i = lane; i < tsize / 2; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
+                        __threadfence_block();
+                        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(async_table(A, slot));
+                        unsigned long long* tab = reinterpret_cast<unsigned long long*>(as_lds + toff);
+                        for (int i = lane; i < tsm; i += 64) {
+                            const unsigned long long key = src[i];
+                            if (key == 0ull) continue;
+                            uint32_t sl = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)(tsize - 1);
+                            while (atomicCAS(tab + sl, 0ull, key) != 0ull) sl = (sl + 1) & (uint32_t)(tsize - 1);
+                        }
+                        tsm = 0;
+                    }
                 } else if (how == 0) {
-                    uint4* t4 = reinterpret_cast<uint4*>(as_lds + SOK_LDS_HEAP);
+                    uint4* t4 = reinterpret_cast<uint4*>(as_lds + toff);
                     for (int i = lane; i < tsize / 2; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
                 }
                 __threadfence_block();
@@ -235,7 +286,7 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
                 if (lane < 4) {
                     bool ex = false;
                     const SokResumeArg ra = {&s_rs, before + remaining};
-                    win = Game::agent(s_game, a, pool, as_lds, tsize, &s_box, P.solver_power, ra, lane, res, ex) ? 1 : 0;
+                    win = Game::agent(s_game, a, pool, as_lds, toff, tsize, &s_box, P.solver_power, ra, lane, res, ex) ? 1 : 0;
                     exh = ex ? 1 : 0;
                 }
                 __threadfence_block();
@@ -268,7 +319,14 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
                 }
                 __threadfence_block();
                 slot = s_slot;
-                if (slot < 0) {                                          // every slot is taken: finish here (the tick is that much longer)
+                if (slot < 0) {
+                    // every slot is taken: the search runs to its end inside this tick (the tick is that much longer) -- here, or, from
+                    // the small launch, once more from the root in the full one (ASYNC_ST_OVERFLOW is counted there)
+                    if (small) {
+                        if (lane == 0) { A.overflow[atomicAdd(tickets + 3, 1)] = e | (mode << 28) | (1 << 30); A.pending[e] = ASYNC_PEND_SEARCH; }
+                        handed = 1;
+                        break;
+                    }
                     if (lane == 0) atomicAdd(A.stats + ASYNC_ST_OVERFLOW, 1ull);
                     remaining = 0x3FFFFFFF;
                     how = s_rs.iterations > 0 ? 2 : 0;
@@ -278,7 +336,9 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
             }
             break;
         }
-        if (done) {
+        if (handed) {
+            __threadfence_block();
+        } else if (done) {
             if (lane == 0) {
                 int32_t s[PCGRL_MAX_STATS];
                 const int32_t* park = (mode == MODE_STEP) ? B.info + (size_t)e * 10 : B.stats + (size_t)e * 8;
@@ -292,12 +352,13 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
         } else {
             if (s_rs.iterations > 0) {
                 async_copy(async_heap(A, slot), as_lds, s_rs.heapn, lane);
-                async_copy(async_table(A, slot), as_lds + SOK_LDS_HEAP, 2 * tsize, lane);
+                async_copy(async_table(A, slot), as_lds + toff, 2 * tsize, lane);
             }
             __threadfence();
             if (lane == 0) {
                 AsyncSlotHdr* hd = async_hdr(A, slot);
                 hd->env = e; hd->mode = mode; hd->agent = a; hd->stamp = A.tick; hd->rs = s_rs;
+                hd->tsmall = (small && s_rs.iterations > 0) ? tsize : 0;
                 A.pending[e] = ASYNC_PEND_SEARCH;
                 __threadfence();
                 __hip_atomic_store(&hd->state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -112,7 +112,7 @@ struct pcgrl_env {
     int obs_hold;     // inside pcgrl_rollout's loop of steps: the bound observation is written once, at the end
     // pcgrl_step_async (kernels_search_async.h): the caller's arena, whether any step may be pending, the tick counter
     AsyncCtl async;
-    int async_on, async_dirty;
+    int async_on, async_dirty, async_split;
     std::vector<hipEvent_t> events;
     size_t ev_used;
     int prof_steps;
@@ -407,6 +407,10 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     if (h->wide_grid < 1) h->wide_grid = 2048;
     h->fused_zelda = tun_or(T.fused_zelda, 1) ? 1 : 0;  // 0: zelda steps as k_update + k_stats
     h->no_fused = tun_or(T.no_fused, 0) ? 1 : 0;
+    // pcgrl_step_async: the fresh jobs of a tick in a launch of their own with small search regions.  Pays where a tick has many of them
+    // (C4: 1 300 fresh jobs of ~30 pops a tick, 240 -> 275 M env-steps/s); MiniDungeons / Dave have under a hundred and the extra
+    // launch -- whose length is one job's chain of pops, like the other's -- costs more than it saves (M1 277 -> 207 M)
+    h->async_split = tun_or(T.async_split, h->cfg.prob == PCGRL_SOKOBAN ? 1 : 0) ? 1 : 0;
     {   // k_step: environments per block (see launch_step_pm).  The largest block that still gives (about) every compute unit one and
         // is resident in one round: 256 environments -> one block per CU (LDS), 128 -> two, 64 -> four.
         const int n_ = h->cfg.num_envs;
@@ -596,7 +600,7 @@ PCGRL_LOCAL int launch_step_zelda(pcgrl_env* h, const int32_t* actions, int pari
 PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st);
 PCGRL_LOCAL int launch_smb(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st, int inline_reset);
 PCGRL_LOCAL int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb);
-PCGRL_LOCAL int launch_search_async(pcgrl_env* h, int32_t* tickets, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, int budget, int resume, hipStream_t st);
+PCGRL_LOCAL int launch_search_async(pcgrl_env* h, int32_t* tickets, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, int budget, int resume, int small, hipStream_t st);
 static int grid_for(int items, int per_block, int cap) {
     int g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -817,15 +821,18 @@ PCGRL_LOCAL int search_device_setup(pcgrl_env* h) {   // the search kernels use 
     HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PCGRL_OK;
 }
-// one launch of a tick of pcgrl_step_async (kernels_search_async.h): `tickets` = two zeroed words
-PCGRL_LOCAL int launch_search_async(pcgrl_env* h, int32_t* tickets, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, int budget, int resume, hipStream_t st) {
-    const size_t lds = (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4;
+// one launch of a tick of pcgrl_step_async (kernels_search_async.h).  small: the launch for the fresh jobs -- a few KB of LDS per
+// block, ASYNC_SMALL_BLOCKS blocks (several per compute unit) --, else the full search region and one block per compute unit
+PCGRL_LOCAL int launch_search_async(pcgrl_env* h, int32_t* tickets, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, int budget, int resume, int small, hipStream_t st) {
+    const int toff = small ? ASYNC_SMALL_HEAP : SOK_LDS_HEAP, tsize = small ? ASYNC_SMALL_TABLE : SOK_LDS_TABLE;
+    const size_t lds = (size_t)(toff + 2 * tsize) * 4;
+    const int grid = small ? ASYNC_SMALL_BLOCKS : SOK_BLOCKS;
     if (h->P.prob == PCGRL_PROB_DDAVE)
-        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_DDAVE>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume);
+        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_DDAVE>, dim3(grid), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume, toff, tsize, small);
     else if (h->P.prob == PCGRL_PROB_MDUNGEON)
-        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_MDUNGEON>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume);
+        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_MDUNGEON>, dim3(grid), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume, toff, tsize, small);
     else
-        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_SOKOBAN>, dim3(SOK_BLOCKS), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume);
+        hipLaunchKernelGGL(k_search_async<PCGRL_PROB_SOKOBAN>, dim3(grid), dim3(128), lds, st, h->P, h->B, h->async, list_a, mode_a, list_b, mode_b, parity, rst_list, tickets, clr, budget, resume, toff, tsize, small);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;
 }
@@ -1083,7 +1090,10 @@ static bool async_applies(const pcgrl_config* c) {
 }
 // head of the arena: pending [N] | counters + the shards of the first one | the tick's list of runnable slots
 static size_t async_stats_bytes() { return 64 + ASYNC_NSHARD * 64; }
-static size_t async_head_bytes(const pcgrl_config* c, int nslots) { return align_up((size_t)c->num_envs, 256) + async_stats_bytes() + align_up((size_t)nslots * 4, 256); }
+static size_t async_small_pool_bytes() { return align_up((size_t)ASYNC_SMALL_BLOCKS * ASYNC_SMALL_NODES * 16, 256); }
+static size_t async_head_bytes(const pcgrl_config* c, int nslots) {       // ... | node pools of the small launch | its hand-over list
+    return align_up((size_t)c->num_envs, 256) + async_stats_bytes() + align_up((size_t)nslots * 4, 256) + async_small_pool_bytes() + align_up((size_t)c->num_envs * 4, 256);
+}
 static size_t async_slot_bytes(const pcgrl_config* c) {
     return align_up((size_t)ASYNC_SLOT_HDR + (size_t)(4 * c->solver_power + 4) * 16 + (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4, 256);
 }
@@ -1102,6 +1112,8 @@ int pcgrl_bind_async(pcgrl_env* h, void* arena, size_t bytes, int32_t nslots, vo
     A.pending = a;
     A.stats = (unsigned long long*)(a + align_up((size_t)h->cfg.num_envs, 256));
     A.runlist = (int32_t*)(a + align_up((size_t)h->cfg.num_envs, 256) + async_stats_bytes());
+    A.small_pool = (uint8_t*)A.runlist + align_up((size_t)nslots * 4, 256);
+    A.overflow = (int32_t*)(A.small_pool + async_small_pool_bytes());
     A.slots = a + async_head_bytes(&h->cfg, nslots);
     A.slot_bytes = async_slot_bytes(&h->cfg);
     A.nslots = nslots; A.nodes_cap = 4 * h->cfg.solver_power + 4; A.tick = 0; A.pad = 0;
@@ -1126,12 +1138,17 @@ static void async_devbufs(pcgrl_env* h, bool on) {
     B.async_slots = on ? A.slots : nullptr; B.async_slot_bytes = A.slot_bytes; B.async_nslots = on ? A.nslots : 0;
     B.async_run = on ? A.runlist : nullptr; B.async_run_n = on ? h->B.sok_sync + 2 : nullptr;
 }
-// the searches of a tick: the suspended ones and the jobs of the step's lists, one launch (an episode a search ends is reset by the next tick)
+// the searches of a tick: the fresh jobs of the step's lists in the small launch, then the suspended ones (and what the small launch
+// could not take) in the full one (an episode a search ends is reset by the next tick).  async_split = 0: one full launch for all.
 static int async_tick_searches(pcgrl_env* h, int budget, hipStream_t st) {
     const int par = h->parity;
     const bool ar = h->P.auto_reset != 0;
+    int rc;
     h->async.tick = (h->async.tick + 1) & 0x3FFFFFFF;
-    return launch_search_async(h, h->B.sok_sync, WL_SOL, MODE_STEP, ar ? (int)WL_SOL2 : -1, MODE_START, par, -1, par ^ 1, budget, 1, st);
+    if (!h->async_split)
+        return launch_search_async(h, h->B.sok_sync, WL_SOL, MODE_STEP, ar ? (int)WL_SOL2 : -1, MODE_START, par, -1, par ^ 1, budget, 1, 0, st);
+    if ((rc = launch_search_async(h, h->B.sok_sync, WL_SOL, MODE_STEP, ar ? (int)WL_SOL2 : -1, MODE_START, par, -1, -1, budget, 0, 1, st))) return rc;
+    return launch_search_async(h, h->B.sok_sync, -1, MODE_STEP, -1, MODE_START, par, -1, par ^ 1, budget, 1, 0, st);
 }
 // everything that is pending, to its end: the suspended searches, then the resets and searches of the episodes they ended
 static int async_finish_all(pcgrl_env* h, hipStream_t st) {
@@ -1140,7 +1157,7 @@ static int async_finish_all(pcgrl_env* h, hipStream_t st) {
     int rc;
     h->async.tick = (h->async.tick + 1) & 0x3FFFFFFF;
     int32_t* sync0 = h->B.sok_sync, *sync1 = h->B.sok_sync + (SOK_SY_WORDS + SOK_HARD_CAP);
-    HIPCHK(hipMemsetAsync(sync0, 0, 3 * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(sync0, 0, 8 * sizeof(int32_t), st));
     async_devbufs(h, true);
     {
         const int nn = n > h->async.nslots ? n : h->async.nslots;
@@ -1148,11 +1165,11 @@ static int async_finish_all(pcgrl_env* h, hipStream_t st) {
     }
     async_devbufs(h, false);
     HIPCHK(hipGetLastError());
-    if ((rc = launch_search_async(h, sync0, -1, MODE_STEP, -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), budget, 1, st))) return rc;
+    if ((rc = launch_search_async(h, sync0, -1, MODE_STEP, -1, MODE_START, par, WL_RST2, ar ? -1 : (par ^ 1), budget, 1, 0, st))) return rc;
     if (ar) {
         if ((rc = launch_reset(h, WL_RST2, WL_SOL3, par, -1, st))) return rc;
-        HIPCHK(hipMemsetAsync(sync1, 0, 2 * sizeof(int32_t), st));
-        if ((rc = launch_search_async(h, sync1, WL_SOL3, MODE_START, -1, 0, par, WL_RST2, par ^ 1, budget, 0, st))) return rc;
+        HIPCHK(hipMemsetAsync(sync1, 0, 8 * sizeof(int32_t), st));
+        if ((rc = launch_search_async(h, sync1, WL_SOL3, MODE_START, -1, 0, par, WL_RST2, par ^ 1, budget, 0, 0, st))) return rc;
     }
     return PCGRL_OK;
 }
@@ -1176,7 +1193,7 @@ int pcgrl_step_async(pcgrl_env* h, const int32_t* actions, int32_t pop_budget, v
     const int par = h->parity;
     const bool ar = h->P.auto_reset != 0;
     int rc;
-    HIPCHK(hipMemsetAsync(h->B.sok_sync, 0, 3 * sizeof(int32_t), st));       // the search launch's tickets and the count of runnable slots
+    HIPCHK(hipMemsetAsync(h->B.sok_sync, 0, 8 * sizeof(int32_t), st));       // the search launches' tickets, the counts of runnable slots and of handed-over jobs
     async_devbufs(h, true);
     rc = launch_update(h, actions, par, st);        // (also lists the runnable slots)
     async_devbufs(h, false);

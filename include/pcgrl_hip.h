@@ -140,6 +140,8 @@ typedef struct pcgrl_tuning {
     int32_t touch_tight;     /* where a full computation also sweeps the second largest component, for a tight bound on "the others": bit 0 the
                                 recomputations of a step, bit 1 the resets (default 1) */
     int32_t step_pair;       /* k_step, zelda: from this many certain resets in a block's step on, a wavefront takes two of them (default 6; 0: never) */
+    int32_t async_split;     /* pcgrl_step_async: 1 = the fresh jobs of a tick in a launch of their own with small search regions, several blocks per
+                                compute unit (the default for sokoban); 0 = one search launch per tick, the full region for every job */
 } pcgrl_tuning;
 
 int pcgrl_abi_version(void);

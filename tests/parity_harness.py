@@ -265,7 +265,7 @@ def fullsize_case(name, use_rollout, max_steps=None):
     return len(idx)
 
 
-def async_case(prob, rep, calls, E, ticks, seed0, rs, pop_budget, nslots, sample=None, flush_every=0):
+def async_case(prob, rep, calls, E, ticks, seed0, rs, pop_budget, nslots, sample=None, flush_every=0, tuning=None):
     """Asynchronous stepping (BatchedPcgrlEnv.tick, pcgrl_step_async) against the oracle: `ticks` ticks of random actions; per
     environment the actions it *took* (the ticks it was not pending at) and the outputs of every step it completed are recorded,
     and afterwards the oracle is stepped through exactly the taken actions -- reward, done, info, cursor, heat map and map of
@@ -274,7 +274,7 @@ def async_case(prob, rep, calls, E, ticks, seed0, rs, pop_budget, nslots, sample
     (the two kinds of stepping on one handle).  Returns a dict of counters; raises AssertionError on a mismatch."""
     import torch
     from gym_pcgrl_amd.envs import BatchedPcgrlEnv
-    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=E, seed=seed0)
+    env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=E, seed=seed0, tuning=tuning)
     try:
         for kw in calls:
             env.adjust_param(**kw)

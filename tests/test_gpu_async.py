@@ -43,7 +43,7 @@ def test_async_slot_overflow_and_lockstep_mix():
 def test_async_budget_invariance():
     """The same actions, taken by every environment in the same order, whatever the budget: a huge budget is lockstep."""
     rs = np.random.RandomState(5)
-    cnt = ph.async_case("sokoban", "narrow", [], 256, 60, 99, rs, 10 ** 6, 16)
+    cnt = ph.async_case("sokoban", "narrow", [], 256, 60, 99, rs, 10 ** 6, 16, tuning={"async_split": 0})
     assert cnt["suspended"] == 0 and cnt["overflow"] == 0, cnt
     # (the only environments that ever sit a tick out are those whose search ended their episode: they are reset by the next tick)
     assert cnt["steps"] + cnt["pending_env_ticks"] == 256 * 60, cnt
@@ -58,3 +58,21 @@ def test_async_no_form_falls_back_to_step():
     o, r, d, i, pend = env.tick(torch.zeros(64, dtype=torch.int32, device="cuda"))
     assert not pend.any()
     env.close()
+
+
+@pytest.mark.parametrize("prob,budget,split", [("sokoban", 20, 0), ("mdungeon", 6, 1), ("ddave", 6, 1)])
+def test_async_other_launch_form(prob, budget, split):
+    """pcgrl_tuning async_split: every job of a tick -- fresh and suspended -- in ONE launch with the full search region (0: the default
+    of mdungeon / ddave), or the fresh jobs in a launch of their own with small regions, what it suspends re-hashed into the full
+    table by the launch that continues it (1: sokoban's default).  Here: the form that is NOT the problem's default."""
+    rs = np.random.RandomState(21)
+    cnt = ph.async_case(prob, "narrow", [], 256, 80, 909, rs, budget, 128, tuning={"async_split": split})
+    assert cnt["suspended"] > 3, cnt
+
+
+def test_async_small_launch_budget_beyond_its_region():
+    """A pop budget beyond what the small launch's regions hold (ASYNC_SMALL_POPS = 128): fresh jobs are cut at 128 there and go on
+    with the full budget from the next tick."""
+    rs = np.random.RandomState(22)
+    cnt = ph.async_case("sokoban", "narrow", [dict(width=6, height=6), FEW_SOK], 256, 60, 313, rs, 700, 256)
+    assert cnt["suspended"] > 10, cnt
