@@ -173,9 +173,15 @@ __device__ __forceinline__ int big_bfs_levels(const uint64_t* comp, int i0, int 
 
 // helper.py:197-207 calc_num_regions + :250-264 calc_longest_path over `pass`.  rest, comp, X, Y, Z: scratch masks (comp must be
 // all zero on entry and is on return; Y, Z only for want_path).  want_path = false: regions only (zelda and the search problems).
+// champ (may be null; NW words): receives the rows of a champion component -- one whose double sweep gave the returned path -- or
+// stays all zero when the path comes from the closed-form tiny components (has_champ says which): big_incremental builds on it.
 __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t* rest, uint64_t* comp, uint64_t* X, uint64_t* Y, uint64_t* Z,
-                                                 const BigGeom& G, int lane, bool want_path, int& regions, int& path) {
+                                                 const BigGeom& G, int lane, bool want_path, int& regions, int& path, uint64_t* champ = nullptr,
+                                                 int* has_champ = nullptr) {
     regions = 0; path = 0;
+    int c_lo = 0, c_hi = 0;                                    // words of the current champion in `champ`
+    if (champ) big_zero(champ, 0, G.NW, lane);
+    if (has_champ) *has_champ = 0;
     // Components of one, two and three cells in closed form, from bit-sliced neighbour counts (pcg_tiny_components in pcgrl_algos.h:
     // most components of a random map): an isolated cell; two cells of degree 1 next to each other; a cell of degree 2 whose two
     // neighbours both have degree 1.  deg1 goes to `comp`, deg2 -- then the cells of the 2- and 3-cell components found from
@@ -242,13 +248,107 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
                     int b1 = 0;
                     const int i1 = big_first(Y, nullptr, fa * G.KW, (fb + 1) * G.KW, lane, b1);       // np.argmax: first cell of the last frontier
                     const int e2 = big_bfs_levels(comp, i1, b1, G, r0, r1, X, Y, Z, lane, fa, fb);
-                    path = e2 > path ? e2 : path;
+                    if (e2 > path) {
+                        path = e2;
+                        if (champ) {
+                            for (int i = c_lo + lane; i < c_hi; i += 64) champ[i] = 0ull;
+                            big_sync();
+                            for (int i = lo + lane; i < hi; i += 64) champ[i] = comp[i];
+                            c_lo = lo; c_hi = hi;
+                            if (has_champ) *has_champ = 1;
+                        }
+                    }
                 }
             }
         }
         for (int i = lo + lane; i < hi; i += 64) { rest[i] &= ~comp[i]; comp[i] = 0ull; }
         big_sync();
     }
+}
+
+// helper.py:250-264 for ONE component `comp` (rows [r0, r1]): BFS from its first cell in row-major order, np.argmax = the first cell
+// of the last frontier, BFS from there.  Returns the second eccentricity, or 0 when the first one already says that the result
+// cannot exceed `path` (e2 <= 2 e1).  X, Y, Z: scratch masks.
+__device__ __forceinline__ int big_double_sweep(const uint64_t* comp, const BigGeom& G, int r0, int r1, uint64_t* X, uint64_t* Y, uint64_t* Z, int lane, int path) {
+    int b0 = 0, fa, fb;
+    const int i0 = big_first(comp, nullptr, r0 * G.KW, (r1 + 1) * G.KW, lane, b0);
+    const int e1 = big_bfs_levels(comp, i0, b0, G, r0, r1, X, Y, Z, lane, fa, fb);
+    if (2 * e1 <= path) return 0;
+    int b1 = 0;
+    const int i1 = big_first(Y, nullptr, fa * G.KW, (fb + 1) * G.KW, lane, b1);
+    return big_bfs_levels(comp, i1, b1, G, r0, r1, X, Y, Z, lane, fa, fb);
+}
+__device__ __forceinline__ bool big_bit_at(const uint64_t* a, const BigGeom& G, int x, int y) { return (a[y * G.KW + (x >> 6)] >> (x & 63)) & 1ull; }
+
+// regions and longest path after ONE cell (cx, cy) changed, from the previous answer (binary_incremental in pcgrl_algos.h, restated on
+// word arrays).  Preconditions (k_update routes everything else to the full computation): the previous map had a champion -- a
+// component whose double sweep gave path_old, rows in `champ` -- and the cell is neither in it nor 4-adjacent to it.  The champion is
+// then still a component, nothing that does not touch the cell can beat it, and only the components around the cell are looked at:
+// the cell became passable (`added`): the k components around it and the cell are one now -- regions + 1 - k, swept if its size
+// allows; it became impassable: its component fell into k pieces -- regions + k - 1, each swept if its size allows.
+// pass: the NEW passable set (temporarily modified, restored).  comp, U: scratch masks, all zero on entry and on return.  champ is
+// replaced when a sweep beats the old path.  Returns whether champ changed.
+__device__ __forceinline__ bool big_incremental(uint64_t* pass, uint64_t* comp, uint64_t* U, uint64_t* X, uint64_t* Y, uint64_t* Z, uint64_t* champ,
+                                                const BigGeom& G, int lane, int cx, int cy, bool added, int regions_old, int path_old, int& regions, int& path) {
+    const int ci = cy * G.KW + (cx >> 6);
+    const uint64_t cbit = 1ull << (cx & 63);
+    if (added && lane == 0) pass[ci] &= ~cbit;                  // base = the new map with the cell impassable
+    big_sync();
+    path = path_old;
+    int k = 0, u0 = cy, u1 = cy;                               // row range of the union
+    bool new_champ = false;
+    int ch_r0 = 0, ch_r1 = -1;                                 // rows of the piece that became the champion (added == false)
+    const int nx[4] = {cx - 1, cx + 1, cx, cx}, ny[4] = {cy, cy, cy - 1, cy + 1};
+    for (int d = 0; d < 4; d++) {
+        const int x = nx[d], y = ny[d];
+        if (x < 0 || x >= G.W || y < 0 || y >= G.H) continue;
+        if (!big_bit_at(pass, G, x, y) || big_bit_at(U, G, x, y)) continue;      // (wave-uniform: LDS words every lane reads alike)
+        int r0 = y, r1 = y;
+        if (lane == 0) comp[y * G.KW + (x >> 6)] = 1ull << (x & 63);
+        big_sync();
+        big_fill(comp, pass, G, lane, r0, r1);
+        ++k;
+        const int lo = r0 * G.KW, hi = (r1 + 1) * G.KW;
+        if (!added) {
+            const int size = big_popcount(comp, lo, hi, lane);
+            if (size - 1 > path) {
+                const int e = big_double_sweep(comp, G, r0, r1, X, Y, Z, lane, path);
+                if (e > path) {
+                    path = e;
+                    big_zero(champ, 0, G.NW, lane);
+                    big_sync();
+                    for (int i = lo + lane; i < hi; i += 64) champ[i] = comp[i];
+                    new_champ = true; ch_r0 = r0; ch_r1 = r1;
+                }
+            }
+        }
+        for (int i = lo + lane; i < hi; i += 64) { U[i] |= comp[i]; comp[i] = 0ull; }
+        u0 = r0 < u0 ? r0 : u0; u1 = r1 > u1 ? r1 : u1;
+        big_sync();
+    }
+    (void)ch_r0; (void)ch_r1;
+    if (added) {
+        regions = regions_old + 1 - k;
+        if (lane == 0) { pass[ci] |= cbit; U[ci] |= cbit; }
+        big_sync();
+        const int lo = u0 * G.KW, hi = (u1 + 1) * G.KW;
+        const int size = big_popcount(U, lo, hi, lane);
+        if (size - 1 > path) {
+            const int e = big_double_sweep(U, G, u0, u1, X, Y, Z, lane, path);
+            if (e > path) {
+                path = e;
+                big_zero(champ, 0, G.NW, lane);
+                big_sync();
+                for (int i = lo + lane; i < hi; i += 64) champ[i] = U[i];
+                new_champ = true;
+            }
+        }
+    } else {
+        regions = regions_old + k - 1;
+    }
+    for (int i = u0 * G.KW + lane; i < (u1 + 1) * G.KW; i += 64) U[i] = 0ull;
+    big_sync();
+    return new_champ;
 }
 
 // Distance from the cells of C (the source set; overwritten) to the nearest cell of dst (dst not containing the source) through pass;
@@ -345,9 +445,9 @@ __device__ __forceinline__ bool big_item_stats(const PcgrlParams& P, const DevBu
             a2[i] = 0ull;
         }
         big_sync();
-        int regions, path;
-        big_regions_path(a0, a1, a2, a3, a4, a5, G, lane, true, regions, path);
-        s[0] = regions; s[1] = path; s[2] = 0;                               // (s[2]: "there is a champion" -- never, on this path)
+        int regions, path, has = 0;
+        big_regions_path(a0, a1, a2, a3, a4, a5, G, lane, true, regions, path, a6, &has);       // a6: the champion component (big_incremental)
+        s[0] = regions; s[1] = path; s[2] = has;                             // s[2]: "there is a champion"
         return false;
     }
     big_planes<3>(m, G, a0, a3, lane);                                      // a0, a1, a2 = bits 0, 1, 2 of the tile id

@@ -15,32 +15,70 @@ template <int PROB>
 __global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity, int inline_reset, int gen_map,
                                             int park_list) {
     extern __shared__ __attribute__((aligned(16))) uint8_t big_lds[];
-    __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1];
+    __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const bool with_rst = mode == MODE_STEP && inline_reset;
     const int n_chg = wl_load_prefix(B, parity, list, s_pref);
     const int n_rst = with_rst ? wl_load_prefix(B, parity, WL_RST, s_pref_rst) : 0;
+    // binary: the changes that neither touch nor neighbour the champion component come on WL_INC (k_update) and are answered from
+    // the previous statistics (big_incremental) -- after the full items, which are the long ones
+    const bool with_inc = PROB == PCGRL_PROB_BINARY && mode == MODE_STEP && B.champ != nullptr;
+    const int n_inc = with_inc ? wl_load_prefix(B, parity, WL_INC, s_pref_inc) : 0;
     const int W = P.width, H = P.height;
     const size_t cells = (size_t)W * H;
     const BigGeom G = big_geom(W, H);
     uint8_t* base = big_lds + (size_t)wv * big_wave_lds(W, H);
     uint32_t* mt = reinterpret_cast<uint32_t*>(base);
     uint64_t* ar = reinterpret_cast<uint64_t*>(base + PCGRL_MT_N * 4);
-    for (int item = blockIdx.x * nwv + wv; item < n_rst + n_chg; item += gridDim.x * nwv) {
-        const bool lone = item < n_rst;
-        const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item - n_rst);
-        const bool reset_only = (raw & WL_RESET_ONLY) != 0;
-        const int e = raw & ~WL_RESET_ONLY;
+    uint64_t* const champ_l = ar + 6 * G.NW;                      // the champion component in LDS (big_item_stats leaves it there: binary)
+    for (int item = blockIdx.x * nwv + wv; item < n_rst + n_chg + n_inc; item += gridDim.x * nwv) {
+        const bool lone = item < n_rst, inc = item >= n_rst + n_chg;
+        const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item) : (inc ? wl_get(B, WL_INC, s_pref_inc, item - n_rst - n_chg) : wl_get(B, list, s_pref, item - n_rst));
+        const bool reset_only = !inc && (raw & WL_RESET_ONLY) != 0;
+        const int e = inc ? (raw & WL_INCBIG_ENV_MASK) : (raw & ~WL_RESET_ONLY);
         const int shard = (item >> 4) & (WL_NSHARD - 1);
         const uint8_t* m = B.map + (size_t)e * cells;
+        uint64_t* const champ_g = B.champ ? reinterpret_cast<uint64_t*>(B.champ) + (size_t)e * G.NW : nullptr;
         int32_t s[PCGRL_MAX_STATS];
+        if (PROB == PCGRL_PROB_BINARY && inc) {
+            // one changed cell away from the champion: the new passable set from the byte map, the champion from memory, the
+            // components around the cell
+            uint64_t *a0 = ar, *a1 = ar + G.NW, *a2 = ar + 2 * G.NW, *a3 = ar + 3 * G.NW, *a4 = ar + 4 * G.NW, *a5 = ar + 5 * G.NW;
+            big_planes<1>(m, G, a0, a3, lane);
+            for (int i = lane; i < G.NW; i += 64) {
+                const int r = big_row(G, i), k = i - r * G.KW;
+                a0[i] = ~a0[i] & (k == G.KW - 1 ? G.last : ~0ull);
+                a1[i] = 0ull; a2[i] = 0ull;
+                champ_l[i] = champ_g[i];
+            }
+            big_sync();
+            const int2 old = *reinterpret_cast<const int2*>(B.stats + (size_t)e * 8);
+            int regions, path;
+            const bool nc = big_incremental(a0, a1, a2, a3, a4, a5, champ_l, G, lane, (raw >> 15) & 255, (raw >> 23) & 255, raw < 0, old.x, old.y, regions, path);
+            if (nc) { for (int i = lane; i < G.NW; i += 64) champ_g[i] = champ_l[i]; }
+            for (int k = 0; k < PCGRL_MAX_STATS; k++) s[k] = 0;
+            s[0] = regions; s[1] = path; s[2] = 1;
+            int want = 0;
+            if (lane == 0) want = finalize_item<PROB>(P, B, e, s, MODE_STEP, parity, shard, !inline_reset) ? 1 : 0;
+            want = __builtin_amdgcn_readfirstlane(want);
+            if (inline_reset && want) {
+                __builtin_amdgcn_wave_barrier();
+                wave_reset_env<PROB>(P, B, e, gen_map, mt, (uint8_t*)nullptr, lane);
+                __threadfence();
+                big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+                if (s[2]) { for (int i = lane; i < G.NW; i += 64) champ_g[i] = champ_l[i]; }
+                if (lane == 0) finalize_item<PROB>(P, B, e, s, MODE_START, parity, shard);
+            }
+            continue;
+        }
         if (mode != MODE_STEP) {
             if (mode == MODE_START) {
                 wave_reset_env<PROB>(P, B, e, gen_map, mt, (uint8_t*)nullptr, lane);
                 __threadfence();               // the new map is read back from memory below
             }
             const bool ns = big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+            if (PROB == PCGRL_PROB_BINARY && champ_g && s[2]) { for (int i = lane; i < G.NW; i += 64) champ_g[i] = champ_l[i]; }
             if (lane == 0) finish_or_park<PROB>(P, B, e, s, ns, mode, parity, shard, true, park_list);
             continue;
         }
@@ -59,6 +97,7 @@ __global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list,
             want = 1;                  // (an unchanged environment whose episode ended: k_update finished its step)
         } else {
             const bool ns = big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+            if (PROB == PCGRL_PROB_BINARY && champ_g && s[2]) { for (int i = lane; i < G.NW; i += 64) champ_g[i] = champ_l[i]; }
             if (lane == 0) want = finish_or_park<PROB>(P, B, e, s, ns, MODE_STEP, parity, shard, !inline_reset, park_list) ? 1 : 0;
             want = __builtin_amdgcn_readfirstlane(want);
         }
@@ -67,6 +106,7 @@ __global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list,
             wave_reset_env<PROB>(P, B, e, gen_map, mt, (uint8_t*)nullptr, lane);
             __threadfence();
             const bool ns = big_item_stats<PROB>(P, B, m, G, ar, lane, s);
+            if (PROB == PCGRL_PROB_BINARY && champ_g && s[2]) { for (int i = lane; i < G.NW; i += 64) champ_g[i] = champ_l[i]; }
             if (lane == 0) finish_or_park<PROB>(P, B, e, s, ns, MODE_START, parity, shard, true, park_list);
         }
     }

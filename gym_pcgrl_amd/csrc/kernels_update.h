@@ -96,7 +96,18 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         // binary, 16-row maps: the three champion rows around the cell, for the routing decision below
         const bool inc_on = P.prob == PCGRL_PROB_BINARY && B.champ != nullptr;
         MaskT ch0 = 0, chu = 0, chd = 0;
-        if (inc_on && writes) {
+        bool big_touch = false;
+        if (inc_on && writes && P.big) {
+            // maps beyond 64 x 64 (bigmap.h): the champion's rows are [H][KW] 64-bit words per environment; is the cell in it or next to it?
+            const int KW = (W + 63) >> 6;
+            const uint64_t* ch = reinterpret_cast<const uint64_t*>(B.champ) + (size_t)e * H * KW;
+            const int xs[5] = {wx, wx - 1, wx + 1, wx, wx}, ys[5] = {wy, wy, wy, wy - 1, wy + 1};
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int xx = xs[q], yy = ys[q];
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) big_touch = big_touch || ((ch[yy * KW + (xx >> 6)] >> (xx & 63)) & 1ull) != 0ull;
+            }
+        } else if (inc_on && writes) {
             const MaskT* ch = reinterpret_cast<const MaskT*>(B.champ) + (size_t)e * G;
             ch0 = ch[wy];
             chu = ch[wy > 0 ? wy - 1 : wy];
@@ -136,7 +147,10 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
         }
         if (tile >= 0 && old != tile) {
             chg = true;
-            if (inc_on && s0.z != 0) {
+            if (inc_on && s0.z != 0 && P.big) {
+                cheap = !big_touch;                           // (big_incremental, bigmap.h)
+                inc_item = wl_incbig_pack(e, wx, wy, tile == 0);
+            } else if (inc_on && s0.z != 0) {
                 // the statistics can be updated from the previous ones when the cell is neither in the champion component
                 // nor next to it (binary_incremental); s0.z = "there is a champion"
                 const MaskT bit = (MaskT)1 << wx;

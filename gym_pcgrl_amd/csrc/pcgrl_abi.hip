@@ -248,7 +248,10 @@ static size_t sok_pool_nodes(int power, int prob = -1) {
 static_assert(SS_SMALL_NODES >= 4 * SS_SMALL_POPS + 4, "a small-tier search pushes up to four nodes per pop");
 // rows of the champion component per environment (binary, maps of at most 16 x 32): the incremental statistics path
 static size_t champ_bytes(const pcgrl_config* c) {
-    if (c->prob != PCGRL_BINARY || big_map(c)) return 0;
+    if (c->prob != PCGRL_BINARY) return 0;
+    if (big_map(c))      // maps beyond 64 x 64 (bigmap.h big_incremental): [H][KW] 64-bit words; the work item packs the cell into 8 + 8 bits and the environment into 15
+        return (c->rep <= PCGRL_REP_TURTLE && c->width <= 256 && c->height <= 256 && c->num_envs <= WL_INCBIG_ENV_MASK + 1)
+                   ? align_up((size_t)c->num_envs * big_words(c->width, c->height) * 8, 256) : 0;
     if (c->height <= 16) return (c->width <= 32 && c->num_envs <= WL_INC_ENV_MASK) ? align_up((size_t)c->num_envs * 64, 256) : 0;
     return c->num_envs <= WL_INC64_ENV_MASK ? align_up((size_t)c->num_envs * 64 * (c->width > 32 ? 8 : 4), 256) : 0;
 }

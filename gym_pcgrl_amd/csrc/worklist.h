@@ -35,6 +35,9 @@ __device__ __forceinline__ int wl_inc_pack(int group, int e, int row, int col, u
     return group == 16 ? (int)((unsigned)e | ((unsigned)(row * 32 + col) << 21) | (code << 30))
                        : (int)((unsigned)e | ((unsigned)(row * 64 + col) << 19) | ((code & 1u) << 31));
 }
+// maps beyond 64 x 64 (k_big, binary): environment in bits 0..14, column in 15..22, row in 23..30, bit 31 = the cell became passable
+#define WL_INCBIG_ENV_MASK 0x7FFF
+__device__ __forceinline__ int wl_incbig_pack(int e, int x, int y, bool added) { return (int)((unsigned)e | ((unsigned)x << 15) | ((unsigned)y << 23) | (added ? 0x80000000u : 0u)); }
 template <int G> __device__ __forceinline__ int wl_inc_env(int raw) { return raw & (G == 16 ? WL_INC_ENV_MASK : WL_INC64_ENV_MASK); }
 template <int G> __device__ __forceinline__ int wl_inc_row(int raw) { return G == 16 ? ((raw >> 26) & 15) : ((raw >> 25) & 63); }
 template <int G> __device__ __forceinline__ int wl_inc_col(int raw) { return G == 16 ? ((raw >> 21) & 31) : ((raw >> 19) & 63); }

@@ -45,6 +45,23 @@ for W in workloads:
             m = lambda d, c: (sum(d[k][c]) / len(d[k][c])) if k in d and c in d[k] else float("nan")
             out.append("| %s | " % k + " | ".join("%d" % m(sq, c) for c in cols) + " | %d | %.0f | %.0f |" % (m(sq2, "SQ_WAIT_ANY"), m(f, "FETCH_SIZE"), m(w, "WRITE_SIZE")))
         out.append("")
+        lds, act = agg(os.path.join(G, "pmc_lds_" + W, W + "_counter_collection.csv")), agg(os.path.join(G, "pmc_act_" + W, W + "_counter_collection.csv"))
+        extra = {}
+        if lds or act:
+            lcols = ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_INSTS_FLAT", "SQ_INSTS_BRANCH",
+                     "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_FLAT", "SQ_ACTIVE_INST_MISC", "SQ_INSTS_SENDMSG", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM"]
+            out.append("What the wavefronts wait on -- LDS and instruction-class counters (separate `--pmc` passes, `tools/profile_gpu.sh %s lds`), average per dispatch:\n\n| kernel | " % W +
+                       " | ".join(lcols) + " |\n|" + "---|" * (len(lcols) + 1))
+            for k in sorted(set(lds) | set(act)):
+                if not k.startswith(("void k_", "k_")):
+                    continue
+                both = dict(lds.get(k, {})); both.update(act.get(k, {}))
+                if not both or len(next(iter(both.values()))) < 4:
+                    continue
+                vals = {c: sum(both[c]) / len(both[c]) for c in lcols if c in both}
+                extra[k.replace("void ", "").split("<")[0]] = vals
+                out.append("| %s | " % k + " | ".join(("%d" % vals[c]) if c in vals else "-" for c in lcols) + " |")
+            out.append("")
         tot_f = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) for k, v in f.items() if k.startswith("void k_") and len(v["FETCH_SIZE"]) > 4)
         tot_w = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in w.items() if k.startswith("void k_") and len(v["WRITE_SIZE"]) > 4)
         out.append("HBM traffic per step (sum over the step's kernels; rocprofv3 KB): FETCH_SIZE %.1f MB + WRITE_SIZE %.1f MB as reported.  Calibrated "
@@ -61,6 +78,9 @@ for W in workloads:
             if k.startswith(("void k_", "k_")) and len(v[cols[0]]) >= 4:
                 kk = k.replace("void ", "").split("<")[0]
                 pm[kk] = {c: sum(v[c]) / len(v[c]) for c in cols if c in v}
+                if k in sq2 and "SQ_WAIT_ANY" in sq2[k]:
+                    pm[kk]["SQ_WAIT_ANY"] = sum(sq2[k]["SQ_WAIT_ANY"]) / len(sq2[k]["SQ_WAIT_ANY"])
+                pm[kk].update(extra.get(kk, {}))
         json.dump({"workload": W, "per_dispatch": pm, "csrc_hash": src_hash}, open(os.path.join(dst, W + "_pmc.json"), "w"))
     for cand in ("bench_%s.json" % W, "bench_%s.log" % W):
         b = os.path.join(G, cand)
