@@ -23,10 +23,15 @@ class RolloutBuffer:
         self.dones = z((n_steps, num_envs), torch.bool)
         self.episode_starts = z((n_steps, num_envs), torch.bool)     # obs[t] is the first observation of an episode
         self.last_obs = z((num_envs,) + tuple(obs_shape), torch.uint8)
+        # asynchronous collection (collect(policy, pop_budget=...)): row t is a TICK.  took[t, e]: environment e took actions[t, e]
+        # (from obs[t, e]); fresh[t, e]: a step of e completed in tick t -- rewards[t, e] / dones[t, e] are the outcome of the LAST
+        # action it took (at tick t or earlier) and the next row's observation is the one that follows it.  Lockstep: all true.
+        self.took = torch.ones((n_steps, num_envs), dtype=torch.bool, device=device)
+        self.fresh = torch.ones((n_steps, num_envs), dtype=torch.bool, device=device)
 
     def as_dict(self):
         return OrderedDict(obs=self.obs, actions=self.actions, rewards=self.rewards, dones=self.dones,
-                           episode_starts=self.episode_starts, last_obs=self.last_obs)
+                           episode_starts=self.episode_starts, last_obs=self.last_obs, took=self.took, fresh=self.fresh)
 
 
 class RolloutCollector:
@@ -53,8 +58,15 @@ class RolloutCollector:
         self.episode_returns, self.episode_lengths = [], []      # per step, the last `keep_steps` steps (default: one rollout)
         self.keep_steps = int(n_steps)
 
-    def collect(self, policy):
+    def collect(self, policy, pop_budget=None):
+        """pop_budget: collect with asynchronous ticks (BatchedPcgrlEnv.tick; sokoban / mdungeon / ddave) -- a row of the buffer is then a
+        tick, `took` / `fresh` say which environments acted in it and which completed a step (an environment whose search is
+        suspended sits ticks out; the policy's action for it is ignored).  Per environment the rows with `took` / `fresh` set, in
+        order, are the transitions a lockstep rollout holds.  No host synchronisation either way."""
         torch, b = self.torch, self.buffer
+        asynchronous = pop_budget is not None
+        if asynchronous and getattr(self, "_pending", None) is None:
+            self._pending = torch.zeros(self.env.num_envs, dtype=torch.bool, device=b.obs.device)
         w = self.env.env                                  # the image wrapper below the Monitor layer: no host sync
         direct = self.direct
         if self._obs is None:
@@ -74,13 +86,23 @@ class RolloutCollector:
             nxt = b.obs[t + 1] if t + 1 < b.n_steps else b.last_obs
             if direct:
                 w.set_observation_target(nxt)             # the step writes the next row itself
-            self._obs, rew, done, _ = w.step(actions)
+            if asynchronous:
+                b.took[t].copy_(~self._pending)
+                self._obs, rew, done, _, pend = w.tick(actions, pop_budget=pop_budget)
+                self._pending = pend != 0
+                b.fresh[t].copy_(~self._pending)
+            else:
+                self._obs, rew, done, _ = w.step(actions)
             if not direct:
                 nxt.copy_(self._obs)
                 self._obs = nxt
             b.rewards[t].copy_(rew)
             b.dones[t].copy_(done)
-            self._start = done.to(torch.bool).clone()
+            if asynchronous:       # an episode starts where a step completed in this tick with done set; pending rows keep their flag
+                self._start = torch.where(b.fresh[t], done.to(torch.bool), self._start)
+                b.dones[t] &= b.fresh[t]
+            else:
+                self._start = done.to(torch.bool).clone()
             if self.env.monitor:
                 st = self.env.episode_stats()
                 m = b.dones[t]

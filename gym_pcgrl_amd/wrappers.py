@@ -100,6 +100,11 @@ class CroppedImagePCGRLWrapper(_ImageWrapper):
         _, reward, done, info = self.pcgrl_env.step(actions)          # the step wrote the image
         return self._obs, reward, done, info
 
+    def tick(self, actions, pop_budget=64):
+        """One asynchronous tick (BatchedPcgrlEnv.tick; the search problems): -> (image, reward, done, info, pending)."""
+        _, reward, done, info, pending = self.pcgrl_env.tick(actions, pop_budget=pop_budget)
+        return self._obs, reward, done, info, pending
+
 
 class ActionMapImagePCGRLWrapper(_ImageWrapper):
     def __init__(self, game, num_envs=1, seed=None, device=None, **kwargs):
@@ -122,6 +127,20 @@ class ActionMapImagePCGRLWrapper(_ImageWrapper):
             self._xyv = torch.empty((self.num_envs, 3), dtype=torch.int32, device=e.device)
         _, reward, done, info = e.step_flat(a, self._xyv)          # decode + step: one call, one launch where the step is fused
         return self._obs, reward, done, info
+
+    def tick(self, actions, pop_budget=64):
+        """One asynchronous tick on flat ActionMap indices (the search problems): -> (image, reward, done, info, pending)."""
+        import ctypes as C
+        from . import _lib
+        e = self.pcgrl_env
+        torch = e._torch
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(actions)
+        a = a.to(device=e.device, dtype=torch.int32).reshape(self.num_envs).contiguous()
+        if self._xyv is None:
+            self._xyv = torch.empty((self.num_envs, 3), dtype=torch.int32, device=e.device)
+        _lib.check(e._lib.pcgrl_action_map(e._handle, C.c_void_p(a.data_ptr()), C.c_void_p(self._xyv.data_ptr()), e._stream()), "pcgrl_action_map")
+        _, reward, done, info, pending = e.tick(self._xyv, pop_budget=pop_budget)
+        return self._obs, reward, done, info, pending
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -76,3 +76,46 @@ def test_async_small_launch_budget_beyond_its_region():
     rs = np.random.RandomState(22)
     cnt = ph.async_case("sokoban", "narrow", [dict(width=6, height=6), FEW_SOK], 256, 60, 313, rs, 700, 256)
     assert cnt["suspended"] > 10, cnt
+
+
+@pytest.mark.parametrize("env_id,rep", [("sokoban-narrow-v0", "narrow"), ("sokoban-wide-v0", "wide"), ("mdungeon-narrow-v0", "narrow")])
+def test_async_collector_holds_the_lockstep_transitions(env_id, rep):
+    """RolloutCollector.collect(policy, pop_budget=...) -- the trainer-shaped loop (utils.make_vec_envs + the image wrappers) on
+    asynchronous ticks, with a policy that is a deterministic function of the image: per environment, the rows flagged `took` /
+    `fresh` must be, in order, exactly the (action, reward, done) transitions of the lockstep collector on a twin batch."""
+    import torch
+    from gym_pcgrl_amd.rollout import RolloutCollector
+    from gym_pcgrl_amd.utils import make_vec_envs
+    N, T_lock, T_tick = 384, 24, 40
+    kw = dict(change_percentage=0.6) if "sokoban" in env_id else {}
+    n_act = None
+
+    def policy(obs):
+        flat = obs.reshape(obs.shape[0], -1).to(torch.int64)
+        w = torch.arange(1, flat.shape[1] + 1, device=obs.device, dtype=torch.int64) % 97 + 1
+        return (flat * w).sum(1) % n_act
+
+    out = []
+    for budget in (None, 6):
+        venv = make_vec_envs(env_id, rep, n_cpu=N, seed=11, device="cuda:0", **kw)
+        a = venv.action_space
+        n_act = int(a.n) if hasattr(a, "n") else None
+        assert n_act is not None
+        col = RolloutCollector(venv, T_lock if budget is None else T_tick)
+        b = col.collect(policy, pop_budget=budget)
+        torch.cuda.synchronize()
+        out.append({k: v.cpu().numpy() for k, v in b.as_dict().items() if k in ("actions", "rewards", "dones", "took", "fresh")})
+        venv.close()
+    lock, asy = out
+    assert lock["took"].all() and lock["fresh"].all()
+    assert (~asy["fresh"]).sum() > 10               # environments really sat ticks out
+    short = 0
+    for e in range(N):
+        acts = asy["actions"][asy["took"][:, e], e]
+        rew = asy["rewards"][asy["fresh"][:, e], e]
+        done = asy["dones"][asy["fresh"][:, e], e]
+        k = min(len(rew), T_lock)
+        short += int(len(rew) < T_tick)
+        assert np.array_equal(acts[:k], lock["actions"][:k, e]), ("actions", e)
+        assert np.array_equal(rew[:k], lock["rewards"][:k, e]) and np.array_equal(done[:k], lock["dones"][:k, e]), ("reward/done", e)
+    assert short > 0          # (an environment with a long search completes fewer steps than there were ticks)
