@@ -25,7 +25,7 @@ struct AsyncSlotHdr {
     int32_t state;                           // 0 free, 1 suspended (runnable), 2 taken (being run or written)
     int32_t env, mode, agent;                // the job: environment, MODE_*, index of the agent that goes on
     int32_t stamp;                           // the tick that suspended it last (a slot is not continued in the launch that wrote it)
-    int32_t tsmall;                          // != 0: the saved visited table is the small launch's (that many slots): re-hashed into the full one
+    int32_t tsaved;                          // slots of the saved visited table (a power of two, sized by the search's pops so far: async_table_need)
     int32_t pad[2];
     SokResume rs;                            // iterations == 0: agent `agent` starts from the root
 };
@@ -62,6 +62,16 @@ __device__ __forceinline__ uint8_t* async_pool(const AsyncCtl& A, int s) { retur
 __device__ __forceinline__ uint32_t* async_heap(const AsyncCtl& A, int s) { return reinterpret_cast<uint32_t*>(async_pool(A, s) + (size_t)A.nodes_cap * 16); }
 __device__ __forceinline__ uint32_t* async_table(const AsyncCtl& A, int s) { return async_heap(A, s) + SOK_LDS_HEAP; }
 
+// The visited table of a piece of a search is as large as the piece needs, not as large as a 5 000-pop search needs: four slots per
+// entry it can hold at the end of the piece (n = pops so far + the piece's budget), a power of two between 512 and `tmax`.  A piece of 64
+// pops of a young search clears / restores / saves 4-16 KB instead of the 64 KB of the full table; when a search outgrows its table
+// the keys are re-hashed into one of twice the size as it is continued (which slot a key sits in depends on the order of insertion,
+// what the table answers does not).
+__device__ __forceinline__ int async_table_need(int n, int tmax) {
+    int t = 512;
+    while (t < tmax && t < 4 * n) t <<= 1;
+    return t < tmax ? t : tmax;
+}
 // 16-byte pieces by the 64 lanes of a wavefront (both sides 16-byte aligned, `words` rounded up to four)
 __device__ __forceinline__ void async_copy(uint32_t* dst, const uint32_t* src, int words, int lane) {
     const int n4 = (words + 3) >> 2;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
             unbounded = 1;
         } else {
             const AsyncSlotHdr* hd = async_hdr(A, slot);
-            e = hd->env; mode = hd->mode; a0 = hd->agent; tsm = hd->tsmall;
+            e = hd->env; mode = hd->mode; a0 = hd->agent; tsm = hd->tsaved;
             if (lane == 0) s_rs = hd->rs;
         }
         Game::build(P, B, B.map + (size_t)e * P.width * P.height, s_game, s_scratch, lane);
@@ -253,31 +263,34 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
         int a = a0, remaining = unbounded ? 0x3FFFFFFF : budget, done = 0, handed = 0;
         int how = (slot >= 0 && s_rs.iterations > 0) ? 1 : 0;          // 0: the agent starts (clear the table), 1: restore from the slot, 2: go on in place
         int res[5] = {0, 0, 0, 0, 0};
+        int tcur = tsize;                                              // slots of the table this piece works on (async_table_need)
         for (;;) {
             for (;;) {
                 if (how == 1) {
                     async_copy(as_lds, async_heap(A, slot), s_rs.heapn, lane);
-                    if (tsm == 0) {
-                        async_copy(as_lds + toff, async_table(A, slot), 2 * tsize, lane);
+                    tcur = async_table_need(s_rs.iterations + (remaining < tsize ? remaining : tsize), tsize);
+                    if (tcur < tsm) tcur = tsm < tsize ? tsm : tsize;      // (never smaller than what was saved)
+                    if (tsm == tcur) {
+                        async_copy(as_lds + toff, async_table(A, slot), 2 * tcur, lane);
                     } else {
-                        // suspended by the small launch: its few keys go into the (cleared) full table -- which slot a key sits in
-                        // depends on the order of insertion, what the table answers does not
+                        // the search has outgrown the table it was saved with (or comes from the small launch): its keys go into a
+                        // cleared larger one
                         uint4* t4 = reinterpret_cast<uint4*>(as_lds + toff);
-                        for (int i = lane; i < tsize / 2; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
+                        for (int i = lane; i < tcur / 2; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
                         __threadfence_block();
                         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(async_table(A, slot));
                         unsigned long long* tab = reinterpret_cast<unsigned long long*>(as_lds + toff);
                         for (int i = lane; i < tsm; i += 64) {
                             const unsigned long long key = src[i];
                             if (key == 0ull) continue;
-                            uint32_t sl = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)(tsize - 1);
-                            while (atomicCAS(tab + sl, 0ull, key) != 0ull) sl = (sl + 1) & (uint32_t)(tsize - 1);
+                            uint32_t sl = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)(tcur - 1);
+                            while (atomicCAS(tab + sl, 0ull, key) != 0ull) sl = (sl + 1) & (uint32_t)(tcur - 1);
                         }
-                        tsm = 0;
                     }
                 } else if (how == 0) {
+                    tcur = async_table_need(remaining < tsize ? remaining : tsize, tsize);
                     uint4* t4 = reinterpret_cast<uint4*>(as_lds + toff);
-                    for (int i = lane; i < tsize / 2; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
+                    for (int i = lane; i < tcur / 2; i += 64) t4[i] = make_uint4(0, 0, 0, 0);
                 }
                 __threadfence_block();
                 AP(3);
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
                 if (lane < 4) {
                     bool ex = false;
                     const SokResumeArg ra = {&s_rs, before + remaining};
-                    win = Game::agent(s_game, a, pool, as_lds, toff, tsize, &s_box, P.solver_power, ra, lane, res, ex) ? 1 : 0;
+                    win = Game::agent(s_game, a, pool, as_lds, toff, tcur, &s_box, P.solver_power, ra, lane, res, ex) ? 1 : 0;
                     exh = ex ? 1 : 0;
                 }
                 __threadfence_block();
@@ -327,8 +340,14 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
                         handed = 1;
                         break;
                     }
+                    // (from the root once more when the piece's table is not the full one: at most a budget's pops are redone)
                     if (lane == 0) atomicAdd(A.stats + ASYNC_ST_OVERFLOW, 1ull);
                     remaining = 0x3FFFFFFF;
+                    if (tcur != tsize && s_rs.iterations > 0) {
+                        __threadfence_block();
+                        if (lane == 0) s_rs = SokResume{};
+                        __threadfence_block();
+                    }
                     how = s_rs.iterations > 0 ? 2 : 0;
                     continue;
                 }
@@ -352,13 +371,13 @@ __global__ __launch_bounds__(128) void k_search_async(PcgrlParams P, DevBufs B, 
         } else {
             if (s_rs.iterations > 0) {
                 async_copy(async_heap(A, slot), as_lds, s_rs.heapn, lane);
-                async_copy(async_table(A, slot), as_lds + toff, 2 * tsize, lane);
+                async_copy(async_table(A, slot), as_lds + toff, 2 * tcur, lane);
             }
             __threadfence();
             if (lane == 0) {
                 AsyncSlotHdr* hd = async_hdr(A, slot);
                 hd->env = e; hd->mode = mode; hd->agent = a; hd->stamp = A.tick; hd->rs = s_rs;
-                hd->tsmall = (small && s_rs.iterations > 0) ? tsize : 0;
+                hd->tsaved = s_rs.iterations > 0 ? tcur : 0;
                 A.pending[e] = ASYNC_PEND_SEARCH;
                 __threadfence();
                 __hip_atomic_store(&hd->state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
