@@ -194,13 +194,16 @@ class MultiGpuPcgrlEnv:
         the `gather` form, infos the list of the shards' InfoBatch objects (live device tables).  With gather="list" the whole
         node is stepped by one call of the library (pcgrl_step_multi) and the call performs no host synchronisation."""
         self._flip ^= 1
-        parts = self.split(actions)
+        torch = self._torch
         if self.gather == "list" and not any(sh.strict_actions or sh._needs_reset for sh in self.shards):
             if self._multi is None:
                 self._prepare_multi()
             M = self._multi
-            torch = self._torch
-            acts = [sh._as_actions(p) for sh, p in zip(self.shards, parts)]
+            i32 = torch.int32
+            if isinstance(actions, (list, tuple)) and len(actions) == M["n"] and all(a.dtype is i32 and a.is_contiguous() for a in actions):
+                acts = actions                 # per-shard int32 tensors on their devices, as a per-shard policy produces them: taken as they are
+            else:
+                acts = [sh._as_actions(p) for sh, p in zip(self.shards, self.split(actions))]
             self._last_actions = acts          # keep the buffers alive until the launches are done
             for g, a in enumerate(acts):
                 M["actions"][g] = a.data_ptr()
@@ -213,6 +216,7 @@ class MultiGpuPcgrlEnv:
                 for g, st in enumerate(self.streams):
                     torch.cuda.current_stream(self.devices[g]).wait_stream(st)
             return M["out"]
+        parts = self.split(actions)
         res = self._each(lambda g, sh: sh.step(parts[g]))
         out = (self._obs([r[0] for r in res]), self._collect("reward", [r[1] for r in res]),
                self._collect("done", [r[2] for r in res]), [r[3] for r in res])
