@@ -566,6 +566,7 @@ class BatchedPcgrlEnv:
         """Everything a batch of environments carries between steps (checkpoint / resume): maps, first maps,
         heatmaps, cursors, counters, current and start stats, last step outputs, binary tile probabilities, both MT19937
         rings with their cursors, and the episode statistics when they are on.  Device tensors (clones)."""
+        self.flush()                       # (asynchronous ticks: a step in flight is finished first -- a checkpoint holds completed steps only)
         self._torch.cuda.synchronize(self.device)
         sd = {k: (v.clone() if v is not None else None) for k, v in self._bufs.items() if k not in ("scratch", "planes")}
         if self._episode is not None:

@@ -223,6 +223,21 @@ class MultiGpuPcgrlEnv:
         self._finish()
         return out
 
+    def enable_async(self, nslots=1024):
+        """BatchedPcgrlEnv.enable_async on every shard (`nslots` suspended searches per shard)."""
+        return all([sh.enable_async(nslots) for sh in self.shards])
+
+    def tick(self, actions, pop_budget=64):
+        """One asynchronous tick of every shard (BatchedPcgrlEnv.tick: the search problems), each on its own stream, all issued before
+        anything waits.  Returns (obs, reward, done, infos, pending) in the `gather` form."""
+        self._flip ^= 1
+        parts = self.split(actions)
+        res = self._each(lambda g, sh: sh.tick(parts[g], pop_budget=pop_budget))
+        out = (self._obs([r[0] for r in res]), self._collect("reward", [r[1] for r in res]), self._collect("done", [r[2] for r in res]),
+               [r[3] for r in res], self._collect("pending", [r[4] for r in res]))
+        self._finish()
+        return out
+
     def step_async(self, actions):
         self._pending = self.step(actions)
 

@@ -119,3 +119,37 @@ def test_async_collector_holds_the_lockstep_transitions(env_id, rep):
         assert np.array_equal(acts[:k], lock["actions"][:k, e]), ("actions", e)
         assert np.array_equal(rew[:k], lock["rewards"][:k, e]) and np.array_equal(done[:k], lock["dones"][:k, e]), ("reward/done", e)
     assert short > 0          # (an environment with a long search completes fewer steps than there were ticks)
+
+
+def test_async_ticks_through_the_node_driver_and_a_checkpoint():
+    """MultiGpuPcgrlEnv.tick (a handle and a stream per shard: here four on this box's one GPU) gives every environment what one
+    batch's tick gives it; state_dict() finishes the steps in flight first, and a batch restored from it goes on like the original."""
+    import torch
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    from gym_pcgrl_amd.node import MultiGpuPcgrlEnv
+    n = 400
+    one = BatchedPcgrlEnv(prob="sokoban", rep="narrow", num_envs=n, seed=5)
+    node = MultiGpuPcgrlEnv(prob="sokoban", rep="narrow", num_envs=n, devices=["cuda:0"] * 4, seed=5)
+    one.reset(); node.reset()
+    assert one.enable_async(64) and node.enable_async(64)
+    rs = np.random.RandomState(2)
+    for t in range(50):
+        a = torch.as_tensor(rs.randint(0, 6, size=n).astype(np.int32), device="cuda")
+        o1, r1, d1, i1, p1 = one.tick(a, pop_budget=9)
+        o2, r2, d2, i2, p2 = node.tick(a, pop_budget=9)
+        p2 = p2.to("cuda:0")
+        assert torch.equal(p1, p2), t
+        ok = p1 == 0
+        assert torch.equal(r1[ok], r2.to("cuda:0")[ok]) and torch.equal(d1[ok], d2.to("cuda:0")[ok]) and torch.equal(o1["map"][ok], o2["map"].to("cuda:0")[ok]), t
+    assert int((one._async["pending"] != 0).sum()) > 0
+    sd = one.state_dict()                              # flushes
+    assert int((one._async["pending"] != 0).sum()) == 0
+    twin = BatchedPcgrlEnv(prob="sokoban", rep="narrow", num_envs=n, seed=5)
+    twin.reset()
+    twin.load_state_dict(sd)
+    for t in range(20):
+        a = rs.randint(0, 6, size=n).astype(np.int32)
+        _, ra, da, _ = one.step(a)
+        _, rb, db, _ = twin.step(a)
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(one._bufs["map"], twin._bufs["map"]), t
+    one.close(); node.close(); twin.close()
