@@ -263,8 +263,9 @@ def node_driver_leg(torch, device, G=8, n_per=256, calls=300):
     """Host cost of stepping a whole node from ONE process (node.MultiGpuPcgrlEnv; SURVEY 8e: at 28 us per C2 step per GPU the host
     must issue the step of all eight GPUs in less than one kernel's time or it is the bottleneck).  G handles with a stream each --
     all on this one GPU: the driver's box has one -- and tiny batches, so that what is timed is the host: microseconds per step()
-    call of all G handles, nothing waited for, (a) through pcgrl_step_multi (gather="list": one call of the library per step) and
-    (b) shard by shard (G calls of pcgrl_step inside torch stream contexts: the round-4 path)."""
+    call of all G handles, nothing waited for, (a) through pcgrl_step_multi (gather="list": one call of the library per step) with
+    per-shard action tensors, (b) shard by shard (G calls of pcgrl_step inside torch stream contexts: the round-4 path), (c) through
+    pcgrl_step_multi with the driver's own action buffers written in place (nothing but the library call is left on the host)."""
     from gym_pcgrl_amd.node import MultiGpuPcgrlEnv
     out = {"handles": G, "envs_per_handle": n_per, "calls": calls, "workload": "binary-narrow-v0 14x14"}
     for name, sync_streams in (("host_us_per_call", False), ("host_us_per_call_with_stream_ordering", True)):
@@ -279,6 +280,18 @@ def node_driver_leg(torch, device, G=8, n_per=256, calls=300):
             env.step(parts)
         out[name] = (time.perf_counter() - t0) / calls * 1e6
         torch.cuda.synchronize(device)
+        if not sync_streams:
+            # (c) the driver's own action buffers, written in place by the policy (MultiGpuPcgrlEnv.action_buffers): step() then is
+            # the one library call and nothing else
+            bufs = env.action_buffers()
+            for _ in range(20):
+                env.step(bufs)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                env.step(bufs)
+            out["host_us_per_call_action_buffers"] = (time.perf_counter() - t0) / calls * 1e6
+            torch.cuda.synchronize(device)
         if sync_streams:
             t0 = time.perf_counter()
             for _ in range(calls):

@@ -19,6 +19,15 @@
 // configurations BASELINE.json names all fit the row-bitboard kernels.
 #pragma once
 
+// developer build only (tools/probe/big_prof.py: -DPCGRL_BIG_PROF): cycles of a full recomputation by phase, summed into g_tl_buf
+#ifdef PCGRL_BIG_PROF
+#define BP_NOW() clock64()
+#define BP_ADD(i, v) do { if (lane == 0 && g_tl_buf) atomicAdd(&g_tl_buf[i], (unsigned long long)(v)); } while (0)
+#else
+#define BP_NOW() 0ull
+#define BP_ADD(i, v) do {} while (0)
+#endif
+
 struct BigGeom {
     int W, H, KW, NW;          // words per row, words per mask
     uint32_t magic;            // floor(i / KW) = (i * magic) >> 16 for i * KW < 65536 (validate_config keeps NW * KW below that)
@@ -171,6 +180,59 @@ __device__ __forceinline__ int big_bfs_levels(const uint64_t* comp, int i0, int 
     }
 }
 
+// A component through a 64 x 64 window, in registers.  Most components of a large map are a few cells to a few hundred: the fills and
+// sweeps of the word arrays cost a loop over LDS words, a wavefront reduction or two and a compiler barrier per round (~9 000 cycles a
+// component, ~1 900 a BFS level: tools/probe/big_prof.py), while the row-bitboard algorithms of the maps up to 64 x 64 (pcgrl_algos.h:
+// pcg_component's run / column fills, pcg_double_sweep with per-lane level bookkeeping) do the same on one 64-bit row mask per lane.
+// So: cut the window [r0, r0 + 64) x [cw0, cw0 + 64) around the seed out of `pass` (lane l = row r0 + l, a funnel shift of two words),
+// extract the component there, and if it does not touch a window edge that is not also the map's, it IS the component -- counted,
+// measured and swept in registers (the first cell in row-major order and the first cell of the last frontier are the same cells in
+// the window's coordinates).  One that reaches an edge is left to the word-array path.
+struct BigWindow { int r0, cw0, kx, sh; };
+__device__ __forceinline__ BigWindow big_window_at(const BigGeom& G, int r0, int c) {
+    BigWindow Wd;
+    int cw0 = c - 32;
+    const int cmax = G.W > 64 ? G.W - 64 : 0;
+    cw0 = cw0 < 0 ? 0 : (cw0 > cmax ? cmax : cw0);
+    Wd.r0 = r0; Wd.cw0 = cw0; Wd.kx = cw0 >> 6; Wd.sh = cw0 & 63;
+    return Wd;
+}
+__device__ __forceinline__ uint64_t big_window_load(const uint64_t* a, const BigGeom& G, const BigWindow& Wd, int lane) {
+    const int row = Wd.r0 + lane;
+    if (row >= G.H) return 0ull;
+    const int i = row * G.KW + Wd.kx;
+    uint64_t v = a[i] >> Wd.sh;
+    if (Wd.sh != 0 && Wd.kx + 1 < G.KW) v |= a[i + 1] << (64 - Wd.sh);
+    return v;
+}
+// a[.] &= ~m (CLEAR) or a[.] = m over the window's rows (the other words of those rows are the caller's business)
+template <bool CLEAR>
+__device__ __forceinline__ void big_window_store(uint64_t* a, const BigGeom& G, const BigWindow& Wd, int lane, uint64_t m) {
+    const int row = Wd.r0 + lane;
+    if (row >= G.H) return;
+    const int i = row * G.KW + Wd.kx;
+    if (CLEAR) {
+        if (m == 0ull) return;
+        a[i] &= ~(m << Wd.sh);
+        if (Wd.sh != 0 && Wd.kx + 1 < G.KW) a[i + 1] &= ~(m >> (64 - Wd.sh));
+    } else {
+        a[i] |= m << Wd.sh;
+        if (Wd.sh != 0 && Wd.kx + 1 < G.KW) a[i + 1] |= m >> (64 - Wd.sh);
+    }
+}
+// The component of the seed (row r0 = the component's top row, column c) if it fits the window: true, comp = its rows in window
+// coordinates.  false: it reaches a window edge beyond which the map goes on.
+__device__ __forceinline__ bool big_window_component(const uint64_t* pass, const BigGeom& G, const BigWindow& Wd, int c, int lane, uint64_t& comp) {
+    DevGroup<64, uint64_t> g;
+    const uint64_t pw = big_window_load(pass, G, Wd, lane);
+    const PcgFillCtx<DevGroup<64, uint64_t>> ctx = pcg_fill_ctx(g, pw);
+    const uint64_t seed = lane == 0 ? 1ull << (c - Wd.cw0) : 0ull;
+    comp = pcg_component(g, seed, ctx);
+    const bool out_l = Wd.cw0 > 0 && (comp & 1ull) != 0ull, out_r = Wd.cw0 + 64 < G.W && (comp >> 63) != 0ull;
+    const bool out_b = lane == 63 && Wd.r0 + 64 < G.H && comp != 0ull;
+    return __ballot(out_l || out_r || out_b) == 0ull;
+}
+
 // helper.py:197-207 calc_num_regions + :250-264 calc_longest_path over `pass`.  rest, comp, X, Y, Z: scratch masks (comp must be
 // all zero on entry and is on return; Y, Z only for want_path).  want_path = false: regions only (zelda and the search problems).
 // champ (may be null; NW words): receives the rows of a champion component -- one whose double sweep gave the returned path -- or
@@ -179,6 +241,7 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
                                                  const BigGeom& G, int lane, bool want_path, int& regions, int& path, uint64_t* champ = nullptr,
                                                  int* has_champ = nullptr) {
     regions = 0; path = 0;
+    const unsigned long long bp_t0 = BP_NOW();
     int c_lo = 0, c_hi = 0;                                    // words of the current champion in `champ`
     if (champ) big_zero(champ, 0, G.NW, lane);
     if (has_champ) *has_champ = 0;
@@ -226,21 +289,58 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
     regions = n_iso + (n_dom >> 1) + n_tri;
     path = n_tri > 0 ? 2 : (n_dom > 0 ? 1 : 0);
     big_sync();
+    BP_ADD(0, BP_NOW() - bp_t0); BP_ADD(8, 1); BP_ADD(9, regions);
     int from = 0;
     for (;;) {
+        const unsigned long long bp_t1 = BP_NOW();
         int b0 = 0;
         const int i0 = big_first(rest, nullptr, from, G.NW, lane, b0);
         if (i0 < 0) break;
         from = i0;
         int r0 = big_row(G, i0), r1 = r0;
+        {   // the component in a 64 x 64 window, in registers (the seed is the first cell of `rest` in row-major order: its top row)
+            const int c0 = 64 * (i0 - r0 * G.KW) + b0;
+            const BigWindow Wd = big_window_at(G, r0, c0);
+            uint64_t cw;
+            if (big_window_component(pass, G, Wd, c0, lane, cw)) {
+                DevGroup<64, uint64_t> g;
+                ++regions;
+                BP_ADD(1, BP_NOW() - bp_t1); BP_ADD(5, 1);
+                const unsigned long long bp_t2 = BP_NOW();
+                if (want_path) {
+                    const int size = g.popcount_sum(cw);
+                    if (size - 1 > path) {
+                        BP_ADD(6, 1);
+                        const int e2 = pcg_double_sweep(g, cw, path);           // 0: the first sweep says it cannot beat `path`
+                        if (e2 > path) {
+                            path = e2;
+                            if (champ) {
+                                for (int i = c_lo + lane; i < c_hi; i += 64) champ[i] = 0ull;
+                                big_sync();
+                                big_window_store<false>(champ, G, Wd, lane, cw);
+                                c_lo = r0 * G.KW; c_hi = (r0 + 64 < G.H ? r0 + 64 : G.H) * G.KW;
+                                if (has_champ) *has_champ = 1;
+                            }
+                        }
+                    }
+                }
+                BP_ADD(2, BP_NOW() - bp_t2);
+                big_window_store<true>(rest, G, Wd, lane, cw);
+                big_sync();
+                continue;
+            }
+        }
         if (lane == 0) comp[i0] = 1ull << b0;
         big_sync();
         big_fill(comp, pass, G, lane, r0, r1);
         const int lo = r0 * G.KW, hi = (r1 + 1) * G.KW;
         ++regions;
+        BP_ADD(1, BP_NOW() - bp_t1); BP_ADD(5, 1);
+        const unsigned long long bp_t2 = BP_NOW();
         if (want_path) {
             const int size = big_popcount(comp, lo, hi, lane);
             if (size - 1 > path) {
+                BP_ADD(6, 1);
                 // the first cell of the component in row-major order is the seed itself (rest only ever loses whole components)
                 int fa, fb;
                 const int e1 = big_bfs_levels(comp, i0, b0, G, r0, r1, X, Y, Z, lane, fa, fb);
@@ -248,6 +348,7 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
                     int b1 = 0;
                     const int i1 = big_first(Y, nullptr, fa * G.KW, (fb + 1) * G.KW, lane, b1);       // np.argmax: first cell of the last frontier
                     const int e2 = big_bfs_levels(comp, i1, b1, G, r0, r1, X, Y, Z, lane, fa, fb);
+                    BP_ADD(7, 1); BP_ADD(10, e1 + e2);
                     if (e2 > path) {
                         path = e2;
                         if (champ) {
@@ -261,9 +362,11 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
                 }
             }
         }
+        BP_ADD(2, BP_NOW() - bp_t2);
         for (int i = lo + lane; i < hi; i += 64) { rest[i] &= ~comp[i]; comp[i] = 0ull; }
         big_sync();
     }
+    BP_ADD(3, BP_NOW() - bp_t0);
 }
 
 // helper.py:250-264 for ONE component `comp` (rows [r0, r1]): BFS from its first cell in row-major order, np.argmax = the first cell
@@ -438,7 +541,9 @@ __device__ __forceinline__ bool big_item_stats(const PcgrlParams& P, const DevBu
     uint64_t *a0 = ar, *a1 = ar + NW, *a2 = ar + 2 * NW, *a3 = ar + 3 * NW, *a4 = ar + 4 * NW, *a5 = ar + 5 * NW, *a6 = ar + 6 * NW;
     for (int k = 0; k < PCGRL_MAX_STATS; k++) s[k] = 0;
     if (PROB == PCGRL_PROB_BINARY) {
+        const unsigned long long bp_tp = BP_NOW();
         big_planes<1>(m, G, a0, a3, lane);                                  // a0 = solid
+        BP_ADD(4, BP_NOW() - bp_tp);
         for (int i = lane; i < NW; i += 64) {
             const int r = big_row(G, i), k = i - r * G.KW;
             a0[i] = ~a0[i] & (k == G.KW - 1 ? G.last : ~0ull);             // a0 = empty (binary_prob.py:82-86: passable = ["empty"])

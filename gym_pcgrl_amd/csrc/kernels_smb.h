@@ -435,13 +435,52 @@ __device__ __forceinline__ int smb_search_two_label(const SmbCols& C, int h, int
     return status;
 }
 
+// Which cells of the level did a search read?  Only expansions read it (smb_window), an expanded state (x, y, airTime) is exactly a
+// bit of the visited bitmap, and what its window reads depends on (x, y) alone: column x in the rows y - 1 .. y + 1, of column x + 1
+// the row y and -- when that cell is free, so that the player can move there -- the rows y - 1 and y + 1 (smb_child_win reads
+// nothing else).  So nothing is recorded while a search runs: afterwards lane l collects, for its columns l + 64 k, the rows with an
+// expanded state from the bitmap and widens them.  A level that differs from this one only in cells outside that set is searched
+// step for step the same way.  seenw: uint32 [W] of the environment (DevBufs::champ), bit y of word c = row y of map column c
+// (engine column c + 3) was read; `first`: the play-through's first search stores, the later ones add -- the set lives in memory, not
+// in registers across the searches (k_smb sits at its register limit).
+__device__ __noinline__ void smb_seen_accumulate(uint64_t c0, uint64_t c1, uint64_t c2, uint64_t c3, const uint32_t* visited, int h, int ew, int W, int lane,
+                                                 uint32_t* seenw, bool first) {
+    // (a real call, and one set of columns at a time: k_smb sits at its register limit and this runs once per search)
+    const int ky = h + SMB_YOFF + 1;
+    uint64_t prev63 = 0ull;                                             // the expanded rows of column 64 k - 1
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 4 && 64 * k < ew + 1; k++) {
+        const int x = 64 * k + lane;
+        uint64_t own = 0ull;
+        if (x < ew) {
+            for (int yy = 0; yy < ky; yy++) {                           // yy = y + SMB_YOFF
+                const int off = (x * ky + yy) * 5, w = off >> 5, sh = off & 31;
+                uint32_t v = visited[w] >> sh;
+                if (sh > 27) v |= visited[w + 1] << (32 - sh);
+                own |= (uint64_t)((v & 31u) != 0u) << yy;
+            }
+        }
+        // the expanded rows of the column to the left: lane l - 1, for lane 0 lane 63 of the previous set
+        uint64_t left = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)own, 1, 64) | ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(own >> 32), 1, 64) << 32);
+        if (lane == 0) left = prev63;
+        prev63 = smb_readlane64(own, 63);
+        const uint64_t col = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+        const uint64_t wide = own | (left & ~col), stayed = left & col;
+        const uint32_t rows = (uint32_t)((wide | (wide << 1) | (wide >> 1) | stayed) >> SMB_YOFF);
+        const int c = x - 3;
+        if (c >= 0 && c < W) seenw[c] = first ? rows : (seenw[c] | rows);
+    }
+}
+
 // SMBProblem.get_stats of one map (`m`: its tile bytes, in global memory or -- right after an in-kernel reset -- in LDS) by one
 // wavefront, and the end of the step / reset it belongs to (finalize_item).  Returns whether the episode ended (auto_reset).
 struct SmbWave {
     uint32_t* heap; uint32_t* visited; uint8_t* arena; int lds_heap_n, vis_words;
 };
+// keep_play (MODE_STEP, flagged by k_update): the change left every cell the last play-through read as it was -- its three results
+// are taken from the previous statistics and nothing is searched.
 __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, const SmbWave& S, int e, int mode, const uint8_t* m, int parity, int rst_list,
-                                        bool push_reset, int lane) {
+                                        bool push_reset, int lane, bool keep_play = false) {
     const int W = P.width, Hh = P.height, cells = W * Hh;
     const int ew = W + 6;
     const int exit_x = Hh > 3 ? W + 4 : -1;
@@ -470,6 +509,16 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
     for (int o = 32; o > 0; o >>= 1) {
         c_floor += __shfl_xor(c_floor, o, 64); c_tubes += __shfl_xor(c_tubes, o, 64); c_enemy += __shfl_xor(c_enemy, o, 64);
         c_empty += __shfl_xor(c_empty, o, 64); c_noise += __shfl_xor(c_noise, o, 64);
+    }
+    if (keep_play) {
+        int done = 0;
+        if (lane == 0) {
+            const int32_t* prev = B.stats + (size_t)e * 8;
+            int32_t s[PCGRL_MAX_STATS] = {c_floor, c_tubes, c_enemy, c_empty, c_noise, prev[5], prev[6], prev[7]};
+            done = finalize_item<PCGRL_PROB_SMB>(P, B, e, s, mode, parity, e & (WL_NSHARD - 1), push_reset, rst_list) ? 1 : 0;
+        }
+        __threadfence_block();
+        return __shfl(done, 0, 64) != 0;
     }
     // ---- the engine's grid (" # ## #": solid, brick, question and tube block) as column masks: lane l holds columns l + 64 k
     SmbCols C;
@@ -504,6 +553,13 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
     const int cap = S.lds_heap_n >= 2048 ? 4095 : S.lds_heap_n - 1;
     SmbResult res = {0, 0, 0, 0, 1, 0};
     int first_iters = 0;
+    // the cells the play-through reads (smb_seen_accumulate after every search; k_update: a change elsewhere keeps the play-through)
+#ifdef PCGRL_SMB_NO_SEEN     /* developer build (tools/smb_prof.py): the searches without the pass over the visited bitmap, for A/B timing */
+    uint32_t* const seenw = nullptr;
+#else
+    uint32_t* const seenw = B.champ != nullptr ? reinterpret_cast<uint32_t*>(B.champ) + (size_t)e * W : nullptr;
+#endif
+    bool seen_first = true;
 #pragma clang loop unroll(disable)
     for (int agent = 0; agent < 2 && !res.won; agent++) {
         for (int i = lane; i < S.vis_words; i += 64) S.visited[i] = 0;
@@ -517,6 +573,9 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
             if (status == 2) {
                 for (int i = lane; i < S.vis_words; i += 64) S.visited[i] = 0;
                 __threadfence_block();
+            } else if (seenw) {
+                smb_seen_accumulate(C.c0, C.c1, C.c2, C.c3, S.visited, Hh, ew, W, lane, seenw, seen_first);
+                seen_first = false;
             }
         }
         if (status == 2) {
@@ -529,6 +588,7 @@ __device__ __forceinline__ bool smb_job(const PcgrlParams& P, const DevBufs& B, 
             res.max_gap = __shfl(res.max_gap, 0, 64); res.x = __shfl(res.x, 0, 64); res.iters = __shfl(res.iters, 0, 64);
             SP_ADD(6, SP_NOW() - t0);
             __threadfence_block();
+            if (seenw) { smb_seen_accumulate(C.c0, C.c1, C.c2, C.c3, S.visited, Hh, ew, W, lane, seenw, seen_first); seen_first = false; }
         }
         if (agent == 0) first_iters = res.iters;
     }
@@ -581,7 +641,9 @@ __global__ __launch_bounds__(SMB_MAX_WAVES * 64) void k_smb(PcgrlParams P, DevBu
         if (t < n_p) { e = wl_get(B, list_pre, s_pref_p, t); mode = mode_a; }
         else if (t < n_a) { e = wl_get(B, list_a, s_pref_a, t - n_p); mode = mode_a; }
         else { e = wl_get(B, list_b, s_pref_b, t - n_a); mode = mode_b; }
-        const bool ended = smb_job(P, B, S, e, mode, B.map + (size_t)e * cells, parity, rst_list, !inline_reset, lane);
+        const bool keep_play = (e & SMB_KEEP_PLAY) != 0;       // (k_update: the play-through of the map before the change still holds)
+        e &= ~SMB_KEEP_PLAY;
+        const bool ended = smb_job(P, B, S, e, mode, B.map + (size_t)e * cells, parity, rst_list, !inline_reset, lane, keep_play);
         if (ended && inline_reset) {
             wave_reset_env<PCGRL_PROB_SMB>(P, B, e, gen_map, mt, tiles, lane);
             __builtin_amdgcn_wave_barrier();

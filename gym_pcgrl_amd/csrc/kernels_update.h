@@ -159,6 +159,15 @@ __device__ __forceinline__ UpdateOut update_env(const PcgrlParams& P, const DevB
                 touch_item = touch != 0 && s0.w != 0;         // s0.w = bound on the other components + 1, 0 = not known
                 inc_item = wl_inc_pack(G, e, wy, wx, tile == 0 ? 1u : 0u);
             }
+            if (P.prob == PCGRL_PROB_SMB && B.champ != nullptr) {
+                // smb: the play-through reads the level only as "blocked / free" (kernels_smb.h: solid, brick, question and tube block),
+                // and only in the cells its searches looked at (DevBufs::champ: a row mask per map column, written by k_smb).  A change
+                // that keeps the cell's kind, or a cell no search read, leaves jumps / jumps-dist / dist-win what they were.
+                const bool so = (0x5Au >> old) & 1u, sn = (0x5Au >> tile) & 1u;
+                const uint32_t seen = reinterpret_cast<const uint32_t*>(B.champ)[(size_t)e * W + wx];
+                cheap = so == sn || ((seen >> wy) & 1u) == 0u;
+                inc_item = e | SMB_KEEP_PLAY;
+            }
             if (B.zelda_inc) {
                 // zelda: what the write does to the cell's passability for the region count (zelda_prob.py:93: everything
                 // but solid = 1 and door = 4), so that k_stats can update the count instead of recounting
@@ -411,7 +420,9 @@ __global__ __launch_bounds__(PCGRL_BLOCK) void k_update(PcgrlParams P, DevBufs B
             return;
         }
         // smb: a level whose last play-through was long goes on the list k_smb starts with (WL_INC, which smb has no other use for)
-        if (P.prob == PCGRL_PROB_SMB && dest == 0 && B.sok_cnt[e] >= SMB_LONG_POPS) dest = 1;
+        // (an smb change that keeps the play-through -- `cheap`, update_env -- is a short job on the plain list, flagged)
+        if (P.prob == PCGRL_PROB_SMB && dest == 1) dest = 0;
+        else if (P.prob == PCGRL_PROB_SMB && dest == 0 && B.sok_cnt[e] >= SMB_LONG_POPS) dest = 1;
         block_append3(dest, v, B, parity, s_cnt, s_base);
     }
 }

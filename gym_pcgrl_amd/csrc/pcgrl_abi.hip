@@ -89,6 +89,9 @@
 
 // ------------------------------------------------------------------------------------------
 // Host side of the ABI
+#if PCGRL_IN_PART(PART_CORE)
+#include "step_pool.h"
+#endif
 struct BigArenaDims { int nblocks, nodes_cap, tsize, stride; size_t heap_off, table_off, block_bytes; };
 struct pcgrl_env {
     BigArenaDims big_dims;     // the general searches' arena as it was cut at pcgrl_bind (search_big.h)
@@ -247,7 +250,9 @@ static size_t sok_pool_nodes(int power, int prob = -1) {
 }
 static_assert(SS_SMALL_NODES >= 4 * SS_SMALL_POPS + 4, "a small-tier search pushes up to four nodes per pop");
 // rows of the champion component per environment (binary, maps of at most 16 x 32): the incremental statistics path
+// (smb: per map column the rows the last play-through read -- uint32 [N][W], kernels_smb.h -- for the representations that change one tile a step)
 static size_t champ_bytes(const pcgrl_config* c) {
+    if (c->prob == PCGRL_SMB) return (c->rep <= PCGRL_REP_TURTLE && c->num_envs < SMB_KEEP_PLAY) ? align_up((size_t)c->num_envs * c->width * 4, 256) : 0;
     if (c->prob != PCGRL_BINARY) return 0;
     if (big_map(c))      // maps beyond 64 x 64 (bigmap.h big_incremental): [H][KW] 64-bit words; the work item packs the cell into 8 + 8 bits and the environment into 15
         return (c->rep <= PCGRL_REP_TURTLE && c->width <= 256 && c->height <= 256 && c->num_envs <= WL_INCBIG_ENV_MASK + 1)
@@ -463,7 +468,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     B.champ = nullptr;
     if (champ_bytes(&h->cfg) && !no_inc) {
         B.champ = s + scratch_bytes_base(&h->cfg);
-        HIPCHK(hipMemsetAsync(B.champ, 0, champ_bytes(&h->cfg), (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(B.champ, h->cfg.prob == PCGRL_SMB ? 0xFF : 0, champ_bytes(&h->cfg), (hipStream_t)stream));   // (smb: "every cell read")
     }
     B.obs = ObsSpec{nullptr, 0, 0, 0, 0, 0, 0, 0};
     B.fifo = nullptr; B.fifo_tag = nullptr;
@@ -604,6 +609,20 @@ PCGRL_LOCAL int launch_search(pcgrl_env* h, int32_t* sync, int list_a, int mode_
 PCGRL_LOCAL int launch_smb(pcgrl_env* h, int32_t* sync, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, hipStream_t st, int inline_reset);
 PCGRL_LOCAL int launch_step_solver(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb);
 PCGRL_LOCAL int launch_search_async(pcgrl_env* h, int32_t* tickets, int list_a, int mode_a, int list_b, int mode_b, int parity, int rst_list, int clr, int budget, int resume, int small, hipStream_t st);
+// A launch with more than 64 KB of dynamic LDS needs the kernel's cap raised first.  That is a driver call (about a microsecond of
+// host time -- a fifth of what issuing a step costs), so it is made only when this process has not yet raised the cap of this kernel
+// on this device that far: the cap only ever grows, whatever mix of handles launches the kernel (benign race: two threads may both set it).
+template <auto KFN>
+static int lds_cap(int device, size_t lds) {
+    static size_t cap[64];
+    if (lds <= 64 * 1024) return PCGRL_OK;
+    const int d = device & 63;
+    if (lds > cap[d]) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(KFN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cap[d] = lds;
+    }
+    return PCGRL_OK;
+}
 static int grid_for(int items, int per_block, int cap) {
     int g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -665,7 +684,7 @@ static int launch_big_p(pcgrl_env* h, int list, int parity, int mode, int clr, i
     nw = nw > 4 ? 4 : nw;
     if (nw < 1) return PCGRL_EINVAL;
     const size_t lds = (size_t)nw * per_wave;
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_big<PROB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int rc = lds_cap<k_big<PROB>>(h->device, lds); if (rc) return rc; }
     const int grid = grid_for(P.num_envs, nw, 2048);
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
     hipLaunchKernelGGL((k_big<PROB>), dim3(grid), dim3(nw * 64), lds, st, P, h->B, list, parity, mode, clr, inline_reset, gen, park_list);
@@ -748,7 +767,7 @@ static int launch_step_pme(pcgrl_env* h, const int32_t* actions, int parity, hip
     const int grid = (P.num_envs + EPB - 1) / EPB;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
 #define PCGRL_LAUNCH_STEP(REPV, MULTI) do { \
-        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<PROB, REPV, MaskT, MULTI, EPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        { const int rca = lds_cap<k_step<PROB, REPV, MaskT, MULTI, EPB>>(h->device, lds); if (rca) return rca; } \
         hipLaunchKernelGGL((k_step<PROB, REPV, MaskT, MULTI, EPB>), dim3(grid), dim3(EPB * 4), lds, st, P, h->B, actions, \
                            parity, gen, R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); } while (0)
     const bool multi = R.steps > 1 || R.reward_out || R.done_out || R.info_out;
@@ -951,7 +970,7 @@ static bool solver_rollout_applies(const pcgrl_env* h, int* envs_per_block) {
 template <int PROB, int REP, class MaskT>
 static int launch_step_solver_t(pcgrl_env* h, const int32_t* actions, hipStream_t st, const RolloutArgs& R, int epb) {
     const size_t lds = (size_t)(SOK_LDS_HEAP + 2 * SOK_LDS_TABLE) * 4;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_solver<PROB, REP, MaskT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int rca = lds_cap<k_step_solver<PROB, REP, MaskT>>(h->device, lds); if (rca) return rca; }
     const int grid = (h->P.num_envs + epb - 1) / epb;
     const int gen = (h->P.random_start || !h->has_old) ? 1 : 0;
     hipLaunchKernelGGL((k_step_solver<PROB, REP, MaskT>), dim3(grid), dim3(SS_THREADS), lds, st, h->P, h->B, actions, gen, R.steps, R.action_stride, epb,
@@ -1243,14 +1262,47 @@ int pcgrl_step(pcgrl_env* h, const int32_t* actions, void* stream) {
 // pcgrl_step on `count` handles (the shards of one batch: one per GPU of a node, or several on one GPU) in ONE call: step k is issued
 // on every handle -- its device made current, on its own stream -- before the call returns; nothing is waited for.  A host thread
 // that drives eight GPUs pays one foreign-function call per step instead of eight (node.MultiGpuPcgrlEnv; SURVEY 8e: the scaling
-// risk of a 28 us step is host launch latency).  Returns the first error (the handles before it have been stepped).
+// risk of a 28 us step is host launch latency).  The handles are issued side by side by a pool of threads (step_pool.h).  Returns the
+// first error seen (every handle has been tried).
 int pcgrl_step_multi(pcgrl_env* const* envs, const int32_t* const* actions, void* const* streams, int32_t count) {
     if (!envs || !actions || !streams || count < 1) return PCGRL_EINVAL;
+    if (count > 1) {       // the handles side by side on the issuing threads (step_pool.h); pcgrl_step_threads(0): all of them here
+        StepPool* pool = StepPool::get(count);
+        if (pool) return pool->step(&pcgrl_step, envs, actions, streams, count);
+    }
     for (int i = 0; i < count; i++) {
         const int rc = pcgrl_step(envs[i], actions[i], streams[i]);
         if (rc) return rc;
     }
     return PCGRL_OK;
+}
+
+// How many issuing threads pcgrl_step_multi uses besides the caller's: n >= 0 sets it (0: none; at most 7; only before the first
+// multi-handle call has made them), n < 0 only asks.  Returns the number in effect.
+int32_t pcgrl_step_threads(int32_t n) {
+    int eff = 0;
+    StepPool::get(0, n, &eff);
+    return eff;
+}
+
+// pcgrl_selftest_step_pool: the issuing threads of pcgrl_step_multi without a GPU -- `calls` calls of `count` stand-in handles; hits[i]
+// counts how often stand-in i was stepped (the stand-in whose index is fail_at reports PCGRL_EINVAL).  Returns how many calls
+// returned an error, -1 when the pool is switched off.
+static int selftest_pool_fn(pcgrl_env* e, const int32_t* a, void*) {
+    int32_t* hit = reinterpret_cast<int32_t*>(e);
+    __atomic_fetch_add(hit, 1, __ATOMIC_RELAXED);
+    return a ? PCGRL_EINVAL : PCGRL_OK;
+}
+int pcgrl_selftest_step_pool(int32_t count, int32_t calls, int32_t fail_at, int32_t* hits) {
+    if (count < 2 || count > 64 || calls < 1 || !hits) return PCGRL_EINVAL;
+    StepPool* pool = StepPool::get(count);
+    if (!pool) return -1;
+    pcgrl_env* envs[64]; const int32_t* acts[64]; void* streams[64];
+    static const int32_t marker = 0;
+    for (int i = 0; i < count; i++) { envs[i] = reinterpret_cast<pcgrl_env*>(hits + i); acts[i] = i == fail_at ? &marker : nullptr; streams[i] = nullptr; }
+    int failed = 0;
+    for (int c = 0; c < calls; c++) failed += pool->step(&selftest_pool_fn, envs, acts, streams, count) != PCGRL_OK;
+    return failed;
 }
 
 // ActionMap.step + PcgrlEnv.step: where the fused step kernel applies the flat indices are decoded by its update wavefronts (one launch
@@ -1430,7 +1482,7 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     return PCGRL_OK;
 }
 
-#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF)
+#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF) || defined(PCGRL_BIG_PROF)
 // debug build only (tools/timeline.py, tools/smb_prof.py): where the kernels write their timeline marks (NULL: off)
 int pcgrl_debug_timeline(void* buf) {
     unsigned long long* p = (unsigned long long*)buf;

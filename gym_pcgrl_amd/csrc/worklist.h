@@ -45,10 +45,11 @@ template <int G> __device__ __forceinline__ unsigned wl_inc_code(int raw) { retu
 // An item of the changed list with this bit set is an unchanged environment whose episode ended (iteration cap):
 // k_stats resets it without recomputing anything.
 #define WL_RESET_ONLY (1 << 30)
+#define SMB_KEEP_PLAY (1 << 29)    /* smb, changed list: the change cannot alter the play-through (k_update), k_smb keeps the previous one */
 
 // Optional in-kernel timeline (tools/timeline.py builds a copy of the library with -DPCGRL_TIMELINE; the product is
 // compiled without it and TL() is nothing): wavefront-private slots, 100 MHz wall clock << 8 | tag.
-#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF)
+#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF) || defined(PCGRL_BIG_PROF)
 __device__ unsigned long long* g_tl_buf;
 #endif
 #ifdef PCGRL_TIMELINE
@@ -77,6 +78,7 @@ struct ObsSpec { uint8_t* out; int32_t oh, ow, depth, centered, pad;
 struct DevBufs {
     uint8_t* map; uint8_t* old_map; uint16_t* heat; uint8_t* pos; void* planes;
     void* champ;                     // mask [N][16]: rows of the champion component (binary, 16-row maps); stats[e][2] = it is valid
+                                     // smb: uint32 [N][W], per map column the rows its last play-through read (kernels_smb.h)
     int32_t* wide_sync;              // tall binary maps (k_stats_wide): i32 [N][4] = {epoch: planes read, epoch: result there, regions | path << 16, claim} --
     int32_t wide_spin;               //   sleeps the odd block of a certain reset waits for the even one before it takes the old half over (pcgrl_tuning wide_spin)
     int32_t wide_few;                //   (regions up to which a tall map counts as "few regions": WL_WIDE_FEW_REGIONS, PCGRL_WIDE_FEW for experiments)

@@ -89,6 +89,7 @@ class MultiGpuPcgrlEnv:
         self._pinned = {}
         self._flip = 0                 # which of the two pinned sets the current call fills (gather="host")
         self._pending = None
+        self._abufs = None             # action_buffers()
 
     # ------------------------------------------------------------------ the surface of BatchedPcgrlEnv
     def __getattr__(self, name):          # spaces, get_border_tile, get_num_tiles, _prob, _rep, _max_changes ...: the same on every shard
@@ -186,7 +187,7 @@ class MultiGpuPcgrlEnv:
             decode = sh._prob.decode_rows if sh._prob.packed_rows else None
             res.append((sh._obs(), b["reward"], b["done"].view(self._torch.bool), InfoBatch(sh._prob.info_keys, b["info"], sh._max_iterations, sh._max_changes, decode)))
         self._multi = dict(lib=self.shards[0]._lib, n=G, handles=VP(*[sh._handle.value for sh in self.shards]), actions=VP(),
-                           streams=VP(*[st.cuda_stream for st in self.streams]), res=res,
+                           streams=VP(*[st.cuda_stream for st in self.streams]), res=res, bound=None,
                            out=(self._obs([r[0] for r in res]), ShardedTensor([r[1] for r in res]), ShardedTensor([r[2] for r in res]), [r[3] for r in res]))
 
     def step(self, actions):
@@ -195,23 +196,28 @@ class MultiGpuPcgrlEnv:
         node is stepped by one call of the library (pcgrl_step_multi) and the call performs no host synchronisation."""
         self._flip ^= 1
         torch = self._torch
-        if self.gather == "list" and not any(sh.strict_actions or sh._needs_reset for sh in self.shards):
-            if self._multi is None:
-                self._prepare_multi()
+        M = self._multi
+        if M is None and self.gather == "list" and not any(sh.strict_actions or sh._needs_reset for sh in self.shards):
+            self._prepare_multi()              # (dropped again by reset() / adjust_param(): the shards are then looked at anew)
             M = self._multi
-            i32 = torch.int32
-            if isinstance(actions, (list, tuple)) and len(actions) == M["n"] and all(a.dtype is i32 and a.is_contiguous() for a in actions):
-                acts = actions                 # per-shard int32 tensors on their devices, as a per-shard policy produces them: taken as they are
-            else:
-                acts = [sh._as_actions(p) for sh, p in zip(self.shards, self.split(actions))]
-            self._last_actions = acts          # keep the buffers alive until the launches are done
-            for g, a in enumerate(acts):
-                M["actions"][g] = a.data_ptr()
+        if M is not None:
+            if actions is not M["bound"]:      # (action_buffers(): the pointers are in place already -- nothing to look at per call)
+                i32 = torch.int32
+                if isinstance(actions, (list, tuple)) and len(actions) == M["n"] and all(a.dtype is i32 and a.is_contiguous() for a in actions):
+                    acts = actions             # per-shard int32 tensors on their devices, as a per-shard policy produces them: taken as they are
+                else:
+                    acts = [sh._as_actions(p) for sh, p in zip(self.shards, self.split(actions))]
+                self._last_actions = acts      # keep the buffers alive until the launches are done
+                for g, a in enumerate(acts):
+                    M["actions"][g] = a.data_ptr()
+                M["bound"] = actions if (actions is self._abufs and acts is actions) else None
             if self.sync_streams:
                 for g, st in enumerate(self.streams):
                     st.wait_stream(torch.cuda.current_stream(self.devices[g]))
-            from . import _lib
-            _lib.check(M["lib"].pcgrl_step_multi(M["handles"], M["actions"], M["streams"], M["n"]), "pcgrl_step_multi")
+            rc = M["lib"].pcgrl_step_multi(M["handles"], M["actions"], M["streams"], M["n"])
+            if rc:
+                from . import _lib
+                _lib.check(rc, "pcgrl_step_multi")
             if self.sync_streams:
                 for g, st in enumerate(self.streams):
                     torch.cuda.current_stream(self.devices[g]).wait_stream(st)
@@ -222,6 +228,18 @@ class MultiGpuPcgrlEnv:
                self._collect("done", [r[2] for r in res]), [r[3] for r in res])
         self._finish()
         return out
+
+    def action_buffers(self):
+        """The driver's own per-shard action tensors (int32, [n_g] or [n_g, k] on the shard's device), for policies that write their
+        actions in place (`torch.argmax(logits, 1, out=...)`, `buf.copy_(a)`): `step(env.action_buffers())` recognises the list by
+        identity and issues the step without looking at the tensors -- the host cost of a step is then the one library call."""
+        if self._abufs is None:
+            torch = self._torch
+            self._abufs = []
+            for g, sh in enumerate(self.shards):
+                k = sh._rep.action_width()
+                self._abufs.append(torch.zeros((sh.num_envs,) if k == 1 else (sh.num_envs, k), dtype=torch.int32, device=self.devices[g]))
+        return self._abufs
 
     def enable_async(self, nslots=1024):
         """BatchedPcgrlEnv.enable_async on every shard (`nslots` suspended searches per shard)."""

@@ -38,7 +38,7 @@ extern "C" {
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
  *    clamped actions.  10: + pcgrl_tuning / pcgrl_set_tuning (the library reads no environment variables any more); pcgrl_config
  *    grew (prob_width, prob_height); maps up to 255 x 255, search levels up to 4096 bordered cells, solver_power up to 1 000 000. */
-#define PCGRL_ABI_VERSION 11
+#define PCGRL_ABI_VERSION 12
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -172,8 +172,14 @@ int pcgrl_step(pcgrl_env* env, const int32_t* actions, void* stream);
 /* pcgrl_step on `count` handles in one call -- the shards of one batch of environments, one handle per GPU of a node (or several
  * on one GPU), each with its own stream: envs / actions / streams are HOST arrays of `count` entries.  Step k is issued on every
  * handle before the call returns and nothing is waited for; what SubprocVecEnv.step_async does for the reference's worker
- * processes (utils.py:60-71), as one foreign-function call per step of the whole node.  Returns the first error. */
+ * processes (utils.py:60-71), as one foreign-function call per step of the whole node.  The handles are issued side by side by a
+ * small pool of host threads inside the library (one handle each; pcgrl_step_threads(0) beforehand: all on the calling thread);
+ * every handle is tried, the first error seen is returned.  One call at a time per process (calls take turns). */
 int pcgrl_step_multi(pcgrl_env* const* envs, const int32_t* const* actions, void* const* streams, int32_t count);
+/* The issuing threads of pcgrl_step_multi besides the caller's (process-wide; default 7 = a thread per GPU of an eight-GPU node):
+ * n >= 0 sets the number -- only until the first multi-handle call has started them --, n < 0 only asks.  Returns the number in
+ * effect.  No reference counterpart (its SubprocVecEnv has a process per environment, utils.py:60-71). */
+int32_t pcgrl_step_threads(int32_t n);
 /* `steps` consecutive pcgrl_step calls on a tape of actions (a random-action rollout as in the reference's README
  * loop `env.step(env.action_space.sample())`, a recorded episode, an evaluation run): actions DEVICE i32
  * [steps, N(, k)] laid out like `steps` action arrays of pcgrl_step one after the other.  Optional DEVICE outputs, one
@@ -251,6 +257,10 @@ int pcgrl_bind_episode_stats(pcgrl_env* env, double* ep_return, int32_t* ep_leng
  * u32 [16384] and n_out DEVICE i32 [1]: the heap array afterwards.  At most 16 384 entries are kept (further pushes are dropped).
  * tests/test_gpu_parity.py holds the result against Python's heapq slot for slot. */
 int pcgrl_selftest_heap(const uint32_t* ops, int32_t n_ops, uint32_t* pops, uint32_t* heap_out, int32_t* n_out, void* stream);
+/* Test hook, no reference counterpart, no GPU needed: the issuing threads of pcgrl_step_multi driven with `count` (2..64) stand-in
+ * handles for `calls` calls; hits HOST i32 [count] is incremented once per stand-in and call, stand-in `fail_at` (-1: none) reports an
+ * error.  Returns the number of calls that returned an error, -1 when the pool is switched off (pcgrl_step_threads(0)). */
+int pcgrl_selftest_step_pool(int32_t count, int32_t calls, int32_t fail_at, int32_t* hits);
 /* Sticky device status word, 0 = fine.  Bit 0 (1): a level was outside a search kernel's limits -- a Sokoban level with more crates
  * than the search takes (32 in the compact searches, 256 in the general ones of csrc/search_big.h), or more than 255 tiles / collected
  * things of one kind in a packed statistics row (Dave, MiniDungeons on large maps): the statistics of that level are then not exact.

@@ -107,3 +107,42 @@ def test_sizes_the_library_takes_and_refuses():
     with pytest.raises(ValueError):
         env.adjust_param(change_percentage=0.9)           # max_changes 72 000 > 65 535
     env.close()
+
+
+@pytest.mark.parametrize("rep,calls", [("narrow", ()), ("turtle", ()), ("wide", (dict(width=40, height=12), dict(probs={"empty": 0.5, "solid": 0.35, "brick": 0.08})))])
+def test_smb_kept_play_throughs_change_nothing(rep, calls):
+    """smb: a change that keeps the cell blocked / free, or a cell the last play-through never read, keeps jumps / jumps-dist /
+    dist-win without a search (k_update flags the job, k_smb takes the three from the previous statistics).  Against the same batch
+    with the shortcut off (tuning no_inc: every change is played through), and the first environments against the oracle."""
+    import torch
+    from gym_pcgrl_amd.envs import BatchedPcgrlEnv
+    n, T, seed = 1536, 50, 90
+    a_env = BatchedPcgrlEnv(prob="smb", rep=rep, num_envs=n, seed=seed)
+    b_env = BatchedPcgrlEnv(prob="smb", rep=rep, num_envs=n, seed=seed, tuning={"no_inc": 1})
+    for kw in calls:
+        a_env.adjust_param(**kw); b_env.adjust_param(**kw)
+    oa = a_env.reset(); ob = b_env.reset()
+    assert torch.equal(oa["map"], ob["map"])
+    sp = a_env.single_action_space
+    rs = np.random.RandomState(4)
+    n_or = 6
+    orc = []
+    for i in range(n_or):
+        o = ol.OracleEnv("smb", rep)
+        for kw in calls:
+            o.adjust_param(**kw)
+        o.seed(seed + i); o.reset()
+        orc.append(o)
+    keys = a_env._prob.info_keys
+    for t in range(T):
+        a = rs.randint(0, sp.n, size=n).astype(np.int32) if hasattr(sp, "n") else np.stack([rs.randint(0, int(k), size=n) for k in sp.nvec], -1).astype(np.int32)
+        o1, r1, d1, i1 = a_env.step(a)
+        o2, r2, d2, i2 = b_env.step(a)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(i1.table, i2.table) and torch.equal(o1["map"], o2["map"]), t
+        rr, dd, tab = r1.cpu().numpy(), d1.cpu().numpy(), i1.table.cpu().numpy()
+        for i, o in enumerate(orc):
+            _, er, ed, einf = o.step(a[i])
+            assert er == rr[i] and ed == bool(dd[i]) and [einf[k] for k in keys] == [int(v) for v in tab[i, :len(keys)]], (t, i)
+            if ed:
+                o.reset()
+    a_env.close(); b_env.close()

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_lib.EXPORTS) == declared
-    assert L.pcgrl_abi_version() == _lib.ABI_VERSION == 11
+    assert L.pcgrl_abi_version() == _lib.ABI_VERSION == 12
     assert L.pcgrl_error_string(-1).decode().startswith("invalid")
 
 
@@ -420,3 +420,23 @@ def test_node_driver_host_logic():
         MultiGpuPcgrlEnv("binary", "narrow", num_envs=8, devices=["cpu", "cpu"])
     with pytest.raises(ValueError):
         MultiGpuPcgrlEnv("binary", "narrow", num_envs=8, devices=[])
+
+
+def test_step_pool_steps_every_handle_once_per_call_and_reports_errors():
+    """pcgrl_step_multi's issuing threads (csrc/step_pool.h), without a GPU: stand-in handles count how often they are stepped."""
+    from gym_pcgrl_amd import _lib
+    L = _lib.load()
+    assert L.pcgrl_step_threads(-1) == 7
+    for count in (2, 8, 13, 64):          # (the pool grows from one worker to seven)
+        hits = np.zeros(count, np.int32)
+        rc = L.pcgrl_selftest_step_pool(count, 500, -1, hits.ctypes.data_as(C.c_void_p))
+        assert rc != -1
+        assert rc == 0 and (hits == 500).all(), (count, rc, hits)
+    hits = np.zeros(8, np.int32)
+    assert L.pcgrl_selftest_step_pool(8, 100, 5, hits.ctypes.data_as(C.c_void_p)) == 100 and (hits == 100).all()
+    # after a pause the workers sleep; they have to wake up again
+    import time
+    time.sleep(0.05)
+    hits = np.zeros(8, np.int32)
+    assert L.pcgrl_selftest_step_pool(8, 3, -1, hits.ctypes.data_as(C.c_void_p)) == 0 and (hits == 3).all()
+    assert L.pcgrl_step_threads(0) == 7          # (the threads exist: the number stays)

@@ -18,7 +18,14 @@ class _Prob:
     decode_rows = None
 
 
+class _Rep:
+    def action_width(self):
+        return 1
+
+
 class _Shard:
+    _rep = _Rep()
+
     def __init__(self, i, n, lib):
         self._handle = C.c_void_p(1000 + i)
         self._lib = lib
@@ -71,7 +78,7 @@ def _driver(G, n, sync_streams, log, lib):
     env.shards = [_Shard(g, n, lib) for g in range(G)]
     env.streams = [_Stream(g, log) for g in range(G)]
     env.sync_streams = sync_streams
-    env._multi, env._pinned, env._flip, env._pending = None, {}, 0, None
+    env._multi, env._pinned, env._flip, env._pending, env._abufs = None, {}, 0, None, None
     return env
 
 
@@ -99,6 +106,33 @@ def test_list_gather_step_is_one_library_call_and_never_synchronises(monkeypatch
     assert out2 is out1 and isinstance(rew, node.ShardedTensor) and len(rew) == G * n and done[3].dtype == torch.bool
     assert obs["map"][2] is env.shards[2]._map and infos[5].table is env.shards[5]._bufs["info"]
     env.shards = []          # (nothing to close)
+
+
+def test_action_buffers_are_stepped_without_looking_at_them(monkeypatch):
+    """step(env.action_buffers()): after the first call the pointers are in place; the call touches no tensor at all."""
+    G, n = 8, 4
+    log, lib = [], _Lib()
+    env = _driver(G, n, False, log, lib)
+    bufs = env.action_buffers()
+    assert len(bufs) == G and all(b.dtype == torch.int32 and tuple(b.shape) == (n,) for b in bufs) and env.action_buffers() is bufs
+    env.step(bufs)
+    want = [b.data_ptr() for b in bufs]
+
+    def boom(*a, **k):
+        raise AssertionError("the bound action buffers were inspected")
+
+    for name in ("data_ptr", "is_contiguous", "to", "contiguous"):
+        monkeypatch.setattr(torch.Tensor, name, boom)
+    bufs[3].fill_(2)
+    env.step(bufs)
+    assert len(lib.calls) == 2 and lib.calls[1][1] == want
+    monkeypatch.undo()
+    other = [torch.ones(n, dtype=torch.int32) for _ in range(G)]          # any other list: looked at again, and the binding is dropped
+    env.step(other)
+    assert lib.calls[2][1] == [a.data_ptr() for a in other] and env._multi["bound"] is None
+    env.step(bufs)
+    assert lib.calls[3][1] == want and env._multi["bound"] is bufs
+    env.shards = []
 
 
 def test_sync_streams_orders_each_shard_stream_against_the_callers(monkeypatch):

@@ -8,8 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gym_pcgrl_amd import _lib
 import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
-so = "/tmp/libpcgrl_hip_smbprof.so"
-subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + _lib.HIPCC_FLAGS + ["-DPCGRL_SMB_PROF"] + _lib.SOURCES + ["-o", so])
+# PCGRL_SMB_PROF_FLAGS: extra -D switches for an A/B build; a library built ahead (`smb_prof.py build`, on the CPU box) travels with the tree
+extra = os.environ.get("PCGRL_SMB_PROF_FLAGS", "").split()
+so = os.path.join(ROOT, "tools", "probe", "libpcgrl_hip_smbprof%s.so" % "".join(f.replace("-D", "_") for f in extra))
+if not os.path.exists(so) or (len(sys.argv) > 1 and sys.argv[1] == "build"):
+    subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + _lib.HIPCC_FLAGS + ["-DPCGRL_SMB_PROF"] + extra + _lib.SOURCES + ["-o", so])
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        sys.exit(0)
 _lib.SO = so
 import torch
 import bench
