@@ -59,7 +59,8 @@ WORKLOADS = {
 WRAPPED = {"C2w": ("cropped", 28), "C3w": ("actionmap", None)}
 # legs of the default run besides the headline workload: every BASELINE.json config (and smb, and the wrapped steps) gets a
 # driver-timed figure.  (steps, warmup, steady warm-up) are sized so that the whole default run stays well under a minute of GPU time.
-LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 45), "C2w": (20, 5, 800), "C3w": (20, 5, 800)}
+LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 45), "C2w": (20, 5, 800), "C3w": (20, 5, 800),
+        "B1": (50, 10, 7000)}       # (B1: an episode is ~6 000 steps long -- max_changes 2 000, a third of the random actions change a tile)
 # asynchronous ticks of the search problems (pcgrl_step_async): (workload, ticks, warm-up ticks, pop budget per search and tick)
 ASYNC_LEGS = {"C4_async": ("C4", 300, 60, 64), "M1_async": ("M1", 300, 60, 64), "D1_async": ("D1", 300, 60, 64)}
 GPU_CLOCK_HZ = 2.4e9     # MI355X engine clock (MI355X_MICROARCH.md), for the cycles-per-pop figures
@@ -484,7 +485,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="process plumbing only (launcher, rendezvous, barrier, max-over-ranks reduction over gloo); "
                                                           "no GPU, no environment: the line carries value null and dry_run true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short legs of the other configs (the `configs` object of the default line)")
-    ap.add_argument("--legs", default="C3,C4,C4_async,M1_async,C5,S1,C2w,C3w,n1_facade,collector,node_driver", help="which legs the default line carries")
+    ap.add_argument("--legs", default="C3,C4,C4_async,M1_async,C5,S1,B1,C2w,C3w,n1_facade,collector,node_driver", help="which legs the default line carries")
     ap.add_argument("--tuning", default="", help="developer switches of the library for A/B runs: field=value[,field=value...] "
                                                  "(include/pcgrl_hip.h pcgrl_tuning, e.g. no_fused=1,step_epb=128)")
     ap.add_argument("--steady-warmup", type=int, default=800, help="steps before the steady_state measurement (0: skip it)")

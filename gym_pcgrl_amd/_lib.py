@@ -34,7 +34,7 @@ class Layout(C.Structure):
 
 
 TUNING_FIELDS = ("no_fused", "fused_zelda", "step_epb", "no_inc", "inline_reset", "pair_min", "no_wide", "wide_waves", "wide_grid",
-                 "wide_pairs", "wide_few", "sok_generic", "sok_hard_cap", "sok_spawn", "md_only_agent", "smb_lds_heap", "full_per_wave", "inc_per_wave", "wide_spin", "step_prio", "no_touch", "touch_tight", "step_pair", "async_split")
+                 "wide_pairs", "wide_few", "sok_generic", "sok_hard_cap", "sok_spawn", "md_only_agent", "smb_lds_heap", "full_per_wave", "inc_per_wave", "wide_spin", "step_prio", "no_touch", "touch_tight", "step_pair", "async_split", "big_team")
 
 
 class Tuning(C.Structure):

@@ -211,8 +211,8 @@ __device__ __forceinline__ void big_window_store(uint64_t* a, const BigGeom& G, 
     const int row = Wd.r0 + lane;
     if (row >= G.H) return;
     const int i = row * G.KW + Wd.kx;
+    if (m == 0ull) return;            // (rows the component does not reach are not touched: they may be another wavefront's, bigmap_team.h)
     if (CLEAR) {
-        if (m == 0ull) return;
         a[i] &= ~(m << Wd.sh);
         if (Wd.sh != 0 && Wd.kx + 1 < G.KW) a[i + 1] &= ~(m >> (64 - Wd.sh));
     } else {
@@ -222,24 +222,64 @@ __device__ __forceinline__ void big_window_store(uint64_t* a, const BigGeom& G, 
 }
 // The component of the seed (row r0 = the component's top row, column c) if it fits the window: true, comp = its rows in window
 // coordinates.  false: it reaches a window edge beyond which the map goes on.
-__device__ __forceinline__ bool big_window_component(const uint64_t* pass, const BigGeom& G, const BigWindow& Wd, int c, int lane, uint64_t& comp) {
+// row_hi: the fill is confined to the rows below it (the row bands of the wavefronts that share a map: bigmap_team.h).
+// A component that leaves the window on one side only gets a second try with the window moved the other way as far as what was
+// filled allows (the seed is the component's top-left cell, not its middle: `Wd` is then the moved window).
+__device__ __forceinline__ bool big_window_fill(const uint64_t* pass, const BigGeom& G, const BigWindow& Wd, int c, int lane, uint64_t& comp, int row_hi,
+                                                bool& out_l, bool& out_r) {
     DevGroup<64, uint64_t> g;
-    const uint64_t pw = big_window_load(pass, G, Wd, lane);
-    const PcgFillCtx<DevGroup<64, uint64_t>> ctx = pcg_fill_ctx(g, pw);
-    const uint64_t seed = lane == 0 ? 1ull << (c - Wd.cw0) : 0ull;
-    comp = pcg_component(g, seed, ctx);
-    const bool out_l = Wd.cw0 > 0 && (comp & 1ull) != 0ull, out_r = Wd.cw0 + 64 < G.W && (comp >> 63) != 0ull;
-    const bool out_b = lane == 63 && Wd.r0 + 64 < G.H && comp != 0ull;
-    return __ballot(out_l || out_r || out_b) == 0ull;
+    const uint64_t pw = Wd.r0 + lane < row_hi ? big_window_load(pass, G, Wd, lane) : 0ull;
+    uint64_t f = lane == 0 ? 1ull << (c - Wd.cw0) : 0ull;
+    // pcg_component for whole-wavefront groups: plain flood steps first (most components are small) -- and the constants of the run /
+    // column fills only for one that is still growing after eight of them
+    bool settled = false;
+    for (int i = 0; i < 4 && !settled; i++) {
+        uint64_t n = pcg_expand(g, f) & pw;
+        n = pcg_expand(g, n) & pw;
+        settled = !g.wave_any(n ^ f);
+        f = n;
+    }
+    if (!settled) {
+        const PcgFillCtx<DevGroup<64, uint64_t>> ctx = pcg_fill_ctx(g, pw);
+        f = pcg_component_fills(g, f, ctx);
+    }
+    comp = f;
+    out_l = __ballot(Wd.cw0 > 0 && (comp & 1ull) != 0ull) != 0ull;
+    out_r = __ballot(Wd.cw0 + 64 < G.W && (comp >> 63) != 0ull) != 0ull;
+    const bool out_b = lane == 63 && Wd.r0 + 64 < (row_hi < G.H ? row_hi : G.H) && comp != 0ull;
+    return __ballot(out_b) == 0ull && !out_l && !out_r;
+}
+__device__ __forceinline__ bool big_window_component(const uint64_t* pass, const BigGeom& G, BigWindow& Wd, int c, int lane, uint64_t& comp, int row_hi = 1 << 30) {
+    bool out_l, out_r;
+    if (big_window_fill(pass, G, Wd, c, lane, comp, row_hi, out_l, out_r)) return true;
+    if (out_l == out_r) return false;                          // both sides (or the bottom alone): too large for a window
+    int shift;                                                 // columns to move the window to the left (negative: to the right)
+    if (out_l) {
+        const int hi = -big_wave_min(comp ? (int)__builtin_clzll(comp) - 63 : 1);      // last column reached
+        shift = 62 - hi < Wd.cw0 ? 62 - hi : Wd.cw0;
+        if (shift <= 0) return false;
+    } else {
+        const int lo = big_wave_min(comp ? (int)__builtin_ctzll(comp) : 64);          // first column reached
+        const int cmax = G.W > 64 ? G.W - 64 : 0;
+        shift = -(lo - 1 < cmax - Wd.cw0 ? lo - 1 : cmax - Wd.cw0);
+        if (shift >= 0) return false;
+    }
+    const int cw0 = Wd.cw0 - shift;
+    Wd.cw0 = cw0; Wd.kx = cw0 >> 6; Wd.sh = cw0 & 63;
+    return big_window_fill(pass, G, Wd, c, lane, comp, row_hi, out_l, out_r);
 }
 
 // helper.py:197-207 calc_num_regions + :250-264 calc_longest_path over `pass`.  rest, comp, X, Y, Z: scratch masks (comp must be
 // all zero on entry and is on return; Y, Z only for want_path).  want_path = false: regions only (zelda and the search problems).
 // champ (may be null; NW words): receives the rows of a champion component -- one whose double sweep gave the returned path -- or
 // stays all zero when the path comes from the closed-form tiny components (has_champ says which): big_incremental builds on it.
+// cand (may be null; cand_cap words of scratch): the sweeps of the components that fit a window are put off until every component
+// has been counted and then made in order of size, largest first -- the answer is a maximum over the components, a component of k
+// cells cannot beat k - 1, and in row-major order a step's full recomputation swept eighteen components of a random 100 x 100 map
+// before the running maximum had grown (tools/probe/big_prof.py); after the largest one or two most of the others need no sweep.
 __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t* rest, uint64_t* comp, uint64_t* X, uint64_t* Y, uint64_t* Z,
                                                  const BigGeom& G, int lane, bool want_path, int& regions, int& path, uint64_t* champ = nullptr,
-                                                 int* has_champ = nullptr) {
+                                                 int* has_champ = nullptr, uint64_t* cand = nullptr, int cand_cap = 0) {
     regions = 0; path = 0;
     const unsigned long long bp_t0 = BP_NOW();
     int c_lo = 0, c_hi = 0;                                    // words of the current champion in `champ`
@@ -290,7 +330,7 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
     path = n_tri > 0 ? 2 : (n_dom > 0 ? 1 : 0);
     big_sync();
     BP_ADD(0, BP_NOW() - bp_t0); BP_ADD(8, 1); BP_ADD(9, regions);
-    int from = 0;
+    int from = 0, ncand = 0;
     for (;;) {
         const unsigned long long bp_t1 = BP_NOW();
         int b0 = 0;
@@ -300,7 +340,7 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
         int r0 = big_row(G, i0), r1 = r0;
         {   // the component in a 64 x 64 window, in registers (the seed is the first cell of `rest` in row-major order: its top row)
             const int c0 = 64 * (i0 - r0 * G.KW) + b0;
-            const BigWindow Wd = big_window_at(G, r0, c0);
+            BigWindow Wd = big_window_at(G, r0, c0);
             uint64_t cw;
             if (big_window_component(pass, G, Wd, c0, lane, cw)) {
                 DevGroup<64, uint64_t> g;
@@ -309,7 +349,10 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
                 const unsigned long long bp_t2 = BP_NOW();
                 if (want_path) {
                     const int size = g.popcount_sum(cw);
-                    if (size - 1 > path) {
+                    if (size - 1 > path && ncand < cand_cap) {
+                        if (lane == 0) cand[ncand] = ((uint64_t)(uint32_t)size << 32) | ((uint64_t)(uint32_t)i0 << 8) | (uint64_t)(uint32_t)b0;
+                        ++ncand;
+                    } else if (size - 1 > path) {
                         BP_ADD(6, 1);
                         const int e2 = pcg_double_sweep(g, cw, path);           // 0: the first sweep says it cannot beat `path`
                         if (e2 > path) {
@@ -348,7 +391,7 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
                     int b1 = 0;
                     const int i1 = big_first(Y, nullptr, fa * G.KW, (fb + 1) * G.KW, lane, b1);       // np.argmax: first cell of the last frontier
                     const int e2 = big_bfs_levels(comp, i1, b1, G, r0, r1, X, Y, Z, lane, fa, fb);
-                    BP_ADD(7, 1); BP_ADD(10, e1 + e2);
+                    BP_ADD(10, e1 + e2);
                     if (e2 > path) {
                         path = e2;
                         if (champ) {
@@ -366,6 +409,41 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
         for (int i = lo + lane; i < hi; i += 64) { rest[i] &= ~comp[i]; comp[i] = 0ull; }
         big_sync();
     }
+    // the sweeps that were put off, largest component first, until the largest one left cannot beat the maximum
+    const unsigned long long bp_t3 = BP_NOW();
+    while (ncand > 0) {
+        big_sync();
+        uint64_t best = 0ull;
+        int at = -1;
+        for (int q = lane; q < ncand; q += 64) { const uint64_t v = cand[q]; if (v > best) { best = v; at = q; } }
+        // (largest size; among equals the entry with the larger word index -- any order is right, this one is fixed)
+        const int msize = -big_wave_min(-(int)(best >> 32));
+        if (msize - 1 <= path) break;
+        const uint32_t low = (int)(best >> 32) == msize ? (uint32_t)best : 0u;
+        const int mlow = -big_wave_min(-(int)low);                      // (word index << 8 | bit: below 2^31)
+        const uint64_t mine = __ballot((int)(best >> 32) == msize && (int)(uint32_t)best == mlow);
+        const int owner = __ffsll((unsigned long long)mine) - 1;
+        const int slot = __builtin_amdgcn_readlane(at, owner);
+        if (lane == 0) cand[slot] = 0ull;
+        const int i0 = mlow >> 8, b0 = mlow & 255, r0 = big_row(G, i0), c0 = 64 * (i0 - r0 * G.KW) + b0;
+        BigWindow Wd = big_window_at(G, r0, c0);
+        uint64_t cw;
+        big_window_component(pass, G, Wd, c0, lane, cw);                // (it fitted when it was counted)
+        DevGroup<64, uint64_t> g;
+        BP_ADD(6, 1);
+        const int e2 = pcg_double_sweep(g, cw, path);
+        if (e2 > path) {
+            path = e2;
+            if (champ) {
+                for (int i = c_lo + lane; i < c_hi; i += 64) champ[i] = 0ull;
+                big_sync();
+                big_window_store<false>(champ, G, Wd, lane, cw);
+                c_lo = r0 * G.KW; c_hi = (r0 + 64 < G.H ? r0 + 64 : G.H) * G.KW;
+                if (has_champ) *has_champ = 1;
+            }
+        }
+    }
+    BP_ADD(7, BP_NOW() - bp_t3);
     BP_ADD(3, BP_NOW() - bp_t0);
 }
 
@@ -481,12 +559,19 @@ __device__ __forceinline__ int big_bfs_dist(uint64_t* C, const uint64_t* dst, co
 template <int NPL>
 __device__ __forceinline__ void big_planes(const uint8_t* __restrict__ m, const BigGeom& G, uint64_t* pl, uint64_t* str, int lane) {
     const int cells = G.W * G.H, nch = (cells + 63) >> 6, sw = nch + 2;
-    for (int c0 = 0; c0 < nch; c0 += 8) {
-        uint8_t t[8];
+    // (thirty-two loads in flight per round: a round costs one trip to memory, and the map of a reset or of another wavefront's
+    //  change is not in any cache -- with eight, a 100 x 100 map took twenty trips, 40 us of a full recomputation's 500)
+    constexpr int U = 32;
+    for (int c0 = 0; c0 < nch; c0 += U) {
+        uint8_t t[U];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int c = (c0 + u) * 64 + lane; t[u] = c < cells ? m[c] : (uint8_t)0; }
+        for (int u = 0; u < U; u++) {      // (an unconditional load of a clamped index: a guarded one is a branch and a wait per load)
+            const int c = (c0 + u) * 64 + lane;
+            const uint8_t v = m[c < cells ? c : cells - 1];
+            t[u] = c < cells ? v : (uint8_t)0;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < U; u++) {
             if (c0 + u >= nch) break;          // wave-uniform
             const uint64_t q0 = __ballot(t[u] & 1), q1 = NPL > 1 ? __ballot(t[u] & 2) : 0ull, q2 = NPL > 1 ? __ballot(t[u] & 4) : 0ull;
             if (lane == 0) { str[c0 + u] = q0; if (NPL > 1) { str[sw + c0 + u] = q1; str[2 * sw + c0 + u] = q2; } }
@@ -551,7 +636,9 @@ __device__ __forceinline__ bool big_item_stats(const PcgrlParams& P, const DevBu
         }
         big_sync();
         int regions, path, has = 0;
-        big_regions_path(a0, a1, a2, a3, a4, a5, G, lane, true, regions, path, a6, &has);       // a6: the champion component (big_incremental)
+        // a6: the champion component (big_incremental); the list of put-off sweeps in the wavefront's MT19937 area, which only a
+        // reset uses (k_big: it sits right below the masks)
+        big_regions_path(a0, a1, a2, a3, a4, a5, G, lane, true, regions, path, a6, &has, ar - PCGRL_MT_N / 2, PCGRL_MT_N / 2);
         s[0] = regions; s[1] = path; s[2] = has;                             // s[2]: "there is a champion"
         return false;
     }

@@ -12,7 +12,7 @@
 //      MODE_SETMAP: statistics of every item of `list`
 // park_list: where maps that need the planner go (the search problems; finish_or_park).
 template <int PROB>
-__global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity, int inline_reset, int gen_map,
+__global__ __launch_bounds__(512) void k_big(PcgrlParams P, DevBufs B, int list, int parity, int mode, int clear_parity, int inline_reset, int gen_map,
                                             int park_list) {
     extern __shared__ __attribute__((aligned(16))) uint8_t big_lds[];
     __shared__ int s_pref[WL_NSHARD + 1], s_pref_rst[WL_NSHARD + 1], s_pref_inc[WL_NSHARD + 1];
@@ -32,7 +32,81 @@ __global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list,
     uint32_t* mt = reinterpret_cast<uint32_t*>(base);
     uint64_t* ar = reinterpret_cast<uint64_t*>(base + PCGRL_MT_N * 4);
     uint64_t* const champ_l = ar + 6 * G.NW;                      // the champion component in LDS (big_item_stats leaves it there: binary)
-    for (int item = blockIdx.x * nwv + wv; item < n_rst + n_chg + n_inc; item += gridDim.x * nwv) {
+    // binary: when a launch has no more full recomputations than blocks (a step: a few dozen among a thousand incremental updates, and
+    // it ends with the slowest of them) each is made by a whole block (bigmap_team.h), then the wavefronts go through the
+    // incremental items on their own.  A launch full of them (a reset of the batch, a representation without the incremental route)
+    // keeps a wavefront per map.
+    int first_item = blockIdx.x * nwv + wv, item_stride = gridDim.x * nwv;
+    if (PROB == PCGRL_PROB_BINARY && B.big_team && nwv >= 2 && nwv <= BIG_TEAM_MAX_WAVES && n_rst + n_chg <= (int)gridDim.x) {
+        __shared__ BigTeamShared s_team;
+        __shared__ int s_want;
+        const int n_full = n_rst + n_chg;
+        uint64_t* const ar0 = reinterpret_cast<uint64_t*>(big_lds + PCGRL_MT_N * 4);
+        uint64_t* const ar1 = reinterpret_cast<uint64_t*>(big_lds + big_wave_lds(W, H) + PCGRL_MT_N * 4);
+        uint64_t* const lists = reinterpret_cast<uint64_t*>(big_lds);
+        uint64_t* const champ0 = ar0 + 6 * G.NW;
+        uint32_t* const mt0 = reinterpret_cast<uint32_t*>(big_lds);
+        for (int item = blockIdx.x; item < n_full; item += gridDim.x) {
+            const bool lone = item < n_rst;
+            const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item) : wl_get(B, list, s_pref, item - n_rst);
+            const bool reset_only = (raw & WL_RESET_ONLY) != 0;
+            const int e = raw & ~WL_RESET_ONLY;
+            const int shard = (item >> 4) & (WL_NSHARD - 1);
+            const uint8_t* m = B.map + (size_t)e * cells;
+            uint64_t* const champ_g = B.champ ? reinterpret_cast<uint64_t*>(B.champ) + (size_t)e * G.NW : nullptr;
+            int32_t s[PCGRL_MAX_STATS];
+            for (int k = 0; k < PCGRL_MAX_STATS; k++) s[k] = 0;
+            // one pass of the statistics by the whole block; the champion's rows go to memory
+            auto team_stats = [&]() {
+                int regions, path, has;
+                big_team_binary(m, G, ar0, ar1, ar, lists, big_wave_lds(W, H) / 8, PCGRL_MT_N / 2, s_team, wv, nwv, lane, regions, path, has);
+                s[0] = regions; s[1] = path; s[2] = has;
+                if (champ_g && has) { for (int i = threadIdx.x; i < G.NW; i += blockDim.x) champ_g[i] = champ0[i]; }
+            };
+            int want = 0;
+            if (mode != MODE_STEP) {
+                if (mode == MODE_START) {
+                    if (wv == 0) { wave_reset_env<PROB>(P, B, e, gen_map, mt0, (uint8_t*)nullptr, lane); __threadfence(); }
+                    __syncthreads();
+                }
+                team_stats();
+                if (threadIdx.x == 0) finish_or_park<PROB>(P, B, e, s, false, mode, parity, shard, true, park_list);
+                __syncthreads();
+                continue;
+            }
+            if (lone) {
+                if (!reset_only) {
+                    int2 pre = make_int2(0, 0);
+                    if (threadIdx.x == 0) pre = reinterpret_cast<const int2*>(B.counters)[e];
+                    team_stats();
+                    if (threadIdx.x == 0) finalize_item<PROB>(P, B, e, s, MODE_STEP, parity, shard, false, WL_RST, &pre);
+                }
+                want = 1;
+            } else if (reset_only) {
+                want = 1;
+            } else {
+                team_stats();
+                if (threadIdx.x == 0) s_want = finish_or_park<PROB>(P, B, e, s, false, MODE_STEP, parity, shard, !inline_reset, park_list) ? 1 : 0;
+                __syncthreads();
+                want = s_want;
+            }
+            if (inline_reset && want) {
+                __syncthreads();                       // (the step is finished: its counters have been read)
+                if (wv == 0) {
+                    const unsigned long long bp_r = BP_NOW();
+                    wave_reset_env<PROB>(P, B, e, gen_map, mt0, (uint8_t*)nullptr, lane); __threadfence();
+                    BP_ADD(26, BP_NOW() - bp_r); BP_ADD(27, 1);
+                }
+                __syncthreads();
+                team_stats();
+                if (threadIdx.x == 0) finish_or_park<PROB>(P, B, e, s, false, MODE_START, parity, shard, true, park_list);
+            }
+            __syncthreads();
+        }
+        first_item = n_full + blockIdx.x * nwv + wv;
+    }
+    const unsigned long long bp_k0 = BP_NOW();
+    for (int item = first_item; item < n_rst + n_chg + n_inc; item += item_stride) {
         const bool lone = item < n_rst, inc = item >= n_rst + n_chg;
         const int raw = lone ? wl_get(B, WL_RST, s_pref_rst, item) : (inc ? wl_get(B, WL_INC, s_pref_inc, item - n_rst - n_chg) : wl_get(B, list, s_pref, item - n_rst));
         const bool reset_only = !inc && (raw & WL_RESET_ONLY) != 0;
@@ -110,6 +184,7 @@ __global__ __launch_bounds__(256) void k_big(PcgrlParams P, DevBufs B, int list,
             if (lane == 0) finish_or_park<PROB>(P, B, e, s, ns, MODE_START, parity, shard, true, park_list);
         }
     }
+    if (wv == 0 && blockIdx.x < 4) BP_ADD(28 + blockIdx.x, BP_NOW() - bp_k0);
 }
 
 // pcgrl_set_maps on such maps: the byte maps are the whole state (no planes to rebuild).  Tile ids beyond the problem's are

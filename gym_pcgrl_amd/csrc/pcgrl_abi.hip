@@ -73,6 +73,7 @@
 #include "kernels_stats.h"
 #include "kernels_reset.h"
 #include "bigmap.h"
+#include "bigmap_team.h"
 #include "kernels_big.h"
 #include "kernels_step.h"
 #include "kernels_sokoban.h"
@@ -116,6 +117,7 @@ struct pcgrl_env {
     // pcgrl_step_async (kernels_search_async.h): the caller's arena, whether any step may be pending, the tick counter
     AsyncCtl async;
     int async_on, async_dirty, async_split;
+    int big_team_waves;       // k_big, binary steps: wavefronts per block (pcgrl_tuning big_team: 1 = the default of 4, else the value)
     std::vector<hipEvent_t> events;
     size_t ev_used;
     int prof_steps;
@@ -465,6 +467,8 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     B.zelda_inc = (h->cfg.prob == PCGRL_ZELDA && h->cfg.rep <= PCGRL_REP_TURTLE && h->cfg.height <= 16 && h->cfg.width <= 32 &&
                    h->cfg.num_envs <= WL_INC_ENV_MASK && !no_inc) ? 1 : 0;
     B.pair_min = tun_or(T.pair_min, 2048);
+    B.big_team = tun_or(T.big_team, 1) ? 1 : 0;
+    h->big_team_waves = tun_or(T.big_team, 1) >= 2 ? (tun_or(T.big_team, 1) > BIG_TEAM_MAX_WAVES ? BIG_TEAM_MAX_WAVES : tun_or(T.big_team, 1)) : 4;
     B.champ = nullptr;
     if (champ_bytes(&h->cfg) && !no_inc) {
         B.champ = s + scratch_bytes_base(&h->cfg);
@@ -681,7 +685,10 @@ static int launch_big_p(pcgrl_env* h, int list, int parity, int mode, int clr, i
     const PcgrlParams& P = h->P;
     const size_t per_wave = big_wave_lds(P.width, P.height);
     int nw = (int)(PCGRL_BIG_LDS_BUDGET / per_wave);
-    nw = nw > 4 ? 4 : nw;
+    // (binary, a step: its few full recomputations are made by whole blocks -- four wavefronts a map measured best: 10.2 / 11.2 / 11.5 /
+    //  11.2 / 10.6 M env-steps/s on B1 with 2 / 3 / 4 / 6 / 8; more bands = more components that cross one)
+    const int nw_max = (PROB == PCGRL_PROB_BINARY && h->B.big_team && mode == MODE_STEP) ? h->big_team_waves : 4;
+    nw = nw > nw_max ? nw_max : nw;
     if (nw < 1) return PCGRL_EINVAL;
     const size_t lds = (size_t)nw * per_wave;
     { const int rc = lds_cap<k_big<PROB>>(h->device, lds); if (rc) return rc; }

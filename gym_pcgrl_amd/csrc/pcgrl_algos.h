@@ -267,6 +267,23 @@ PCGRL_D typename B::mask_t pcg_fill_cols(B& g, typename B::mask_t f, const PcgFi
     return r;
 }
 
+// The run / column fills of pcg_component from a connected start set (also on its own: bigmap.h takes the plain flood steps first and
+// makes the fill constants only for a component that is still growing after them).
+template <class B>
+PCGRL_D typename B::mask_t pcg_component_fills(B& g, typename B::mask_t seed, const PcgFillCtx<B>& c) {
+    typedef typename B::mask_t M;
+    M f = pcg_fill_rows(g, seed, c.pass, c.rpass);
+    for (;;) {
+        M n = pcg_fill_cols(g, f, c);
+        f = pcg_fill_rows(g, n, c.pass, c.rpass);
+        // done when no passable cell borders the set (it grew from one seed, so it is then exactly the seed's component): a
+        // ten-instruction test instead of one more round of fills that finds nothing to add.  (An extra round is harmless: a
+        // group that is done idles while another one of the wavefront still grows.)
+        if (!g.wave_any(pcg_neighbours(g, f) & c.pass & ~f)) break;
+    }
+    return f;
+}
+
 // The 4-connected component containing `seed`: alternate full-column and full-row fills until stable
 // (one round per "turn" of the most winding path instead of one step per cell).
 template <class B>
@@ -286,16 +303,7 @@ PCGRL_D typename B::mask_t pcg_component(B& g, typename B::mask_t seed, const Pc
         }
         seed = f;
     }
-    M f = pcg_fill_rows(g, seed, c.pass, c.rpass);
-    for (;;) {
-        M n = pcg_fill_cols(g, f, c);
-        f = pcg_fill_rows(g, n, c.pass, c.rpass);
-        // done when no passable cell borders the set (it grew from one seed, so it is then exactly the seed's component): a
-        // ten-instruction test instead of one more round of fills that finds nothing to add.  (An extra round is harmless: a
-        // group that is done idles while another one of the wavefront still grows.)
-        if (!g.wave_any(pcg_neighbours(g, f) & c.pass & ~f)) break;
-    }
-    return f;
+    return pcg_component_fills(g, seed, c);
 }
 
 // Components with at most 3 cells, from neighbour counts.  Returns their union; adds their number to

@@ -117,6 +117,7 @@ struct DevBufs {
     int32_t step_tight;              //   bit 0: a full recomputation of the step sweeps the second largest component for a tight bound, bit 1: a reset does
     const int32_t* flat;             // k_step, wide representation: this step's actions as the ActionMap wrapper's flat indices (pcgrl_step_flat), else null
     int32_t step_pair;               // k_step: certain resets per block and step from which a wavefront takes two of them (0: never; pcgrl_tuning step_pair)
+    int32_t big_team;                // k_big, binary: the full recomputations of a step by whole blocks (bigmap_team.h; pcgrl_tuning big_team)
     int32_t step_touch;              // k_step, binary: changes in or next to the champion try binary_touch before a full recomputation (pcgrl_tuning no_touch)
     uint8_t* big_arena;              // search_big.h: per-block node pool + heap + visited table (levels / solver_power beyond the compact searches)
     // pcgrl_step_async (kernels_search_async.h): non-null only inside a tick -- pending[e] != 0: environment e's step is in flight

@@ -142,6 +142,9 @@ typedef struct pcgrl_tuning {
     int32_t step_pair;       /* k_step, zelda: from this many certain resets in a block's step on, a wavefront takes two of them (default 6; 0: never) */
     int32_t async_split;     /* pcgrl_step_async: 1 = the fresh jobs of a tick in a launch of their own with small search regions, several blocks per
                                 compute unit (the default for sokoban); 0 = one search launch per tick, the full region for every job */
+    int32_t big_team;        /* k_big, binary maps beyond 64 x 64: 1 = a step's few full recomputations are made by all wavefronts of a block
+                                together (csrc/bigmap_team.h; the default: four wavefronts a block), 2..8 = that many, 0 = a wavefront
+                                per map throughout */
 } pcgrl_tuning;
 
 int pcgrl_abi_version(void);

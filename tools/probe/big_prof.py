@@ -41,5 +41,10 @@ calls = max(a[8], 1)
 print("%d envs, %d steps: %.3f ms/step; %.1f full recomputations a step" % (n, steps, dt / steps * 1e3, a[8] / steps))
 print("per full recomputation (cycles): planes %.0f, tiny components %.0f, first + fill %.0f (%.1f components, %.0f cycles each), size + sweeps %.0f, whole %.0f"
       % (a[4] / calls, a[0] / calls, a[1] / calls, a[5] / calls, a[1] / max(a[5], 1), a[2] / calls, a[3] / calls))
-print("regions from the closed forms %.1f; components whose size called for a sweep %.1f, second sweeps %.1f, levels of the double sweeps %.1f"
-      % (a[9] / calls, a[6] / calls, a[7] / calls, a[10] / calls))
+print("regions from the closed forms %.1f; double sweeps started %.1f; the sweeps put off to the end: %.0f cycles (part of `whole`)"
+      % (a[9] / calls, a[6] / calls, a[7] / calls))
+if a[25]:
+    t = a[25]
+    print("team form: %.1f a step; cycles each: planes + tiny %.0f, phase A %.0f, phase B %.0f, sweeps %.0f, champion %.0f; resets %.1f a step, %.0f cycles each"
+          % (t / steps, a[20] / t, a[21] / t, a[22] / t, a[23] / t, a[24] / t, a[27] / steps, a[26] / max(a[27], 1)))
+    print("incremental items of blocks 0..3 (cycles per step, wavefront 0):", [int(a[28 + k] / steps) for k in range(4)])
