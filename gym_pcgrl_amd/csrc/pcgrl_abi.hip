@@ -168,7 +168,7 @@ static bool solver_prob(int prob) { return prob == PCGRL_SOKOBAN || prob == PCGR
 #define PCGRL_MAX_DIM 255
 #define PCGRL_MAX_DIM_WIDE 4096
 #define PCGRL_BIG_LDS_BUDGET ((size_t)150 * 1024)      /* k_big: LDS of one wavefront's masks (launch_big_p) */
-#define PCGRL_MAX_LEVEL_CELLS 4096
+#define PCGRL_MAX_LEVEL_CELLS 16384
 #define PCGRL_MAX_SOLVER_POWER 1000000
 static bool big_map(const pcgrl_config* c) { return c->prob != PCGRL_SMB && (c->width > 64 || c->height > 64); }
 static bool big_search(const pcgrl_config* c) {
@@ -871,6 +871,7 @@ static int launch_search_big_p(pcgrl_env* h, int32_t* sync, int list_a, int mode
     const BigSearchArena A = {h->B.big_arena, D.block_bytes, D.heap_off, D.table_off, D.nodes_cap, D.tsize};
     const int cells = (h->P.width + 2) * (h->P.height + 2);
     const size_t lds = (((size_t)cells * 4 + 15) & ~(size_t)15) + (size_t)(BIG_MAX_WORDS + SOKB_MAXC / 64) * 8;
+    { const int rca = lds_cap<k_search_big<PROB>>(h->device, lds); if (rca) return rca; }       // (levels beyond ~15 000 cells: more than 64 KB of cell coordinates)
     hipLaunchKernelGGL((k_search_big<PROB>), dim3(D.nblocks), dim3(64), lds, st, h->P, h->B, A, list_a, mode_a, list_b, mode_b, parity, rst_list, sync, clr);
     HIPCHK(hipGetLastError());
     return PCGRL_OK;

@@ -1,5 +1,5 @@
 // The planners of the search problems beyond the limits of the compact searches: bordered levels of more than 256 cells (up to
-// PCGRL_MAX_LEVEL_CELLS = 4096, e.g. adjust_param(width=20, height=20) -> 22 x 22 = 484), solver_power beyond 16 383, Sokoban levels
+// PCGRL_MAX_LEVEL_CELLS = 16384, e.g. adjust_param(width=20, height=20) -> 22 x 22 = 484), solver_power beyond 16 383, Sokoban levels
 // with more than 32 crates (up to SOKB_MAXC).  The reference takes any of these (sokoban_prob.py:60-73, mdungeon_prob.py:68-84,
 // ddave_prob.py:67-82).  Part of the single translation unit pcgrl_abi.hip.
 //
@@ -16,7 +16,7 @@
 #pragma once
 
 #define SOKB_MAXC 256                 /* crates of a Sokoban level (more: reported through the status word) */
-#define BIG_MAX_WORDS 64              /* PCGRL_MAX_LEVEL_CELLS / 64 */
+#define BIG_MAX_WORDS 256             /* PCGRL_MAX_LEVEL_CELLS / 64: 16 384 bordered cells (126 x 126 maps; round 5: 4 096 before) */
 
 PCGRL_D bool big_hlt(uint64_t a, uint64_t b) { return a < (b & 0xFFFFFFFF00000000ull); }       // priority(a) < priority(b)
 PCGRL_D void big_siftdown(uint64_t* heap, int startpos, int pos) {       // heapq._siftdown
@@ -251,7 +251,7 @@ struct MdbLevel { uint64_t solid[BIG_MAX_WORDS], potion[BIG_MAX_WORDS], treasure
 struct MdbNode { uint64_t alive[BIG_MAX_WORDS]; };
 struct MdbTail { uint16_t player, treasures; int32_t h; uint32_t depth; uint8_t health, flags, jumps_lo, jumps_hi; };
 PCGRL_HD int mdb_stride(int nwb) { return nwb * 8 + 16; }
-#define MDB_PRIO_BIAS 65536           /* 2h >= -8 * 4096 */
+#define MDB_PRIO_BIAS (1 << 18)       /* 2h >= -8 * 16384 */
 PCGRL_D int mdb_heuristic(const BigSearchCtx& C, int door, int player, int health, int treasures) {       // engine.py:271-275
     return abs((int)C.cx[player] - (int)C.cx[door]) + abs((int)C.cy[player] - (int)C.cy[door]) + 4 * (5 - health) - 4 * treasures;
 }
@@ -354,7 +354,7 @@ PCGRL_D bool mdb_search(const BigSearchCtx& C, const MdbLevel& L, MdbWork& w, in
 // probs/ddave/engine.py as used by DDaveProblem._run_game (ddave_prob.py:92-127); see ddave_solver.h.  The node is MiniDungeons'
 // with other meanings: alive = diamonds still there, flags = health | key still on the floor << 1 | air time << 4, jumps in two bytes.
 struct DdbLevel { uint64_t solid[BIG_MAX_WORDS], spike[BIG_MAX_WORDS], diamond0[BIG_MAX_WORDS]; int door, keycell; };
-#define DDB_PRIO_BIAS 65536           /* 2h >= -10 * 4096 */
+#define DDB_PRIO_BIAS (1 << 18)       /* 2h >= -10 * 16384 */
 PCGRL_D int ddb_diamonds(const BigSearchCtx& C, const DdbLevel& L, const uint64_t* alive) {
     int n = 0;
     for (int i = 0; i < C.nwb; i++) n += md_popcount(L.diamond0[i] & ~alive[i]);

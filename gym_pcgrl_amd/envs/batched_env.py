@@ -251,7 +251,7 @@ class BatchedPcgrlEnv:
                 self._update_spaces()
                 raise ValueError("adjust_param(%s): outside what the library takes (include/pcgrl_hip.h: map side <= 255 -- the wide representation, which "
                                  "has no cursor: any size whose row masks fit a compute unit's LDS --, max_changes <= 65535, search levels of at most "
-                                 "4096 bordered cells, 1 <= solver_power <= 10^6; smb: width <= 250, height 3..32, solver_power <= 16383)" %
+                                 "16384 bordered cells, 1 <= solver_power <= 10^6; smb: width <= 250, height 3..32, solver_power <= 16383)" %
                                  ", ".join("%s=%r" % kv for kv in kwargs.items()))
             rc = self._lib.pcgrl_configure(self._handle, C.byref(cfg))
             if rc == _lib.PCGRL_EINVAL and not self._needs_reset:

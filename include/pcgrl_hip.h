@@ -37,7 +37,7 @@ extern "C" {
  * 5: + the ddave problem: pcgrl_config grew (max_diamonds, min_spikes, target_jumps).  6: + pcgrl_rollout.
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
  *    clamped actions.  10: + pcgrl_tuning / pcgrl_set_tuning (the library reads no environment variables any more); pcgrl_config
- *    grew (prob_width, prob_height); maps up to 255 x 255, search levels up to 4096 bordered cells, solver_power up to 1 000 000. */
+ *    grew (prob_width, prob_height); maps up to 255 x 255, search levels up to 16 384 bordered cells, solver_power up to 1 000 000. */
 #define PCGRL_ABI_VERSION 12
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -51,7 +51,7 @@ enum { PCGRL_NARROW = 0, PCGRL_WIDE = 1, PCGRL_TURTLE = 2, PCGRL_NARROW_CAST = 3
 typedef struct pcgrl_config {
     int32_t prob, rep;
     int32_t num_envs;
-    int32_t width, height;                 /* the maps' width / height: 1..255 each (search problems: (width + 2) * (height + 2) <= 4096;
+    int32_t width, height;                 /* the maps' width / height: 1..255 each (search problems: (width + 2) * (height + 2) <= 16384;
                                               smb: width up to 250, height 3..32).  Up to 64 x 64 the row-bitboard kernels, beyond
                                               them the general path (csrc/bigmap.h) */
     int32_t prob_width, prob_height;       /* Problem._width/_height when they differ from the maps' -- adjust_param(width, height)

@@ -333,6 +333,54 @@ def gen_stats_big_search():
              solver_power=np.array(power), keys=np.array(STAT_KEYS["ddave"]))
 
 
+def gen_stats_huge_search():
+    """Search levels of more than 4 096 bordered cells (round 5): sokoban 70 x 70 and mdungeon 66 x 80 -- the
+    reference takes any size (sokoban_prob.py:60-73, mdungeon_prob.py:68-84)."""
+    rs = np.random.RandomState(977)
+    prob = PROBLEMS["sokoban"]()
+    h, w, power = 70, 70, 150
+    prob._width, prob._height, prob._solver_power = w, h, power
+    maps = engineer_sokoban(rs, h, w, 6, 2, 0.05)
+    t0 = time.time()
+    res, agents = [], []
+    for m in maps:
+        st = stats_of(prob, m)
+        row = [int(st[k]) if k != "sol-length" else len(st["solution"]) for k in STAT_KEYS["sokoban"]]
+        res.append(row)
+        if st["player"] == 1 and st["crate"] == st["target"] and st["crate"] > 0 and st["regions"] == 1:
+            iters, win, dist, sl = run_agents(prob, m)
+            assert dist == row[4] and sl == row[5], (dist, sl, row)
+            agents.append(iters + [win])
+        else:
+            agents.append([0, 0, 0, 0, -2])
+    res = np.array(res, dtype=np.int64); agents = np.array(agents, dtype=np.int64)
+    print("  sokoban %dx%d power %d: %d maps, solver ran %d, wins by agent %s, %.1fs" % (
+        h, w, power, len(maps), int((agents[:, 4] > -2).sum()), [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)], time.time() - t0))
+    save("stats_sokoban_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+         solver_power=np.array(power), keys=np.array(STAT_KEYS["sokoban"]))
+    prob = PROBLEMS["mdungeon"]()
+    h, w, power = 66, 80, 150
+    prob._width, prob._height, prob._solver_power = w, h, power
+    maps = engineer_mdungeon(rs, h, w, 5, 0.04, 0.3)
+    t0 = time.time()
+    res, agents = [], []
+    for m in maps:
+        st = stats_of(prob, m)
+        row = [int(st[k]) for k in STAT_KEYS["mdungeon"]]
+        res.append(row)
+        if st["player"] == 1 and st["exit"] == 1 and st["regions"] == 1:
+            iters, win, dist, sl, gs = run_agents_mdungeon(prob, m)
+            assert dist == row[9] and sl == row[10], (dist, sl, row)
+            agents.append(iters + [win])
+        else:
+            agents.append([0, 0, 0, 0, -2])
+    res = np.array(res, dtype=np.int64); agents = np.array(agents, dtype=np.int64)
+    print("  mdungeon %dx%d power %d: %d maps, solver ran %d, wins by agent %s, %.1fs" % (
+        h, w, power, len(maps), int((agents[:, 4] > -2).sum()), [int((agents[:, 4] == k).sum()) for k in (-1, 0, 1, 2, 3)], time.time() - t0))
+    save("stats_mdungeon_%dx%d_p%d" % (h, w, power), maps=np.array(maps), stats=res, agents=agents,
+         solver_power=np.array(power), keys=np.array(STAT_KEYS["mdungeon"]))
+
+
 def engineer_sokoban(rs, h, w, n, max_k=3, solid_max=0.35):
     maps = []
     for _ in range(n):
@@ -993,7 +1041,7 @@ def main():
     jobs = {
         "rng": gen_rng, "stats_binary": gen_stats_binary, "stats_zelda": gen_stats_zelda,
         "stats_sokoban": gen_stats_sokoban, "stats_mdungeon": gen_stats_mdungeon, "stats_ddave": gen_stats_ddave, "stats_smb": gen_stats_smb, "range_reward": gen_range_reward, "adjust_param": gen_adjust_param,
-        "wrappers": gen_wrappers, "stats_big": gen_stats_big, "stats_big_search": gen_stats_big_search, "heat_boundary": gen_heat_boundary,
+        "wrappers": gen_wrappers, "stats_big": gen_stats_big, "stats_big_search": gen_stats_big_search, "stats_huge_search": gen_stats_huge_search, "heat_boundary": gen_heat_boundary,
     }
     for k, fn in jobs.items():
         if a.only in (None, k):

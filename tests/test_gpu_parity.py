@@ -168,6 +168,10 @@ ORACLE_CASES = [
                                                          probs={"empty": 0.8, "solid": 0.18, "player": 0.004, "exit": 0.004, "diamond": 0.004, "key": 0.004,
                                                                 "spike": 0.004})), 48, 100),
     ("sokoban", "wide", (dict(width=70, height=40), dict(change_percentage=0.001, solver_power=100)), 10, 40),
+    # round 5: levels of more than 4 096 bordered cells (up to 16 384)
+    ("sokoban", "narrow", (dict(width=70, height=70), dict(change_percentage=0.0008, solver_power=120,
+                                                           probs={"empty": 0.96, "solid": 0.03, "player": 0.0003, "crate": 0.0003, "target": 0.0003})), 8, 30),
+    ("mdungeon", "wide", (dict(width=126, height=126), dict(change_percentage=0.0003, solver_power=80)), 4, 16),
     ("sokoban", "wide", (dict(solver_power=17000, change_percentage=0.9, probs={"empty": 0.8, "solid": 0.05, "player": 0.05, "crate": 0.05, "target": 0.05}),), 64, 60),
 ]
 

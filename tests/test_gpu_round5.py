@@ -146,3 +146,18 @@ def test_smb_kept_play_throughs_change_nothing(rep, calls):
             if ed:
                 o.reset()
     a_env.close(); b_env.close()
+
+
+@pytest.mark.parametrize("team", [0, 2, 3, 4, 8])
+def test_big_binary_maps_by_whole_blocks_vs_oracle(team, monkeypatch):
+    """k_big, binary maps beyond 64 x 64: the few full recomputations of a step are made by all wavefronts of a block (bigmap_team.h:
+    a band of rows per wavefront, crossing components by wavefront 0, sweeps claimed largest first).  Every step against the oracle,
+    with 2 / 3 / 4 / 8 wavefronts a block and with the one-wavefront form (0); short episodes, so that resets -- and the first
+    statistics of fresh maps -- come through the same path; 100 x 100 (two words a row) and 130 x 70 (three)."""
+    from gym_pcgrl_amd import _lib
+    monkeypatch.setitem(_lib.TUNING_OVERRIDES, "big_team", team)
+    rs = np.random.RandomState(40 + team)
+    err = ph.run_config("binary", "narrow", [dict(width=100, height=100), dict(change_percentage=0.002)], 6, 150, 8100, rs, use_rollout=False)
+    assert err is None, err
+    err = ph.run_config("binary", "turtle", [dict(width=130, height=70), dict(change_percentage=0.001)], 5, 120, 8200, rs, use_rollout=False)
+    assert err is None, err

@@ -47,15 +47,15 @@ def test_layout_query_and_validation():
     assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == 0
     c.width = 256
     assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == _lib.PCGRL_EINVAL
-    # the search problems: levels of up to 4096 bordered cells, solver_power up to 1 000 000 (csrc/search_big.h beyond 256 cells / 16 383)
+    # the search problems: levels of up to 16 384 bordered cells, solver_power up to 1 000 000 (csrc/search_big.h beyond 256 cells / 16 383)
     c.prob, c.width, c.height, c.solver_power = 2, 20, 20, 5000
     assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == 0 and lay.nplanes == 3
     small = lay.scratch
     c.solver_power = 20000
     assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == 0 and lay.scratch > small
-    c.width, c.height = 62, 62
+    c.width, c.height = 126, 126
     assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == 0
-    c.width = 63
+    c.width = 127
     assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == _lib.PCGRL_EINVAL
     c.width, c.height, c.solver_power = 5, 5, 1000001
     assert L.pcgrl_query_layout(C.byref(c), C.byref(lay)) == _lib.PCGRL_EINVAL

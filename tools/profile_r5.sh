@@ -21,6 +21,10 @@ for w in C4 M1 D1; do tools/probe/trace_async.sh $w 64 > gpurun_out/trace_async_
 python tools/probe/async_prof.py C4 64 > gpurun_out/async_prof_C4.txt 2>&1
 python tools/probe/async_prof.py M1 64 > gpurun_out/async_prof_M1.txt 2>&1
 python tools/timeline.py C2 > gpurun_out/timeline_C2.txt 2>&1
+# cycle counters of the map path beyond 64 x 64 and of the smb searches (libraries built ahead on the CPU box: tools/probe/*.so)
+python tools/probe/big_prof.py 50 > gpurun_out/big_prof_B1.txt 2>&1
+python tools/smb_prof.py 16384 10 > gpurun_out/smb_prof_S1.txt 2>&1
+python tools/probe/step_multi_cost.py > gpurun_out/step_multi_cost.txt 2>&1
 # gpurun copies at most 64 MiB back: the summaries are made here, the raw traces and counter files stay on the box
 python tools/make_profile_summary.py r5_round5 C2 C3 C2w C3w C5 C4 C5b C3d M1 D1 S1 B1 K1 C2R C4R > /dev/null 2>&1
 mkdir -p gpurun_out/r5_summary
