@@ -269,6 +269,109 @@ __device__ __forceinline__ bool big_window_component(const uint64_t* pass, const
     return big_window_fill(pass, G, Wd, c, lane, comp, row_hi, out_l, out_r);
 }
 
+// A component too large for a window, on maps of at most 128 x 128: the whole map in registers -- lane l holds rows l and 64 + l, two
+// words each -- and helper.py:222-237's level-synchronous BFS on that: ~70 instructions a level and no LDS, where the word-array form
+// (big_bfs_levels) pays a loop over LDS words, a compiler barrier and two wavefront reductions (~2 400 cycles a level on a component
+// that spans the map).  It is the case that matters in use: a generator trained on the binary problem makes ONE large region with a
+// long path (binary_prob.py:100-118), not the hundreds of small ones of a random map.  The BFS from a seed over the passable set
+// yields the component itself (the visited set), its size, the first eccentricity and the last frontier in one go -- no separate fill.
+struct Big128 { uint64_t a0, a1, b0, b1; };       // rows l (a) and 64 + l (b), words 0 and 1
+__device__ __forceinline__ bool big128_fits(const BigGeom& G) { return G.H <= 128 && G.KW <= 2; }
+__device__ __forceinline__ Big128 big128_load(const uint64_t* m, const BigGeom& G, int lane) {
+    Big128 v = {0ull, 0ull, 0ull, 0ull};
+    if (lane < G.H) { v.a0 = m[lane * G.KW]; if (G.KW > 1) v.a1 = m[lane * G.KW + 1]; }
+    if (lane + 64 < G.H) { v.b0 = m[(lane + 64) * G.KW]; if (G.KW > 1) v.b1 = m[(lane + 64) * G.KW + 1]; }
+    return v;
+}
+template <bool CLEAR>       // m &= ~v, or m = v (every row of the mask)
+__device__ __forceinline__ void big128_store(uint64_t* m, const BigGeom& G, int lane, const Big128& v) {
+    if (lane < G.H) {
+        if (CLEAR) { m[lane * G.KW] &= ~v.a0; if (G.KW > 1) m[lane * G.KW + 1] &= ~v.a1; }
+        else { m[lane * G.KW] = v.a0; if (G.KW > 1) m[lane * G.KW + 1] = v.a1; }
+    }
+    if (lane + 64 < G.H) {
+        if (CLEAR) { m[(lane + 64) * G.KW] &= ~v.b0; if (G.KW > 1) m[(lane + 64) * G.KW + 1] &= ~v.b1; }
+        else { m[(lane + 64) * G.KW] = v.b0; if (G.KW > 1) m[(lane + 64) * G.KW + 1] = v.b1; }
+    }
+}
+__device__ __forceinline__ uint64_t big128_readlane(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ Big128 big128_bit(int row, int col, int lane) {
+    Big128 v = {0ull, 0ull, 0ull, 0ull};
+    const uint64_t bit = 1ull << (col & 63);
+    if (lane == (row & 63)) {
+        if (row < 64) { if (col < 64) v.a0 = bit; else v.a1 = bit; }
+        else { if (col < 64) v.b0 = bit; else v.b1 = bit; }
+    }
+    return v;
+}
+__device__ __forceinline__ bool big128_any(const Big128& v) { return __ballot((v.a0 | v.a1 | v.b0 | v.b1) != 0ull) != 0ull; }
+// the four neighbours of the cells of f (rows beyond the map and columns beyond a row's end are cut off by the caller's mask)
+__device__ __forceinline__ Big128 big128_neighbours(const Big128& f, int lane) {
+    Big128 n;
+    n.a0 = (f.a0 << 1) | (f.a0 >> 1) | (f.a1 << 63);
+    n.a1 = (f.a1 << 1) | (f.a1 >> 1) | (f.a0 >> 63);
+    n.b0 = (f.b0 << 1) | (f.b0 >> 1) | (f.b1 << 63);
+    n.b1 = (f.b1 << 1) | (f.b1 >> 1) | (f.b0 >> 63);
+    // the row above a row: lane l - 1 of the same set, and for row 64 (lane 0 of b) row 63 (lane 63 of a); below: the other way round
+    const uint64_t a0_63 = big128_readlane(f.a0, 63), a1_63 = big128_readlane(f.a1, 63), b0_0 = big128_readlane(f.b0, 0), b1_0 = big128_readlane(f.b1, 0);
+    uint64_t ub0 = dpp_mov0<0x138>(f.b0), ub1 = dpp_mov0<0x138>(f.b1), da0 = dpp_mov0<0x130>(f.a0), da1 = dpp_mov0<0x130>(f.a1);
+    if (lane == 0) { ub0 = a0_63; ub1 = a1_63; }
+    if (lane == 63) { da0 = b0_0; da1 = b1_0; }
+    n.a0 |= dpp_mov0<0x138>(f.a0) | da0;
+    n.a1 |= dpp_mov0<0x138>(f.a1) | da1;
+    n.b0 |= ub0 | dpp_mov0<0x130>(f.b0);
+    n.b1 |= ub1 | dpp_mov0<0x130>(f.b1);
+    return n;
+}
+// BFS inside `in` from the cells of src (a subset of it): returns the number of levels (the eccentricity for a single cell), V = every
+// cell reached, last = the last frontier (src itself when nothing is reached)
+__device__ __forceinline__ int big128_bfs(const Big128& in, const Big128& src, Big128& V, Big128& last, int lane) {
+    V = src;
+    Big128 f = src;
+    int ecc = 0;
+    for (;;) {
+        Big128 n = big128_neighbours(f, lane);
+        n.a0 &= in.a0 & ~V.a0; n.a1 &= in.a1 & ~V.a1; n.b0 &= in.b0 & ~V.b0; n.b1 &= in.b1 & ~V.b1;
+        if (!big128_any(n)) break;
+        V.a0 |= n.a0; V.a1 |= n.a1; V.b0 |= n.b0; V.b1 |= n.b1;
+        f = n;
+        ++ecc;
+    }
+    last = f;
+    return ecc;
+}
+// first cell of s in row-major order (s not empty)
+__device__ __forceinline__ void big128_first(const Big128& s, int& row, int& col) {
+    const uint64_t za = __ballot((s.a0 | s.a1) != 0ull);
+    uint64_t w0, w1;
+    if (za) { const int l = __ffsll((unsigned long long)za) - 1; row = l; w0 = big128_readlane(s.a0, l); w1 = big128_readlane(s.a1, l); }
+    else {
+        const uint64_t zb = __ballot((s.b0 | s.b1) != 0ull);
+        const int l = __ffsll((unsigned long long)zb) - 1;
+        row = 64 + l; w0 = big128_readlane(s.b0, l); w1 = big128_readlane(s.b1, l);
+    }
+    col = w0 ? __ffsll((unsigned long long)w0) - 1 : 64 + __ffsll((unsigned long long)w1) - 1;
+}
+__device__ __forceinline__ int big128_popcount(const Big128& v) { return big_wave_sum(__popcll(v.a0) + __popcll(v.a1) + __popcll(v.b0) + __popcll(v.b1)); }
+// The component of the cell (row, col) of `pass` and -- if its size and its first sweep allow it to beat `path` -- its double sweep
+// (helper.py:250-264: BFS from the component's first cell in row-major order, which (row, col) must be; np.argmax = the first cell of the
+// last frontier; BFS from there).  Returns the second eccentricity or 0; comp = the component, size = its cells.
+__device__ __forceinline__ int big128_component_sweep(const uint64_t* pass, const BigGeom& G, int row, int col, int lane, bool want_path, int path,
+                                                      Big128& comp, int& size) {
+    const Big128 P = big128_load(pass, G, lane);
+    Big128 last;
+    const int e1 = big128_bfs(P, big128_bit(row, col, lane), comp, last, lane);
+    size = want_path ? big128_popcount(comp) : 0;
+    if (!want_path || size - 1 <= path || 2 * e1 <= path) return 0;
+    int r2, c2;
+    big128_first(last, r2, c2);
+    Big128 V2, l2;
+    return big128_bfs(comp, big128_bit(r2, c2, lane), V2, l2, lane);
+}
+
 // helper.py:197-207 calc_num_regions + :250-264 calc_longest_path over `pass`.  rest, comp, X, Y, Z: scratch masks (comp must be
 // all zero on entry and is on return; Y, Z only for want_path).  want_path = false: regions only (zelda and the search problems).
 // champ (may be null; NW words): receives the rows of a champion component -- one whose double sweep gave the returned path -- or
@@ -372,6 +475,24 @@ __device__ __forceinline__ void big_regions_path(const uint64_t* pass, uint64_t*
                 big_sync();
                 continue;
             }
+        }
+        if (big128_fits(G)) {          // too large for a window, the map small enough for the registers: the whole component at once
+            Big128 cv;
+            int size;
+            const int e2 = big128_component_sweep(pass, G, r0, 64 * (i0 - r0 * G.KW) + b0, lane, want_path, path, cv, size);
+            ++regions;
+            BP_ADD(1, BP_NOW() - bp_t1); BP_ADD(5, 1);
+            if (e2 > path) {
+                path = e2;
+                if (champ) {
+                    big128_store<false>(champ, G, lane, cv);
+                    c_lo = 0; c_hi = G.NW;
+                    if (has_champ) *has_champ = 1;
+                }
+            }
+            big128_store<true>(rest, G, lane, cv);
+            big_sync();
+            continue;
         }
         if (lane == 0) comp[i0] = 1ull << b0;
         big_sync();

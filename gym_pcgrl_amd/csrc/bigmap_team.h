@@ -223,6 +223,21 @@ __device__ __forceinline__ void big_team_binary(const uint8_t* __restrict__ m, c
                 big_sync();
                 continue;
             }
+            if (big128_fits(G)) {      // too large for a window, the map small enough for the registers (bigmap.h big128_*)
+                Big128 cv;
+                int size;
+                const int snap = __hip_atomic_load(&T.path, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int e2 = big128_component_sweep(pass, G, r0, c0, lane, true, snap, cv, size);
+                ++my_regions;
+                if (e2 > snap) {
+                    if (lane == 0) { atomicMax(&T.path, e2); T.lds_path = e2; T.lds_has = 1; }
+                    big128_store<false>(champ, G, lane, cv);
+                    c_lo = 0; c_hi = NW;
+                }
+                big128_store<true>(cross, G, lane, cv);
+                big_sync();
+                continue;
+            }
             // the word-array path (bigmap.h), swept at once when its size calls for it
             if (lane == 0) comp[i0] = 1ull << b0;
             big_sync();

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe (GPU box): where the cycles of a full recomputation on a map beyond 64 x 64 go (k_big, bigmap.h big_regions_path).
 Builds a copy of the library with -DPCGRL_BIG_PROF and steps the B1 workload.
-    python tools/probe/big_prof.py [steps]"""
+    python tools/probe/big_prof.py [steps] [warm-up steps]"""
 import ctypes as C, os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,14 +17,15 @@ import torch
 import bench
 from gym_pcgrl_amd.envs import BatchedPcgrlEnv
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 20       # (7000: every step then holds a reset -- an episode of B1 is ~6 000 steps)
 prob, rep, adj, n, _ = bench.WORKLOADS["B1"]
 env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, seed=0)
 for kw in adj:
     env.adjust_param(**kw)
 env.reset()
 acts = bench.make_actions(torch, rep, steps + 20, n, 100, 100, 2, env.device, 1234)
-for t in range(20):
-    env.step(acts[t])
+for t in range(warm):
+    env.step(acts[t % 20])
 L = _lib.load()
 L.pcgrl_debug_timeline.argtypes = [C.c_void_p]
 buf = torch.zeros((64,), dtype=torch.int64, device=env.device)
@@ -32,7 +33,7 @@ _lib.check(L.pcgrl_debug_timeline(C.c_void_p(buf.data_ptr())), "timeline")
 torch.cuda.synchronize()
 t0 = time.time()
 for t in range(steps):
-    env.step(acts[20 + t])
+    env.step(acts[20 + t % steps])
 torch.cuda.synchronize()
 dt = time.time() - t0
 _lib.check(L.pcgrl_debug_timeline(None), "timeline")
