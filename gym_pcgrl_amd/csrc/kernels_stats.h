@@ -483,6 +483,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     __shared__ int2 s_pre;
     if (clear_parity >= 0 && blockIdx.x == 0) wl_clear(B, clear_parity);
     TL_INIT(); TL(1);
+    WTL(0, wall_clock64());
     DevGroup<64, MaskT> g;
     // with the in-kernel reset, k_update puts the environments that are certain to be reset on WL_RST: those come first;
     // the incremental items of a step (WL_INC) are taken, a wavefront each, by the blocks that have no full item
@@ -513,9 +514,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
     const int n_many = pair_few ? s_pref[WL_NSHARD / 2] : n_chg;
     const int n_items = 2 * n_rst + n_many + (n_chg - n_many + 1) / 2;
     const int epoch = B.wide_epoch;
+    WTL(1, wall_clock64());
+    WTL(5, (unsigned long long)n_items | ((unsigned long long)n_rst << 16) | ((unsigned long long)n_many << 32) | ((unsigned long long)n_inc << 48));
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const bool lone = item < 2 * n_rst;                  // certain reset (block-uniform, like everything below that is not per lane)
         const bool old_half = lone && (item & 1) == 0;
+        WTL(2, (old_half ? 1 : (lone ? 2 : (item >= 2 * n_rst + n_many ? 4 : 3))) | (item << 8));
         if (item >= 2 * n_rst + n_many) {
             constexpr int TS = NWAVES / 2;
             const int team = wv / TS, tw = wv % TS;
@@ -647,6 +651,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         __syncthreads();
     }
     TL(27);
+    WTL(3, wall_clock64());
     if (n_inc > 0) {
         // incremental items: by the blocks beyond the full items if there are any, else by all
         const int first = ((int)gridDim.x > n_items) ? n_items : 0;
@@ -659,4 +664,5 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         }
     }
     TL(28);
+    WTL(4, wall_clock64());
 }

@@ -1490,7 +1490,7 @@ static int set_maps_one(pcgrl_env* h, const uint8_t* maps, void* stream) {
     return PCGRL_OK;
 }
 
-#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF) || defined(PCGRL_BIG_PROF)
+#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF) || defined(PCGRL_BIG_PROF) || defined(PCGRL_WIDE_TL)
 // debug build only (tools/timeline.py, tools/smb_prof.py): where the kernels write their timeline marks (NULL: off)
 int pcgrl_debug_timeline(void* buf) {
     unsigned long long* p = (unsigned long long*)buf;

@@ -49,8 +49,15 @@ template <int G> __device__ __forceinline__ unsigned wl_inc_code(int raw) { retu
 
 // Optional in-kernel timeline (tools/timeline.py builds a copy of the library with -DPCGRL_TIMELINE; the product is
 // compiled without it and TL() is nothing): wavefront-private slots, 100 MHz wall clock << 8 | tag.
-#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF) || defined(PCGRL_BIG_PROF)
+#if defined(PCGRL_TIMELINE) || defined(PCGRL_SMB_PROF) || defined(PCGRL_BIG_PROF) || defined(PCGRL_WIDE_TL)
 __device__ unsigned long long* g_tl_buf;
+#endif
+// developer build (tools/probe/wide_blocks.py, -DPCGRL_WIDE_TL): k_stats_wide, per block eight words -- entry, lists read, item kind, item
+// done, end (100 MHz wall clock) -- written by thread 0 only, so that the kernel keeps its registers and its two blocks per compute unit
+#ifdef PCGRL_WIDE_TL
+#define WTL(i, v) do { if (threadIdx.x == 0 && g_tl_buf) g_tl_buf[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define WTL(i, v) do {} while (0)
 #endif
 #ifdef PCGRL_TIMELINE
 #define TL_SLOTS 48

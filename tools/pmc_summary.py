@@ -9,7 +9,7 @@ def agg(path):
     for r in csv.DictReader(open(path)):
         d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
-for sub in ("pmc_sq_", "pmc_sq2_", "pmc_fetch_", "pmc_write_"):
+for sub in ("pmc_sq_", "pmc_sq2_", "pmc_lds_", "pmc_act_", "pmc_fetch_", "pmc_write_"):
     d = agg(os.path.join(root, sub + W, W + "_counter_collection.csv"))
     for k, v in d.items():
         if k.startswith(("void k_", "k_")) and len(next(iter(v.values()))) > 3:
