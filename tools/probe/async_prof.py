@@ -5,8 +5,12 @@ import ctypes as C, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from gym_pcgrl_amd import _lib
-so = "/tmp/libpcgrl_hip_asyncprof.so"
-subprocess.check_call(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPCGRL_ASYNC_PROF", "-DPCGRL_SMB_PROF"] + _lib.SOURCES + ["-o", so], stderr=subprocess.DEVNULL)
+# (`async_prof.py build` on the CPU box: the library travels with the tree and the GPU call does not spend minutes compiling)
+so = os.path.join(ROOT, "tools", "probe", "libpcgrl_hip_asyncprof.so")
+if not os.path.exists(so) or (len(sys.argv) > 1 and sys.argv[1] == "build"):
+    subprocess.check_call(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPCGRL_ASYNC_PROF", "-DPCGRL_SMB_PROF"] + _lib.SOURCES + ["-o", so], stderr=subprocess.DEVNULL)
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        sys.exit(0)
 _lib.SO = so
 import torch, bench
 from gym_pcgrl_amd.envs import BatchedPcgrlEnv

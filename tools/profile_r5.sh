@@ -25,6 +25,9 @@ python tools/timeline.py C2 > gpurun_out/timeline_C2.txt 2>&1
 python tools/probe/big_prof.py 50 > gpurun_out/big_prof_B1.txt 2>&1
 python tools/smb_prof.py 16384 10 > gpurun_out/smb_prof_S1.txt 2>&1
 python tools/probe/step_multi_cost.py > gpurun_out/step_multi_cost.txt 2>&1
+# k_stats_wide block by block in the product's schedule (two blocks per compute unit), and what one BFS level costs a wavefront
+python tools/probe/wide_blocks.py C5 800 3 2>&1 | grep -v amdgpu.ids > gpurun_out/wide_blocks_C5.txt
+[ -x tools/probe/bfs_level_cost ] && tools/probe/bfs_level_cost > gpurun_out/bfs_level_cost.txt 2>&1
 # gpurun copies at most 64 MiB back: the summaries are made here, the raw traces and counter files stay on the box
 python tools/make_profile_summary.py r5_round5 C2 C3 C2w C3w C5 C4 C5b C3d M1 D1 S1 B1 K1 C2R C4R > /dev/null 2>&1
 mkdir -p gpurun_out/r5_summary

@@ -12,8 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gym_pcgrl_amd import _lib
 import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> the binding's tuning overrides (developer tools only)
-so = "/tmp/libpcgrl_hip_tl.so"
-subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + _lib.HIPCC_FLAGS + ["-DPCGRL_TIMELINE"] + os.environ.get("PCGRL_TL_FLAGS", "").split() + _lib.SOURCES + ["-o", so])
+# (`timeline.py build` on the CPU box: the library travels with the tree and the GPU call does not spend minutes compiling; A/B builds
+#  with PCGRL_TL_FLAGS are compiled where they run)
+so = os.path.join(ROOT, "tools", "probe", "libpcgrl_hip_tl.so") if not os.environ.get("PCGRL_TL_FLAGS") else "/tmp/libpcgrl_hip_tl.so"
+if not os.path.exists(so) or os.environ.get("PCGRL_TL_FLAGS") or (len(sys.argv) > 1 and sys.argv[1] == "build"):
+    subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + _lib.HIPCC_FLAGS + ["-DPCGRL_TIMELINE"] + os.environ.get("PCGRL_TL_FLAGS", "").split() + _lib.SOURCES + ["-o", so])
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        sys.exit(0)
 _lib.SO = so
 import torch
 import bench
