@@ -29,6 +29,8 @@ VARIANTS = {
 
 def measure(workload, tuning):
     prob, rep, calls, n, _ = bench.WORKLOADS[{"C5few": "C5", "C5bfew": "C5b"}.get(workload, workload)]
+    if workload in bench.WRAPPED:
+        raise SystemExit("bare workloads only")
     env = BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=n, device="cuda:0", seed=0, tuning=tuning)
     for kw in calls:
         env.adjust_param(**kw)
@@ -48,6 +50,12 @@ def measure(workload, tuning):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--defaults":      # A/B of two builds: the defaults only, three times each workload
+        for w in sys.argv[2:]:
+            for i in range(3):
+                f, s = measure(w, {})
+                print("%-6s defaults  %7.2f / %7.2f" % (w, f, s), flush=True)
+        return
     todo = sys.argv[1:] or list(VARIANTS)
     for w in todo:
         print("## %s  (us per step, GPU events: first window / steady; best of %d)" % (w, REPEATS), flush=True)
