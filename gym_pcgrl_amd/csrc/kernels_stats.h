@@ -582,6 +582,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
         }
         if (lone) {
             // the reset, then the statistics of the regenerated map; the step is finished with the counters read before the reset
+            // (generation + statistics of a fresh map is one of the step's longest items: its wavefronts are served before those of the
+            //  compute unit's other block until its first sweep ends -- the sweeps themselves run at level 3, rlp_process_seed.  C5 steady
+            //  49.05 -> 48.75 us on one box, profiles/r5_round5/probe/ab_lone_prio.txt; the same for the paired items measured nothing)
+            __builtin_amdgcn_s_setprio(1);
             if (threadIdx.x == 0) s_pre = reinterpret_cast<const int2*>(B.counters)[e];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -625,6 +629,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_stats_wide(PcgrlParams P, DevBu
                 int32_t st[PCGRL_MAX_STATS] = {s_regions[0], s_best[0], s_owner[0] >= 0 ? 1 : 0, 0, 0, 0, 0, 0};
                 finalize_item<PCGRL_PROB_BINARY>(P, B, e, st, MODE_START, parity, shard);
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             continue;
         }

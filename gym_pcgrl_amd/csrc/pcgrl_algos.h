@@ -673,6 +673,15 @@ __device__ __forceinline__ void tl_mark(int tag);       // worklist.h (developer
 #else
 #define PCGRL_TLA(tag) do {} while (0)
 #endif
+// (device, k_stats_wide: a step is as long as its longest double sweep -- one wavefront's chain of 500-700 levels, which shares its SIMD
+//  with wavefronts of the compute unit's other block that are extracting components: a level costs 88 cycles alone, 150 next to one
+//  other busy wavefront, 270 next to three -- tools/probe/bfs_level_cost.hip.  The sweeping wavefront is served first: C5 42.5 -> 41.0 us
+//  first window, C5b 39.2 / 38.4 -> 37.5 / 36.8, same box, alternating libraries: profiles/r5_round5/probe/ab_sweep_prio.txt.)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__) && !defined(PCGRL_EXP_NO_SWEEP_PRIO)
+#define PCGRL_SWEEP_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define PCGRL_SWEEP_PRIO(p) do {} while (0)
+#endif
 template <class B, class Shared>
 PCGRL_D void rlp_process_seed(B& g, typename B::mask_t seed, const PcgFillCtx<B>& ctx, Shared& sh, int& regions, int& my_best,
                               typename B::mask_t& my_champ) {
@@ -684,7 +693,9 @@ PCGRL_D void rlp_process_seed(B& g, typename B::mask_t seed, const PcgFillCtx<B>
     const int best = sh.best();
     if (g.popcount_sum(comp) - 1 > best) {
         PCGRL_TLA(31);
+        PCGRL_SWEEP_PRIO(3);
         const int e = pcg_double_sweep(g, comp, best);
+        PCGRL_SWEEP_PRIO(0);
         if (e > my_best) { my_best = e; my_champ = comp; }
         sh.raise(e);
         PCGRL_TLA(32);

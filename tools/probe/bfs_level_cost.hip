@@ -6,6 +6,7 @@
 //   mode 2  bfs_levels<true>  the written-out loop of bfs_asm.h on 64-bit masks (kHistBfs = 1; not used by the product)
 //   mode 3  bfs_levels<false> the same, second-sweep form
 //   mode 4/5 the 32-bit-mask forms (maps of at most 32 columns): compiler / written out
+// (block of 4 / 8 / 16 wavefronts = 1 / 2 / 4 per SIMD, all sweeping; the slowest wavefront's time is reported)
 // Map: a serpentine -- even rows open, odd rows open in one end cell, alternating ends -- so a sweep from the first cell runs ~2 000 levels.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gym_pcgrl_amd/csrc tools/probe/bfs_level_cost.hip -o tools/probe/bfs_level_cost
 #include <hip/hip_runtime.h>
@@ -63,7 +64,8 @@ __global__ void k(int* ecc_out, long long* cyc, int slot) {
         }
         ecc += (int)(last & 1);
     }
-    if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[slot] = t1 - t0; ecc_out[slot] = ecc; }
+    // the SLOWEST wavefront of the block counts (the issue arbiter serves the oldest first: wavefront 0 alone would look unshared)
+    if (lane == 0 && blockIdx.x == 0) { atomicMax((unsigned long long*)&cyc[slot], (unsigned long long)(t1 - t0)); ecc_out[slot] = ecc; }
 }
 template <int MODE>
 void run(const char* name, int* ecc, long long* cyc, int slot0) {
@@ -71,6 +73,8 @@ void run(const char* name, int* ecc, long long* cyc, int slot0) {
     long long hc[4]; int he[4];
     for (int i = 0; i < 4; i++) {
         k<MODE><<<1, 64 * nw[i]>>>(ecc, cyc, slot0 + i);     // warm (code fetch)
+        hipDeviceSynchronize();
+        hipMemset(cyc + slot0 + i, 0, sizeof(long long));
         k<MODE><<<1, 64 * nw[i]>>>(ecc, cyc, slot0 + i);
     }
     hipDeviceSynchronize();
