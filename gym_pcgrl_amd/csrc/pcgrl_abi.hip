@@ -90,6 +90,12 @@
 
 // ------------------------------------------------------------------------------------------
 // Host side of the ABI
+// the HIP error behind the last PCGRL_EHIP of the calling thread (pcgrl_last_hip_error)
+#if PCGRL_IN_PART(PART_CORE)
+PCGRL_LOCAL thread_local int g_last_hip = 0;
+#else
+extern PCGRL_LOCAL thread_local int g_last_hip;
+#endif
 #if PCGRL_IN_PART(PART_CORE)
 #include "step_pool.h"
 #endif
@@ -134,11 +140,6 @@ static int prof_mark(pcgrl_env* h, hipStream_t st) {
     return PCGRL_OK;
 }
 
-#if PCGRL_IN_PART(PART_CORE)
-PCGRL_LOCAL thread_local int g_last_hip = 0;
-#else
-extern PCGRL_LOCAL thread_local int g_last_hip;
-#endif
 #define HIPCHK(expr) do { hipError_t err_ = (expr); if (err_ != hipSuccess) { g_last_hip = (int)err_; return PCGRL_EHIP; } } while (0)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1299,6 +1300,7 @@ int32_t pcgrl_step_threads(int32_t n) {
 static int selftest_pool_fn(pcgrl_env* e, const int32_t* a, void*) {
     int32_t* hit = reinterpret_cast<int32_t*>(e);
     __atomic_fetch_add(hit, 1, __ATOMIC_RELAXED);
+    if (a) g_last_hip = 9000 + *a;      // a stand-in "HIP error" of the failing handle: the caller's pcgrl_last_hip_error() must show it
     return a ? PCGRL_EINVAL : PCGRL_OK;
 }
 int pcgrl_selftest_step_pool(int32_t count, int32_t calls, int32_t fail_at, int32_t* hits) {
@@ -1306,7 +1308,7 @@ int pcgrl_selftest_step_pool(int32_t count, int32_t calls, int32_t fail_at, int3
     StepPool* pool = StepPool::get(count);
     if (!pool) return -1;
     pcgrl_env* envs[64]; const int32_t* acts[64]; void* streams[64];
-    static const int32_t marker = 0;
+    const int32_t marker = fail_at;
     for (int i = 0; i < count; i++) { envs[i] = reinterpret_cast<pcgrl_env*>(hits + i); acts[i] = i == fail_at ? &marker : nullptr; streams[i] = nullptr; }
     int failed = 0;
     for (int c = 0; c < calls; c++) failed += pool->step(&selftest_pool_fn, envs, acts, streams, count) != PCGRL_OK;

@@ -39,6 +39,8 @@ struct StepPool {
     std::atomic<unsigned> gen{0};
     std::atomic<int> left{0};           // workers that have not finished the call in flight
     std::atomic<int> rc{0};             // first error of the call in flight
+    std::atomic<int> hip{0};            // ... and the HIP error code behind it: pcgrl_last_hip_error is per thread, and the step that
+                                        // failed may have run on a worker -- step() hands the code to the calling thread
     std::atomic<int> sleepers{0};
     std::mutex m;                       // callers take turns; also the condition variable's mutex
     std::mutex call_m;
@@ -47,7 +49,7 @@ struct StepPool {
     void run_share(int w, int stride) {
         for (int i = w; i < count; i += stride) {
             const int r = fn(envs[i], actions[i], streams[i]);
-            if (r) { int zero = 0; rc.compare_exchange_strong(zero, r); }
+            if (r) { int zero = 0; if (rc.compare_exchange_strong(zero, r)) hip.store(g_last_hip, std::memory_order_release); }
         }
     }
     void worker(int w, unsigned seen) {        // seen: the generation at the time the worker was made (no call was in flight)
@@ -56,11 +58,13 @@ struct StepPool {
             const auto t0 = std::chrono::steady_clock::now();
             unsigned g;
             int spins = 0;
-            while ((g = gen.load(std::memory_order_acquire)) == seen) {
+            while ((g = gen.load(std::memory_order_seq_cst)) == seen) {
                 if ((++spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) {
                     std::unique_lock<std::mutex> lk(m);
                     sleepers.fetch_add(1, std::memory_order_seq_cst);
-                    cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
+                    // (seq_cst on both sides of the sleepers / gen handshake: the caller bumps gen and then reads sleepers, the worker
+                    //  announces itself and then re-reads gen -- Dekker-style, which acquire / release alone does not order)
+                    cv.wait(lk, [&] { return gen.load(std::memory_order_seq_cst) != seen; });
                     sleepers.fetch_sub(1, std::memory_order_seq_cst);
                 } else {
                     PCGRL_CPU_RELAX();
@@ -75,12 +79,15 @@ struct StepPool {
         std::lock_guard<std::mutex> turn(call_m);
         fn = f; envs = e; actions = a; streams = s; count = n;
         rc.store(0, std::memory_order_relaxed);
+        hip.store(0, std::memory_order_relaxed);
         left.store(nworkers, std::memory_order_relaxed);
         gen.fetch_add(1, std::memory_order_seq_cst);
         if (sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
         run_share(0, nworkers + 1);
         while (left.load(std::memory_order_acquire) > 0) PCGRL_CPU_RELAX();
-        return rc.load(std::memory_order_relaxed);
+        const int r = rc.load(std::memory_order_acquire);
+        if (r) g_last_hip = hip.load(std::memory_order_acquire);      // what pcgrl_last_hip_error() reports on the caller's thread
+        return r;
     }
     // handles > 0: the pool for a call of that many handles (made now if there is none), or null when the calling thread is to do
     // everything (threads switched off, or a forked child of the process that owns them).  handles == 0: pcgrl_step_threads -- sets

@@ -228,6 +228,8 @@ class BatchedPcgrlEnv:
         """pcgrl_env.py:106-115, including the ordering quirk: max_changes is recomputed only when
         change_percentage is passed, and both limits use the width/height from *before* this call."""
         import copy
+        if self._async is not None and self._handle is not None and not self._needs_reset:
+            self.flush()           # suspended steps are finished under the parameters they were taken with, as in lockstep
         before = (copy.deepcopy(self._prob.__dict__), copy.deepcopy(self._rep.__dict__), self._max_changes, self._max_iterations)
         if "change_percentage" in kwargs:
             percentage = min(1, max(0, kwargs.get("change_percentage")))
@@ -440,7 +442,15 @@ class BatchedPcgrlEnv:
             self._async = None
             return
         arena = torch.empty((need,), dtype=torch.uint8, device=self.device)          # (zeroed by the call)
-        _lib.check(self._lib.pcgrl_bind_async(self._handle, C.c_void_p(arena.data_ptr()), need, self._async_nslots, self._stream()), "pcgrl_bind_async")
+        rc = self._lib.pcgrl_bind_async(self._handle, C.c_void_p(arena.data_ptr()), need, self._async_nslots, self._stream())
+        if rc == _lib.PCGRL_EINVAL:
+            # the handle's search arena was cut for another solver_power than the one in effect (an in-place adjust_param(solver_power=
+            # smaller)): no asynchronous form on THIS allocation -- tick() steps in lockstep, nothing ever pending -- and the next
+            # reset() re-allocates, after which the slots fit
+            self._async = None
+            self._realloc = True
+            return
+        _lib.check(rc, "pcgrl_bind_async")
         n = self.num_envs
         off = (n + 255) // 256 * 256
         self._async = dict(arena=arena, pending=arena[:n], counters=arena[off:off + 64 + 16 * 64].view(torch.int64))
@@ -452,7 +462,8 @@ class BatchedPcgrlEnv:
         Returns (obs, reward, done, info, pending): the usual live views plus pending uint8 [N] (a live view too) -- where it is
         0 the outputs are those of the environment's last taken action and it takes the next one; elsewhere (1: a search is
         suspended, 2: its search ended the episode and the next tick resets it) the environment's rows are to be ignored.  Per environment the sequence of (taken action -> outputs) is bitwise that of
-        step().  step() / rollout() / set_maps() finish what is pending first (flush()); reset() drops it."""
+        step().  step() / rollout() / adjust_param() finish what is pending first (flush()); reset() and set_maps() drop it (every map is
+        replaced: what was in flight is void)."""
         if self._needs_reset:
             raise RuntimeError("reset() must be called before tick()")
         if self._async is None:

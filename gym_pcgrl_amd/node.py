@@ -186,9 +186,25 @@ class MultiGpuPcgrlEnv:
             b = sh._bufs
             decode = sh._prob.decode_rows if sh._prob.packed_rows else None
             res.append((sh._obs(), b["reward"], b["done"].view(self._torch.bool), InfoBatch(sh._prob.info_keys, b["info"], sh._max_iterations, sh._max_changes, decode)))
-        self._multi = dict(lib=self.shards[0]._lib, n=G, handles=VP(*[sh._handle.value for sh in self.shards]), actions=VP(),
+        want = []
+        for g, sh in enumerate(self.shards):
+            d = self._torch.device(self.devices[g])
+            if d.type == "cuda" and d.index is None:          # (a tensor's device always carries its ordinal)
+                d = self._torch.device("cuda", self._torch.cuda.current_device())
+            want.append((d, sh.num_envs * sh._rep.action_width()))
+        self._multi = dict(lib=self.shards[0]._lib, n=G, handles=VP(*[sh._handle.value for sh in self.shards]), actions=VP(), want=want,
+                           hvals=[sh._handle.value for sh in self.shards],
                            streams=VP(*[st.cuda_stream for st in self.streams]), res=res, bound=None,
                            out=(self._obs([r[0] for r in res]), ShardedTensor([r[1] for r in res]), ShardedTensor([r[2] for r in res]), [r[3] for r in res]))
+
+    def _multi_valid(self, M):
+        """The cached handles are the shards' current ones and no shard asks for the per-shard path (strict actions, a pending
+        reset): three attribute reads per shard and call, against a use-after-free of a destroyed handle."""
+        for sh, hv in zip(self.shards, M["hvals"]):
+            h = sh._handle
+            if h is None or h.value != hv or sh.strict_actions or sh._needs_reset:
+                return False
+        return True
 
     def step(self, actions):
         """pcgrl_env.py:129-150 for every environment of every shard.  Returns (obs, reward, done, infos): obs / reward / done in
@@ -197,15 +213,20 @@ class MultiGpuPcgrlEnv:
         self._flip ^= 1
         torch = self._torch
         M = self._multi
-        if M is None and self.gather == "list" and not any(sh.strict_actions or sh._needs_reset for sh in self.shards):
+        if M is not None and not self._multi_valid(M):
+            M = self._multi = None             # (a shard was closed / re-allocated / switched to strict actions behind the cache's back)
+        if M is None and self.gather == "list" and not any(sh.strict_actions or sh._needs_reset or sh._handle is None for sh in self.shards):
             self._prepare_multi()              # (dropped again by reset() / adjust_param(): the shards are then looked at anew)
             M = self._multi
         if M is not None:
             if actions is not M["bound"]:      # (action_buffers(): the pointers are in place already -- nothing to look at per call)
                 i32 = torch.int32
-                if isinstance(actions, (list, tuple)) and len(actions) == M["n"] and all(a.dtype is i32 and a.is_contiguous() for a in actions):
+                want = M["want"]               # per shard: (device, element count) -- a raw pointer goes to the kernels, so both are checked
+                if (isinstance(actions, (list, tuple)) and len(actions) == M["n"] and
+                        all(torch.is_tensor(a) and a.dtype is i32 and a.is_contiguous() and a.device == w[0] and a.numel() == w[1]
+                            for a, w in zip(actions, want))):
                     acts = actions             # per-shard int32 tensors on their devices, as a per-shard policy produces them: taken as they are
-                else:
+                else:                          # anything else (host tensors, another GPU, another length): moved / reshaped / refused by the shard
                     acts = [sh._as_actions(p) for sh, p in zip(self.shards, self.split(actions))]
                 self._last_actions = acts      # keep the buffers alive until the launches are done
                 for g, a in enumerate(acts):
@@ -289,6 +310,7 @@ class MultiGpuPcgrlEnv:
         return [sh.check_status() for sh in self.shards]
 
     def close(self):
+        self._multi = None             # (the cached handle values die with the shards)
         for sh in self.shards:
             sh.close()
 

@@ -25,7 +25,8 @@ class RolloutBuffer:
         self.last_obs = z((num_envs,) + tuple(obs_shape), torch.uint8)
         # asynchronous collection (collect(policy, pop_budget=...)): row t is a TICK.  took[t, e]: environment e took actions[t, e]
         # (from obs[t, e]); fresh[t, e]: a step of e completed in tick t -- rewards[t, e] / dones[t, e] are the outcome of the LAST
-        # action it took (at tick t or earlier) and the next row's observation is the one that follows it.  Lockstep: all true.
+        # action it took (at tick t or earlier) and the next row's observation is the one that follows it; where fresh is false the
+        # collector writes reward 0 and done False.  Lockstep: all true.
         self.took = torch.ones((n_steps, num_envs), dtype=torch.bool, device=device)
         self.fresh = torch.ones((n_steps, num_envs), dtype=torch.bool, device=device)
 
@@ -61,7 +62,7 @@ class RolloutCollector:
     def collect(self, policy, pop_budget=None):
         """pop_budget: collect with asynchronous ticks (BatchedPcgrlEnv.tick; sokoban / mdungeon / ddave) -- a row of the buffer is then a
         tick, `took` / `fresh` say which environments acted in it and which completed a step (an environment whose search is
-        suspended sits ticks out; the policy's action for it is ignored).  Per environment the rows with `took` / `fresh` set, in
+        suspended sits ticks out; the policy's action for it is ignored; its reward and done in those rows are zero).  Per environment the rows with `took` / `fresh` set, in
         order, are the transitions a lockstep rollout holds.  No host synchronisation either way."""
         torch, b = self.torch, self.buffer
         asynchronous = pop_budget is not None
@@ -101,6 +102,10 @@ class RolloutCollector:
             if asynchronous:       # an episode starts where a step completed in this tick with done set; pending rows keep their flag
                 self._start = torch.where(b.fresh[t], done.to(torch.bool), self._start)
                 b.dones[t] &= b.fresh[t]
+                # ... and no reward: the environment's reward row still holds that of its last completed step, which an earlier row of
+                # the buffer already carries -- a consumer that sums rewards over rows (returns, GAE) without looking at `fresh` would
+                # count it once per tick sat out.  (The obs rows of such ticks are in-flight images: pair `took` rows with the `fresh` rows that follow them.)
+                b.rewards[t].masked_fill_(~b.fresh[t], 0)
             else:
                 self._start = done.to(torch.bool).clone()
             if self.env.monitor:

@@ -109,6 +109,9 @@ def test_async_collector_holds_the_lockstep_transitions(env_id, rep):
     lock, asy = out
     assert lock["took"].all() and lock["fresh"].all()
     assert (~asy["fresh"]).sum() > 10               # environments really sat ticks out
+    # rows in which no step completed carry reward 0 / done False: summing the reward rows of an environment gives the
+    # sum over its completed steps, with or without looking at `fresh`
+    assert (asy["rewards"][~asy["fresh"]] == 0).all() and not asy["dones"][~asy["fresh"]].any()
     short = 0
     for e in range(N):
         acts = asy["actions"][asy["took"][:, e], e]
@@ -153,3 +156,53 @@ def test_async_ticks_through_the_node_driver_and_a_checkpoint():
         _, rb, db, _ = twin.step(a)
         assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(one._bufs["map"], twin._bufs["map"]), t
     one.close(); node.close(); twin.close()
+
+
+def test_make_vec_envs_async_ticks_gives_the_lockstep_transitions_per_environment():
+    """the asynchronous form behind the reference-shaped surface -- make_vec_envs(..., async_ticks=budget).step()
+    returns the usual four values, `infos.took` / `infos.fresh` say who acted and who completed a step; per environment the
+    (took action -> fresh outcome) pairs are bitwise the transitions of the lockstep environment, and reward / done are zero in the
+    calls an environment sat out."""
+    import torch
+    from gym_pcgrl_amd.utils import make_vec_envs
+    N, T_lock, T_tick = 320, 20, 36
+    n_act = None
+
+    def policy(obs):
+        flat = obs.reshape(obs.shape[0], -1).to(torch.int64)
+        w = torch.arange(1, flat.shape[1] + 1, device=obs.device, dtype=torch.int64) % 89 + 1
+        return (flat * w).sum(1) % n_act
+
+    rec = []
+    for budget in (None, 5):
+        venv = make_vec_envs("sokoban-narrow-v0", "narrow", n_cpu=N, seed=23, device="cuda:0", monitor=True, async_ticks=budget, change_percentage=0.6)
+        n_act = int(venv.action_space.n)
+        obs = venv.reset()
+        rows = dict(a=[], r=[], d=[], took=[], fresh=[], ep=[])
+        for t in range(T_lock if budget is None else T_tick):
+            a = policy(obs)
+            obs, rew, done, infos = venv.step(a)
+            rows["a"].append(a.cpu().numpy()); rows["r"].append(rew.cpu().numpy()); rows["d"].append(done.cpu().numpy())
+            if budget is None:
+                assert not hasattr(infos, "took")
+                rows["took"].append(np.ones(N, bool)); rows["fresh"].append(np.ones(N, bool))
+            else:
+                rows["took"].append(infos.took.cpu().numpy()); rows["fresh"].append(infos.fresh.cpu().numpy())
+            rows["ep"].append(dict(getattr(infos, "episodes", {})))
+        rec.append({k: (np.stack(v) if k != "ep" else v) for k, v in rows.items()})
+        venv.close()
+    lock, asy = rec
+    assert (~asy["fresh"]).sum() > 10 and (asy["r"][~asy["fresh"]] == 0).all() and not asy["d"][~asy["fresh"]].any()
+    n_eps = 0
+    for e in range(N):
+        acts = asy["a"][asy["took"][:, e], e]
+        rew, done = asy["r"][asy["fresh"][:, e], e], asy["d"][asy["fresh"][:, e], e]
+        k = min(len(rew), T_lock)
+        assert np.array_equal(acts[:k], lock["a"][:k, e]) and np.array_equal(rew[:k], lock["r"][:k, e]) and np.array_equal(done[:k], lock["d"][:k, e]), e
+        # Monitor's episode entries come with the call in which the episode's last step completed, and are the lockstep ones
+        eps_l = [lock["ep"][t][e] for t in range(T_lock) if e in lock["ep"][t]]
+        eps_a = [asy["ep"][t][e] for t in range(T_tick) if e in asy["ep"][t]]
+        m = min(len(eps_l), len(eps_a))
+        assert eps_a[:m] == eps_l[:m], e
+        n_eps += m
+    assert n_eps > 0

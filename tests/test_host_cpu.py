@@ -434,6 +434,11 @@ def test_step_pool_steps_every_handle_once_per_call_and_reports_errors():
         assert rc == 0 and (hits == 500).all(), (count, rc, hits)
     hits = np.zeros(8, np.int32)
     assert L.pcgrl_selftest_step_pool(8, 100, 5, hits.ctypes.data_as(C.c_void_p)) == 100 and (hits == 100).all()
+    # the failing stand-in ran on a worker thread and left its "HIP error" (9000 + its index) in that thread's slot: the call hands
+    # it to the calling thread, where pcgrl_last_hip_error() is read
+    assert L.pcgrl_last_hip_error() == 9005
+    hits = np.zeros(8, np.int32)
+    assert L.pcgrl_selftest_step_pool(8, 10, 0, hits.ctypes.data_as(C.c_void_p)) == 10 and L.pcgrl_last_hip_error() == 9000     # (the caller's own share)
     # after a pause the workers sleep; they have to wake up again
     import time
     time.sleep(0.05)

@@ -148,3 +148,58 @@ def test_sync_streams_orders_each_shard_stream_against_the_callers(monkeypatch):
     env.step(torch.zeros(G * n, dtype=torch.int32))
     assert log == ["wait_stream"] * G + ["current.wait_stream"] * G and len(lib.calls) == 1
     env.shards = []
+
+
+def test_fast_path_takes_only_tensors_it_can_hand_to_the_kernels():
+    """the per-shard list goes to the kernels as raw pointers, so the fast path checks device and element count and sends
+    everything else through the shard's own conversion (which moves / reshapes / refuses) instead of launching on a bad pointer."""
+    G, n = 4, 6
+    log, lib = [], _Lib()
+    env = _driver(G, n, False, log, lib)
+    seen = []
+    for sh in env.shards:
+        sh._as_actions = (lambda a, _sh=sh: (seen.append(tuple(a.shape)), a.to(torch.int32).contiguous().reshape(-1)[:_sh.num_envs])[1])
+    good = [torch.zeros(n, dtype=torch.int32) for _ in range(G)]
+    env.step(good)
+    assert seen == [] and lib.calls[-1][1] == [a.data_ptr() for a in good]
+    short = [torch.zeros(n, dtype=torch.int32) for _ in range(G)]
+    short[2] = torch.zeros(n - 1, dtype=torch.int32)                      # wrong length: not taken as it is
+    env.step(short)
+    assert len(seen) == G and seen[2] == (n - 1,)
+    seen.clear()
+    other_dev = [torch.zeros(n, dtype=torch.int32) for _ in range(G)]
+    env._multi["want"][1] = (torch.device("meta"), n)                     # shard 1 lives on another device than the tensor offered for it
+    env.step(other_dev)
+    assert len(seen) == G
+    env.shards = []
+
+
+def test_cached_handles_are_dropped_when_a_shard_changes_behind_the_cache():
+    """ADVICE r5: close() and shard-level re-allocation invalidate the pcgrl_step_multi cache (no destroyed handle reaches the library);
+    strict_actions / a pending reset switch to the per-shard path."""
+    G, n = 3, 4
+    log, lib = [], _Lib()
+    env = _driver(G, n, False, log, lib)
+    acts = torch.zeros(G * n, dtype=torch.int32)
+    env.step(acts)
+    assert lib.calls[-1][0] == [1000, 1001, 1002]
+    env.shards[1]._handle = C.c_void_p(5555)                              # re-allocated: a new handle value
+    env.step(acts)
+    assert lib.calls[-1][0] == [1000, 5555, 1002]
+    stepped = []
+    for sh in env.shards:
+        sh.step = (lambda a, _sh=sh: (stepped.append(_sh._handle.value), (_sh._obs(), _sh._bufs["reward"], _sh._bufs["done"], None))[1])
+    env._each = lambda f: [f(g, sh) for g, sh in enumerate(env.shards)]
+    env.shards[0].strict_actions = True                                   # the shard wants to look at every action itself
+    ncalls = len(lib.calls)
+    env.step(acts)
+    assert len(lib.calls) == ncalls and stepped == [1000, 5555, 1002] and env._multi is None
+    env.shards[0].strict_actions = False
+    env.step(acts)
+    assert len(lib.calls) == ncalls + 1
+    closed = []
+    for sh in env.shards:
+        sh.close = (lambda _sh=sh: closed.append(_sh))
+    env.close()
+    assert env._multi is None and len(closed) == G
+    env.shards = []
