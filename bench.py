@@ -335,7 +335,25 @@ def run_leg(torch, device, workload, steps, warmup, steady_warmup, seed=0):
     if prob in ("sokoban", "mdungeon", "ddave"):
         leg["search"] = search_chain(torch, env, step, acts, warmup + steps)
     env.close()
+    add_traffic(leg, workload, n * (b_alg + obs_bytes))
     return leg
+
+
+def add_traffic(leg, workload, alg_bytes_per_step):
+    """The counter-measured HBM line traffic of the workload's step (measured_traffic: the last committed rocprofv3 PMC passes) next to
+    the leg's NOMINAL roofline fraction -- which prices the algorithmic bytes 2*H*W + 64 per env-step whether or not the step touched
+    them (incremental statistics leave most maps alone: C5's counter traffic is a tenth of its algorithmic bytes) -- and the HBM
+    bandwidth the step really drew: traffic / GPU time of a step."""
+    traffic, src, head = measured_traffic(workload)
+    if traffic is None:
+        return
+    gms = leg.get("gpu_ms_per_step")
+    leg["traffic"] = {"bytes_per_step": traffic, "source": src, "stale": head != tree_hash(), "vs_algorithmic": traffic / float(alg_bytes_per_step),
+                      "hbm_gbps_drawn": (traffic / (gms * 1e-3) / 1e9) if gms else None,
+                      "hbm_frac_drawn": (traffic / (gms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if gms else None}
+    st = leg.get("steady_state")
+    if st and st.get("gpu_ms_per_step"):
+        st["hbm_gbps_drawn"] = traffic / (st["gpu_ms_per_step"] * 1e-3) / 1e9
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 VALU_ISSUE_PEAK = 1.0e12  # wave64 VALU instructions per second, whole chip: measured (profiles/r3a_round3/valu_calibration.md); 1 024 SIMDs x 2.4 GHz / 2.45
@@ -439,6 +457,51 @@ def cpu_baseline(prob, rep, calls, budget_s=12.0):
             "single_core": rate1}
 
 
+TALL = "C5"        # BASELINE.json config 5 (north_star's 8-GPU one): binary-turtle 64x64, 8 192 environments per GPU
+
+
+def tall_maps_leg(torch, dist, device, rank, world, use_dist, same_gpu, steps=20, warmup=5, steady_warmup=800):
+    """Under N > 1 every rank also times BASELINE config 5 on its own GPU (8 192 environments per rank, seeded with their global
+    indices: rank r owns [r * 8192, (r + 1) * 8192)), first window and steady state, between barriers; the times are the MAX over
+    ranks and the values whole-job env-steps/s, like the headline.  No collective on the step path."""
+    prob, rep, calls, n, desc = WORKLOADS[TALL]
+    env, step, reset, _ = make_stepper(torch, TALL, n, device, rank * n)
+    reset()
+    W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
+    acts = make_actions(torch, rep, steps + warmup + 64, n, W, H, nt, device, 4321 + rank)
+
+    def window(t0):
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        wall, gms = timed_steps(torch, device, step, acts, t0, steps)
+        if use_dist:
+            dist.barrier()
+            tt = torch.tensor([wall, gms], device="cpu" if same_gpu else device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall, gms = float(tt[0].item()), float(tt[1].item())
+        return wall, gms
+
+    for t in range(warmup):
+        step(acts[t])
+    wall, gms = window(warmup)
+    b_alg = 2 * H * W + 64
+    leg = {"workload": desc, "envs_per_gpu": n, "n_gpus": world, "steps": steps, "warmup": warmup, "value": float(n) * world * steps / wall,
+           "unit": "env-steps/s (whole job, max-over-ranks time)", "ms_per_step": wall / steps * 1e3, "gpu_ms_per_step": gms,
+           "dominant_kernel": DOMINANT[TALL], "algorithmic_bytes_per_env_step": b_alg, "roofline_frac": n * b_alg / (gms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    t_now = warmup + steps
+    for t in range(t_now, steady_warmup):
+        step(acts[t % acts.shape[0]])
+    t_now = max(t_now, steady_warmup)
+    swall, sgms = window(t_now)
+    leg["steady_state"] = {"after_steps": t_now, "value": float(n) * world * steps / swall, "ms_per_step": swall / steps * 1e3, "gpu_ms_per_step": sgms,
+                           "roofline_frac": n * b_alg / (sgms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    env.close()
+    if rank == 0:
+        add_traffic(leg, TALL, n * b_alg)
+    return leg
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -528,8 +591,12 @@ def main():
         if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         if rank == 0:
-            print(json.dumps({"metric": "env-steps/sec (whole node)", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
-                              "warmup": a.warmup, "dry_run": True, "max_over_ranks_s": float(tt[0]), "scaling": "weak"}))
+            line = {"metric": "env-steps/sec (whole node)", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+                    "warmup": a.warmup, "dry_run": True, "max_over_ranks_s": float(tt[0]), "scaling": "weak"}
+            if world > 1:      # the shape of the N > 1 line: BASELINE config 5 is timed on every rank as well (tall_maps_leg)
+                line["configs"] = {TALL: {"workload": WORKLOADS[TALL][4], "envs_per_gpu": WORKLOADS[TALL][3], "n_gpus": world, "value": None,
+                                          "unit": "env-steps/s (whole job, max-over-ranks time)", "dry_run": True}}
+            print(json.dumps(line))
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -580,6 +647,10 @@ def main():
         tt = torch.tensor([dt, gpu_ms_per_step], device="cpu" if same_gpu else device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, gpu_ms_per_step = float(tt[0].item()), float(tt[1].item())
+    # N > 1: BASELINE config 5 (north_star: 8 192 tall-map environments per GPU, the 8-GPU configuration) on every rank as well
+    tall = None
+    if world > 1 and a.workload == "C2" and n == n_default and not a.no_legs:
+        tall = tall_maps_leg(torch, dist, device, rank, world, use_dist, same_gpu)
     # informational per-kernel breakdown: a second pass with HIP events around every launch
     # (each event record costs a few us on the stream, so it is kept out of the timed region)
     phase_ms, prof_steps = {}, 0
@@ -729,6 +800,8 @@ def main():
                     if base:
                         legs[wname]["gpu_time_vs_bare_step"] = legs[wname]["gpu_ms_per_step"] / base
             out["configs"] = legs
+        if tall is not None:
+            out.setdefault("configs", {})[TALL] = tall
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

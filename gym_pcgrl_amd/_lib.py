@@ -65,13 +65,13 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
 
 
-ABI_VERSION = 12         # include/pcgrl_hip.h PCGRL_ABI_VERSION
+ABI_VERSION = 13         # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",
            "pcgrl_profile_read", "pcgrl_bind_episode_stats", "pcgrl_seed_words", "pcgrl_rollout", "pcgrl_bind_observation", "pcgrl_selftest_heap",
            "pcgrl_tuning_defaults", "pcgrl_set_tuning", "pcgrl_clear_status", "pcgrl_step_flat",
-           "pcgrl_async_bytes", "pcgrl_bind_async", "pcgrl_step_async", "pcgrl_async_flush", "pcgrl_step_multi", "pcgrl_selftest_step_pool", "pcgrl_step_threads")
+           "pcgrl_async_bytes", "pcgrl_bind_async", "pcgrl_step_async", "pcgrl_async_flush", "pcgrl_step_multi", "pcgrl_selftest_step_pool", "pcgrl_step_threads", "pcgrl_selftest_range_reward")
 NPHASE = 6
 # the six intervals between the seven event marks of a step; sokoban: update, stats, reset, solver, reset2, solver2;
 # other problems: update, stats(+resets), -, reset (only with PCGRL_INLINE_RESET=0), -, -
@@ -183,6 +183,7 @@ def load():
     L.pcgrl_step_flat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_selftest_heap.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcgrl_selftest_step_pool.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.pcgrl_selftest_range_reward.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.pcgrl_step_threads.argtypes = [C.c_int32]
     L.pcgrl_step_threads.restype = C.c_int32
     L.pcgrl_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]

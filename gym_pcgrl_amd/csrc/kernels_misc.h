@@ -13,6 +13,13 @@ __global__ void k_action_map(const int32_t* __restrict__ flat, int32_t* __restri
     }
 }
 
+// pcgrl_selftest_range_reward: helper.py:366-376 in the integer form every reward of the step kernels goes through (range_reward_i,
+// pcgrl_algos.h), on the device, one thread per row of a table (new value, old value, low, high).
+__global__ void k_selftest_range_reward(const int32_t* __restrict__ rows, int n, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = range_reward_i(rows[4 * i], rows[4 * i + 1], rows[4 * i + 2], rows[4 * i + 3]);
+}
+
 __global__ void k_fill_all(DevBufs B, int n, int parity, int list) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) B.wl_items[list][(size_t)(i & (WL_NSHARD - 1)) * B.wl_cap[list] + (i >> 6)] = i;

@@ -1286,6 +1286,17 @@ int pcgrl_step_multi(pcgrl_env* const* envs, const int32_t* const* actions, void
     return PCGRL_OK;
 }
 
+// pcgrl_selftest_range_reward: get_range_reward (helper.py:366-376) as the DEVICE evaluates it -- range_reward_i on `n` rows of
+// (new value, old value, low, high), INT_MAX / INT_MIN standing for +-inf -- so that the reference's exhaustive table is held against
+// the kernels' own integer form on the GPU and not only through trajectories.
+int pcgrl_selftest_range_reward(const int32_t* rows, int32_t n, int32_t* out, void* stream) {
+    if (!rows || !out || n < 0) return PCGRL_EINVAL;
+    if (n == 0) return PCGRL_OK;
+    hipLaunchKernelGGL(k_selftest_range_reward, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, n, out);
+    HIPCHK(hipGetLastError());
+    return PCGRL_OK;
+}
+
 // How many issuing threads pcgrl_step_multi uses besides the caller's: n >= 0 sets it (0: none; at most 7; only before the first
 // multi-handle call has made them), n < 0 only asks.  Returns the number in effect.
 int32_t pcgrl_step_threads(int32_t n) {

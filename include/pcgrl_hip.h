@@ -38,7 +38,7 @@ extern "C" {
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
  *    clamped actions.  10: + pcgrl_tuning / pcgrl_set_tuning (the library reads no environment variables any more); pcgrl_config
  *    grew (prob_width, prob_height); maps up to 255 x 255, search levels up to 16 384 bordered cells, solver_power up to 1 000 000. */
-#define PCGRL_ABI_VERSION 12
+#define PCGRL_ABI_VERSION 13
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -264,6 +264,11 @@ int pcgrl_selftest_heap(const uint32_t* ops, int32_t n_ops, uint32_t* pops, uint
  * handles for `calls` calls; hits HOST i32 [count] is incremented once per stand-in and call, stand-in `fail_at` (-1: none) reports an
  * error.  Returns the number of calls that returned an error, -1 when the pool is switched off (pcgrl_step_threads(0)). */
 int pcgrl_selftest_step_pool(int32_t count, int32_t calls, int32_t fail_at, int32_t* hits);
+/* Test hook for get_range_reward (helper.py:366-376), which every reward term of every problem goes through: the integer form the
+ * step kernels evaluate (bounds are integers or +-inf, statistics are small integers; INT32_MAX / INT32_MIN stand for +-inf), run
+ * on the current device over a table.  rows DEVICE i32 [n][4] = (new value, old value, low, high); out DEVICE i32 [n].
+ * tests/test_gpu_parity.py holds it against the reference's exhaustive table (tests/golden/range_reward.npz). */
+int pcgrl_selftest_range_reward(const int32_t* rows, int32_t n, int32_t* out, void* stream);
 /* Sticky device status word, 0 = fine.  Bit 0 (1): a level was outside a search kernel's limits -- a Sokoban level with more crates
  * than the search takes (32 in the compact searches, 256 in the general ones of csrc/search_big.h), or more than 255 tiles / collected
  * things of one kind in a packed statistics row (Dave, MiniDungeons on large maps): the statistics of that level are then not exact.

@@ -1158,6 +1158,29 @@ class _HeapWord:
 
 
 @pytest.mark.gpu
+def test_range_reward_table_on_the_device():
+    """get_range_reward (helper.py:366-376) is what every reward term of every problem goes through; the kernels evaluate it in
+    integers (range_reward_i, csrc/pcgrl_algos.h).  The reference's exhaustive table (tests/golden/range_reward.npz: every band the
+    problems use, +-inf bounds, values on both sides of and inside the band) through pcgrl_selftest_range_reward ON THE DEVICE --
+    until round 6 the table was held against the oracle and the host build of the header only, the device form through trajectories."""
+    import ctypes as C
+    torch = _torch()
+    from gym_pcgrl_amd import _lib
+    L = _lib.load()
+    tab = np.load(os.path.join(os.path.dirname(__file__), "golden", "range_reward.npz"))["table"]
+    enc = lambda b: 2147483647 if b == np.inf else (-2147483648 if b == -np.inf else int(b))
+    rows = np.array([[int(nv), int(ov), enc(lo), enc(hi)] for lo, hi, nv, ov, _ in tab], np.int32)
+    assert len(rows) == 3240 and np.isinf(tab[:, :2]).any()
+    t_rows = torch.from_numpy(rows).to("cuda:0")
+    t_out = torch.full((len(rows),), 12345, dtype=torch.int32, device="cuda:0")
+    _lib.check(L.pcgrl_selftest_range_reward(C.c_void_p(t_rows.data_ptr()), len(rows), C.c_void_p(t_out.data_ptr()), None), "pcgrl_selftest_range_reward")
+    torch.cuda.synchronize()
+    got = t_out.cpu().numpy()
+    assert np.array_equal(got.astype(np.float64), tab[:, 4]), np.nonzero(got != tab[:, 4])[0][:10]
+
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,spread,n_ops,p_push", [(0, 1, 30000, 0.75), (1, 2, 30000, 0.7), (2, 3, 60000, 0.62), (3, 40, 60000, 0.6),
                                                       (4, 400, 40000, 0.8), (5, 2, 3000, 0.5)])
 def test_heap_server_primitives_match_heapq(seed, spread, n_ops, p_push):
@@ -1709,6 +1732,29 @@ def test_bench_eight_ranks_tall_maps_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["config"]["width"] == 64 and d["config"]["height"] == 64 and d["config"]["max_changes"] == 39
     assert abs(d["value"] - 8 * 256 * 5 / (d["ms_per_step"] * 1e-3 * 5)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_carry_the_tall_map_config_on_the_headline_line():
+    """under N > 1 the default line (C2 headline) also carries `configs.C5` -- BASELINE config 5, 8 192 tall-map
+    environments per rank, first window and steady state, max-over-ranks -- so that the day an 8-GPU node runs it the one line tells
+    both stories.  Two ranks on cuda:0 over gloo here."""
+    import json, subprocess, sys
+    _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCGRL_BENCH_SAME_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--steady-warmup", "0", "--no-rollout",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 65536
+    c5 = d["configs"]["C5"]
+    assert c5["n_gpus"] == 2 and c5["envs_per_gpu"] == 8192 and c5["dominant_kernel"] == "k_stats_wide"
+    assert abs(c5["value"] - 2 * 8192 * c5["steps"] / (c5["ms_per_step"] * 1e-3 * c5["steps"])) / c5["value"] < 1e-6
+    assert c5["steady_state"]["after_steps"] >= 800 and c5["steady_state"]["gpu_ms_per_step"] > 0
 
 
 @pytest.mark.gpu

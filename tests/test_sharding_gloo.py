@@ -114,6 +114,10 @@ def test_bench_gpus2_starts_its_own_ranks():
     d = lines[0]
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 2 and d["dry_run"] is True and d["value"] is None
     assert d["max_over_ranks_s"] >= 0.02          # rank 1 sleeps 20 ms: the reduction is a max over the ranks
+    # the N > 1 line also carries BASELINE config 5 (north_star's 8-GPU configuration: 8 192 tall-map environments per GPU), timed on
+    # every rank between barriers (bench.py tall_maps_leg); the dry run shows its place on the line
+    c5 = d["configs"]["C5"]
+    assert c5["n_gpus"] == 2 and c5["envs_per_gpu"] == 8192 and "64x64" in c5["workload"] and c5["value"] is None
 
 
 def test_bench_refuses_to_report_fewer_gpus_than_asked():
