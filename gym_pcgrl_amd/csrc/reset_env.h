@@ -94,6 +94,7 @@ __device__ __forceinline__ uint64_t reset_row_bits(uint64_t q, int base, int o, 
     if (sh >= 64 || sh + W <= 0) return 0ull;
     return sh >= 0 ? (q >> sh) : (q << -sh);
 }
+
 struct ResetRows { uint64_t m0, m1, m2; };      // bit planes of the tile ids of one row of the regenerated map
 
 // `row` / `rows` (optional): the lanes that pass a row index 0 .. H-1 get that row of the new map as bit planes of the tile ids
@@ -139,9 +140,13 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
             mt[sl] = B.fifo[(size_t)e * PCGRL_FIFO_N + lane];
         }
     }
+    // the words this reset puts into the ring are the `dirty` ones from dirty0 on (the lazy ring makes one word per draw, in place): only
+    // those go back to memory at the end -- 352 of 624 for an 11 x 16 map, 400 for 14 x 14 -- instead of the whole ring
+    int dirty0 = cur - pend; dirty0 = dirty0 < 0 ? dirty0 + PCGRL_MT_N : dirty0;
+    int dirty = pend;
     __builtin_amdgcn_wave_barrier();
     TL(13);
-    if (step_draws) { int sx, sy; cur = wave_draw_xy(mt, cur, W, H, lane, sx, sy); }
+    if (step_draws) { int sx, sy; const int c0 = cur; cur = wave_draw_xy(mt, cur, W, H, lane, sx, sy); dirty += cur >= c0 ? cur - c0 : cur - c0 + PCGRL_MT_N; }
     if (gen_map) {
         // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
         // the number of tiles is a property of the problem: constant indices only -- a run-time index into the by-value
@@ -203,6 +208,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
             }
             __builtin_amdgcn_wave_barrier();
             cur += 2 * (nA + nB); cur = cur >= PCGRL_MT_N ? cur - PCGRL_MT_N : cur;
+            dirty += 2 * (nA + nB);
         }
     } else {
         // representation.py:44-45: restore the first map of this environment
@@ -224,7 +230,9 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     TL(14);
     if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33: x = randint(W), y = randint(H)
         int xv, yv;
+        const int c0 = cur;
         cur = wave_draw_xy(mt, cur, W, H, lane, xv, yv);
+        dirty += cur >= c0 ? cur - c0 : cur - c0 + PCGRL_MT_N;
         if (lane == 0) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)xv, (unsigned char)yv);
     }
     __builtin_amdgcn_wave_barrier();
@@ -234,7 +242,14 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         B.fifo[(size_t)e * PCGRL_FIFO_N + lane] = mt_twist(mt[sl], mt[mt_wrap(sl + 1)], mt[mt_wrap(sl + PCGRL_MT_M)]);
         if (lane == 0) B.fifo_tag[e] = cur;
     }
-    for (int i = lane; i < PCGRL_MT_N; i += 64) ring_g[i] = mt[i];
+    if (dirty >= PCGRL_MT_N) {
+        for (int i = lane; i < PCGRL_MT_N; i += 64) ring_g[i] = mt[i];
+    } else {
+        for (int k = lane; k < dirty; k += 64) {
+            int i = dirty0 + k; i = i >= PCGRL_MT_N ? i - PCGRL_MT_N : i;
+            ring_g[i] = mt[i];
+        }
+    }
     uint16_t* heat_g = B.heat + (size_t)e * cells;
     for (int c = lane; c < cells; c += 64) heat_g[c] = 0;        // pcgrl_env.py:72
     if (lane == 0) {
