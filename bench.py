@@ -63,6 +63,8 @@ LEGS = {"C3": (20, 5, 800), "C4": (10, 3, 40), "C5": (20, 5, 800), "S1": (5, 2, 
         "B1": (50, 10, 7000)}       # (B1: an episode is ~6 000 steps long -- max_changes 2 000, a third of the random actions change a tile)
 # asynchronous ticks of the search problems (pcgrl_step_async): (workload, ticks, warm-up ticks, pop budget per search and tick)
 ASYNC_LEGS = {"C4_async": ("C4", 300, 60, 64), "M1_async": ("M1", 300, 60, 64), "D1_async": ("D1", 300, 60, 64)}
+# the batch as K sub-batches on K streams of the one GPU (sub_batch_leg): (workload, K)
+SUB_BATCH_LEGS = {"C2_sub2": ("C2", 2), "C3_sub2": ("C3", 2)}
 GPU_CLOCK_HZ = 2.4e9     # MI355X engine clock (MI355X_MICROARCH.md), for the cycles-per-pop figures
 DOMINANT = {"B1": "k_big", "K1": "k_search_big", "C2": "k_step", "C3": "k_step", "C3d": "k_step", "C4": "k_sokoban", "C5": "k_stats_wide", "C5b": "k_stats_wide", "M1": "k_mdungeon",
             "D1": "k_ddave", "S1": "k_smb", "C2w": "k_step (writes the image)", "C3w": "k_step (writes the image)"}
@@ -301,6 +303,50 @@ def node_driver_leg(torch, device, G=8, n_per=256, calls=300):
             torch.cuda.synchronize(device)
         env.close()
     return out
+
+
+def sub_batch_leg(torch, device, workload, K=2, steps=200, warmup=20, steady_warmup=800):
+    """The same batch stepped as K sub-batches -- K handles with a stream each on this ONE GPU, one pcgrl_step_multi call per step
+    (node.MultiGpuPcgrlEnv with the same device K times): the double-buffered form of a rollout, in which the policy works on one
+    sub-batch while the other steps.  Nothing orders sub-batch A's step k + 1 behind sub-batch B's step k, so the tail of one k_step launch
+    (single wavefronts finishing the longest tasks, most SIMDs idle) runs under the front of the other's.  Per environment the results
+    are those of the one-batch form (contiguous slices, global-index seeds: test_node_driver_shard_invariance, bitwise).  Wall clock
+    per step of ALL n environments between two device synchronisations; NOT the headline `value`, which is one batch on one stream."""
+    from gym_pcgrl_amd.node import MultiGpuPcgrlEnv
+    prob, rep, calls, n, desc = WORKLOADS[workload]
+    env = MultiGpuPcgrlEnv(prob=prob, rep=rep, num_envs=n, devices=[str(device)] * K, seed=0, sync_streams=False)
+    for kw in calls:
+        env.adjust_param(**kw)
+    env.reset()
+    sh = env.shards[0]
+    W, H, nt = sh._prob._width, sh._prob._height, sh.get_num_tiles()
+    L = steps + warmup + 64
+    acts = make_actions(torch, rep, L, n, W, H, nt, device, 1234)
+    parts = [[acts[t][lo:hi].contiguous() for (lo, hi) in env.ranges] for t in range(L)]
+
+    def timed(t0):
+        torch.cuda.synchronize(device)
+        w0 = time.perf_counter()
+        for t in range(t0, t0 + steps):
+            env.step(parts[t % L])
+        h = time.perf_counter() - w0
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - w0) / steps, h / steps
+    for t in range(warmup):
+        env.step(parts[t])
+    first, host1 = timed(warmup)
+    for t in range(warmup + steps, steady_warmup):
+        env.step(parts[t % L])
+    steady, host2 = timed(max(warmup + steps, steady_warmup))
+    env.close()
+    b_alg = 2 * H * W + 64
+    return {"workload": desc, "sub_batches": K, "envs_per_sub_batch": n // K, "envs": n, "steps": steps, "warmup": warmup,
+            "value": n / first, "unit": "env-steps/s", "ms_per_step": first * 1e3, "host_issue_ms_per_step": host1 * 1e3,
+            "roofline_frac": n * b_alg / first / 1e9 / HBM_PEAK_GBPS,
+            "steady_state": {"value": n / steady, "ms_per_step": steady * 1e3, "host_issue_ms_per_step": host2 * 1e3, "after_steps": max(warmup + steps, steady_warmup),
+                             "roofline_frac": n * b_alg / steady / 1e9 / HBM_PEAK_GBPS},
+            "what": "K handles + streams on one GPU, one pcgrl_step_multi call per step of all of them; wall clock per step of all envs (no per-kernel figure: "
+                    "the sub-batches' launches overlap)"}
 
 
 def run_leg(torch, device, workload, steps, warmup, steady_warmup, seed=0):
@@ -548,7 +594,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="process plumbing only (launcher, rendezvous, barrier, max-over-ranks reduction over gloo); "
                                                           "no GPU, no environment: the line carries value null and dry_run true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short legs of the other configs (the `configs` object of the default line)")
-    ap.add_argument("--legs", default="C3,C4,C4_async,M1_async,C5,S1,B1,C2w,C3w,n1_facade,collector,node_driver", help="which legs the default line carries")
+    ap.add_argument("--legs", default="C3,C4,C4_async,M1_async,C5,S1,B1,C2w,C3w,C2_sub2,C3_sub2,n1_facade,collector,node_driver", help="which legs the default line carries")
     ap.add_argument("--tuning", default="", help="developer switches of the library for A/B runs: field=value[,field=value...] "
                                                  "(include/pcgrl_hip.h pcgrl_tuning, e.g. no_fused=1,step_epb=128)")
     ap.add_argument("--steady-warmup", type=int, default=800, help="steps before the steady_state measurement (0: skip it)")
@@ -784,6 +830,8 @@ def main():
                     legs[name] = run_leg(torch, device, name, *LEGS[name])
                 if name in ASYNC_LEGS:
                     legs[name] = async_leg(torch, device, *ASYNC_LEGS[name])
+                if name in SUB_BATCH_LEGS:
+                    legs[name] = sub_batch_leg(torch, device, *SUB_BATCH_LEGS[name])
             # what a user of the reference's surfaces gets: the single environment (C1's counterpart) and the trainer's loop
             if "n1_facade" in a.legs.split(","):
                 legs["n1_facade"] = n1_facade_leg()

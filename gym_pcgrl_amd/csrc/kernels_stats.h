@@ -135,7 +135,8 @@ __device__ __forceinline__ double zelda_reward_lanes(const ZeldaRewardTab* T, co
 // What one wavefront does with its share of the work of a launch (k_stats, and the fused step kernel k_step): `lone` -- a
 // certain reset (two when `pair`), an even lane group for the map the step ended on and the odd one next to it for the
 // regenerated map; `inc` -- incremental items; else full recomputations.  `have` / `raw`: this lane group's item.
-template <int PROB, int G, class MaskT>
+// FUSED (compile time): the caller is the fused step kernel (SL is given).
+template <int PROB, int G, class MaskT, bool FUSED = false>
 __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevBufs& B, DevGroup<G, MaskT>& g, int lane64, int gw, bool lone,
                                                 bool inc, bool pair, bool zinc, bool have, int raw, int shard, int mode, int parity,
                                                 int inline_reset, int gen_map, uint32_t* mt, uint8_t* tiles, MaskT rowmask,
@@ -179,7 +180,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
             const int step_draws = (SL && P.rep == PCGRL_REP_NARROW && P.random_tile) ? 1 : 0;
             if (SL && lane64 == 0) SL->dirty[ek - SL->e0] = 1;
             ResetRows rr;
-            wave_reset_env<PROB>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, step_draws, gw == 2 * k + 1 ? g.lane : -1, &rr);
+            wave_reset_env<PROB, !FUSED>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, step_draws, gw == 2 * k + 1 ? g.lane : -1, &rr);
             MaskT t0, t1, t2;
             reset_rows_to_planes<MaskT>(P, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == 2 * k + 1 ? g.lane : -1, rr.m0, rr.m1, rr.m2, t0, t1, t2);
             if (gw == 2 * k + 1) { b0 = t0; b1 = t1; b2 = t2; }
@@ -276,7 +277,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
                         pend = __builtin_amdgcn_readfirstlane(pend);
                     }
                     ResetRows rr;
-                    wave_reset_env<PROB>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, 0, gw == k ? g.lane : -1, &rr, pend);
+                    wave_reset_env<PROB, !FUSED>(P, B, ek, gen_map, mt, (uint8_t*)nullptr, lane64, 0, gw == k ? g.lane : -1, &rr, pend);
                     MaskT t0, t1, t2;
                     reset_rows_to_planes<MaskT>(P, reinterpret_cast<MaskT*>(B.planes) + (size_t)ek * NPL * G, gw == k ? g.lane : -1, rr.m0, rr.m1, rr.m2, t0, t1, t2);
                     if (gw == k) { b0 = t0; b1 = t1; b2 = t2; mine = true; }

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             const int want = lone ? (prio & 3) : (inc ? ((prio >> 4) & 3) : ((prio_nfull == 0 || wid - w_lone < prio_nfull) ? ((prio >> 2) & 3) : 0));
             if (want != prio_now) { prio_now = want; step_set_prio(want); }
         }
-        stats_wave_task<PROB, G, MaskT>(P, B, g, lane64, gw, lone, inc, PROB == PCGRL_PROB_ZELDA && pair, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
+        stats_wave_task<PROB, G, MaskT, true>(P, B, g, lane64, gw, lone, inc, PROB == PCGRL_PROB_ZELDA && pair, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
         TL(7);
     }
     if (prio_now) { prio_now = 0; step_set_prio(0); }

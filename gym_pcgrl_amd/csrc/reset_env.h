@@ -46,7 +46,11 @@ __device__ __forceinline__ void reset_rows_to_planes(const PcgrlParams& P, MaskT
 // lanes make the next eight words at once (every operand is an old word), two ballots pick the first accepted x and the first
 // accepted y after it; only if eight words do not hold both (probability < 1e-4 for any W, H) lane 0 goes on one word at a time.
 // The consumed words are written to the staged ring; returns the cursor after them, x / y in every lane.
-__device__ __forceinline__ int wave_draw_xy(uint32_t* mt, int cur, int W, int H, int lane, int& xv, int& yv) {
+// `ring_g` (optional; wave_reset_env with only part of the ring staged): before lane 0 goes on one word at a time -- it may then read
+// any word -- the rest of the ring is staged: every word outside the `dirty` ones from dirty0 on, which are newer in `mt` than in memory.
+template <bool RESTAGE = false>
+__device__ __forceinline__ int wave_draw_xy(uint32_t* mt, int cur, int W, int H, int lane, int& xv, int& yv, const uint32_t* ring_g = nullptr,
+                                            int dirty0 = 0, int dirty = 0) {
     const uint32_t rx = (uint32_t)(W - 1), ry = (uint32_t)(H - 1);
     uint32_t mx = rx, my = ry;
     mx |= mx >> 1; mx |= mx >> 2; mx |= mx >> 4; mx |= mx >> 8; mx |= mx >> 16;
@@ -68,6 +72,14 @@ __device__ __forceinline__ int wave_draw_xy(uint32_t* mt, int cur, int W, int H,
         yv = ry == 0 ? 0 : (int)(__shfl(v, iy < 0 ? 0 : iy, 64) & my);
         cur = mt_wrap(cur + used);
     } else {
+        if (RESTAGE && ring_g) {
+#pragma clang loop unroll(disable)
+            for (int i = lane; i < PCGRL_MT_N; i += 64) {
+                int d = i - dirty0; d = d < 0 ? d + PCGRL_MT_N : d;
+                if (d >= dirty) mt[i] = ring_g[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         int x = 0, y = 0;
         if (lane == 0) {
             x = mt_randint(mt, cur, W);
@@ -101,7 +113,9 @@ struct ResetRows { uint64_t m0, m1, m2; };      // bit planes of the tile ids of
 // (bit x of m_b = bit b of the tile of cell (x, row)) -- cut out of the wave ballots of the tiles as they are made, so that no lane
 // has to walk over the bytes of its row afterwards (planes_from_tiles: fourteen dependent LDS reads per row on a 14-column map);
 // lanes with row < 0 or >= H get zeros.  `tiles` may be null when nobody needs the tile bytes in LDS.
-template <int PROB>
+// PARTIAL (compile time): stage only the stretches of the ring a small map's reset reads (below).  Off in the fused step kernel: its
+// BASELINE shapes make 350-400 words -- all of the ring is read -- and the second path cost the kernel registers (C2 + 0.4 us a step).
+template <int PROB, bool PARTIAL = true>
 __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBufs& B, int e, int gen_map, uint32_t* mt,
                                                uint8_t* tiles, int lane, int step_draws = 0, int row = -1, ResetRows* rows = nullptr, int pend = 0) {
     const int W = P.width, H = P.height, cells = W * H;
@@ -113,8 +127,32 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     uint8_t* map_g = B.map + (size_t)e * cells;
     uint8_t* old_g = B.old_map + (size_t)e * cells;
     const int2 curs = reinterpret_cast<const int2*>(B.rng_cur)[e];
+    // Small maps (round 6): a reset that makes fewer than 227 words -- the reach of MT19937's recurrence -- reads only old words, and only
+    // those at the offsets 0 .. n + 1 and 397 .. 397 + n from where it starts: two short stretches of the ring are staged instead of
+    // all 624 words (a 5 x 5 Sokoban level: 2 x 76 words; an 11 x 7 zelda map: 2 x 180).  The count includes eight words for each of
+    // the (at most two) cursor draws; the one reset in a few hundred whose rejection sampling needs more stages the rest of the ring then
+    // (wave_draw_xy).
+    // (... and, with a draw cache to rebuild at the end, the nine words after the last draw)
+    const int need = (step_draws ? 8 : 0) + (gen_map ? 2 * cells : 0) + 8 + (B.fifo ? PCGRL_FIFO_N + 1 : 0);
+    const bool partial = PARTIAL && pend + need + 2 <= 226;
     int cur = curs.x;
-    {   // the ring: every load first, then the LDS stores (one round trip; 624 = 9 x 64 + 48)
+    if (partial) {
+        int base = cur - pend; base = base < 0 ? base + PCGRL_MT_N : base;
+        const int len = pend + need + 2;
+        uint32_t ra[4], rb[4];                                 // (every load first, then the LDS stores: one round trip; len <= 226)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = j * 64 + lane;
+            ra[j] = k < len ? ring_g[mt_wrap(base + k)] : 0u;
+            rb[j] = k < len ? ring_g[mt_wrap(mt_wrap(base + PCGRL_MT_M) + k)] : 0u;
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = j * 64 + lane;
+            if (k < len) { mt[mt_wrap(base + k)] = ra[j]; mt[mt_wrap(mt_wrap(base + PCGRL_MT_M) + k)] = rb[j]; }
+        }
+    } else {   // the ring: every load first, then the LDS stores (one round trip; 624 = 9 x 64 + 48)
         uint32_t rw[10];
 #pragma unroll
         for (int j = 0; j < 10; j++) rw[j] = (j < 9 || lane < PCGRL_MT_N - 9 * 64) ? ring_g[j * 64 + lane] : 0u;
@@ -146,7 +184,12 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     int dirty = pend;
     __builtin_amdgcn_wave_barrier();
     TL(13);
-    if (step_draws) { int sx, sy; const int c0 = cur; cur = wave_draw_xy(mt, cur, W, H, lane, sx, sy); dirty += cur >= c0 ? cur - c0 : cur - c0 + PCGRL_MT_N; }
+    if (step_draws) {
+        int sx, sy;
+        const int c0 = cur;
+        cur = wave_draw_xy<PARTIAL>(mt, cur, W, H, lane, sx, sy, partial ? ring_g : (const uint32_t*)nullptr, dirty0, dirty);
+        dirty += cur >= c0 ? cur - c0 : cur - c0 + PCGRL_MT_N;
+    }
     if (gen_map) {
         // helper.py:310-312 gen_random_map == RandomState.choice(keys, (H,W), p), Representation.reset
         // the number of tiles is a property of the problem: constant indices only -- a run-time index into the by-value
@@ -231,7 +274,7 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
     if (P.rep != PCGRL_REP_WIDE) {   // narrow_rep.py:28-31, turtle_rep.py:30-33: x = randint(W), y = randint(H)
         int xv, yv;
         const int c0 = cur;
-        cur = wave_draw_xy(mt, cur, W, H, lane, xv, yv);
+        cur = wave_draw_xy<PARTIAL>(mt, cur, W, H, lane, xv, yv, partial ? ring_g : (const uint32_t*)nullptr, dirty0, dirty);
         dirty += cur >= c0 ? cur - c0 : cur - c0 + PCGRL_MT_N;
         if (lane == 0) reinterpret_cast<uchar2*>(B.pos)[e] = make_uchar2((unsigned char)xv, (unsigned char)yv);
     }
@@ -242,10 +285,10 @@ __device__ __forceinline__ void wave_reset_env(const PcgrlParams& P, const DevBu
         B.fifo[(size_t)e * PCGRL_FIFO_N + lane] = mt_twist(mt[sl], mt[mt_wrap(sl + 1)], mt[mt_wrap(sl + PCGRL_MT_M)]);
         if (lane == 0) B.fifo_tag[e] = cur;
     }
-    if (dirty >= PCGRL_MT_N) {
-        for (int i = lane; i < PCGRL_MT_N; i += 64) ring_g[i] = mt[i];
-    } else {
-        for (int k = lane; k < dirty; k += 64) {
+    {   // (one loop: a whole ring is the stretch of 624 words from dirty0 on)
+        const int nd = dirty < PCGRL_MT_N ? dirty : PCGRL_MT_N;
+#pragma clang loop unroll(disable)
+        for (int k = lane; k < nd; k += 64) {
             int i = dirty0 + k; i = i >= PCGRL_MT_N ? i - PCGRL_MT_N : i;
             ring_g[i] = mt[i];
         }

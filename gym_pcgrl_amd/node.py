@@ -45,6 +45,47 @@ class ShardedTensor:
         return torch.cat([p.cpu() for p in self.parts], 0)
 
 
+def _pair_overlaps(torch, a, b, cycles=100000):
+    """Do kernels of streams a and b (one device) run side by side?  A spinning kernel on each: next to each other they end together,
+    on one hardware queue one after the other."""
+    dev = a.device
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in ev:
+        with torch.cuda.stream(a):
+            e.record()
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(a):                      # one spin alone: the yardstick
+        ev[0].record(); torch.cuda._sleep(cycles); ev[1].record()
+    torch.cuda.synchronize(dev)
+    alone = ev[0].elapsed_time(ev[1])
+    with torch.cuda.stream(a):
+        ev[2].record(); torch.cuda._sleep(cycles)
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(cycles); ev[3].record()
+    torch.cuda.synchronize(dev)
+    return ev[2].elapsed_time(ev[3]) < 1.5 * alone
+
+
+def side_by_side_streams(torch, device, k, tries=None):
+    """k streams of `device` whose kernels overlap pairwise (different hardware queues), found by trying: streams come from torch's
+    pool, a candidate that serialises with one already chosen is passed over.  When the device has fewer queues than k (or nothing
+    overlaps at all) the remaining places are filled with fresh streams -- correct either way, only not concurrent."""
+    chosen = []
+    for _ in range(tries if tries is not None else 3 * k + 4):
+        if len(chosen) == k:
+            break
+        c = torch.cuda.Stream(device=device)
+        if all(c.cuda_stream != o.cuda_stream and _pair_overlaps(torch, o, c) for o in chosen):
+            chosen.append(c)
+    for _ in range(64):
+        if len(chosen) == k:
+            break
+        c = torch.cuda.Stream(device=device)
+        if all(c.cuda_stream != o.cuda_stream for o in chosen):
+            chosen.append(c)
+    return chosen
+
+
 class MultiGpuPcgrlEnv:
     def __init__(self, prob="binary", rep="narrow", num_envs=1, devices=None, seed=0, auto_reset=True, gather="list", sync_streams=True):
         """gather: what reset()/step() return per output -- "list": a ShardedTensor of live per-device views (zero copy, no
@@ -83,7 +124,17 @@ class MultiGpuPcgrlEnv:
         for g, (lo, hi) in enumerate(self.ranges):
             s = (self.base_seed + lo) if self.base_seed is not None else [int(v) for v in seed[lo:hi]]
             self.shards.append(BatchedPcgrlEnv(prob=prob, rep=rep, num_envs=hi - lo, device=self.devices[g], seed=s, auto_reset=auto_reset))
-            self.streams.append(torch.cuda.Stream(device=self.devices[g]))
+        # a stream per shard.  Shards that share a device (sub-batches of one GPU: the double-buffered rollout) only
+        # overlap when their streams sit on different hardware queues -- HIP has four by default and hands them out as it sees fit:
+        # two fresh streams were seen to serialise (2 x 23 us instead of 25 us a C3 step) -- so those are picked by trying them out
+        by_dev = {}
+        for g, d in enumerate(self.devices):
+            by_dev.setdefault(str(d), []).append(g)
+        self.streams = [None] * G
+        for d, gs in by_dev.items():
+            ss = [torch.cuda.Stream(device=d)] if len(gs) == 1 else side_by_side_streams(torch, d, len(gs))
+            for g, st in zip(gs, ss):
+                self.streams[g] = st
         self.sync_streams = bool(sync_streams)
         self._multi = None             # step() through pcgrl_step_multi: ctypes arrays + the cached live views (built by reset())
         self._pinned = {}

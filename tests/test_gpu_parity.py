@@ -663,6 +663,34 @@ def test_vec_env_monitor_and_rollout_collector():
         assert set(lst[i]["episode"]) == {"r", "l"}
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_name,rep", [("binary-narrow-v0", "narrow"), ("zelda-wide-v0", "wide")])
+def test_double_buffered_collector_matches_one_batch(env_name, rep):
+    """Two sub-batches of one GPU on two streams (rollout.DoubleBufferedCollector: policy and step of one sub-batch next to those of the
+    other) hold the transitions of the one batch with the same seeds -- observations, actions, rewards, dones, episode starts, row by
+    row -- under a policy that looks at nothing but an environment's own observation."""
+    from gym_pcgrl_amd.rollout import DoubleBufferedCollector, RolloutCollector
+    from gym_pcgrl_amd.utils import make_vec_envs
+    torch = _torch()
+    N, T, seed = 192, 90, 11
+    one = make_vec_envs(env_name, rep, log_dir=None, n_cpu=N, seed=seed)
+    n_act = one.action_space.n
+    policy = lambda obs: (obs.reshape(obs.shape[0], -1).to(torch.int64) * torch.arange(1, obs[0].numel() + 1, device=obs.device)).sum(1) % n_act
+    ref = RolloutCollector(one, n_steps=T)
+    halves = [make_vec_envs(env_name, rep, log_dir=None, n_cpu=N // 2, seed=seed + k * (N // 2)) for k in range(2)]
+    col = DoubleBufferedCollector(halves, n_steps=T)
+    assert col.streams[0].cuda_stream != col.streams[1].cuda_stream
+    for rollout in range(2):            # (the second one goes on where the first stopped)
+        b = ref.collect(policy)
+        parts = col.collect(policy)
+        torch.cuda.synchronize()
+        assert rep != "narrow" or int(b.dones.sum()) > 0          # (episode ends and in-kernel resets are part of what is compared)
+        for name in ("obs", "actions", "rewards", "dones", "episode_starts", "last_obs"):
+            whole = getattr(b, name)
+            got = torch.cat([getattr(q, name) for q in parts], dim=0 if name == "last_obs" else 1)
+            assert torch.equal(whole, got), (rollout, name)
+
+
 # ------------------------------------------------------------------ both Sokoban search implementations on the device
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "stats_sokoban_*.npz"))), ids=os.path.basename)
@@ -1685,6 +1713,21 @@ def test_node_driver_shard_invariance(name, G):
         for k in ref[0]:
             assert torch.equal(obs[k].to("cuda:0"), ref[0][k]), (k, t)
     assert env.check_status() == [0] * G
+    env.close()
+
+
+@pytest.mark.gpu
+def test_sub_batch_streams_run_side_by_side():
+    """Sub-batches of one GPU (MultiGpuPcgrlEnv with the same device twice: the double-buffered rollout) get streams whose kernels
+    really overlap -- two streams of one device can share a hardware queue, and then the sub-batches would run one after the other."""
+    torch = _torch()
+    from gym_pcgrl_amd import node
+    for _ in range(3):          # (streams come from torch's pool: a few rounds see different ones)
+        ss = node.side_by_side_streams(torch, "cuda:0", 2)
+        assert len(ss) == 2 and ss[0].cuda_stream != ss[1].cuda_stream
+        assert node._pair_overlaps(torch, ss[0], ss[1])
+    env = node.MultiGpuPcgrlEnv(prob="binary", rep="narrow", num_envs=256, devices=["cuda:0"] * 2, seed=1, sync_streams=False)
+    assert node._pair_overlaps(torch, env.streams[0], env.streams[1])
     env.close()
 
 

@@ -11,7 +11,10 @@ import _tuning_env; _tuning_env.apply()      # PCGRL_* environment variables -> 
 so = "/tmp/libpcgrl_hip_sokprof.so"
 MIN_POPS = int(sys.argv[1]) if len(sys.argv) > 1 else 0       # only searches of at least that many pops
 PROB = sys.argv[2] if len(sys.argv) > 2 else "sokoban"         # or mdungeon: own work / waiting of the two wavefronts only
-subprocess.check_call(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPCGRL_SMB_PROF", "-DPCGRL_SKD_MIN_POPS=%d" % MIN_POPS] + _lib.SOURCES + ["-o", so], stderr=subprocess.DEVNULL)
+if os.environ.get("PCGRL_PROF_SO"):      # built ahead on the CPU box: python tools/exp_build_local.py "-DPCGRL_SMB_PROF -DPCGRL_SKD_MIN_POPS=4000" sokprof
+    so = os.path.join(ROOT, os.environ["PCGRL_PROF_SO"])
+else:
+    subprocess.check_call(["hipcc"] + _lib.HIPCC_FLAGS + ["-DPCGRL_SMB_PROF", "-DPCGRL_SKD_MIN_POPS=%d" % MIN_POPS] + _lib.SOURCES + ["-o", so], stderr=subprocess.DEVNULL)
 _lib.SO = so
 import torch, bench
 from gym_pcgrl_amd.envs import BatchedPcgrlEnv
