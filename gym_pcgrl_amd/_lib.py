@@ -34,7 +34,7 @@ class Layout(C.Structure):
 
 
 TUNING_FIELDS = ("no_fused", "fused_zelda", "step_epb", "no_inc", "inline_reset", "pair_min", "no_wide", "wide_waves", "wide_grid",
-                 "wide_pairs", "wide_few", "sok_generic", "sok_hard_cap", "sok_spawn", "md_only_agent", "smb_lds_heap", "full_per_wave", "inc_per_wave", "wide_spin", "step_prio", "no_touch", "touch_tight", "step_pair", "async_split", "big_team")
+                 "wide_pairs", "wide_few", "sok_generic", "sok_hard_cap", "sok_spawn", "md_only_agent", "smb_lds_heap", "full_per_wave", "inc_per_wave", "wide_spin", "step_prio", "no_touch", "touch_tight", "step_pair", "async_split", "big_team", "obs_at_end")
 
 
 class Tuning(C.Structure):
@@ -65,7 +65,7 @@ class Buffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_NAMES]
 
 
-ABI_VERSION = 13         # include/pcgrl_hip.h PCGRL_ABI_VERSION
+ABI_VERSION = 14         # include/pcgrl_hip.h PCGRL_ABI_VERSION
 EXPORTS = ("pcgrl_abi_version", "pcgrl_error_string", "pcgrl_last_hip_error", "pcgrl_query_layout", "pcgrl_create",
            "pcgrl_destroy", "pcgrl_bind", "pcgrl_configure", "pcgrl_seed", "pcgrl_set_tile_probs", "pcgrl_reset",
            "pcgrl_step", "pcgrl_set_maps", "pcgrl_observe", "pcgrl_action_map", "pcgrl_status", "pcgrl_profile",

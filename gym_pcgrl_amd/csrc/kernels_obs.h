@@ -21,10 +21,7 @@
 //                    that do not run the fused step kernel
 #pragma once
 
-struct ObsView {          // one block's view: environments [0, ne) relative to the block's first one
-    uint8_t* out;         // the block's stretch of the output: image of its first environment (16-byte aligned)
-    int oh, ow, depth, centered, pad, W, H;
-};
+// (struct ObsView: worklist.h -- one block's view of the target: environments [0, ne) relative to the block's first one)
 
 // exact floor(i / d) while i * d < 2^32:  __umulhi(i, obs_magic(d))   (the general routine; 32-bit multiplies are slow)
 __device__ __forceinline__ uint32_t obs_magic(int d) { return 0xFFFFFFFFu / (uint32_t)d + 1u; }
@@ -185,6 +182,80 @@ __device__ __forceinline__ void obs_write_env_lean(const Src& src, const ObsView
         }
     }
 }
+// The piece of a map image (one-hot over eight tiles, three planes; not centred) that holds map cell (x, y) of environment e -- what one
+// change of the wide representation leaves to write when the target still holds the previous image.  One lane.
+template <class Src>
+__device__ __forceinline__ void obs_write_delta_piece(const Src& src, const ObsView& V, int e, int x, int y) {
+    x = x < 0 ? 0 : (x > V.W - 1 ? V.W - 1 : x); y = y < 0 ? 0 : (y > V.H - 1 ? V.H - 1 : y);      // (update_env clamps the same way)
+    if (x >= V.ow || y >= V.oh) return;                         // (a window smaller than the map)
+    const float inv_ow = 1.0f / (float)V.ow;
+    const int ppe = (V.oh * V.ow * V.depth) >> 4;
+    const int i = (y * V.ow + x) & ~1;                          // first cell of the piece (8 bytes a cell: a piece is two cells of one image)
+    const uint2 a = obs_hot8<false>(src, V, e, i, 0, 0, inv_ow), b = obs_hot8<false>(src, V, e, i + 1, 0, 0, inv_ow);
+    reinterpret_cast<uint4*>(V.out)[e * ppe + (i >> 1)] = make_uint4(a.x, a.y, b.x, b.y);
+}
+// k_step's tasks: the block's view out of its StepLocal (LDS) into scalar registers, where a task that writes images needs it
+__device__ __forceinline__ ObsView obs_view_from_lds(const ObsView* v) {
+    ObsView V;
+    const uint64_t o = (uint64_t)v->out;
+    V.out = (uint8_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
+    V.oh = __builtin_amdgcn_readfirstlane(v->oh); V.ow = __builtin_amdgcn_readfirstlane(v->ow); V.depth = __builtin_amdgcn_readfirstlane(v->depth);
+    V.centered = __builtin_amdgcn_readfirstlane(v->centered); V.pad = __builtin_amdgcn_readfirstlane(v->pad);
+    V.W = __builtin_amdgcn_readfirstlane(v->W); V.H = __builtin_amdgcn_readfirstlane(v->H);
+    return V;
+}
+
+// The binary tile-id images (kPlanes == 1) of NB environments e0, e0 + stride, ... (< ne) by one wavefront, side by side: an image is a
+// chain of dependent LDS round trips (cursor -> window origin -> two plane rows -> the piece) that one wavefront walks at a fraction of
+// the rate the stores could leave at -- 65 536 crops of 28 x 28 cost k_step 8 us of wavefront time, not of store bandwidth (round 6:
+// moving the images under the tasks of the step did not shorten it) -- so NB chains are walked together: the loads of all of them
+// first, and what does not depend on the environment (row and column of a piece) computed once.
+template <int NB, class Src>
+__device__ __forceinline__ void obs_write_envs_rows(const Src& src, const ObsView& V, const uint8_t* pos, int e0, int stride, int ne, int lane) {
+    const int ppe = (V.oh * V.ow) >> 4;
+    const float inv_ow = 1.0f / (float)V.ow;
+    const uint32_t all = V.ow >= 32 ? ~0u : ((1u << V.ow) - 1u);
+    typedef decltype(src.row(0, 0)[0] + 0) WordT;            // uint32_t / uint64_t
+    const WordT in = V.W >= (int)(8 * sizeof(WordT)) ? ~(WordT)0 : (((WordT)1 << V.W) - 1);
+    const uint32_t padbits = V.pad ? all : 0u;
+    uint32_t p[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int e = e0 + b * stride;
+        p[b] = (V.centered && e < ne) ? (uint32_t)reinterpret_cast<const uint16_t*>(pos)[e] : 0u;
+    }
+    int ox[NB], oy[NB];
+    uint32_t valid[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(p[b]);
+        ox[b] = V.centered ? (int)(q & 255u) - (V.ow >> 1) : 0; oy[b] = V.centered ? (int)(q >> 8) - (V.oh >> 1) : 0;
+        valid[b] = obs_shr(in, ox[b]) & all;
+    }
+    for (int j = lane; j < ppe; j += 64) {
+        const int rem = j << 4, r0 = obs_fdiv(rem, inv_ow), c0 = rem - (int)__umul24(r0, V.ow);     // (see obs_write_env_lean)
+        uint32_t a[NB], c[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int e = e0 + b * stride < ne ? e0 + b * stride : e0;
+            a[b] = obs_row32(src, V, e, r0, oy[b], ox[b], valid[b], padbits);
+            c[b] = obs_row32(src, V, e, r0 + 1, oy[b], ox[b], valid[b], padbits);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int e = e0 + b * stride;
+            if (e >= ne) continue;                            // wave-uniform
+            const uint32_t acc = (uint32_t)((((uint64_t)c[b] << V.ow) | a[b]) >> c0);
+            uint4 w;
+            w.x = __umul24(acc & 15u, 0x204081u) & 0x01010101u;                              // bit j -> byte j
+            w.y = __umul24((acc >> 4) & 15u, 0x204081u) & 0x01010101u;
+            w.z = __umul24((acc >> 8) & 15u, 0x204081u) & 0x01010101u;
+            w.w = __umul24((acc >> 12) & 15u, 0x204081u) & 0x01010101u;
+            (reinterpret_cast<uint4*>(V.out) + e * ppe)[j] = w;
+        }
+    }
+}
+
 // k_step's form (lean shapes only; `nthreads` threads = whole wavefronts call it): every image, a wavefront per environment --
 // or, `delta` (the wide representation's map image, one-hot over eight tiles; the target still holds the image of the previous
 // state): the piece that holds map cell (x, y) of every environment with `changed[e]` (x, y from its action act[e * 3 ..]) and
@@ -194,17 +265,14 @@ __device__ __forceinline__ void obs_write_block_lean(const Src& src, const ObsVi
                                                      const uint8_t* changed, const uint8_t* fresh, int tid, int nthreads) {
     const int lane = tid & 63, nw = nthreads >> 6;
     if (delta && Src::kPlanes == 3) {
-        const float inv_ow = 1.0f / (float)V.ow;
-        const int ppe = (V.oh * V.ow * V.depth) >> 4;
         for (int e = tid; e < ne; e += nthreads) {
             if (!changed[e] || fresh[e]) continue;
-            int x = act[3 * e], y = act[3 * e + 1];
-            x = x < 0 ? 0 : (x > V.W - 1 ? V.W - 1 : x); y = y < 0 ? 0 : (y > V.H - 1 ? V.H - 1 : y);      // (update_env clamps the same way)
-            if (x >= V.ow || y >= V.oh) continue;                       // (a window smaller than the map)
-            const int i = (y * V.ow + x) & ~1;                          // first cell of the piece (8 bytes a cell: a piece is two cells of one image)
-            const uint2 a = obs_hot8<false>(src, V, e, i, 0, 0, inv_ow), b = obs_hot8<false>(src, V, e, i + 1, 0, 0, inv_ow);
-            reinterpret_cast<uint4*>(V.out)[e * ppe + (i >> 1)] = make_uint4(a.x, a.y, b.x, b.y);
+            obs_write_delta_piece(src, V, e, act[3 * e], act[3 * e + 1]);
         }
+    }
+    if (Src::kPlanes == 1) {        // binary tile ids: four images a wavefront at a time
+        for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < ne; e += 4 * nw) obs_write_envs_rows<4>(src, V, pos, e, nw, ne, lane);
+        return;
     }
     for (int e = __builtin_amdgcn_readfirstlane(tid >> 6); e < ne; e += nw)
         if (!(delta && Src::kPlanes == 3) || fresh[e]) obs_write_env_lean(src, V, pos, e, lane);

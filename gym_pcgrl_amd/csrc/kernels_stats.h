@@ -140,7 +140,7 @@ template <int PROB, int G, class MaskT, bool FUSED = false>
 __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevBufs& B, DevGroup<G, MaskT>& g, int lane64, int gw, bool lone,
                                                 bool inc, bool pair, bool zinc, bool have, int raw, int shard, int mode, int parity,
                                                 int inline_reset, int gen_map, uint32_t* mt, uint8_t* tiles, MaskT rowmask,
-                                                StepLocal* SL = nullptr) {
+                                                StepLocal* SL = nullptr, bool step_obs = false) {
     // (the problems with a search kernel never reset inside the statistics kernel -- their resets wait for the search -- so the reset
     //  code is not compiled into their instantiations: it cost k_stats<sokoban> its registers, 68 bytes of scratch per lane)
     constexpr bool kCanReset = PROB == PCGRL_PROB_BINARY || PROB == PCGRL_PROB_ZELDA;
@@ -202,6 +202,18 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
             if (kInc && champ_base) champ_base[(size_t)e * G + g.lane] = champ_l;
             if (g.lane == 0) finish_or_park<PROB>(P, B, e, sl, ns, MODE_START, parity, shard);
         }
+        if (FUSED && step_obs) {
+            // k_step with a bound observation: the image of the regenerated map goes out now, from this wavefront (the rows and the
+            // cursor of the new episode are in the block's LDS copy) -- a store stream under the tasks that are still running,
+            // instead of at the end of the launch behind everything
+#pragma unroll
+            for (int k = 0; k < GPW / 2; k++) {
+                if (k > 0 && !pair) break;                        // wave-uniform
+                if (!__builtin_amdgcn_readlane((int)have, 2 * k * G)) continue;
+                const ObsPlanes<MaskT, NPL> src = {reinterpret_cast<const MaskT*>(B.planes), G};        // (k_step: B's per-environment arrays are the block's LDS copy)
+                obs_write_env_lean(src, obs_view_from_lds(&SL->obs_v), B.pos, __builtin_amdgcn_readlane(e, 2 * k * G), lane64);
+            }
+        }
         return;
     }
     int32_t s[PCGRL_MAX_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -262,7 +274,7 @@ __device__ __forceinline__ void stats_wave_task(const PcgrlParams& P, const DevB
             for (int k = 0; k < GPW; k++) {
                 if ((want >> (k * G)) & 1ull) {               // wave-uniform
                     const int ek = __builtin_amdgcn_readlane(e, k * G);
-                    if (SL && lane64 == 0) SL->dirty[ek - SL->e0] = 1;
+                    if (SL && lane64 == 0) { SL->dirty[ek - SL->e0] = 1; SL->late[ek - SL->e0] = 1; SL->n_late = 1; }
                     int pend = 0;
                     if (SL) {
                         // k_step: the draws of this step may still be in the environment's draw cache, not in its ring -- take them

@@ -123,7 +123,10 @@ __device__ __forceinline__ void step_set_prio(int p) {
 // nothing for it.  EPB: environments per block, 64 (four wavefronts) or 128 (eight): a block of 128 pools the tasks of twice
 // as many environments over twice as many wavefronts, which evens out the spread between blocks -- a block that happens to
 // hold four certain resets used to end 10 us after the median block, and the launch ends with the last block.
-template <int PROB, int REP, class MaskT, bool MULTI, int EPB>
+// OBS (single step, 32-bit row masks, an observation bound whose shape has a lean routine): the images are written while the step
+// runs -- a kernel of its own so that the steps without an image carry none of it (the observation view is fourteen scalar registers:
+// in zelda's kernel, which is at its limit of 100, they were 80 bytes of scratch and 2.7 us of the bare C3 step).
+template <int PROB, int REP, class MaskT, bool MULTI, int EPB, bool OBS = false>
 __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_step(PcgrlParams P, DevBufs Bg, const int32_t* __restrict__ actions, int parity, int gen_map,
                                                                                                      int steps, size_t action_stride, double* reward_out, uint8_t* done_out, int32_t* info_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // the block's state copy, then per wave MT ring + tile bytes (in-kernel resets)
@@ -132,6 +135,8 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     __shared__ int s_n[2][4];           // list lengths and the task ticket of the step, double-buffered by step parity: the
                                         // set of the NEXT step is zeroed while this one runs (no extra barrier)
     __shared__ StepLocal s_loc;
+    __shared__ int s_obs_ticket;        // (OBS) the observation tasks' own ticket
+    static_assert(!(OBS && MULTI), "the tape form writes its images at the end");
     constexpr int G = 16, GPW = 4;
     constexpr int NPL = (PROB == PCGRL_PROB_BINARY) ? 1 : 3;
     constexpr int kPlaneRow = G * NPL * (int)sizeof(MaskT);
@@ -215,9 +220,27 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         if (AW == 3 && Bg.flat) blk_copy<TPB>(smem + L.flat, reinterpret_cast<const uint8_t*>(Bg.flat + e0), ne * 4);
         else blk_copy<TPB>(smem + L.act, reinterpret_cast<const uint8_t*>(actions + (size_t)e0 * AW), ne * 4 * AW);
     }
-    if (threadIdx.x < EPB) s_loc.dirty[threadIdx.x] = 0;
+    if (threadIdx.x < EPB) { s_loc.dirty[threadIdx.x] = 0; if (OBS) { s_loc.obs_skip[threadIdx.x] = 0; s_loc.late[threadIdx.x] = 0; } }
     if (threadIdx.x < 8) s_n[threadIdx.x >> 2][threadIdx.x & 3] = 0;
-    if (threadIdx.x == 0) { s_loc.e0 = 0; s_loc.need = NUPD; s_loc.refill_done[0] = 0; s_loc.refill_done[1] = 0; }
+    if (threadIdx.x == 0) { s_loc.e0 = 0; s_loc.need = NUPD; s_loc.refill_done[0] = 0; s_loc.refill_done[1] = 0; s_loc.n_late = 0; s_obs_ticket = 0; }
+    // ---- the wrapped observation of the block's environments (pcgrl_bind_observation), straight from the LDS copy: the row planes are
+    // the map, the cursors are there too -- no byte map is read.  (Only the shapes with a lean routine -- kernels_obs.h: binary tile
+    // ids, one-hot over eight tiles -- are written here, the host sends the others to k_obs: Bg.obs.fused.)  Single step: the
+    // images are written WHILE the step runs (round 6; until then all of them at the end of the launch: every block ends at about
+    // the same time, so the whole image traffic -- 51 MB for 65 536 crops of 28 x 28 -- came after the compute instead of under it):
+    //   * an environment that is certain to be reset: by its reset's wavefront, as soon as the new map is there (stats_wave_task);
+    //   * the wide representation's map image whose target still holds the previous state (Bg.obs.delta): the one piece a change
+    //     touches, by the update wavefront's lane right behind the task barrier;
+    //   * every other image: "observation tasks" of OBS_PER_TASK environments each, with a ticket of their own: a wavefront takes one
+    //     after every statistics task, so the stores leave from the first tasks' end on instead of all behind the compute;
+    //   * an episode end nobody saw coming rewrites planes and cursor under such a task: those few images are written again at the
+    //     end, behind a barrier before which every wavefront has waited for its own stores.
+    constexpr int OBS_PER_TASK = 8;
+    // (the host launches the OBS instantiation only with Bg.obs.out && Bg.obs.fused)
+    const bool obs_delta = OBS && REP == PCGRL_REP_WIDE && NPL == 3 && Bg.obs.delta;
+    const int n_obs = (OBS && !obs_delta) ? (ne + OBS_PER_TASK - 1) / OBS_PER_TASK : 0;
+    const ObsPlanes<MaskT, NPL> obs_src = {reinterpret_cast<const MaskT*>(smem + L.planes), G};
+    if (OBS && threadIdx.x == 0) s_loc.obs_v = obs_view(P, Bg.obs, e0);       // (visible behind the barrier at the top of the step)
     if (PROB == PCGRL_PROB_ZELDA && threadIdx.x == 64) zelda_reward_tab(P, &s_loc.zr);
     uint8_t* reset_scratch = smem + L.total;
     // steps > 1 (pcgrl_rollout): the environments of a block do not depend on any other block, so the block simply goes on
@@ -264,6 +287,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         // (binary: a change in or next to the champion goes to the full list as a packed item with bit 31 set: binary_touch first)
         else if (u.chg) { dest = u.cheap ? 2 : 1; v = (u.cheap || packed_full) ? u.inc_item : ((u.touch && B.step_touch) ? (u.inc_item | (int)0x80000000) : e); }
         if (u.chg) s_loc.dirty[e] = 1;
+        if (OBS && first && e < EPB) s_loc.obs_skip[e] = 1;
         const uint64_t m0 = __ballot(dest == 0), m1 = __ballot(dest == 1), m2 = __ballot(dest == 2);
         const uint64_t below = (1ull << lane64) - 1ull;
         // this wavefront's stretch of each list (one LDS atomic per list)
@@ -300,6 +324,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
         int k_used = 0, cur0 = 0;
         if (lane64 == 0) s_loc.late_done[wv] = 0;
         if (e < ne && !first) update_env_cursor<REP, MaskT>(P, B, e, mid, k_used, cur0);
+        if (OBS && REP == PCGRL_REP_WIDE && NPL == 3 && obs_delta && e < ne && !first && u.chg) obs_write_delta_piece(obs_src, obs_view_from_lds(&s_loc.obs_v), e, act_lds[3 * e], act_lds[3 * e + 1]);
         // the consumed draws stay in the draw cache for now (StepLocal::pend): writing them to the rings and topping the caches up
         // is ring traffic nothing waits for, and this wavefront is a quarter of the block's capacity for the tasks -- it does that
         // after the task loop (below)
@@ -311,6 +336,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     //  loop -- scalar loads of the parameter block, address arithmetic of every task kind: ~2.4 us on the timeline -- then runs
     //  while they would only be waiting for the lists)
     int n0 = 0, n1 = 0, n2 = 0, w_full = 0, w_total = 0, w_lone = 0;
+    bool stats_left = true, obs_left = OBS;
     bool pair = false;      // two certain resets per wavefront task (four statistics side by side) from DevBufs::step_pair of them on
     // maps per wavefront task (of the GPW = 4 lane groups): the four maps of a task run their component and sweep loops in lockstep,
     // so a task lasts as long as its slowest map in every phase, and a block has only about one and a half tasks per wavefront --
@@ -340,11 +366,33 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             w_lone = pair ? (n0 + 1) >> 1 : n0;
             w_total = w_lone + w_full + (n2 + ipw - 1) / ipw;
         }
+        if (OBS && !first_round && obs_left) {
+            // an observation task between two statistics tasks: the images of OBS_PER_TASK environments.  The cursors are final once the
+            // update wavefronts are through with the cursor moves of the step (refill_done: long the case after a first task); rows and
+            // cursor of an environment that is being reset under this task give a torn image, which the end of the launch writes
+            // again (StepLocal::late).
+            int oid = 0;
+            if (lane64 == 0) oid = atomicAdd(&s_obs_ticket, 1);
+            oid = __builtin_amdgcn_readfirstlane(oid);
+            if (oid >= n_obs) obs_left = false;
+            else {
+                if (prio_now) { prio_now = 0; step_set_prio(0); }
+                while (__hip_atomic_load(&s_loc.refill_done[sp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NUPD) __builtin_amdgcn_s_sleep(2);
+                const int o0 = oid * OBS_PER_TASK;
+                const ObsView V = obs_view_from_lds(&s_loc.obs_v);
+#pragma clang loop unroll(disable)
+                for (int j = 0; j < OBS_PER_TASK; j++) {
+                    const int eo = o0 + j;                    // wave-uniform
+                    if (eo < ne && !s_loc.obs_skip[eo]) obs_write_env_lean(obs_src, V, smem + L.pos, eo, lane64);
+                }
+            }
+        }
+        if (!stats_left) { if (!OBS || !obs_left) break; continue; }
         int wid = 0;
         if (lane64 == 0) wid = atomicAdd(&s_n[sp][3], 1);
         wid = __builtin_amdgcn_readfirstlane(wid);
         TL(18);
-        if (wid >= w_total) break;
+        if (wid >= w_total) { stats_left = false; if (!OBS || !obs_left) break; continue; }
         const bool lone = wid < w_lone, inc = wid >= w_lone + w_full;
         const int item = lone ? (pair ? 2 * wid + (gw >> 1) : wid) : (inc ? (wid - w_lone - w_full) * ipw + gw : (wid - w_lone) * fpw + gw);
         const bool have = lone ? (item < n0 && (pair || gw < 2)) : (gw < (inc ? ipw : fpw) && item < (inc ? n2 : n1));
@@ -354,7 +402,7 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
             const int want = lone ? (prio & 3) : (inc ? ((prio >> 4) & 3) : ((prio_nfull == 0 || wid - w_lone < prio_nfull) ? ((prio >> 2) & 3) : 0));
             if (want != prio_now) { prio_now = want; step_set_prio(want); }
         }
-        stats_wave_task<PROB, G, MaskT, true>(P, B, g, lane64, gw, lone, inc, PROB == PCGRL_PROB_ZELDA && pair, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc);
+        stats_wave_task<PROB, G, MaskT, true>(P, B, g, lane64, gw, lone, inc, PROB == PCGRL_PROB_ZELDA && pair, zinc, have, raw, lane64, MODE_STEP, parity, 1, gen_map, mt, tiles, rowmask, &s_loc, OBS);
         TL(7);
     }
     if (prio_now) { prio_now = 0; step_set_prio(0); }
@@ -403,9 +451,16 @@ __global__ __launch_bounds__(EPB * 4) __attribute__((amdgpu_waves_per_eu(4, 8)))
     // (only the shapes with a lean routine -- kernels_obs.h: binary tile ids, one-hot over eight tiles -- are written here, the
     // host sends the others to k_obs: Bg.obs.fused.  Wide representation, single step, the target still holding the previous
     // image: only what changed, Bg.obs.delta.)
-    if (Bg.obs.out && Bg.obs.fused) {
+    if (!OBS && Bg.obs.out && Bg.obs.fused) {        // (the tape form, 64-bit row masks, pcgrl_tuning obs_at_end: all images here)
         const ObsPlanes<MaskT, NPL> src = {reinterpret_cast<const MaskT*>(smem + L.planes), G};
         obs_write_block_lean(src, obs_view(P, Bg.obs, e0), smem + L.pos, ne, REP == PCGRL_REP_WIDE && !MULTI && Bg.obs.delta, act_lds, s_loc.dirty,
                              smem + L.done, (int)threadIdx.x, TPB);
+    }
+    if (OBS && s_loc.n_late) {                    // block-uniform (read behind the barrier above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores of this wavefront's observation tasks have landed ...
+        __syncthreads();                                          // ... everybody's have
+        const ObsView V = obs_view_from_lds(&s_loc.obs_v);
+        for (int eo = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); eo < ne; eo += TPB >> 6)
+            if (s_loc.late[eo]) obs_write_env_lean(obs_src, V, smem + L.pos, eo, (int)threadIdx.x & 63);
     }
 }

@@ -115,7 +115,7 @@ struct pcgrl_env {
     int alloc_solver_power;
     // developer switches (pcgrl_set_tuning; A/B measurements and tests), resolved at pcgrl_bind
     pcgrl_tuning tun;
-    int no_wide, wide_waves, wide_grid, wide_pairs, fused_zelda, no_fused, step_epb, smb_heap;
+    int no_wide, wide_waves, wide_grid, wide_pairs, fused_zelda, no_fused, step_epb, smb_heap, obs_at_end;
     int profiling;
     int obs_incremental;       // pcgrl_bind_observation(incremental): the bound target is the library's to update in place
     const uint8_t* obs_synced; // the buffer that holds the image of the current state (written by the last step / reset), or NULL
@@ -418,6 +418,7 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
     if (h->wide_grid < 1) h->wide_grid = 2048;
     h->fused_zelda = tun_or(T.fused_zelda, 1) ? 1 : 0;  // 0: zelda steps as k_update + k_stats
     h->no_fused = tun_or(T.no_fused, 0) ? 1 : 0;
+    h->obs_at_end = tun_or(T.obs_at_end, 0) ? 1 : 0;
     // pcgrl_step_async: the fresh jobs of a tick in a launch of their own with small search regions.  Pays where a tick has many of them
     // (C4: 1 300 fresh jobs of ~30 pops a tick, 240 -> 275 M env-steps/s); MiniDungeons / Dave have under a hundred and the extra
     // launch -- whose length is one job's chain of pops, like the other's -- costs more than it saves (M1 277 -> 207 M)
@@ -774,16 +775,22 @@ static int launch_step_pme(pcgrl_env* h, const int32_t* actions, int parity, hip
     const size_t lds = (size_t)SL.total + (EPB / 16) * (size_t)(PCGRL_MT_N * 4 + ((P.width * P.height + 15) & ~15));
     const int grid = (P.num_envs + EPB - 1) / EPB;
     const int gen = (P.random_start || !h->has_old) ? 1 : 0;
-#define PCGRL_LAUNCH_STEP(REPV, MULTI) do { \
-        { const int rca = lds_cap<k_step<PROB, REPV, MaskT, MULTI, EPB>>(h->device, lds); if (rca) return rca; } \
-        hipLaunchKernelGGL((k_step<PROB, REPV, MaskT, MULTI, EPB>), dim3(grid), dim3(EPB * 4), lds, st, P, h->B, actions, \
+#define PCGRL_LAUNCH_STEP(REPV, MULTI, OBSV) do { \
+        { const int rca = lds_cap<k_step<PROB, REPV, MaskT, MULTI, EPB, OBSV>>(h->device, lds); if (rca) return rca; } \
+        hipLaunchKernelGGL((k_step<PROB, REPV, MaskT, MULTI, EPB, OBSV>), dim3(grid), dim3(EPB * 4), lds, st, P, h->B, actions, \
                            parity, gen, R.steps, R.action_stride, R.reward_out, R.done_out, R.info_out); } while (0)
     const bool multi = R.steps > 1 || R.reward_out || R.done_out || R.info_out;
+    // a single step with a bound observation of a lean shape: the instantiation that writes the images while it runs (32-bit row masks)
+    constexpr bool kObsKernel = sizeof(MaskT) == 4;
+    const bool obs = kObsKernel && !multi && h->B.obs.out && h->B.obs.fused && !h->obs_at_end;
+#define PCGRL_LAUNCH_STEP3(REPV) do { if (multi) PCGRL_LAUNCH_STEP(REPV, true, false); else if (obs) PCGRL_LAUNCH_STEP(REPV, false, kObsKernel); \
+                                      else PCGRL_LAUNCH_STEP(REPV, false, false); } while (0)
     switch (P.rep) {
-        case PCGRL_REP_NARROW: if (multi) PCGRL_LAUNCH_STEP(PCGRL_REP_NARROW, true); else PCGRL_LAUNCH_STEP(PCGRL_REP_NARROW, false); break;
-        case PCGRL_REP_WIDE: if (multi) PCGRL_LAUNCH_STEP(PCGRL_REP_WIDE, true); else PCGRL_LAUNCH_STEP(PCGRL_REP_WIDE, false); break;
-        default: if (multi) PCGRL_LAUNCH_STEP(PCGRL_REP_TURTLE, true); else PCGRL_LAUNCH_STEP(PCGRL_REP_TURTLE, false); break;
+        case PCGRL_REP_NARROW: PCGRL_LAUNCH_STEP3(PCGRL_REP_NARROW); break;
+        case PCGRL_REP_WIDE: PCGRL_LAUNCH_STEP3(PCGRL_REP_WIDE); break;
+        default: PCGRL_LAUNCH_STEP3(PCGRL_REP_TURTLE); break;
     }
+#undef PCGRL_LAUNCH_STEP3
 #undef PCGRL_LAUNCH_STEP
     HIPCHK(hipGetLastError());
     return PCGRL_OK;

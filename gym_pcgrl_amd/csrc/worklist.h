@@ -140,6 +140,10 @@ struct DevBufs {
 // the per-environment state of its 64 environments in LDS (DevBufs pointers rebased into it) for the whole launch.
 // zelda's reward by lanes (zelda_reward_lanes, kernels_stats.h): weight and band of term k, in the order get_reward sums them
 struct ZeldaRewardTab { double w[8]; int lo[8]; int hi[8]; };
+struct ObsView {          // one block's view of the observation target: environments [0, ne) relative to the block's first one (kernels_obs.h)
+    uint8_t* out;         // the block's stretch of the output: image of its first environment (16-byte aligned)
+    int oh, ow, depth, centered, pad, W, H;
+};
 struct StepLocal {
     int e0;
     int par, need;              // this step's slot of refill_done; how many update wavefronts have to report
@@ -151,6 +155,12 @@ struct StepLocal {
     int pend[256];
     int late_done[4];
     uint8_t dirty[256];         // planes / champion / start statistics changed: write them back
+    // the wrapped observation written by k_step while it runs (round 6; kernels_step.h "observation tasks"):
+    uint8_t obs_skip[256];      //   certain to be reset in this step: the image is written by the reset's wavefront, not by an observation task
+    uint8_t late[256];          //   reset by an episode end nobody saw coming: the image is written again at the end of the launch
+    int n_late;
+    ObsView obs_v;              //   the block's view, written once by thread 0: a task that writes an image reads it from here (kept in scalar
+                                //   registers across the kernel it cost zelda's instantiation, which is at its limit of 100, 80 bytes of scratch)
     ZeldaRewardTab zr;          // (zelda; written once by thread 0 at the start of k_step: constant indices into the parameter block only)
 };
 

@@ -38,7 +38,7 @@ extern "C" {
  * 7: + the smb problem: pcgrl_config grew (min_empty, min_enemies, min_jumps; `reserved_` is gone); pcgrl_status reports
  *    clamped actions.  10: + pcgrl_tuning / pcgrl_set_tuning (the library reads no environment variables any more); pcgrl_config
  *    grew (prob_width, prob_height); maps up to 255 x 255, search levels up to 16 384 bordered cells, solver_power up to 1 000 000. */
-#define PCGRL_ABI_VERSION 13
+#define PCGRL_ABI_VERSION 14
 #define PCGRL_OK 0
 #define PCGRL_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define PCGRL_EHIP (-2)     /* a HIP runtime call failed (see pcgrl_last_hip_error) */
@@ -145,6 +145,9 @@ typedef struct pcgrl_tuning {
     int32_t big_team;        /* k_big, binary maps beyond 64 x 64: 1 = a step's few full recomputations are made by all wavefronts of a block
                                 together (csrc/bigmap_team.h; the default: four wavefronts a block), 2..8 = that many, 0 = a wavefront
                                 per map throughout */
+    int32_t obs_at_end;      /* k_step with a bound observation (pcgrl_bind_observation): 1 = every image at the end of the launch (the form up to
+                                round 5); default 0 = the images leave while the step runs -- a reset's wavefront writes its new map's, a wide
+                                change's lane its piece, "observation tasks" between the statistics tasks the rest (csrc/kernels_step.h) */
 } pcgrl_tuning;
 
 int pcgrl_abi_version(void);

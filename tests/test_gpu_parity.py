@@ -511,6 +511,44 @@ def test_bound_observation_every_step(prob, rep, calls, n, oh, ow, centered, one
     env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("at_end", [0, 1])
+@pytest.mark.parametrize("epb", [64, 128, 256])
+@pytest.mark.parametrize("prob,rep,calls,oh,ow,centered,onehot", [
+    ("binary", "narrow", (), 28, 28, 1, 0), ("zelda", "wide", (dict(width=11, height=16),), 16, 11, 0, 1), ("zelda", "narrow", (), 22, 22, 1, 1),
+    ("binary", "turtle", (), 28, 28, 1, 0)], ids=lambda v: str(v) if not isinstance(v, tuple) else "adj%d" % len(v))
+def test_images_written_while_the_step_runs(prob, rep, calls, oh, ow, centered, onehot, epb, at_end, monkeypatch):
+    """k_step with a bound observation writes the images while it runs (round 6): a reset's wavefront its new map's, the wide
+    representation's lane the piece its change touches, observation tasks between the statistics tasks the rest, and the images of
+    episode ends nobody saw coming again at the end -- for every block size, against the wrappers' rule after every step, with
+    short episodes (many certain resets, and unannounced ones: a tenth of the steps' resets), next to the form that writes
+    everything at the end (pcgrl_tuning obs_at_end)."""
+    torch = _torch()
+    _tune(monkeypatch, "step_epb", str(epb))
+    _tune(monkeypatch, "obs_at_end", str(at_end))
+    n = 700
+    env = _make(prob, rep, n, list(calls) + [dict(change_percentage=0.08)], seed=4100 + epb)
+    pad = env.get_border_tile()
+    depth = env.get_num_tiles() if onehot else 1
+    img = env.bind_observation(oh, ow, centered, pad, onehot)
+    env.reset()
+    has_pos = env._rep.has_pos
+    sp = env.single_action_space
+    rs = np.random.RandomState(9)
+    draw = (lambda: rs.randint(0, sp.n, size=(n,))) if hasattr(sp, "n") else (lambda: np.stack([rs.randint(0, int(k), size=(n,)) for k in sp.nvec], -1))
+    ndone = 0
+    for t in range(60):
+        _, _, done, _ = env.step(torch.as_tensor(draw().astype(np.int32), device="cuda"))
+        ndone += int(done.sum().item())
+        m = env._bufs["map"].cpu().numpy()
+        pos = env._bufs["pos"].cpu().numpy() if has_pos else np.zeros((n, 2), np.uint8)
+        exp = _expected_image(m, pos, oh, ow, centered, pad, depth)
+        bad = np.nonzero((img.cpu().numpy() != exp).reshape(n, -1).any(1))[0]
+        assert bad.size == 0, (t, bad[:5])
+    assert ndone > 20 and env.check_status() == 0
+    env.close()
+
+
 # ------------------------------------------------------------------ edge shapes (layout corners of the kernels)
 @pytest.mark.parametrize("prob,rep,w,h", [
     ("binary", "narrow", 1, 1), ("binary", "turtle", 1, 9), ("binary", "wide", 9, 1), ("binary", "narrow", 32, 16),

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert set(_lib.EXPORTS) == declared
-    assert L.pcgrl_abi_version() == _lib.ABI_VERSION == 13
+    assert L.pcgrl_abi_version() == _lib.ABI_VERSION == 14
     assert L.pcgrl_error_string(-1).decode().startswith("invalid")
 
 

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r6
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r6/t11.log 2>&1; tail -4 gpurun_out/r6/t11.log
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/r6/t15.log 2>&1; tail -4 gpurun_out/r6/t15.log
