@@ -67,9 +67,13 @@ def _pair_overlaps(torch, a, b, cycles=100000):
 
 
 def side_by_side_streams(torch, device, k, tries=None):
-    """k streams of `device` whose kernels overlap pairwise (different hardware queues), found by trying: streams come from torch's
-    pool, a candidate that serialises with one already chosen is passed over.  When the device has fewer queues than k (or nothing
-    overlaps at all) the remaining places are filled with fresh streams -- correct either way, only not concurrent."""
+    """k streams of `device` whose kernels overlap pairwise (different hardware queues) at the time of the call, found by trying:
+    streams come from torch's pool, a candidate that serialises with one already chosen is passed over.  That is best effort: HIP
+    multiplexes streams onto a few hardware queues (four by default) and was seen to move them -- two streams that overlapped when
+    they were chosen sat on one queue by the time an environment stepped on them (2 x 23 us instead of 25 us a C3 step), and apart
+    again a few hundred launches later (tools/probe/sub_diag.py, profiles/r6_round6/probe/sub_diag_*.txt; a normal- and a
+    high-priority stream always pass the test but twice in eleven environments stepped at 67 us: not used).  `streams_overlap()`
+    of the environment says how things stand; correct either way, only the overlap is at stake."""
     chosen = []
     for _ in range(tries if tries is not None else 3 * k + 4):
         if len(chosen) == k:
@@ -352,6 +356,27 @@ class MultiGpuPcgrlEnv:
             dev = "cpu" if self.gather == "host" else self.gather
             out = (torch.cat([r.to(dev) for r in rew], 1), torch.cat([d.to(dev) for d in done], 1), [r[2] for r in res])
         return out
+
+    def streams_overlap(self):
+        """Do the streams of the shards that share a device run side by side right now (the spin test of side_by_side_streams)?
+        HIP may have moved them onto one hardware queue since they were chosen; `repick_streams()` chooses again.  Synchronises."""
+        by_dev = {}
+        for g, d in enumerate(self.devices):
+            by_dev.setdefault(str(d), []).append(g)
+        return all(_pair_overlaps(self._torch, self.streams[a], self.streams[b]) for gs in by_dev.values() for i, a in enumerate(gs) for b in gs[i + 1:])
+
+    def repick_streams(self):
+        """New streams for the shards that share a device (everything queued on the old ones is waited for first)."""
+        torch = self._torch
+        self.synchronize()
+        by_dev = {}
+        for g, d in enumerate(self.devices):
+            by_dev.setdefault(str(d), []).append(g)
+        for d, gs in by_dev.items():
+            if len(gs) > 1:
+                for g, st in zip(gs, side_by_side_streams(torch, d, len(gs))):
+                    self.streams[g] = st
+        self._multi = None
 
     def synchronize(self):
         for st in self.streams:

@@ -4,6 +4,8 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch, bench
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _tuning_env; print("tuning", _tuning_env.apply())
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 for wl in sys.argv[1:]:
