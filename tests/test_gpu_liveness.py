@@ -129,7 +129,15 @@ def test_large_batches_never_hang_under_random_switches():
         for it in range(max(REPEATS // 5, 2)):
             rs = np.random.RandomState(9000 + it)
             tuning = _random_tuning(rs, tall)
+            obs_bound = (not tall) and it % 2 == 1      # every other setting of the fused shapes: with the policy's image bound (round 6:
+            if obs_bound:                               #  written by tasks of the step kernel, or all at its end)
+                tuning["obs_at_end"] = int(rs.randint(2))
             env = _make(prob, rep, n, calls, 0, tuning)
+            if obs_bound:
+                if rep == "wide":
+                    env.bind_observation(16, 11, 0, env.get_border_tile(), 1)
+                else:
+                    env.bind_observation(28, 28, 1, env.get_border_tile(), 0)
             env.reset()
             W, H, nt = env._prob._width, env._prob._height, env.get_num_tiles()
             g = torch.Generator(device="cuda").manual_seed(it)
