@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r6
-timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/r6/t17.log 2>&1; tail -4 gpurun_out/r6/t17.log
+(timeout 600 python tools/probe/collector_graph.py; timeout 600 python tools/probe/collector_graph.py zelda-wide-v0 wide) 2>&1 | grep -v amdgpu.ids | tail -30 > gpurun_out/r6/collector_graph.txt; cat gpurun_out/r6/collector_graph.txt
