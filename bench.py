@@ -189,8 +189,22 @@ def collector_leg(torch, device, n=65536, n_steps=8, warm_steps=2):
     dt = time.perf_counter() - t0
     gpu_ms = a0.elapsed_time(a1)
     env_ms = sum(e0.elapsed_time(e1) for e0, e1 in marks)
+    # the same loop with a policy that is next to nothing (64 bytes of the image -> an action: five small kernels): what the collector's
+    # own row costs -- the wrapped step plus ~ 15 dependent small kernels (copies of actions / rewards / dones / episode starts) at ~ 3.5 us
+    # each; GPU-side: the rollout captured into a HIP graph replays no faster (profiles/r6_round6/NOTES.md)
+    w.step = step0
+    wts = torch.arange(1, 65, device=device, dtype=torch.int32)
+    small = lambda obs: (obs.reshape(obs.shape[0], -1)[:, 360:424].to(torch.int32) * wts).sum(1) % 3
+    col.collect(small)
+    torch.cuda.synchronize(device)
+    s0 = time.perf_counter()
+    for _ in range(4):
+        col.collect(small)
+    torch.cuda.synchronize(device)
+    small_us = (time.perf_counter() - s0) / (4 * n_steps) * 1e6
     venv.close()
-    return {"workload": "RolloutCollector over make_vec_envs('binary-narrow-v0', 'narrow', n_cpu=%d): stand-in Cnn1-shaped policy (3 conv + fc512, bf16, random weights) "
+    return {"small_policy": {"what": "the same collector with a 64-byte policy: the loop's own cost per row", "us_per_row": small_us, "value": n / small_us * 1e6, "unit": "env-steps/s"},
+            "workload": "RolloutCollector over make_vec_envs('binary-narrow-v0', 'narrow', n_cpu=%d): stand-in Cnn1-shaped policy (3 conv + fc512, bf16, random weights) "
                         "-> actions -> wrapped step writing the [N,28,28,1] image into the rollout buffer" % n,
             "envs": n, "steps": n_steps, "value": n * n_steps / dt, "unit": "env-steps/s", "ms_per_step": dt / n_steps * 1e3,
             "gpu_ms_per_step": gpu_ms / n_steps, "env_gpu_ms_per_step": env_ms / n_steps, "env_share_of_gpu_time": env_ms / gpu_ms,
