@@ -437,7 +437,9 @@ int pcgrl_bind(pcgrl_env* h, const pcgrl_buffers* b, void* stream) {
         // wavefront priorities in k_step: certain resets and full recomputations of the binary problem at level 3, its incremental
         // updates at 0 (C2: 30.4 -> 28.9 us first window, 29.4 -> 28.7 steady).  Zelda's tasks are all of one kind and about one
         // length; every setting measured there was 0.3-0.7 us slower than none.
-        h->B.step_prio = tun_or(T.step_prio, h->cfg.prob == PCGRL_BINARY ? 15 : 0) & 0xFFF;
+        // (round 6: with the narrow representation the update wavefronts -- cursor draws, ring refills -- at level 3 as well: C2 steady 29.05 ->
+        //  28.6 us, first window unchanged; zelda loses 0.4 us with it, the wrapped steps do not care: profiles/r6_round6/probe/ab_step_prio_update.txt)
+        h->B.step_prio = tun_or(T.step_prio, h->cfg.prob == PCGRL_BINARY ? (h->cfg.rep == PCGRL_NARROW ? (15 | (3 << 6)) : 15) : 0) & 0xFFF;
         h->B.step_ipw = (i == 1 || i == 2) ? i : 4;
         h->B.step_touch = tun_or(T.no_touch, 0) ? 0 : 1;
         h->B.step_pair = tun_or(T.step_pair, 6);        // (C3: fifteen certain resets a block and step; 32.2 -> 29.8 us.  C2 has two or three: unaffected)
