@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r6
-bash tools/probe/ab_tuning.sh "C2" "step_prio=207 step_prio=223 step_prio=1231 step_prio=203 step_prio=206 step_prio=239" 3 2>&1 | tee gpurun_out/r6/ab_step_prio_around207.txt
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/r6/t18.log 2>&1; tail -3 gpurun_out/r6/t18.log
+bash tools/profile_r6.sh > gpurun_out/r6/profile_r6.log 2>&1; tail -3 gpurun_out/r6/profile_r6.log
