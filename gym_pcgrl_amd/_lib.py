@@ -13,7 +13,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 SO = os.path.join(LIBDIR, "libpcgrl_hip.so")
 SOURCES = [os.path.join(CSRC, "pcgrl_abi.hip")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# (-amdgpu-sched-strategy=max-ilp, round 6: the step kernels are chains of dependent instructions at a fraction of the issue peak -- the
+#  compiler's default strategy schedules for occupancy first; same box, alternating libraries: C2 28.6 -> 28.2 / 28.6 -> 28.05 us, C3 28.9 ->
+#  28.3 / 27.8 -> 27.1, C3w 31.5 -> 30.2: profiles/r6_round6/probe/ab_compiler_sched*.txt)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 PCGRL_OK, PCGRL_EINVAL, PCGRL_EHIP, PCGRL_ESTATE = 0, -1, -2, -3
 
@@ -93,6 +96,7 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(ROOT, "include", "pcgrl_hip.h")]
+    h.update(" ".join(HIPCC_FLAGS).encode() + b"\0")          # (the compiler flags are part of what the library was built from)
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:

@@ -1,3 +1,2 @@
 mkdir -p gpurun_out/r6
-timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/r6/t18.log 2>&1; tail -3 gpurun_out/r6/t18.log
-bash tools/profile_r6.sh > gpurun_out/r6/profile_r6.log 2>&1; tail -3 gpurun_out/r6/profile_r6.log
+bash tools/probe/ab_phases.sh "C2 C3 C5" "gym_pcgrl_amd/lib/libpcgrl_hip.so gym_pcgrl_amd/lib/libexp_iterilp.so gym_pcgrl_amd/lib/libexp_trackers.so gym_pcgrl_amd/lib/libexp_nopostra.so gym_pcgrl_amd/lib/libexp_aasched.so" 3 2>&1 | cut -c1-84 | tee gpurun_out/r6/ab_compiler_sched4.txt
