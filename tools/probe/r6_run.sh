@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r6
-timeout 1500 python tools/knob_sweep.py C2 C3 C5 2>&1 | grep -v amdgpu.ids > gpurun_out/r6/knob_sweep_maxilp.txt; cat gpurun_out/r6/knob_sweep_maxilp.txt | cut -c1-100
+bash tools/probe/ab_phases.sh "C2 C3 C5" "gym_pcgrl_amd/lib/libpcgrl_hip.so gym_pcgrl_amd/lib/libexp_os.so gym_pcgrl_amd/lib/libexp_nounroll.so gym_pcgrl_amd/lib/libexp_o2.so" 3 2>&1 | cut -c1-84 | tee gpurun_out/r6/ab_compiler_size.txt
