@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r6
-bash tools/probe/ab_phases.sh "C2 C3 C5" "gym_pcgrl_amd/lib/libpcgrl_hip.so gym_pcgrl_amd/lib/libexp_os.so gym_pcgrl_amd/lib/libexp_nounroll.so gym_pcgrl_amd/lib/libexp_o2.so" 3 2>&1 | cut -c1-84 | tee gpurun_out/r6/ab_compiler_size.txt
+bash tools/probe/ab_tuning.sh "C3" "step_prio=0 step_prio=4 step_prio=16 step_prio=20 step_prio=48 step_prio=1" 3 2>&1 | tee gpurun_out/r6/ab_step_prio_zelda.txt
